@@ -1,0 +1,177 @@
+/*
+ * splitvae.h -- C ABI of libsplitvae_hip.so: the MI355X (gfx950) SPLIT-VAE training path.
+ *
+ * The reference (51616/split-vae) has no FFI/plugin layer: its hot path is Python calling
+ * TensorFlow-2.0 library kernels.  Every entry point below therefore cites the reference *call
+ * site(s)* whose TF op sequence it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers + explicit sizes, `stream` is a hipStream_t passed as void*;
+ *   - the caller owns every buffer including the workspace; no entry point allocates device
+ *     memory, synchronises the host, or keeps global mutable state (plans are caller-owned);
+ *   - return 0 on success, <0 = sv_status error, >0 = a hipError_t from a launch;
+ *   - activations are NHWC; conv kernels HWIO fp32; dense kernels [in,out] fp32 (Keras layouts);
+ *   - `dtype` selects the arithmetic type of the MFMA contractions (SV_BF16: bf16 operands,
+ *     fp32 accumulate; SV_F32: exact fp32 MFMA).  Master weights, ELBO terms, KL, Adam are fp32.
+ */
+#ifndef SPLITVAE_H
+#define SPLITVAE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { SV_OK = 0, SV_E_BADARG = -1, SV_E_UNSUPPORTED = -2, SV_E_WORKSPACE = -3, SV_E_STATE = -4 } sv_status;
+typedef enum { SV_F32 = 0, SV_BF16 = 1 } sv_dtype;
+typedef enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1 } sv_act;
+
+const char* sv_version(void);
+
+/* ---------------------------------------------------------------- A1: patch scramble
+ * Replaces Augmentator.scramble (augmentation.py:43-57) as wired at vae/main.py:54-61:
+ * extract_patches -> reshape -> shuffle -> split/unstack/concat -> concat([x, x_aug], axis=2).
+ * x[B,H,W,3] fp32, perm[B,(H/patch)*(W/patch)] int32 (destination patch n takes source patch
+ * perm[n]); images6[B,H,W,6] fp32 = [x | x_aug].  Pure index bookkeeping: bit-exact. */
+int sv_scramble_gather(const float* x, const int32_t* perm, float* images6,
+                       int32_t B, int32_t H, int32_t W, int32_t patch, void* stream);
+/* tf.random.shuffle (augmentation.py:49) stand-in: one uniform permutation per image from a
+ * counter-based Philox stream keyed by (seed, step, global sample index = sample_offset + b),
+ * so 1-GPU and N-GPU runs draw identical permutations.  n_patch <= 4096. */
+int sv_random_perm(int32_t* perm, int32_t B, int32_t n_patch, uint64_t seed, uint64_t step,
+                   int64_t sample_offset, void* stream);
+
+/* ---------------------------------------------------------------- A6: discretised logistic NLL
+ * Replaces discretised_logistic_loss (vae/trainer.py:21-38) + reduce_sum[1,2,3] (:127-128) and,
+ * when grad != NULL, its adjoint under tape.gradient (:137).
+ * images6[B,H,W,6] fp32; channels [ch_off, ch_off+3) are the targets (0: x, 3: x_hat).
+ * out6[B,H,W,6] fp32 decoder head: ch 0-2 mean, 3-5 log_scale (vae/model.py:169).
+ * nll[B] fp32 per-image sums.  grad[B,H,W,8] (dtype) = d(mean_b nll)/d(out6) * grad_scale in
+ * ch 0-5, zeros in ch 6-7 (the padded layout the conv dgrad/wgrad kernels consume). */
+int sv_dlogistic_nll(const float* images6, int32_t ch_off, const float* out6, float* nll,
+                     void* grad, int32_t grad_dtype, float grad_scale,
+                     int32_t B, int32_t H, int32_t W, float* partial_ws, void* stream);
+int64_t sv_dlogistic_nll_workspace_bytes(int32_t B, int32_t H, int32_t W);
+
+/* ---------------------------------------------------------------- A4+A7: reparameterise + KL
+ * Replaces Sampling.call (vae/model.py:9-13), the Dense bias/softplus epilogues of e4_mean/e4_sd
+ * (:41-42,:111-112) and kl_divergence (vae/trainer.py:11-15).
+ * pre[B,2L] fp32 = [f@W_mean | f@W_sd] WITHOUT bias; bias[2L]; eps[B,L] (NULL: drawn from Philox
+ * keyed by (seed, step, stream_id, sample_offset+b, j) and written to eps_out).
+ * Outputs: z_mean,z_sig,z [B,L] fp32; z_lp (dtype) [B, ldz] at column z_col (decoder input,
+ * the tf.concat of vae/model.py:197 is this write); kl[B] = -1/2 sum_j(1+log sig^2-mu^2-sig^2). */
+int sv_reparam_kl_fwd(const float* pre, const float* bias, const float* eps, float* eps_out,
+                      float* z_mean, float* z_sig, float* z, void* z_lp, int32_t z_dtype,
+                      int32_t ldz, int32_t z_col, float* kl, int32_t B, int32_t L,
+                      uint64_t seed, uint64_t step, int32_t stream_id, int64_t sample_offset,
+                      void* stream);
+/* Adjoint: dz[B,L] fp32 (ld_dz, optional second addend dz2) -> g_pre[B,2L] (dtype) =
+ * [dz + kl_scale*mu | (dz*eps + kl_scale*(sig-1/sig)) * (1-exp(-sig))]; kl_scale = beta/B. */
+int sv_reparam_kl_bwd(const float* dz, int32_t ld_dz, const float* dz2, int32_t ld_dz2,
+                      const float* z_mean, const float* z_sig, const float* eps, float kl_scale,
+                      void* g_pre, int32_t g_dtype, int32_t B, int32_t L, void* stream);
+
+/* ---------------------------------------------------------------- K14: Keras Adam
+ * Replaces tf.keras.optimizers.Adam(lr).apply_gradients (vae/main.py:65, vae/trainer.py:138):
+ * alpha=lr*sqrt(1-b2^t)/(1-b1^t); m+=(g-m)(1-b1); v+=(g*g-v)(1-b2); p-=alpha*m/(sqrt(v)+eps).
+ * One launch over the flat parameter buffer; g is multiplied by grad_scale first (1/world). */
+int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int64_t t, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------- K10a: bilinear 2x
+ * Replaces tf.image.resize(x,[2H,2W]) (vae/model.py:163,:165,:167; bilinear, half-pixel centres,
+ * edge clamp) and its adjoint (ResizeBilinearGrad) fused with the ReLU mask of the producer. */
+int sv_upsample2x_fwd(const void* in, void* out, int32_t dtype, int32_t B, int32_t H, int32_t W,
+                      int32_t C, void* stream);
+int sv_upsample2x_bwd(const void* g_hi, const void* y_lo_mask, void* g_lo, int32_t dtype,
+                      int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
+ * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the
+ * Conv2DBackpropInput / Conv2DBackpropFilter / BiasAddGrad / ReluGrad nodes of tape.gradient
+ * (vae/trainer.py:137).  Dense layers (vae/model.py:41-42,:152) are the H=W=KH=KW=1 case.
+ * Channel counts are padded to a multiple of 8 in the low-precision activation tensors. */
+typedef struct {
+  int32_t B, H, W;          /* input spatial size (power-of-two H, W) */
+  int32_t Cin, Cout;        /* real channel counts (HWIO weight shape = [KH,KW,Cin,Cout]) */
+  int32_t KH, KW, stride;   /* TF 'SAME' padding is implied: out=ceil(in/stride) */
+  int32_t act;              /* sv_act fused into the forward epilogue */
+  int32_t dtype;            /* sv_dtype of activations / prepared weights */
+  int32_t ldx;              /* channels per input pixel in memory  (>= Cin, multiple of 8) */
+  int32_t ldy;              /* channels per output pixel in memory (>= Cout; multiple of 8 unless y_f32) */
+  int32_t y_f32;            /* forward output written as fp32 (decoder head) */
+} sv_conv_desc;
+
+/* element counts (of `dtype`) of the prepared forward / dgrad weight images */
+int64_t sv_conv2d_wprep_elems(const sv_conv_desc* d, int32_t for_dgrad);
+/* fp32 HWIO master -> MFMA-ready [Cout_pad][taps][Cin_pad] (fwd) and per-parity-class
+ * [Cin_pad][taps'][Cout_pad] (dgrad) images in `dtype`. */
+int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio, void* w_fwd, void* w_dgrad,
+                           void* stream);
+int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                       void* y, void* stream);
+/* dx = conv-transpose(dy, w) * (mask>0 if mask!=NULL); dy[B,OH,OW,ldy], dx[B,H,W,ldx] (dtype).
+ * dx_f32_atomic!=0: K is split over workgroups and dx (fp32, pre-zeroed) is accumulated atomically. */
+int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
+                         const void* relu_mask, void* dx, int32_t dx_f32_atomic, void* stream);
+/* dw[KH,KW,Cin,Cout] += x^T*dy, dbias[Cout] += colsum(dy) (fp32 HWIO, atomically accumulated:
+ * zero them first). */
+int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
+                         float* dbias, void* stream);
+
+/* ---------------------------------------------------------------- A2/A3/A5/A8: the whole LGVae step
+ * Replaces LGVae.call (vae/model.py:189-200) and train_step_lg_vae (vae/trainer.py:120-144)
+ * with one native launch sequence on `stream` (captured into a hipGraph by the caller if wanted). */
+typedef struct {
+  int32_t B, H, W;                       /* per-device batch; H==W power of two, multiple of 8 */
+  int32_t global_latent, local_latent;   /* vae/main.py:16-17 (multiples of 8) */
+  int32_t dtype;                         /* sv_dtype of the contractions */
+  float beta;                            /* vae/main.py:19 */
+} sv_lgvae_desc;
+
+typedef struct sv_lgvae_plan sv_lgvae_plan;
+
+/* the 40 trainable variables, Keras creation order, flat fp32 buffer */
+int64_t sv_lgvae_param_count(const sv_lgvae_desc* d);
+int sv_lgvae_param_info(const sv_lgvae_desc* d, int32_t index, int64_t* offset, int32_t* ndim,
+                        int64_t shape[4], char name[96]);
+
+int sv_lgvae_plan_create(const sv_lgvae_desc* d, sv_lgvae_plan** plan);
+void sv_lgvae_plan_destroy(sv_lgvae_plan* plan);
+int64_t sv_lgvae_workspace_bytes(const sv_lgvae_plan* plan);
+/* carve the caller-owned workspace; uploads the (tiny) weight-prep job table on `stream`. */
+int sv_lgvae_plan_bind(sv_lgvae_plan* plan, void* workspace, int64_t bytes, void* stream);
+/* byte offset/size of a named workspace buffer (for zero-copy views of outputs); <0 if unknown */
+int sv_lgvae_buffer(const sv_lgvae_plan* plan, const char* name, int64_t* offset, int64_t* bytes);
+
+enum { SV_PHASE_PREP = 1, SV_PHASE_FORWARD = 2, SV_PHASE_LOSS = 4, SV_PHASE_BWD_DECODERS = 8,
+       SV_PHASE_BWD_ENCODERS = 16, SV_PHASE_ADAM = 32, SV_PHASE_ALL = 63 };
+
+typedef struct {
+  float* params;            /* flat fp32 [param_count] */
+  float* grads;             /* flat fp32 [param_count] (zeroed by PHASE_LOSS) */
+  float* adam_m;            /* flat fp32 */
+  float* adam_v;            /* flat fp32 */
+  const float* images6;     /* [B,H,W,6] fp32, output of sv_scramble_gather */
+  const float* eps_x;       /* [B,global_latent] or NULL -> Philox */
+  const float* eps_x_hat;   /* [B,local_latent]  or NULL -> Philox */
+  uint64_t seed, step;
+  int64_t sample_offset;    /* global index of this rank's first sample */
+  float lr, beta1, beta2, adam_eps;
+  int64_t t;                /* Adam iteration (iterations+1) */
+  float grad_scale;         /* applied in Adam (1/world_size for DP) */
+  int32_t phases;           /* SV_PHASE_* mask */
+  int32_t accumulate_metrics; /* add the 5 scalars into the running-mean accumulators (K15) */
+} sv_lgvae_step_args;
+
+int sv_lgvae_step(sv_lgvae_plan* plan, const sv_lgvae_step_args* a, void* stream);
+
+/* per-kernel hipEvent timing (bench roofline): enable, run steps, read average ms per launch */
+int sv_lgvae_profile_enable(sv_lgvae_plan* plan, int32_t enable);
+int sv_lgvae_profile_read(sv_lgvae_plan* plan, int32_t max_entries, char names[][64],
+                          double* total_ms, int32_t* launches, double* flops_per_launch,
+                          double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

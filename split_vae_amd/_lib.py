@@ -1,0 +1,106 @@
+"""ctypes binding of libsplitvae_hip.so (include/splitvae.h).
+
+The HIP library IS the product path: if it is missing or fails to load, importing this module
+raises -- there is no CPU/PyTorch fallback anywhere in split_vae_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplitvae_hip.so")
+
+SV_F32, SV_BF16 = 0, 1
+SV_ACT_NONE, SV_ACT_RELU = 0, 1
+PHASE_PREP, PHASE_FORWARD, PHASE_LOSS, PHASE_BWD_DECODERS, PHASE_BWD_ENCODERS, PHASE_ADAM = 1, 2, 4, 8, 16, 32
+PHASE_ALL = 63
+PHASE_INFER = PHASE_PREP | PHASE_FORWARD
+
+STATUS = {0: "SV_OK", -1: "SV_E_BADARG", -2: "SV_E_UNSUPPORTED", -3: "SV_E_WORKSPACE", -4: "SV_E_STATE"}
+
+
+class SplitVaeError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "act", "dtype", "ldx", "ldy", "y_f32")]
+
+
+class LGVaeDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("global_latent", C.c_int32),
+                ("local_latent", C.c_int32), ("dtype", C.c_int32), ("beta", C.c_float)]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("images6", C.c_void_p), ("eps_x", C.c_void_p), ("eps_x_hat", C.c_void_p),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("sample_offset", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("t", C.c_int64), ("grad_scale", C.c_float), ("phases", C.c_int32),
+                ("accumulate_metrics", C.c_int32)]
+
+
+# every symbol include/splitvae.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+SYMBOLS = {
+    "sv_version": (C.c_char_p, []),
+    "sv_scramble_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sv_random_perm": (C.c_int, [_vp, _i32, _i32, _u64, _u64, _i64, _vp]),
+    "sv_dlogistic_nll": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f, _i32, _i32, _i32, _vp, _vp]),
+    "sv_dlogistic_nll_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "sv_reparam_kl_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32,
+                                    _u64, _u64, _i32, _i64, _vp]),
+    "sv_reparam_kl_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f, _vp, _i32, _i32, _i32, _vp]),
+    "sv_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _vp]),
+    "sv_upsample2x_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_upsample2x_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_conv2d_wprep_elems": (_i64, [C.POINTER(ConvDesc), _i32]),
+    "sv_conv2d_prep_weights": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "sv_conv2d_nhwc_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "sv_conv2d_nhwc_dgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp]),
+    "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "sv_lgvae_param_count": (_i64, [C.POINTER(LGVaeDesc)]),
+    "sv_lgvae_param_info": (C.c_int, [C.POINTER(LGVaeDesc), _i32, C.POINTER(_i64), C.POINTER(_i32),
+                                      C.POINTER(_i64 * 4), C.c_char_p]),
+    "sv_lgvae_plan_create": (C.c_int, [C.POINTER(LGVaeDesc), C.POINTER(_vp)]),
+    "sv_lgvae_plan_destroy": (None, [_vp]),
+    "sv_lgvae_workspace_bytes": (_i64, [_vp]),
+    "sv_lgvae_plan_bind": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sv_lgvae_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sv_lgvae_step": (C.c_int, [_vp, C.POINTER(StepArgs), _vp]),
+    "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
+    "sv_lgvae_profile_read": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises SplitVaeError when it is absent: build it with
+    `python -m split_vae_amd.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SplitVaeError(
+            "libsplitvae_hip.so not found at %s -- the HIP extension is required (no CPU fallback). "
+            "Build it: python split_vae_amd/build.py" % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SplitVaeError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI drifted from the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise SplitVaeError("%s failed: %s" % (what, STATUS.get(rc, str(rc))))
+    raise SplitVaeError("%s failed: hipError_t %d" % (what, rc))

@@ -1,0 +1,303 @@
+// Geometry + weight preparation + the public sv_conv2d_* entry points.
+// TF 'SAME' padding [TF-2.0 semantics]: out = ceil(in/s), pad = max((out-1)s + k - in, 0),
+// before = pad/2 (the extra row/column goes to the bottom/right: k4s1 -> 1/2, k6s1 -> 2/3).
+#include "common.hip.h"
+#include "kernels.h"
+#include "conv_geom.h"
+
+// ============================================================================ weight preparation
+// dst[(row*ntaps + t)*inner_ld + inner_off + c]:
+//   forward  (transpose=0): row = co, c = ci : src[(srctap[t]*Cin + c)*Cout + row]
+//   dgrad    (transpose=1): row = ci, c = co : src[(srctap[t]*Cin + row)*Cout + c]
+// zero where row/c exceed the real channel counts (padding rows/channels of the MFMA tiles).
+template <typename T>
+__device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
+                                           T* __restrict__ arena, int block_in_job) {
+  const int64_t total = (int64_t)j.rows * j.ntaps * j.inner;
+  const int64_t idx = (int64_t)block_in_job * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % j.inner);
+  const int64_t t2 = idx / j.inner;
+  const int t = (int)(t2 % j.ntaps);
+  const int row = (int)(t2 / j.ntaps);
+  float v = 0.f;
+  const int st = j.srctap[t];
+  if (!j.transpose) {
+    if (row < j.Cout && c < j.Cin) v = params[j.src_off + ((int64_t)st * j.Cin + c) * j.Cout + row];
+  } else {
+    if (row < j.Cin && c < j.Cout) v = params[j.src_off + ((int64_t)st * j.Cin + row) * j.Cout + c];
+  }
+  arena[j.dst_off + ((int64_t)row * j.ntaps + t) * j.inner_ld + j.inner_off + c] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_table_kernel(const float* __restrict__ params, T* __restrict__ arena,
+                                                         const PrepJob* __restrict__ jobs, int njobs) {
+  // binary search the job owning this block (first_block is ascending)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PrepJob j = jobs[lo];
+  prep_block<T>(j, params, arena, (int)blockIdx.x - j.first_block);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_single_kernel(const float* __restrict__ params, T* __restrict__ arena,
+                                                          const PrepJob j) {
+  prep_block<T>(j, params, arena, (int)blockIdx.x);
+}
+
+int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
+                     int total_blocks, hipStream_t st) {
+  if (dtype == SV_BF16)
+    hipLaunchKernelGGL((prep_table_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, st, params,
+                       (bf16_t*)arena, jobs_dev, njobs);
+  else
+    hipLaunchKernelGGL((prep_table_kernel<float>), dim3(total_blocks), dim3(256), 0, st, params,
+                       (float*)arena, jobs_dev, njobs);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+static int prep_single(const float* params, void* arena, int dtype, const PrepJob& j, hipStream_t st) {
+  if (dtype == SV_BF16)
+    hipLaunchKernelGGL((prep_single_kernel<bf16_t>), dim3(j.nblocks), dim3(256), 0, st, params, (bf16_t*)arena, j);
+  else
+    hipLaunchKernelGGL((prep_single_kernel<float>), dim3(j.nblocks), dim3(256), 0, st, params, (float*)arena, j);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ geometry
+int svg_check(const sv_conv_desc* d) {
+  if (!d) return SV_E_BADARG;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SV_E_BADARG;
+  if (d->dtype != SV_BF16 && d->dtype != SV_F32) return SV_E_BADARG;
+  if (d->stride != 1 && d->stride != 2) return SV_E_UNSUPPORTED;
+  if (d->KH * d->KW > SV_MAX_TAPS) return SV_E_UNSUPPORTED;
+  if (ilog2_exact(d->H) < 0 || ilog2_exact(d->W) < 0) return SV_E_UNSUPPORTED;
+  if (d->stride == 2 && ((d->H & 1) || (d->W & 1) || (d->KH & 1) || (d->KW & 1))) return SV_E_UNSUPPORTED;
+  if (d->ldx < d->Cin || d->ldx % 8) return SV_E_BADARG;
+  if (ilog2_exact(svg_cin_pad(d)) < 0 || ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
+  if (d->ldy < d->Cout) return SV_E_BADARG;
+  if (!d->y_f32 && d->ldy % 8) return SV_E_BADARG;
+  if ((int64_t)d->B * d->H * d->W * d->ldx >= (1LL << 31)) return SV_E_UNSUPPORTED;
+  if ((int64_t)d->B * svg_oh(d) * svg_ow(d) * svg_gdy(d) >= (1LL << 31)) return SV_E_UNSUPPORTED;
+  return SV_OK;
+}
+
+void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int epp = svg_epp(d), cpad = svg_cin_pad(d);
+  const int OH = svg_oh(d), OW = svg_ow(d);
+  int pt, pl;
+  svg_pads(d, &pt, &pl);
+  a->M = d->B * OH * OW;
+  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW);
+  a->IH = d->H; a->IW = d->W; a->lda = d->ldx;
+  a->cl2 = ilog2_exact(cpad / epp);
+  a->ntaps = d->KH * d->KW;
+  a->Ktot = a->ntaps * cpad;
+  a->P = a->Ktot / epp;
+  a->S = d->stride;
+  a->N = d->Cout;
+  a->OHF = OH; a->OWF = OW; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldy;
+  a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1;
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) {
+      a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
+      a->dx[kh * d->KW + kw] = (int8_t)(kw - pl);
+    }
+}
+
+int svg_dgrad_classes(const sv_conv_desc* d) { return d->stride * d->stride; }
+
+// class cls = ph*stride + pw handles input pixels (ih, iw) = (stride*i2 + ph, stride*j2 + pw)
+void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srctap[SV_MAX_TAPS]) {
+  memset(a, 0, sizeof(*a));
+  const int epp = svg_epp(d), gdy = svg_gdy(d);
+  const int OH = svg_oh(d), OW = svg_ow(d), s = d->stride;
+  int pt, pl;
+  svg_pads(d, &pt, &pl);
+  const int ph = cls / s, pw = cls % s;
+  const int gy = d->H / s, gx = d->W / s;     // iteration grid of this class
+  a->M = d->B * gy * gx;
+  a->lOY = ilog2_exact(gy); a->lOX = ilog2_exact(gx);
+  a->IH = OH; a->IW = OW; a->lda = gdy;
+  a->cl2 = ilog2_exact(gdy / epp);
+  a->S = 1;
+  a->N = d->Cin;
+  a->OHF = d->H; a->OWF = d->W; a->OS = s; a->ooy = ph; a->oox = pw; a->ldo = d->ldx;
+  a->act = SV_ACT_NONE; a->out_f32 = 0; a->splitk = 1;
+  int nt = 0;
+  if (s == 1) {
+    // dx[ih] = sum_kh dy[ih - kh + pt] w[kh]; kh = KH-1-kh' -> offset kh' - (KH-1-pt)
+    for (int khp = 0; khp < d->KH; ++khp)
+      for (int kwp = 0; kwp < d->KW; ++kwp) {
+        a->dy[nt] = (int8_t)(khp - (d->KH - 1 - pt));
+        a->dx[nt] = (int8_t)(kwp - (d->KW - 1 - pl));
+        srctap[nt] = (uint8_t)((d->KH - 1 - khp) * d->KW + (d->KW - 1 - kwp));
+        ++nt;
+      }
+  } else {
+    // kh = kh0 + 2a with kh0 = (ph+pt)&1 ; oh = i2 + (ph+pt-kh0)/2 - a
+    const int kh0 = (ph + pt) & 1, kw0 = (pw + pl) & 1;
+    for (int ay = 0; ay < d->KH / 2; ++ay)
+      for (int ax = 0; ax < d->KW / 2; ++ax) {
+        a->dy[nt] = (int8_t)((ph + pt - kh0) / 2 - ay);
+        a->dx[nt] = (int8_t)((pw + pl - kw0) / 2 - ax);
+        srctap[nt] = (uint8_t)((kh0 + 2 * ay) * d->KW + (kw0 + 2 * ax));
+        ++nt;
+      }
+  }
+  a->ntaps = nt;
+  a->Ktot = nt * gdy;
+  a->P = a->Ktot / epp;
+}
+
+void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int epp = svg_epp(d), cpad = svg_cin_pad(d);
+  const int OH = svg_oh(d), OW = svg_ow(d);
+  int pt, pl;
+  svg_pads(d, &pt, &pl);
+  a->M = d->B * OH * OW;
+  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW);
+  a->IH = d->H; a->IW = d->W; a->lda = d->ldx; a->S = d->stride;
+  a->ldy = svg_gdy(d);
+  a->ycols = svg_gdy(d);
+  a->cl2 = ilog2_exact(cpad / epp);
+  a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout;
+  a->ntaps = d->KH * d->KW;
+  a->Nrows = a->ntaps * cpad;
+  for (int kh = 0; kh < d->KH; ++kh)
+    for (int kw = 0; kw < d->KW; ++kw) {
+      a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
+      a->dx[kh * d->KW + kw] = (int8_t)(kw - pl);
+    }
+  const int cfg = svg_pick_cfg(d->Cout);
+  static const int BRt[4] = {64, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
+  const int ms = d->dtype == SV_BF16 ? 64 : 32;
+  const int tiles = ((a->Nrows + BRt[cfg] - 1) / BRt[cfg]) * ((a->N + BNt[cfg] - 1) / BNt[cfg]);
+  int z = 1024 / (tiles > 0 ? tiles : 1);
+  const int maxz = (a->M + ms - 1) / ms;
+  if (z < 1) z = 1;
+  if (z > maxz) z = maxz;
+  a->msplit = round_up((a->M + z - 1) / z, ms);
+}
+
+void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  static const int BNt[4] = {128, 64, 32, 16};
+  j->ntaps = d->KH * d->KW;
+  j->Cin = d->Cin; j->Cout = d->Cout;
+  j->rows = round_up(d->Cout, BNt[svg_pick_cfg(d->Cout)]);
+  j->inner = svg_cin_pad(d);
+  j->inner_ld = j->inner; j->inner_off = 0;
+  j->transpose = 0;
+  for (int t = 0; t < j->ntaps; ++t) j->srctap[t] = (uint8_t)t;
+  j->nblocks = (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+}
+
+void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  static const int BNt[4] = {128, 64, 32, 16};
+  TapGemmArgs a;
+  svg_dgrad_args(d, cls, &a, j->srctap);
+  j->ntaps = a.ntaps;
+  j->Cin = d->Cin; j->Cout = d->Cout;
+  j->rows = round_up(d->Cin, BNt[svg_pick_cfg(d->Cin)]);
+  j->inner = svg_gdy(d);
+  j->inner_ld = j->inner; j->inner_off = 0;
+  j->transpose = 1;
+  j->nblocks = (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+}
+
+int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
+  PrepJob j;
+  if (for_dgrad) svg_prep_job_dgrad(d, cls, &j); else svg_prep_job_fwd(d, &j);
+  return (int64_t)j.rows * j.ntaps * j.inner;
+}
+
+// ============================================================================ public API
+extern "C" int64_t sv_conv2d_wprep_elems(const sv_conv_desc* d, int32_t for_dgrad) {
+  if (svg_check(d) != SV_OK) return -1;
+  if (!for_dgrad) return svg_wprep_elems_class(d, 0, 0);
+  int64_t n = 0;
+  for (int c = 0; c < svg_dgrad_classes(d); ++c) n += svg_wprep_elems_class(d, 1, c);
+  return n;
+}
+
+extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio, void* w_fwd, void* w_dgrad,
+                                      void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!w_hwio) return SV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (w_fwd) {
+    PrepJob j;
+    svg_prep_job_fwd(d, &j);
+    rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
+    if (rc) return rc;
+  }
+  if (w_dgrad) {
+    int64_t off = 0;
+    for (int c = 0; c < svg_dgrad_classes(d); ++c) {
+      PrepJob j;
+      svg_prep_job_dgrad(d, c, &j);
+      j.dst_off = off;
+      rc = prep_single(w_hwio, w_dgrad, d->dtype, j, st);
+      if (rc) return rc;
+      off += (int64_t)j.rows * j.ntaps * j.inner;
+    }
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                                  void* y, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!x || !w_fwd || !y) return SV_E_BADARG;
+  TapGemmArgs a;
+  svg_fwd_args(d, &a);
+  a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
+  return svk_tap_gemm(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+}
+
+extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
+                                    const void* relu_mask, void* dx, int32_t dx_f32_atomic, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!dy || !w_dgrad || !dx) return SV_E_BADARG;
+  if (dx_f32_atomic && relu_mask) return SV_E_BADARG;
+  const size_t esz = d->dtype == SV_BF16 ? 2 : 4;
+  int64_t off = 0;
+  for (int c = 0; c < svg_dgrad_classes(d); ++c) {
+    TapGemmArgs a;
+    uint8_t srctap[SV_MAX_TAPS];
+    svg_dgrad_args(d, c, &a, srctap);
+    a.A = dy; a.Wt = (const char*)w_dgrad + off * esz; a.out = dx; a.mask = relu_mask;
+    if (dx_f32_atomic) {
+      a.out_f32 = 1;
+      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
+    }
+    rc = svk_tap_gemm(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
+    if (rc) return rc;
+    off += svg_wprep_elems_class(d, 1, c);
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
+                                    float* dbias, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!x || !dy || !dw) return SV_E_BADARG;
+  WgradArgs a;
+  svg_wgrad_args(d, &a);
+  a.A = x; a.dY = dy; a.dW = dw; a.dbias = dbias;
+  return svk_wgrad(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+}

@@ -1,0 +1,47 @@
+// Host-side geometry helpers shared by conv_api.hip and lgvae_plan.hip.
+#pragma once
+#include <string.h>
+#include "../../include/splitvae.h"
+#include "kernels.h"
+
+static inline int svg_epp(const sv_conv_desc* d) { return d->dtype == SV_BF16 ? 8 : 4; }
+static inline int svg_r8(int v) { return (v + 7) / 8 * 8; }
+static inline int svg_cin_pad(const sv_conv_desc* d) { return svg_r8(d->Cin); }
+// channels per pixel of the GRADIENT tensor dY (the forward y may be an unpadded fp32 head)
+static inline int svg_gdy(const sv_conv_desc* d) { return svg_r8(d->Cout); }
+static inline int svg_oh(const sv_conv_desc* d) { return (d->H + d->stride - 1) / d->stride; }
+static inline int svg_ow(const sv_conv_desc* d) { return (d->W + d->stride - 1) / d->stride; }
+static inline void svg_pads(const sv_conv_desc* d, int* pt, int* pl) {
+  int ph = (svg_oh(d) - 1) * d->stride + d->KH - d->H;
+  int pw = (svg_ow(d) - 1) * d->stride + d->KW - d->W;
+  if (ph < 0) ph = 0;
+  if (pw < 0) pw = 0;
+  *pt = ph / 2;
+  *pl = pw / 2;
+}
+// N tile selection of the tap GEMM: 0: 128, 1: 64, 2: 32, 3: 16 columns
+static inline int svg_pick_cfg(int N) {
+  if (N % 128 == 0) return 0;
+  if (N % 64 == 0) return 1;
+  if (N % 32 == 0) return 2;
+  return 3;
+}
+// split K across workgroups when the M x N tile grid cannot fill 256 CUs
+static inline int svg_choose_splitk(int M, int N, int nk) {
+  static const int BMt[4] = {128, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
+  const int cfg = svg_pick_cfg(N);
+  const int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
+  if (tiles >= 128) return 1;
+  int s = (256 + tiles - 1) / tiles;
+  if (s > nk / 2) s = nk / 2;
+  return s < 1 ? 1 : s;
+}
+
+int svg_check(const sv_conv_desc* d);
+void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a);
+int svg_dgrad_classes(const sv_conv_desc* d);
+void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srctap[SV_MAX_TAPS]);
+void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a);
+void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);
+void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j);
+int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls);

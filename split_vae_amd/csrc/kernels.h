@@ -1,0 +1,73 @@
+// Internal (non-ABI) launch helpers shared by the translation units of libsplitvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SV_MAX_TAPS 36
+
+// ---- generic "tap GEMM": out[m, n] = sum_{t, c} A[pix(m) + tap t, c] * Wt[n][t][c]
+// rows m enumerate (b, oy, ox) over a power-of-two OY x OX grid; taps are (dy, dx) offsets on an
+// input grid sampled at stride S.  Forward convs, every dgrad (per parity class for stride 2)
+// and the dense layers are all instances.
+struct TapGemmArgs {
+  const void* A;        // [B, IH, IW, lda] activations (dtype T)
+  const void* Wt;       // [Npad][ntaps*Cin] prepared weights (dtype T), Npad multiple of the N tile
+  const float* bias;    // [N] or null
+  void* out;            // T, or float when out_f32
+  const void* mask;     // optional ReLU mask (T), indexed like out
+  int M;                // B*OY*OX
+  int lOY, lOX;         // log2 of the per-image iteration grid
+  int IH, IW, lda;
+  int cl2;              // log2(16-byte pieces per tap) ; Cin = (1<<cl2)*EPP
+  int P;                // total 16-byte pieces along K
+  int Ktot;             // ntaps*Cin  (row length of Wt in elements)
+  int S;                // input coordinate = o*S + d
+  int N;                // real output channels
+  int OHF, OWF, OS, ooy, oox, ldo;   // out pixel = ((b*OHF + oy*OS+ooy)*OWF + ox*OS+oox), ldo channels
+  int act, out_f32, splitk, ntaps;
+  int8_t dy[SV_MAX_TAPS];
+  int8_t dx[SV_MAX_TAPS];
+};
+// cfg: 0 = 128x128 tile, 1 = 128x64, 2 = 256x32, 3 = 256x16
+int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st);
+
+// ---- weight gradient: dW[(t,ci)][co] += sum_m A[pix(m)+tap t, ci] * dY[m, co]; dbias += colsum(dY)
+struct WgradArgs {
+  const void* A;      // [B, IH, IW, lda]
+  const void* dY;     // [M, ldy]
+  float* dW;          // [ntaps*Cin_real][N] fp32, atomically accumulated
+  float* dbias;       // [N] or null
+  int M, lOY, lOX, IH, IW, lda, S;
+  int ldy, ycols;     // dY row stride and number of valid columns from the dY pointer (multiple of 8)
+  int cl2;            // log2(pieces per tap)
+  int Cin_pad, Cin_real, N, Nrows;   // Nrows = ntaps*Cin_pad (padded wrow count)
+  int ntaps, msplit;  // msplit = rows of m per blockIdx.z slice (multiple of the m-step)
+  int8_t dy[SV_MAX_TAPS];
+  int8_t dx[SV_MAX_TAPS];
+};
+// cfg: 0 = 64 wrows x 128 cols, 1 = 128 x 64, 2 = 256 x 32, 3 = 256 x 16
+int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st);
+
+// ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
+struct PrepJob {
+  int64_t src_off;     // element offset into the flat fp32 parameter buffer
+  int64_t dst_off;     // element offset (of dtype) into the prepared-weight arena
+  int32_t ntaps;       // taps in the destination image
+  int32_t Cin, Cout;   // real channel counts of the HWIO master
+  int32_t rows, inner; // destination [rows][ntaps][inner] ...
+  int32_t inner_ld, inner_off; // ... stored with row pitch inner_ld at column offset inner_off
+  int32_t transpose;   // 0: rows=co, inner=ci (forward); 1: rows=ci, inner=co (dgrad)
+  int32_t first_block; // first block of this job in the launch
+  int32_t nblocks;
+  uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap
+};
+int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
+                     int total_blocks, hipStream_t st);
+
+int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st);
+int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,
+                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st);
+int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* bias_sd, const float* eps,
+                        float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
+                        int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
+                        int64_t sample_offset, hipStream_t st);

@@ -1,0 +1,670 @@
+// The SPLIT-VAE (LGVae) training step as one native launch sequence.
+//
+// Replaces LGVae.call (vae/model.py:189-200) + train_step_lg_vae (vae/trainer.py:120-144) +
+// Adam.apply_gradients (vae/main.py:65): weight preparation, both encoders, reparameterisation/KL,
+// both decoders, discretised-logistic ELBO, the full backward pass and the Keras-Adam update are
+// enqueued on one HIP stream from C++ (no Python per kernel), over a caller-owned workspace.
+// The phase mask lets the data-parallel driver slip its RCCL all-reduce between the decoder
+// backward, the encoder backward and Adam.
+#include <string>
+#include <vector>
+#include <map>
+#include <stdio.h>
+#include "common.hip.h"
+#include "kernels.h"
+#include "conv_geom.h"
+
+namespace {
+
+struct Buf { std::string name; int64_t off, bytes; };
+
+struct ParamInfo { std::string name; int64_t off; int ndim; int64_t shape[4]; int64_t count; };
+
+static std::vector<ParamInfo> build_params(const sv_lgvae_desc* d) {
+  std::vector<ParamInfo> v;
+  int64_t off = 0;
+  auto add = [&](const std::string& n, std::initializer_list<int64_t> shp) {
+    ParamInfo p;
+    p.name = n; p.off = off; p.ndim = (int)shp.size(); p.count = 1;
+    int i = 0;
+    for (auto s : shp) { p.shape[i++] = s; p.count *= s; }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    off += (p.count + 3) / 4 * 4;   // keep every tensor 16-B aligned in the flat buffer
+    v.push_back(p);
+  };
+  const int64_t F = (int64_t)(d->H / 8) * (d->W / 8) * 128;
+  // vae/model.py:152 writes image_shape[1]//8*image_shape[2]//8*128 = ((H//8)*W)//8*128
+  const int64_t D1 = ((int64_t)(d->H / 8) * d->W) / 8 * 128;
+  auto enc = [&](const std::string& pre, int64_t L) {
+    add(pre + "/e1/kernel", {6, 6, 3, 32}); add(pre + "/e1/bias", {32});
+    add(pre + "/e2/kernel", {6, 6, 32, 64}); add(pre + "/e2/bias", {64});
+    add(pre + "/e3/kernel", {4, 4, 64, 128}); add(pre + "/e3/bias", {128});
+    add(pre + "/e4_mean/kernel", {F, L}); add(pre + "/e4_mean/bias", {L});
+    add(pre + "/e4_sd/kernel", {F, L}); add(pre + "/e4_sd/bias", {L});
+  };
+  auto dec = [&](const std::string& pre, int64_t L) {
+    add(pre + "/d1/kernel", {L, D1}); add(pre + "/d1/bias", {D1});
+    add(pre + "/d2/kernel", {4, 4, 128, 128}); add(pre + "/d2/bias", {128});
+    add(pre + "/d3/kernel", {4, 4, 128, 64}); add(pre + "/d3/bias", {64});
+    add(pre + "/d4/kernel", {6, 6, 64, 32}); add(pre + "/d4/bias", {32});
+    add(pre + "/d5/kernel", {6, 6, 32, 6}); add(pre + "/d5/bias", {6});
+  };
+  enc("encoder_x", d->global_latent);
+  enc("encoder_x_hat", d->local_latent);
+  dec("decoder_x", d->global_latent + d->local_latent);
+  dec("decoder_x_hat", d->local_latent);
+  return v;
+}
+
+static int check_desc(const sv_lgvae_desc* d) {
+  if (!d) return SV_E_BADARG;
+  if (d->B <= 0 || d->H < 8 || d->W < 8) return SV_E_BADARG;
+  if (d->H != d->W || ilog2_exact(d->H) < 0) return SV_E_UNSUPPORTED;
+  if (d->global_latent <= 0 || d->local_latent <= 0) return SV_E_BADARG;
+  if (ilog2_exact(d->global_latent) < 0 || ilog2_exact(d->local_latent) < 0 || d->global_latent < 8 ||
+      d->local_latent < 8 || d->global_latent != d->local_latent)
+    return SV_E_UNSUPPORTED;   // MFMA K-pieces want power-of-two channel counts (reference default 128/128)
+  if (d->dtype != SV_BF16 && d->dtype != SV_F32) return SV_E_BADARG;
+  return SV_OK;
+}
+
+struct ProfEntry { std::string name; double flops, bytes, total_ms; int launches; };
+struct ProfPending { int entry; hipEvent_t a, b; };
+
+// one conv-like layer instance with everything needed for fwd / dgrad / wgrad
+struct Layer {
+  std::string name;
+  sv_conv_desc d;
+  int kparam, bparam;           // indices into the param table (kernel, bias); head uses two kernels
+  int64_t wf_off;               // prepared forward weights (element offset in arena)
+  int64_t wd_off[4];            // prepared dgrad weights per parity class
+  bool need_dgrad;
+};
+
+}  // namespace
+
+struct sv_lgvae_plan {
+  sv_lgvae_desc d;
+  std::vector<ParamInfo> params;
+  int64_t nparams;
+  std::vector<Buf> bufs;
+  std::map<std::string, int> bufidx;
+  int64_t ws_bytes;
+  char* ws;
+  bool bound;
+  // layers: [enc_x e1,e2,e3,head][enc_xh ...][dec_x d1..d5][dec_xh ...]
+  Layer enc[2][4];
+  Layer dec[2][5];
+  std::vector<PrepJob> jobs;
+  int prep_blocks;
+  int64_t arena_elems;
+  // profiling
+  bool prof_on;
+  std::vector<ProfEntry> prof;
+  std::map<std::string, int> profidx;
+  std::vector<ProfPending> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  size_t esz() const { return d.dtype == SV_BF16 ? 2 : 4; }
+  int64_t add_buf(const std::string& n, int64_t bytes) {
+    Buf b;
+    b.name = n; b.off = ws_bytes; b.bytes = bytes;
+    ws_bytes += (bytes + 255) / 256 * 256;
+    bufidx[n] = (int)bufs.size();
+    bufs.push_back(b);
+    return b.off;
+  }
+  void* bp(const std::string& n) const {
+    auto it = bufidx.find(n);
+    return it == bufidx.end() ? nullptr : (void*)(ws + bufs[it->second].off);
+  }
+  int64_t bbytes(const std::string& n) const { return bufs[bufidx.at(n)].bytes; }
+};
+
+namespace {
+
+struct Scope {   // hipEvent bracket around one launch when profiling is on
+  sv_lgvae_plan* p; hipStream_t st; int entry; hipEvent_t a, b; bool on;
+  Scope(sv_lgvae_plan* p_, hipStream_t st_, const std::string& name, double flops, double bytes) : p(p_), st(st_), on(p_->prof_on) {
+    if (!on) return;
+    auto it = p->profidx.find(name);
+    if (it == p->profidx.end()) {
+      entry = (int)p->prof.size();
+      p->profidx[name] = entry;
+      p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0});
+    } else entry = it->second;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!p->event_pool.empty()) { e = p->event_pool.back(); p->event_pool.pop_back(); }
+      else hipEventCreate(&e);
+      return e;
+    };
+    a = get(); b = get();
+    hipEventRecord(a, st);
+  }
+  ~Scope() {
+    if (!on) return;
+    hipEventRecord(b, st);
+    p->pending.push_back(ProfPending{entry, a, b});
+  }
+};
+
+static void build_layers(sv_lgvae_plan* p) {
+  const sv_lgvae_desc& d = p->d;
+  const int H = d.H, W = d.W, B = d.B;
+  const int F = (H / 8) * (W / 8) * 128;
+  const int Lg = d.global_latent, Ll = d.local_latent;
+  auto mk = [&](const std::string& name, int h, int w, int cin, int cout, int k, int s, int act, int ldx,
+                int ldy, int yf32, int kparam, bool need_dgrad) {
+    Layer L;
+    L.name = name;
+    L.d = sv_conv_desc{B, h, w, cin, cout, k, k, s, act, d.dtype, ldx, ldy, yf32};
+    L.kparam = kparam; L.bparam = kparam + 1; L.need_dgrad = need_dgrad;
+    L.wf_off = 0;
+    for (int i = 0; i < 4; ++i) L.wd_off[i] = 0;
+    return L;
+  };
+  for (int e = 0; e < 2; ++e) {
+    const int pb = e * 10;
+    const int L = e == 0 ? Lg : Ll;
+    const std::string pre = e == 0 ? "enc_x." : "enc_xh.";
+    p->enc[e][0] = mk(pre + "e1", H, W, 3, 32, 6, 2, SV_ACT_RELU, 8, 32, 0, pb + 0, false);
+    p->enc[e][1] = mk(pre + "e2", H / 2, W / 2, 32, 64, 6, 2, SV_ACT_RELU, 32, 64, 0, pb + 2, true);
+    p->enc[e][2] = mk(pre + "e3", H / 4, W / 4, 64, 128, 4, 2, SV_ACT_RELU, 64, 128, 0, pb + 4, true);
+    // e4_mean | e4_sd as ONE dense GEMM with N = 2L (vae/model.py:41-42,:111-112)
+    p->enc[e][3] = mk(pre + "head", 1, 1, F, 2 * L, 1, 1, SV_ACT_NONE, F, 2 * L, 1, pb + 6, true);
+  }
+  for (int k = 0; k < 2; ++k) {
+    const int pb = 20 + k * 10;
+    const int Lz = k == 0 ? Lg + Ll : Ll;
+    const std::string pre = k == 0 ? "dec_x." : "dec_xh.";
+    p->dec[k][0] = mk(pre + "d1", 1, 1, Lz, F, 1, 1, SV_ACT_RELU, Lg + Ll, F, 0, pb + 0, true);
+    p->dec[k][1] = mk(pre + "d2", H / 8, W / 8, 128, 128, 4, 1, SV_ACT_RELU, 128, 128, 0, pb + 2, true);
+    p->dec[k][2] = mk(pre + "d3", H / 4, W / 4, 128, 64, 4, 1, SV_ACT_RELU, 128, 64, 0, pb + 4, true);
+    p->dec[k][3] = mk(pre + "d4", H / 2, W / 2, 64, 32, 6, 1, SV_ACT_RELU, 64, 32, 0, pb + 6, true);
+    p->dec[k][4] = mk(pre + "d5", H, W, 32, 6, 6, 1, SV_ACT_NONE, 32, 6, 1, pb + 8, true);
+  }
+}
+
+static void build_prep_jobs(sv_lgvae_plan* p) {
+  int64_t arena = 0;
+  int blocks = 0;
+  auto push = [&](PrepJob j) {
+    j.first_block = blocks;
+    blocks += j.nblocks;
+    p->jobs.push_back(j);
+  };
+  auto align = [&]() { arena = (arena + 127) / 128 * 128; };
+  auto do_layer = [&](Layer& L, bool is_head) {
+    if (!is_head) {
+      PrepJob j;
+      svg_prep_job_fwd(&L.d, &j);
+      j.src_off = p->params[L.kparam].off;
+      align(); L.wf_off = arena; j.dst_off = arena;
+      arena += (int64_t)j.rows * j.ntaps * j.inner;
+      push(j);
+      if (L.need_dgrad)
+        for (int c = 0; c < svg_dgrad_classes(&L.d); ++c) {
+          PrepJob jd;
+          svg_prep_job_dgrad(&L.d, c, &jd);
+          jd.src_off = p->params[L.kparam].off;
+          align(); L.wd_off[c] = arena; jd.dst_off = arena;
+          arena += (int64_t)jd.rows * jd.ntaps * jd.inner;
+          push(jd);
+        }
+    } else {
+      // two Keras tensors [F,L] (mean at kparam, sd at kparam+2) -> one [2L][F] forward image
+      // and one [F][2L] dgrad image
+      const int F = L.d.Cin, L2 = L.d.Cout, Lh = L2 / 2;
+      align(); L.wf_off = arena;
+      for (int h = 0; h < 2; ++h) {
+        PrepJob j;
+        memset(&j, 0, sizeof(j));
+        j.src_off = p->params[L.kparam + 2 * h].off;
+        j.ntaps = 1; j.Cin = F; j.Cout = Lh; j.rows = Lh; j.inner = F; j.inner_ld = F; j.inner_off = 0;
+        j.transpose = 0; j.srctap[0] = 0;
+        j.dst_off = arena + (int64_t)h * Lh * F;
+        j.nblocks = (int)(((int64_t)j.rows * j.inner + 255) / 256);
+        push(j);
+      }
+      arena += (int64_t)L2 * F;
+      align(); L.wd_off[0] = arena;
+      for (int h = 0; h < 2; ++h) {
+        PrepJob j;
+        memset(&j, 0, sizeof(j));
+        j.src_off = p->params[L.kparam + 2 * h].off;
+        j.ntaps = 1; j.Cin = F; j.Cout = Lh; j.rows = F; j.inner = Lh; j.inner_ld = L2; j.inner_off = h * Lh;
+        j.transpose = 1; j.srctap[0] = 0;
+        j.dst_off = arena;
+        j.nblocks = (int)(((int64_t)j.rows * j.inner + 255) / 256);
+        push(j);
+      }
+      arena += (int64_t)F * L2;
+    }
+  };
+  for (int e = 0; e < 2; ++e)
+    for (int l = 0; l < 4; ++l) do_layer(p->enc[e][l], l == 3);
+  for (int k = 0; k < 2; ++k)
+    for (int l = 0; l < 5; ++l) do_layer(p->dec[k][l], false);
+  p->arena_elems = arena + 128;
+  p->prep_blocks = blocks;
+}
+
+static void build_buffers(sv_lgvae_plan* p) {
+  const sv_lgvae_desc& d = p->d;
+  const int64_t B = d.B, H = d.H, W = d.W, es = (int64_t)p->esz();
+  const int64_t F = (H / 8) * (W / 8) * 128;
+  const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
+  p->ws_bytes = 0;
+  p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
+  p->add_buf("warena", p->arena_elems * es);
+  p->add_buf("losses", 8 * 4);
+  p->add_buf("metric_acc", 8 * 4);
+  p->add_buf("zcat", B * Lc * es);
+  const char* en[2] = {"x", "xh"};
+  for (int e = 0; e < 2; ++e) {
+    const std::string s = en[e];
+    const int64_t L = e == 0 ? Lg : Ll;
+    p->add_buf("in8_" + s, B * H * W * 8 * es);
+    p->add_buf("a1_" + s, B * (H / 2) * (W / 2) * 32 * es);
+    p->add_buf("a2_" + s, B * (H / 4) * (W / 4) * 64 * es);
+    p->add_buf("a3_" + s, B * F * es);
+    p->add_buf("pre_" + s, B * 2 * L * 4);
+    p->add_buf("z_mean_" + s, B * L * 4);
+    p->add_buf("z_sig_" + s, B * L * 4);
+    p->add_buf("z_" + s, B * L * 4);
+    p->add_buf("eps_" + s, B * L * 4);
+    p->add_buf("kl_" + s, B * 4);
+    p->add_buf("ghead_" + s, B * 2 * L * es);
+    p->add_buf("ga3_" + s, B * F * es);
+    p->add_buf("ga2_" + s, B * (H / 4) * (W / 4) * 64 * es);
+    p->add_buf("ga1_" + s, B * (H / 2) * (W / 2) * 32 * es);
+    // decoder k == e
+    const int64_t Lz = e == 0 ? Lc : Ll;
+    p->add_buf("h1_" + s, B * F * es);
+    p->add_buf("h2_" + s, B * F * es);
+    p->add_buf("u2_" + s, B * (H / 4) * (W / 4) * 128 * es);
+    p->add_buf("h3_" + s, B * (H / 4) * (W / 4) * 64 * es);
+    p->add_buf("u3_" + s, B * (H / 2) * (W / 2) * 64 * es);
+    p->add_buf("h4_" + s, B * (H / 2) * (W / 2) * 32 * es);
+    p->add_buf("u4_" + s, B * H * W * 32 * es);
+    p->add_buf("out6_" + s, B * H * W * 6 * 4);
+    p->add_buf("nll_" + s, B * 4);
+    p->add_buf("nllpart_" + s, sv_dlogistic_nll_workspace_bytes((int)B, (int)H, (int)W));
+    p->add_buf("g5_" + s, B * H * W * 8 * es);
+    p->add_buf("gu4_" + s, B * H * W * 32 * es);
+    p->add_buf("g4_" + s, B * (H / 2) * (W / 2) * 32 * es);
+    p->add_buf("gu3_" + s, B * (H / 2) * (W / 2) * 64 * es);
+    p->add_buf("g3_" + s, B * (H / 4) * (W / 4) * 64 * es);
+    p->add_buf("gu2_" + s, B * (H / 4) * (W / 4) * 128 * es);
+    p->add_buf("g2_" + s, B * F * es);
+    p->add_buf("g1_" + s, B * F * es);
+    p->add_buf("gz_" + s, B * Lz * 4);
+  }
+}
+
+static double conv_flops(const sv_conv_desc& d) {
+  return 2.0 * d.B * svg_oh(&d) * svg_ow(&d) * (double)d.Cout * d.KH * d.KW * d.Cin;
+}
+
+#define SV_TRY(x)            \
+  do {                       \
+    int rc__ = (x);          \
+    if (rc__) return rc__;   \
+  } while (0)
+
+static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float* params, void* y, hipStream_t st) {
+  TapGemmArgs a;
+  svg_fwd_args(&L.d, &a);
+  a.A = x;
+  a.Wt = (char*)p->bp("warena") + L.wf_off * p->esz();
+  a.bias = params + p->params[L.bparam].off;
+  a.out = y;
+  Scope sc(p, st, "fwd." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
+  return svk_tap_gemm(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+}
+
+static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const void* mask, void* dx, bool f32_atomic,
+                           hipStream_t st) {
+  Scope sc(p, st, "dgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
+  for (int c = 0; c < svg_dgrad_classes(&L.d); ++c) {
+    TapGemmArgs a;
+    uint8_t srctap[SV_MAX_TAPS];
+    svg_dgrad_args(&L.d, c, &a, srctap);
+    a.A = dy;
+    a.Wt = (char*)p->bp("warena") + L.wd_off[c] * p->esz();
+    a.out = dx;
+    a.mask = mask;
+    if (f32_atomic) {
+      a.out_f32 = 1;
+      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
+    }
+    SV_TRY(svk_tap_gemm(a, L.d.dtype, svg_pick_cfg(L.d.Cin), st));
+  }
+  return SV_OK;
+}
+
+static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void* dy, float* grads, hipStream_t st) {
+  WgradArgs a;
+  svg_wgrad_args(&L.d, &a);
+  a.A = x; a.dY = dy;
+  a.dW = grads + p->params[L.kparam].off;
+  a.dbias = grads + p->params[L.bparam].off;
+  Scope sc(p, st, "wgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
+  return svk_wgrad(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+}
+
+static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  Scope sc(p, st, "prep_weights", 0, (double)p->nparams * (4 + 2.0 * p->esz()));
+  return svk_prep_weights(s->params, p->bp("warena"), p->d.dtype, (const PrepJob*)p->bp("jobs"),
+                          (int)p->jobs.size(), p->prep_blocks, st);
+}
+
+static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  const sv_lgvae_desc& d = p->d;
+  const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
+  const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
+  const char* en[2] = {"x", "xh"};
+  {
+    Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
+    SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
+  }
+  for (int e = 0; e < 2; ++e) {
+    const std::string sfx = en[e];
+    const int L = e == 0 ? Lg : Ll;
+    SV_TRY(run_fwd_layer(p, p->enc[e][0], p->bp("in8_" + sfx), s->params, p->bp("a1_" + sfx), st));
+    SV_TRY(run_fwd_layer(p, p->enc[e][1], p->bp("a1_" + sfx), s->params, p->bp("a2_" + sfx), st));
+    SV_TRY(run_fwd_layer(p, p->enc[e][2], p->bp("a2_" + sfx), s->params, p->bp("a3_" + sfx), st));
+    // head: split-K GEMM into the zeroed fp32 pre-activation; bias + softplus live in reparam_kl_fwd
+    {
+      Layer& Lh = p->enc[e][3];
+      if (hipMemsetAsync(p->bp("pre_" + sfx), 0, p->bbytes("pre_" + sfx), st) != hipSuccess) return (int)hipGetLastError();
+      TapGemmArgs a;
+      svg_fwd_args(&Lh.d, &a);
+      a.A = p->bp("a3_" + sfx);
+      a.Wt = (char*)p->bp("warena") + Lh.wf_off * p->esz();
+      a.bias = nullptr; a.out = p->bp("pre_" + sfx); a.out_f32 = 1;
+      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
+      Scope sc(p, st, "fwd.head", conv_flops(Lh.d), 0);
+      SV_TRY(svk_tap_gemm(a, dt, svg_pick_cfg(Lh.d.Cout), st));
+    }
+    {
+      Scope sc(p, st, "reparam_kl_fwd", 0, (double)B * L * 16);
+      const Layer& Lh = p->enc[e][3];
+      // mean bias and sd bias are separate Keras tensors: two-pointer form of sv_reparam_kl_fwd
+      const float* eps = e == 0 ? s->eps_x : s->eps_x_hat;
+      SV_TRY(svk_reparam_kl_fwd2((const float*)p->bp("pre_" + sfx), s->params + p->params[Lh.kparam + 1].off,
+                                 s->params + p->params[Lh.kparam + 3].off, eps, (float*)p->bp("eps_" + sfx),
+                                 (float*)p->bp("z_mean_" + sfx), (float*)p->bp("z_sig_" + sfx),
+                                 (float*)p->bp("z_" + sfx), p->bp("zcat"), dt, Lc, e == 0 ? 0 : Lg,
+                                 (float*)p->bp("kl_" + sfx), B, L, s->seed, s->step, e, s->sample_offset, st));
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    const std::string sfx = en[k];
+    const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
+    SV_TRY(run_fwd_layer(p, p->dec[k][0], zin, s->params, p->bp("h1_" + sfx), st));
+    SV_TRY(run_fwd_layer(p, p->dec[k][1], p->bp("h1_" + sfx), s->params, p->bp("h2_" + sfx), st));
+    {
+      Scope sc(p, st, "upsample_fwd", 0, 0);
+      SV_TRY(sv_upsample2x_fwd(p->bp("h2_" + sfx), p->bp("u2_" + sfx), dt, B, H / 8, W / 8, 128, st));
+    }
+    SV_TRY(run_fwd_layer(p, p->dec[k][2], p->bp("u2_" + sfx), s->params, p->bp("h3_" + sfx), st));
+    {
+      Scope sc(p, st, "upsample_fwd", 0, 0);
+      SV_TRY(sv_upsample2x_fwd(p->bp("h3_" + sfx), p->bp("u3_" + sfx), dt, B, H / 4, W / 4, 64, st));
+    }
+    SV_TRY(run_fwd_layer(p, p->dec[k][3], p->bp("u3_" + sfx), s->params, p->bp("h4_" + sfx), st));
+    {
+      Scope sc(p, st, "upsample_fwd", 0, 0);
+      SV_TRY(sv_upsample2x_fwd(p->bp("h4_" + sfx), p->bp("u4_" + sfx), dt, B, H / 2, W / 2, 32, st));
+    }
+    SV_TRY(run_fwd_layer(p, p->dec[k][4], p->bp("u4_" + sfx), s->params, p->bp("out6_" + sfx), st));
+  }
+  return SV_OK;
+}
+
+static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_grad, hipStream_t st) {
+  const sv_lgvae_desc& d = p->d;
+  const char* en[2] = {"x", "xh"};
+  for (int k = 0; k < 2; ++k) {
+    const std::string sfx = en[k];
+    // algorithmic bytes: read x, m, log_scale (12 B/element) + write dm, dls (2 * esz B/element)
+    Scope sc(p, st, "dlogistic_nll", 0, (double)d.B * d.H * d.W * 3 * (12.0 + (with_grad ? 2.0 * p->esz() : 0.0)));
+    SV_TRY(sv_dlogistic_nll(s->images6, k == 0 ? 0 : 3, (const float*)p->bp("out6_" + sfx), (float*)p->bp("nll_" + sfx),
+                            with_grad ? p->bp("g5_" + sfx) : nullptr, d.dtype, 1.0f / (float)d.B, d.B, d.H, d.W,
+                            (float*)p->bp("nllpart_" + sfx), st));
+  }
+  SV_TRY(svk_finalize_losses((const float*)p->bp("nll_x"), (const float*)p->bp("nll_xh"), (const float*)p->bp("kl_x"),
+                             (const float*)p->bp("kl_xh"), d.B, d.beta, (float*)p->bp("losses"),
+                             (float*)p->bp("metric_acc"), s->accumulate_metrics, st));
+  return SV_OK;
+}
+
+static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  const sv_lgvae_desc& d = p->d;
+  const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
+  const int Lg = d.global_latent;
+  const char* en[2] = {"x", "xh"};
+  for (int k = 0; k < 2; ++k) {
+    const std::string sfx = en[k];
+    Layer* L = p->dec[k];
+    // d5
+    SV_TRY(run_wgrad_layer(p, L[4], p->bp("u4_" + sfx), p->bp("g5_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[4], p->bp("g5_" + sfx), nullptr, p->bp("gu4_" + sfx), false, st));
+    { Scope sc(p, st, "upsample_bwd", 0, 0);
+      SV_TRY(sv_upsample2x_bwd(p->bp("gu4_" + sfx), p->bp("h4_" + sfx), p->bp("g4_" + sfx), dt, B, H / 2, W / 2, 32, st)); }
+    // d4
+    SV_TRY(run_wgrad_layer(p, L[3], p->bp("u3_" + sfx), p->bp("g4_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[3], p->bp("g4_" + sfx), nullptr, p->bp("gu3_" + sfx), false, st));
+    { Scope sc(p, st, "upsample_bwd", 0, 0);
+      SV_TRY(sv_upsample2x_bwd(p->bp("gu3_" + sfx), p->bp("h3_" + sfx), p->bp("g3_" + sfx), dt, B, H / 4, W / 4, 64, st)); }
+    // d3
+    SV_TRY(run_wgrad_layer(p, L[2], p->bp("u2_" + sfx), p->bp("g3_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[2], p->bp("g3_" + sfx), nullptr, p->bp("gu2_" + sfx), false, st));
+    { Scope sc(p, st, "upsample_bwd", 0, 0);
+      SV_TRY(sv_upsample2x_bwd(p->bp("gu2_" + sfx), p->bp("h2_" + sfx), p->bp("g2_" + sfx), dt, B, H / 8, W / 8, 128, st)); }
+    // d2 (input h1 = relu(d1): mask fused in the dgrad epilogue)
+    SV_TRY(run_wgrad_layer(p, L[1], p->bp("h1_" + sfx), p->bp("g2_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[1], p->bp("g2_" + sfx), p->bp("h1_" + sfx), p->bp("g1_" + sfx), false, st));
+    // d1 (dense): dz accumulated in fp32 over split K
+    const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
+    SV_TRY(run_wgrad_layer(p, L[0], zin, p->bp("g1_" + sfx), s->grads, st));
+    if (hipMemsetAsync(p->bp("gz_" + sfx), 0, p->bbytes("gz_" + sfx), st) != hipSuccess) return (int)hipGetLastError();
+    {
+      // dz has its own row pitch (Lz), not the zcat pitch: patch ldo after building the args
+      Layer Ld = L[0];
+      Ld.d.ldx = Ld.d.Cin;
+      SV_TRY(run_dgrad_layer(p, Ld, p->bp("g1_" + sfx), nullptr, p->bp("gz_" + sfx), true, st));
+    }
+  }
+  return SV_OK;
+}
+
+static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  const sv_lgvae_desc& d = p->d;
+  const int B = d.B, dt = d.dtype;
+  const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
+  const char* en[2] = {"x", "xh"};
+  const float kl_scale = d.beta / (float)B;
+  {
+    Scope sc(p, st, "reparam_kl_bwd", 0, 0);
+    SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x"), Lc, nullptr, 0, (const float*)p->bp("z_mean_x"),
+                             (const float*)p->bp("z_sig_x"), (const float*)p->bp("eps_x"), kl_scale, p->bp("ghead_x"),
+                             dt, B, Lg, st));
+    SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x") + Lg, Lc, (const float*)p->bp("gz_xh"), Ll,
+                             (const float*)p->bp("z_mean_xh"), (const float*)p->bp("z_sig_xh"),
+                             (const float*)p->bp("eps_xh"), kl_scale, p->bp("ghead_xh"), dt, B, Ll, st));
+  }
+  for (int e = 0; e < 2; ++e) {
+    const std::string sfx = en[e];
+    Layer* L = p->enc[e];
+    const int Lh = e == 0 ? Lg : Ll;
+    // head: two Keras kernels/biases -> two wgrad launches on column halves of ghead
+    for (int h = 0; h < 2; ++h) {
+      WgradArgs a;
+      svg_wgrad_args(&L[3].d, &a);
+      a.A = p->bp("a3_" + sfx);
+      a.dY = (const char*)p->bp("ghead_" + sfx) + (size_t)h * Lh * p->esz();
+      a.ycols = Lh; a.N = Lh;
+      a.dW = s->grads + p->params[L[3].kparam + 2 * h].off;
+      a.dbias = s->grads + p->params[L[3].kparam + 2 * h + 1].off;
+      Scope sc(p, st, "wgrad.head", conv_flops(L[3].d) / 2, 0);
+      SV_TRY(svk_wgrad(a, dt, svg_pick_cfg(Lh), st));
+    }
+    SV_TRY(run_dgrad_layer(p, L[3], p->bp("ghead_" + sfx), p->bp("a3_" + sfx), p->bp("ga3_" + sfx), false, st));
+    SV_TRY(run_wgrad_layer(p, L[2], p->bp("a2_" + sfx), p->bp("ga3_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[2], p->bp("ga3_" + sfx), p->bp("a2_" + sfx), p->bp("ga2_" + sfx), false, st));
+    SV_TRY(run_wgrad_layer(p, L[1], p->bp("a1_" + sfx), p->bp("ga2_" + sfx), s->grads, st));
+    SV_TRY(run_dgrad_layer(p, L[1], p->bp("ga2_" + sfx), p->bp("a1_" + sfx), p->bp("ga1_" + sfx), false, st));
+    SV_TRY(run_wgrad_layer(p, L[0], p->bp("in8_" + sfx), p->bp("ga1_" + sfx), s->grads, st));
+  }
+  return SV_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t sv_lgvae_param_count(const sv_lgvae_desc* d) {
+  if (check_desc(d) != SV_OK) return -1;
+  auto v = build_params(d);
+  return v.back().off + (v.back().count + 3) / 4 * 4;
+}
+
+extern "C" int sv_lgvae_param_info(const sv_lgvae_desc* d, int32_t index, int64_t* offset, int32_t* ndim,
+                                   int64_t shape[4], char name[96]) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  auto v = build_params(d);
+  if (index < 0 || index >= (int)v.size()) return SV_E_BADARG;
+  const ParamInfo& p = v[index];
+  if (offset) *offset = p.off;
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  if (name) snprintf(name, 96, "%s", p.name.c_str());
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_plan_create(const sv_lgvae_desc* d, sv_lgvae_plan** out) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!out) return SV_E_BADARG;
+  sv_lgvae_plan* p = new sv_lgvae_plan();
+  p->d = *d;
+  p->params = build_params(d);
+  p->nparams = p->params.back().off + (p->params.back().count + 3) / 4 * 4;
+  p->ws = nullptr; p->bound = false; p->prof_on = false;
+  build_layers(p);
+  for (int e = 0; e < 2; ++e)
+    for (int l = 0; l < 4; ++l)
+      if ((rc = svg_check(&p->enc[e][l].d))) { delete p; return rc; }
+  for (int k = 0; k < 2; ++k)
+    for (int l = 0; l < 5; ++l)
+      if ((rc = svg_check(&p->dec[k][l].d))) { delete p; return rc; }
+  build_prep_jobs(p);
+  build_buffers(p);
+  *out = p;
+  return SV_OK;
+}
+
+extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
+  if (!p) return;
+  for (auto& pe : p->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+  for (auto e : p->event_pool) hipEventDestroy(e);
+  delete p;
+}
+
+extern "C" int64_t sv_lgvae_workspace_bytes(const sv_lgvae_plan* p) { return p ? p->ws_bytes : -1; }
+
+extern "C" int sv_lgvae_plan_bind(sv_lgvae_plan* p, void* workspace, int64_t bytes, void* stream) {
+  if (!p || !workspace) return SV_E_BADARG;
+  if (bytes < p->ws_bytes) return SV_E_WORKSPACE;
+  if ((uintptr_t)workspace & 255) return SV_E_BADARG;
+  p->ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(p->bp("jobs"), p->jobs.data(), p->jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(p->bp("metric_acc"), 0, 32, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamSynchronize(st);   // the job table lives in plan-owned host memory: finish the copy now
+  if (e != hipSuccess) return (int)e;
+  p->bound = true;
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_buffer(const sv_lgvae_plan* p, const char* name, int64_t* offset, int64_t* bytes) {
+  if (!p || !name) return SV_E_BADARG;
+  auto it = p->bufidx.find(name);
+  if (it == p->bufidx.end()) return SV_E_BADARG;
+  if (offset) *offset = p->bufs[it->second].off;
+  if (bytes) *bytes = p->bufs[it->second].bytes;
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void* stream) {
+  if (!p || !s) return SV_E_BADARG;
+  if (!p->bound) return SV_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  const int ph = s->phases;
+  const bool train = ph & (SV_PHASE_BWD_DECODERS | SV_PHASE_BWD_ENCODERS);
+  if ((ph & (SV_PHASE_PREP | SV_PHASE_FORWARD | SV_PHASE_ADAM | SV_PHASE_BWD_DECODERS | SV_PHASE_BWD_ENCODERS)) && !s->params) return SV_E_BADARG;
+  if ((ph & (SV_PHASE_FORWARD | SV_PHASE_LOSS)) && !s->images6) return SV_E_BADARG;
+  if (train && !s->grads) return SV_E_BADARG;
+  if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
+  if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, st));
+  if (ph & SV_PHASE_LOSS) {
+    if (s->grads) {
+      Scope sc(p, st, "zero_grads", 0, (double)p->nparams * 4);
+      if (hipMemsetAsync(s->grads, 0, (size_t)p->nparams * 4, st) != hipSuccess) return (int)hipGetLastError();
+    }
+    SV_TRY(phase_loss(p, s, s->grads != nullptr, st));
+  }
+  if (ph & SV_PHASE_BWD_DECODERS) SV_TRY(phase_bwd_decoders(p, s, st));
+  if (ph & SV_PHASE_BWD_ENCODERS) SV_TRY(phase_bwd_encoders(p, s, st));
+  if (ph & SV_PHASE_ADAM) {
+    if (!s->grads || !s->adam_m || !s->adam_v) return SV_E_BADARG;
+    Scope sc(p, st, "adam_step", 0, (double)p->nparams * 28);
+    SV_TRY(sv_adam_step(s->params, s->grads, s->adam_m, s->adam_v, p->nparams, s->lr, s->beta1, s->beta2,
+                        s->adam_eps, s->t, s->grad_scale, st));
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_profile_enable(sv_lgvae_plan* p, int32_t enable) {
+  if (!p) return SV_E_BADARG;
+  p->prof_on = enable != 0;
+  if (enable) {
+    for (auto& pe : p->pending) { p->event_pool.push_back(pe.a); p->event_pool.push_back(pe.b); }
+    p->pending.clear();
+    p->prof.clear();
+    p->profidx.clear();
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_profile_read(sv_lgvae_plan* p, int32_t max_entries, char names[][64], double* total_ms,
+                                     int32_t* launches, double* flops_per_launch, double* bytes_per_launch) {
+  if (!p) return SV_E_BADARG;
+  for (auto& pe : p->pending) {
+    hipEventSynchronize(pe.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+      p->prof[pe.entry].total_ms += ms;
+      p->prof[pe.entry].launches += 1;
+    }
+    p->event_pool.push_back(pe.a);
+    p->event_pool.push_back(pe.b);
+  }
+  p->pending.clear();
+  int n = (int)p->prof.size();
+  if (n > max_entries) n = max_entries;
+  for (int i = 0; i < n; ++i) {
+    if (names) snprintf(names[i], 64, "%s", p->prof[i].name.c_str());
+    if (total_ms) total_ms[i] = p->prof[i].total_ms;
+    if (launches) launches[i] = p->prof[i].launches;
+    if (flops_per_launch) flops_per_launch[i] = p->prof[i].flops;
+    if (bytes_per_launch) bytes_per_launch[i] = p->prof[i].bytes;
+  }
+  return n;
+}
+
+extern "C" const char* sv_version(void) { return "splitvae-hip 0.1 (gfx950)"; }

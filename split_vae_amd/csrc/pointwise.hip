@@ -1,0 +1,579 @@
+// HBM-bound kernels of the SPLIT-VAE step: patch scramble, ELBO terms, reparameterisation/KL,
+// bilinear 2x (+adjoint), Keras-Adam.  One pass over the data each, 64-lane wavefront reductions.
+#include "common.hip.h"
+#include "kernels.h"
+
+// ============================================================================ A1 scramble
+// augmentation.py:43-57.  x_aug[r*s+i, c*s+j] = x[pr*s+i, pc*s+j], (pr,pc) = divmod(perm[r*G+c], G).
+// One thread per destination pixel; both halves of the 6-channel pixel are written by the same
+// thread so the 24-B output pixel is produced in one place.
+__global__ __launch_bounds__(256) void scramble_kernel(const float* __restrict__ x,
+                                                       const int32_t* __restrict__ perm,
+                                                       float* __restrict__ out, int B, int H, int W,
+                                                       int s, int G) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int xw = (int)(idx % W);
+    const int64_t t = idx / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int r = y / s, i = y - r * s, c = xw / s, j = xw - c * s;
+    const int p = perm[(int64_t)b * G * G + r * G + c];
+    const int pr = p / G, pc = p - pr * G;
+    const float* src0 = x + idx * 3;
+    const float* src1 = x + (((int64_t)b * H + pr * s + i) * W + pc * s + j) * 3;
+    float* dst = out + idx * 6;
+    const float a0 = src0[0], a1 = src0[1], a2 = src0[2];
+    const float b0 = src1[0], b1 = src1[1], b2 = src1[2];
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
+  }
+}
+
+extern "C" int sv_scramble_gather(const float* x, const int32_t* perm, float* images6, int32_t B,
+                                  int32_t H, int32_t W, int32_t patch, void* stream) {
+  if (!x || !perm || !images6 || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return SV_E_BADARG;
+  if (H != W || H % patch) return SV_E_UNSUPPORTED;   // augmentation.py:44-46 assumes square, s | H
+  const int64_t total = (int64_t)B * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(scramble_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, perm,
+                     images6, B, H, W, patch, W / patch);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// tf.random.shuffle stand-in: sort Philox keys (ties impossible: index in the low word).
+__global__ __launch_bounds__(256) void random_perm_kernel(int32_t* __restrict__ perm, int n, int npow2,
+                                                          uint64_t seed, uint64_t step,
+                                                          int64_t sample_offset) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint64_t* keys = (uint64_t*)smem_raw;
+  const int b = blockIdx.x;
+  const uint64_t gs = (uint64_t)(sample_offset + b);
+  Philox ph(seed ^ 0x5ca1ab1e5eedULL);
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    uint64_t k = ~0ULL;
+    if (i < n) {
+      uint32_t c[4] = {(uint32_t)i, (uint32_t)gs, (uint32_t)(gs >> 32) ^ 0x7065726du, (uint32_t)step};
+      ph(c);
+      k = ((uint64_t)c[0] << 32) | (uint32_t)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = keys[i], c = keys[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) perm[(int64_t)b * n + i] = (int32_t)(uint32_t)keys[i];
+}
+
+extern "C" int sv_random_perm(int32_t* perm, int32_t B, int32_t n_patch, uint64_t seed, uint64_t step,
+                              int64_t sample_offset, void* stream) {
+  if (!perm || B <= 0 || n_patch <= 0) return SV_E_BADARG;
+  if (n_patch > 4096) return SV_E_UNSUPPORTED;
+  int npow2 = 1;
+  while (npow2 < n_patch) npow2 <<= 1;
+  hipLaunchKernelGGL(random_perm_kernel, dim3(B), dim3(256), npow2 * sizeof(uint64_t),
+                     (hipStream_t)stream, perm, n_patch, npow2, seed, step, sample_offset);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ A6 discretised logistic
+// vae/trainer.py:21-38, one element.  Returns nll and d nll/d m, d nll/d log_scale.
+__device__ __forceinline__ void sig_pair(float v, float& s, float& sc, float& ds) {
+  const float e = expf(-fabsf(v));
+  const float hi = 1.f / (1.f + e), lo = e * hi;
+  s = v >= 0.f ? hi : lo;     // sigmoid(v)
+  sc = v >= 0.f ? lo : hi;    // 1 - sigmoid(v)
+  ds = hi * lo;               // sigmoid'(v)
+}
+
+__device__ __forceinline__ void dll_elem(float x, float m, float ls, float& nll, float& dm, float& dls) {
+  const float c = x - m;
+  const float s = expf(-ls);
+  const float p = s * (c + (1.f / 255.f));
+  const float q = s * (c - (1.f / 255.f));
+  float sp, spc, dsp, sq, sqc, dsq;
+  sig_pair(p, sp, spc, dsp);
+  sig_pair(q, sq, sqc, dsq);
+  if (x < -0.999f) {              // log_cdf_plus = p - softplus(p) = -softplus(-p)
+    nll = softplus_f(-p);
+    dm = s * spc;
+    dls = p * spc;
+  } else if (x > 0.999f) {        // log_one_minus_cdf_min = -softplus(q)
+    nll = softplus_f(q);
+    dm = -s * sq;
+    dls = -q * sq;
+  } else {
+    const float delta = sp - sq;
+    if (delta > 1e-5f) {
+      const float inv = 1.f / delta;   // max(delta,1e-12) == delta here
+      nll = -logf(delta);
+      dm = s * (dsp - dsq) * inv;
+      dls = (p * dsp - q * dsq) * inv;
+    } else {                      // log_pdf_mid - log(127.5)
+      const float mid = s * c;
+      float sm, smc, dsm;
+      sig_pair(mid, sm, smc, dsm);
+      const float k = smc - sm;   // 1 - 2 sigmoid(mid)
+      nll = -(mid - ls - 2.f * softplus_f(mid)) + 4.8481163645436525f;  // log(127.5)
+      dm = s * k;
+      dls = mid * k + 1.f;
+    }
+  }
+}
+
+template <typename TG, bool GRAD>
+__global__ __launch_bounds__(256) void dlogistic_kernel(const float* __restrict__ images6, int ch_off,
+                                                        const float* __restrict__ out6,
+                                                        TG* __restrict__ grad, float gscale,
+                                                        float* __restrict__ partial, int HW,
+                                                        int pix_per_block) {
+  const int part = blockIdx.x, b = blockIdx.y, P = gridDim.x;
+  const int64_t base = (int64_t)b * HW;
+  const int p0 = part * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  float acc = 0.f;
+  for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    const float* xi = images6 + (base + p) * 6 + ch_off;
+    const float* oi = out6 + (base + p) * 6;
+    const float2 o01 = *(const float2*)(oi), o23 = *(const float2*)(oi + 2), o45 = *(const float2*)(oi + 4);
+    const float x0 = xi[0], x1 = xi[1], x2 = xi[2];
+    float n0, n1, n2, dm0, dm1, dm2, dl0, dl1, dl2;
+    dll_elem(x0, o01.x, o23.y, n0, dm0, dl0);
+    dll_elem(x1, o01.y, o45.x, n1, dm1, dl1);
+    dll_elem(x2, o23.x, o45.y, n2, dm2, dl2);
+    acc += (n0 + n1) + n2;
+    if (GRAD) {
+      TG* gp = grad + (base + p) * 8;
+      if constexpr (sizeof(TG) == 2) {
+        bf16x8 v;
+        v[0] = (bf16_t)(dm0 * gscale); v[1] = (bf16_t)(dm1 * gscale); v[2] = (bf16_t)(dm2 * gscale);
+        v[3] = (bf16_t)(dl0 * gscale); v[4] = (bf16_t)(dl1 * gscale); v[5] = (bf16_t)(dl2 * gscale);
+        v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
+        *(bf16x8*)gp = v;
+      } else {
+        float4 a = make_float4(dm0 * gscale, dm1 * gscale, dm2 * gscale, dl0 * gscale);
+        float4 c = make_float4(dl1 * gscale, dl2 * gscale, 0.f, 0.f);
+        *(float4*)gp = a;
+        *(float4*)(gp + 4) = c;
+      }
+    }
+  }
+  // per-image reduction: 64-lane shuffle, then 4 waves through LDS (deterministic order)
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)b * P + part] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void rowsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ nll, int B, int P) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int i = 0; i < P; ++i) s += partial[(int64_t)b * P + i];
+  nll[b] = s;
+}
+
+static inline int dll_parts(int HW) { return HW > 1024 ? HW / 1024 : 1; }
+
+extern "C" int64_t sv_dlogistic_nll_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+  return (int64_t)B * dll_parts(H * W) * sizeof(float);
+}
+
+extern "C" int sv_dlogistic_nll(const float* images6, int32_t ch_off, const float* out6, float* nll,
+                                void* grad, int32_t grad_dtype, float grad_scale, int32_t B,
+                                int32_t H, int32_t W, float* partial_ws, void* stream) {
+  if (!images6 || !out6 || !nll || !partial_ws || B <= 0 || H <= 0 || W <= 0) return SV_E_BADARG;
+  if (ch_off != 0 && ch_off != 3) return SV_E_BADARG;
+  const int HW = H * W, P = dll_parts(HW);
+  const int ppb = (HW + P - 1) / P;
+  dim3 grid(P, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (!grad)
+    hipLaunchKernelGGL((dlogistic_kernel<float, false>), grid, block, 0, st, images6, ch_off, out6,
+                       (float*)nullptr, 0.f, partial_ws, HW, ppb);
+  else if (grad_dtype == SV_BF16)
+    hipLaunchKernelGGL((dlogistic_kernel<bf16_t, true>), grid, block, 0, st, images6, ch_off, out6,
+                       (bf16_t*)grad, grad_scale, partial_ws, HW, ppb);
+  else if (grad_dtype == SV_F32)
+    hipLaunchKernelGGL((dlogistic_kernel<float, true>), grid, block, 0, st, images6, ch_off, out6,
+                       (float*)grad, grad_scale, partial_ws, HW, ppb);
+  else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rowsum_partials_kernel, dim3((B + 255) / 256), dim3(256), 0, st, partial_ws, nll, B, P);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ A4 + A7 reparam / KL
+template <typename TZ>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
+    const float* __restrict__ pre, const float* __restrict__ bias_mean, const float* __restrict__ bias_sd,
+    const float* __restrict__ eps, float* __restrict__ eps_out, float* __restrict__ z_mean, float* __restrict__ z_sig,
+    float* __restrict__ z, TZ* __restrict__ z_lp, int ldz, int z_col, float* __restrict__ kl, int B,
+    int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  Philox ph(seed ^ 0xe9515eedULL);
+  const uint64_t gs = (uint64_t)(sample_offset + b);
+  float acc = 0.f;
+  for (int j = lane; j < L; j += 64) {
+    const float mu = pre[(int64_t)b * 2 * L + j] + bias_mean[j];
+    const float sg = softplus_f(pre[(int64_t)b * 2 * L + L + j] + bias_sd[j]);
+    float e;
+    if (eps) {
+      e = eps[(int64_t)b * L + j];
+    } else {
+      uint32_t c[4] = {(uint32_t)j, (uint32_t)gs, (uint32_t)(gs >> 32) ^ (0x65707300u + (uint32_t)stream_id),
+                       (uint32_t)step};
+      ph(c);
+      const float u1 = u32_to_unit_open(c[0]), u2 = u32_to_unit_open(c[1]);
+      e = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+    }
+    if (eps_out) eps_out[(int64_t)b * L + j] = e;
+    const float zz = mu + sg * e;                        // vae/model.py:13
+    z_mean[(int64_t)b * L + j] = mu;
+    z_sig[(int64_t)b * L + j] = sg;
+    z[(int64_t)b * L + j] = zz;
+    z_lp[(int64_t)b * ldz + z_col + j] = from_f32<TZ>(zz);
+    const float lv = logf(sg * sg);                      // vae/trainer.py:12
+    acc += 1.f + lv - mu * mu - expf(lv);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) kl[b] = -0.5f * acc;
+}
+
+int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* bias_sd, const float* eps,
+                        float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
+                        int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
+                        int64_t sample_offset, hipStream_t st) {
+  if (!pre || !bias_mean || !bias_sd || !z_mean || !z_sig || !z || !z_lp || !kl || B <= 0 || L <= 0) return SV_E_BADARG;
+  dim3 grid((B + 3) / 4), block(256);
+  if (z_dtype == SV_BF16)
+    hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), grid, block, 0, st, pre, bias_mean, bias_sd, eps, eps_out,
+                       z_mean, z_sig, z, (bf16_t*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset);
+  else if (z_dtype == SV_F32)
+    hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), grid, block, 0, st, pre, bias_mean, bias_sd, eps, eps_out,
+                       z_mean, z_sig, z, (float*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset);
+  else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_reparam_kl_fwd(const float* pre, const float* bias, const float* eps, float* eps_out,
+                                 float* z_mean, float* z_sig, float* z, void* z_lp, int32_t z_dtype,
+                                 int32_t ldz, int32_t z_col, float* kl, int32_t B, int32_t L,
+                                 uint64_t seed, uint64_t step, int32_t stream_id,
+                                 int64_t sample_offset, void* stream) {
+  if (!bias) return SV_E_BADARG;
+  return svk_reparam_kl_fwd2(pre, bias, bias + L, eps, eps_out, z_mean, z_sig, z, z_lp, z_dtype, ldz, z_col, kl, B,
+                             L, seed, step, stream_id, sample_offset, (hipStream_t)stream);
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
+    const float* __restrict__ dz, int ld_dz, const float* __restrict__ dz2, int ld_dz2,
+    const float* __restrict__ z_mean, const float* __restrict__ z_sig, const float* __restrict__ eps,
+    float kl_scale, TG* __restrict__ g_pre, int B, int L) {
+  const int64_t total = (int64_t)B * L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), j = (int)(i - (int64_t)b * L);
+    float g = dz[(int64_t)b * ld_dz + j];
+    if (dz2) g += dz2[(int64_t)b * ld_dz2 + j];
+    const float mu = z_mean[i], sg = z_sig[i], e = eps[i];
+    const float dmu = g + kl_scale * mu;
+    const float dsg = g * e + kl_scale * (sg - 1.f / sg);
+    const float dpre = dsg * (1.f - expf(-sg));          // softplus'(pre) = 1 - exp(-softplus(pre))
+    g_pre[(int64_t)b * 2 * L + j] = from_f32<TG>(dmu);
+    g_pre[(int64_t)b * 2 * L + L + j] = from_f32<TG>(dpre);
+  }
+}
+
+extern "C" int sv_reparam_kl_bwd(const float* dz, int32_t ld_dz, const float* dz2, int32_t ld_dz2,
+                                 const float* z_mean, const float* z_sig, const float* eps,
+                                 float kl_scale, void* g_pre, int32_t g_dtype, int32_t B, int32_t L,
+                                 void* stream) {
+  if (!dz || !z_mean || !z_sig || !eps || !g_pre || B <= 0 || L <= 0) return SV_E_BADARG;
+  const int64_t total = (int64_t)B * L;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (g_dtype == SV_BF16)
+    hipLaunchKernelGGL((reparam_kl_bwd_kernel<bf16_t>), grid, block, 0, st, dz, ld_dz, dz2, ld_dz2,
+                       z_mean, z_sig, eps, kl_scale, (bf16_t*)g_pre, B, L);
+  else if (g_dtype == SV_F32)
+    hipLaunchKernelGGL((reparam_kl_bwd_kernel<float>), grid, block, 0, st, dz, ld_dz, dz2, ld_dz2,
+                       z_mean, z_sig, eps, kl_scale, (float*)g_pre, B, L);
+  else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ K14 Keras Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n4, int64_t n, float alpha, float omb1,
+                                                   float omb2, float eps, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = ((float4*)p)[i], gg = ((const float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+#define SV_ADAM1(c)                               \
+  {                                               \
+    const float gc = gg.c * gscale;               \
+    mm.c = mm.c + (gc - mm.c) * omb1;             \
+    vv.c = vv.c + (gc * gc - vv.c) * omb2;        \
+    pp.c = pp.c - alpha * mm.c / (sqrtf(vv.c) + eps); \
+  }
+    SV_ADAM1(x) SV_ADAM1(y) SV_ADAM1(z) SV_ADAM1(w)
+    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float gc = g[i] * gscale;
+      float mi = m[i], vi = v[i];
+      mi = mi + (gc - mi) * omb1;
+      vi = vi + (gc * gc - vi) * omb2;
+      p[i] = p[i] - alpha * mi / (sqrtf(vi) + eps);
+      m[i] = mi; v[i] = vi;
+    }
+  }
+}
+
+extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                            float beta1, float beta2, float eps, int64_t t, float grad_scale,
+                            void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || t <= 0) return SV_E_BADARG;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SV_E_BADARG;
+  const double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     n4, n, (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ K10a bilinear 2x
+// tf.image.resize (half-pixel centres): out[2i] = .25 in[i-1] + .75 in[i]; out[2i+1] = .75 in[i] + .25 in[i+1]
+// with clamped neighbours.  One thread per (output pixel, 16-B channel piece).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                             int B, int H, int W, int C) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  const int cp = C / EPP;
+  const int64_t total = (int64_t)B * 2 * H * 2 * W * cp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cp);
+    int64_t t = idx / cp;
+    const int ox = (int)(t % (2 * W)); t /= 2 * W;
+    const int oy = (int)(t % (2 * H));
+    const int b = (int)(t / (2 * H));
+    const int iy = oy >> 1, ix = ox >> 1;
+    const int y0 = (oy & 1) ? iy : max(iy - 1, 0), y1 = (oy & 1) ? min(iy + 1, H - 1) : iy;
+    const int x0 = (ox & 1) ? ix : max(ix - 1, 0), x1 = (ox & 1) ? min(ix + 1, W - 1) : ix;
+    const float fy = (oy & 1) ? 0.25f : 0.75f;   // weight of the second (y1) sample
+    const float fx = (ox & 1) ? 0.25f : 0.75f;
+    const T* base = in + (int64_t)b * H * W * C + c * EPP;
+    T v00[EPP], v01[EPP], v10[EPP], v11[EPP], r[EPP];
+    *(uint4*)v00 = *(const uint4*)(base + ((int64_t)y0 * W + x0) * C);
+    *(uint4*)v01 = *(const uint4*)(base + ((int64_t)y0 * W + x1) * C);
+    *(uint4*)v10 = *(const uint4*)(base + ((int64_t)y1 * W + x0) * C);
+    *(uint4*)v11 = *(const uint4*)(base + ((int64_t)y1 * W + x1) * C);
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) {
+      const float top = to_f32(v00[e]) + (to_f32(v01[e]) - to_f32(v00[e])) * fx;
+      const float bot = to_f32(v10[e]) + (to_f32(v11[e]) - to_f32(v10[e])) * fx;
+      r[e] = from_f32<T>(top + (bot - top) * fy);
+    }
+    *(uint4*)(out + (((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + c * EPP) = *(uint4*)r;
+  }
+}
+
+// adjoint: g_lo[i,j] = sum_{a,b in -1..2} wy[a] wx[b] g_hi[clamp(2i+a), clamp(2j+b)], w = (.25,.75,.75,.25);
+// then the ReLU mask of the low-res producer (y_lo > 0).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ g_hi, const T* __restrict__ mask,
+                                                             T* __restrict__ g_lo, int B, int H, int W, int C) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  const int cp = C / EPP;
+  const int64_t total = (int64_t)B * H * W * cp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cp);
+    int64_t t = idx / cp;
+    const int j = (int)(t % W); t /= W;
+    const int i = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc[EPP];
+#pragma unroll
+    for (int e = 0; e < EPP; ++e) acc[e] = 0.f;
+    const T* base = g_hi + (int64_t)b * 4 * H * W * C + c * EPP;
+#pragma unroll
+    for (int a = -1; a <= 2; ++a) {
+      const int oy = min(max(2 * i + a, 0), 2 * H - 1);
+      const float wy = (a == -1 || a == 2) ? 0.25f : 0.75f;
+#pragma unroll
+      for (int d = -1; d <= 2; ++d) {
+        const int ox = min(max(2 * j + d, 0), 2 * W - 1);
+        const float w = wy * ((d == -1 || d == 2) ? 0.25f : 0.75f);
+        T v[EPP];
+        *(uint4*)v = *(const uint4*)(base + ((int64_t)oy * 2 * W + ox) * C);
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) acc[e] += w * to_f32(v[e]);
+      }
+    }
+    const int64_t o = (((int64_t)b * H + i) * W + j) * C + c * EPP;
+    T r[EPP];
+    if (mask) {
+      T mv[EPP];
+      *(uint4*)mv = *(const uint4*)(mask + o);
+#pragma unroll
+      for (int e = 0; e < EPP; ++e) r[e] = from_f32<T>(to_f32(mv[e]) > 0.f ? acc[e] : 0.f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPP; ++e) r[e] = from_f32<T>(acc[e]);
+    }
+    *(uint4*)(g_lo + o) = *(uint4*)r;
+  }
+}
+
+static inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  if (b > 256 * 32) b = 256 * 32;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+extern "C" int sv_upsample2x_fwd(const void* in, void* out, int32_t dtype, int32_t B, int32_t H, int32_t W,
+                                 int32_t C, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return SV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SV_BF16) {
+    if (C % 8) return SV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<bf16_t>), dim3(grid_for((int64_t)B * 4 * H * W * (C / 8))),
+                       dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, B, H, W, C);
+  } else if (dtype == SV_F32) {
+    if (C % 4) return SV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((upsample2x_fwd_kernel<float>), dim3(grid_for((int64_t)B * 4 * H * W * (C / 4))),
+                       dim3(256), 0, st, (const float*)in, (float*)out, B, H, W, C);
+  } else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_upsample2x_bwd(const void* g_hi, const void* y_lo_mask, void* g_lo, int32_t dtype,
+                                 int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!g_hi || !g_lo || B <= 0 || H <= 0 || W <= 0 || C <= 0) return SV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SV_BF16) {
+    if (C % 8) return SV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<bf16_t>), dim3(grid_for((int64_t)B * H * W * (C / 8))),
+                       dim3(256), 0, st, (const bf16_t*)g_hi, (const bf16_t*)y_lo_mask, (bf16_t*)g_lo, B, H, W, C);
+  } else if (dtype == SV_F32) {
+    if (C % 4) return SV_E_UNSUPPORTED;
+    hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), dim3(grid_for((int64_t)B * H * W * (C / 4))),
+                       dim3(256), 0, st, (const float*)g_hi, (const float*)y_lo_mask, (float*)g_lo, B, H, W, C);
+  } else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// ============================================================================ step-internal helpers
+// images6 fp32 -> two 8-channel (zero padded) low-precision NHWC tensors (vae/model.py:190 split).
+template <typename T>
+__global__ __launch_bounds__(256) void split_pad_kernel(const float* __restrict__ images6, T* __restrict__ x8,
+                                                        T* __restrict__ xh8, int64_t npix) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float* s = images6 + i * 6;
+    const float2 a = *(const float2*)s, b = *(const float2*)(s + 2), c = *(const float2*)(s + 4);
+    T u[8], w[8];
+    u[0] = from_f32<T>(a.x); u[1] = from_f32<T>(a.y); u[2] = from_f32<T>(b.x);
+    w[0] = from_f32<T>(b.y); w[1] = from_f32<T>(c.x); w[2] = from_f32<T>(c.y);
+#pragma unroll
+    for (int e = 3; e < 8; ++e) { u[e] = from_f32<T>(0.f); w[e] = from_f32<T>(0.f); }
+    if constexpr (sizeof(T) == 2) {
+      *(uint4*)(x8 + i * 8) = *(uint4*)u;
+      *(uint4*)(xh8 + i * 8) = *(uint4*)w;
+    } else {
+      *(uint4*)(x8 + i * 8) = *(uint4*)u; *(uint4*)(x8 + i * 8 + 4) = *(uint4*)(u + 4);
+      *(uint4*)(xh8 + i * 8) = *(uint4*)w; *(uint4*)(xh8 + i * 8 + 4) = *(uint4*)(w + 4);
+    }
+  }
+}
+
+int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st) {
+  if (dtype == SV_BF16)
+    hipLaunchKernelGGL((split_pad_kernel<bf16_t>), dim3(grid_for(npix)), dim3(256), 0, st, images6,
+                       (bf16_t*)x8, (bf16_t*)xh8, npix);
+  else
+    hipLaunchKernelGGL((split_pad_kernel<float>), dim3(grid_for(npix)), dim3(256), 0, st, images6,
+                       (float*)x8, (float*)xh8, npix);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// the five scalars of vae/trainer.py:127-135 (+ total) and the running means of :140-144
+__global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __restrict__ nll_x,
+                                                              const float* __restrict__ nll_xh,
+                                                              const float* __restrict__ kl_x,
+                                                              const float* __restrict__ kl_xh, int B,
+                                                              float beta, float* __restrict__ losses,
+                                                              float* __restrict__ metric_acc, int accumulate) {
+  __shared__ float red[4][4];
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    a[0] += nll_x[b]; a[1] += nll_xh[b]; a[2] += kl_x[b]; a[3] += kl_xh[b];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s[4];
+    for (int k = 0; k < 4; ++k) s[k] = ((red[0][k] + red[1][k]) + (red[2][k] + red[3][k])) / (float)B;
+    const float total_kl = beta * (s[2] + s[3]);
+    losses[0] = s[0];        // x_recon_loss
+    losses[1] = s[2];        // x_kl_loss
+    losses[2] = s[1];        // x_hat_recon_loss
+    losses[3] = s[3];        // x_hat_kl_loss
+    losses[4] = total_kl;    // total_kl_loss
+    losses[5] = s[0] + s[1] + total_kl;
+    if (accumulate) {
+      for (int k = 0; k < 5; ++k) metric_acc[k] += losses[k];
+      metric_acc[5] += 1.f;
+    }
+  }
+}
+
+int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,
+                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, st, nll_x, nll_xh, kl_x, kl_xh, B,
+                     beta, losses, metric_acc, accumulate);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -1,0 +1,215 @@
+// Implicit-GEMM NHWC convolution on the gfx950 matrix cores ("tap GEMM").
+//
+//   out[m, n] = act( bias[n] + sum_{tap t} sum_{c} A[pix(m) + (dy_t, dx_t), c] * Wt[n][t][c] )
+//
+// One kernel serves the forward convs (vae/model.py:36-38,:153-156), their data gradients
+// (stride-1: flipped taps; stride-2: one launch per output parity class), and the dense layers
+// (:41-42,:152) as the 1x1 / H=W=1 case.  K is walked in 16-byte "pieces" (8 bf16 / 4 fp32
+// channels of one tap), eight pieces (128 B per row) per K-step:
+//   global --(16 B/lane, zero-filled at the SAME-padding border)--> registers --> LDS (XOR-
+//   swizzled 128-B rows, 2 buffers) --(ds_read_b128)--> MFMA 16x16x32 bf16 | 4x 16x16x4 f32.
+// The next K-step's global loads are issued before the current step's MFMAs (register-staged
+// software pipeline, one barrier per K-step).  256 threads = 4 waves, each wave owns WM rows of
+// the BM = 4*WM row tile and all BN columns.
+#include "common.hip.h"
+#include "kernels.h"
+
+template <typename T> struct MmaOp;
+template <> struct MmaOp<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaOp<float> {
+  // a 16-B piece holds k = 4g..4g+3 for lane group g; MFMA j consumes element j of every lane,
+  // i.e. k-slot g <-> k = 4g + j on both operands, so four 16x16x4 MFMAs cover the 16 k's.
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    const float4 af = __builtin_bit_cast(float4, a), bf = __builtin_bit_cast(float4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int WM>
+__global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
+  constexpr int BM = 4 * WM, MF = WM / 16, NF = BN / 16;
+  constexpr int AR = BM / 32;                       // A pieces per thread per K-step
+  constexpr int BRN = BN >= 32 ? BN / 32 : 1;       // B pieces per thread per K-step
+  constexpr int EPP = ElemTraits<T>::EPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + 2 * BM * 128;
+  int* sTap = (int*)(sB + 2 * BN * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (tid < g.ntaps) {
+    sTap[tid * 3 + 0] = g.dy[tid];
+    sTap[tid * 3 + 1] = g.dx[tid];
+    sTap[tid * 3 + 2] = ((int)g.dy[tid] * g.IW + (int)g.dx[tid]) * g.lda;
+  }
+  const int pp = tid & 7, r0 = tid >> 3;
+  int iy0[AR], ix0[AR], roff[AR];
+  {
+    const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      if (m < g.M) {
+        const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+        iy0[i] = oy * g.S;
+        ix0[i] = ox * g.S;
+        roff[i] = ((b * g.IH + iy0[i]) * g.IW + ix0[i]) * g.lda;
+      } else {
+        iy0[i] = -(1 << 20); ix0[i] = 0; roff[i] = 0;
+      }
+    }
+  }
+  const T* __restrict__ Ab = (const T*)g.A;
+  const T* __restrict__ Wb = (const T*)g.Wt;
+  const int nk_all = (g.P + 7) >> 3;
+  const int ks_begin = (int)(((int64_t)nk_all * blockIdx.z) / g.splitk);
+  const int ks_end = (int)(((int64_t)nk_all * (blockIdx.z + 1)) / g.splitk);
+  __syncthreads();   // tap table visible
+
+  uint4 ra[AR], rb[BRN];
+  auto load_stage = [&](int ks) {
+    const int p = ks * 8 + pp;
+    const bool pv = p < g.P;
+    const int tap = pv ? (p >> g.cl2) : 0;
+    const int ci0 = (p & ((1 << g.cl2) - 1)) * EPP;
+    const int tdy = sTap[tap * 3], tdx = sTap[tap * 3 + 1], toff = sTap[tap * 3 + 2] + ci0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int iy = iy0[i] + tdy, ix = ix0[i] + tdx;
+      const bool ok = pv && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+      ra[i] = ok ? *(const uint4*)(Ab + (int64_t)(roff[i] + toff)) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BRN; ++i) {
+      const int n = r0 + 32 * i;
+      const bool ok = pv && n < BN;
+      rb[i] = ok ? *(const uint4*)(Wb + (int64_t)(n0 + n) * g.Ktot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto write_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = r0 + 32 * i;
+      *(uint4*)(sA + buf * (BM * 128) + r * 128 + ((pp ^ (r & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BRN; ++i) {
+      const int n = r0 + 32 * i;
+      if (n < BN) *(uint4*)(sB + buf * (BN * 128) + n * 128 + ((pp ^ (n & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (ks_begin < ks_end) {
+    load_stage(ks_begin);
+    write_stage(0);
+  }
+  __syncthreads();
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    const bool more = ks + 1 < ks_end;
+    if (more) load_stage(ks + 1);
+    const char* cA = sA + buf * (BM * 128);
+    const char* cB = sB + buf * (BN * 128);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[MF], bfr[NF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int r = wave * WM + i * 16 + lr;
+        af[i] = *(const uint4*)(cA + r * 128 + (((kk * 4 + lg) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = j * 16 + lr;
+        bfr[j] = *(const uint4*)(cB + n * 128 + (((kk * 4 + lg) ^ (n & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) MmaOp<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+    if (more) write_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&15 (n), row = (lane>>4)*4 + reg (m)
+  const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * WM + i * 16 + lg * 4 + r;
+      if (m >= g.M) continue;
+      const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+      const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = n0 + j * 16 + lr;
+        if (n >= g.N) continue;
+        float v = acc[i][j][r];
+        const int64_t o = pix * g.ldo + n;
+        if (g.splitk > 1) {
+          atomicAdd((float*)g.out + o, v);
+          continue;
+        }
+        if (g.bias) v += g.bias[n];
+        if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
+        if (g.mask) v = to_f32(((const T*)g.mask)[o]) > 0.f ? v : 0.f;
+        if (g.out_f32) ((float*)g.out)[o] = v;
+        else ((T*)g.out)[o] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int WM>
+static int launch_tap(const TapGemmArgs& a, hipStream_t st) {
+  constexpr int BM = 4 * WM;
+  const int Npad = round_up(a.N, BN);
+  dim3 grid((a.M + BM - 1) / BM, Npad / BN, a.splitk), block(256);
+  const size_t lds = 2 * BM * 128 + 2 * BN * 128 + SV_MAX_TAPS * 3 * sizeof(int);
+  static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation (idempotent)
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st) {
+  if (a.ntaps > SV_MAX_TAPS || a.splitk < 1) return SV_E_BADARG;
+  if (a.splitk > 1 && (!a.out_f32 || a.bias || a.act != SV_ACT_NONE || a.mask)) return SV_E_BADARG;
+  if (dtype == SV_BF16) {
+    switch (cfg) {
+      case 0: return launch_tap<bf16_t, 128, 32>(a, st);
+      case 1: return launch_tap<bf16_t, 64, 32>(a, st);
+      case 2: return launch_tap<bf16_t, 32, 64>(a, st);
+      case 3: return launch_tap<bf16_t, 16, 64>(a, st);
+    }
+  } else if (dtype == SV_F32) {
+    switch (cfg) {
+      case 0: return launch_tap<float, 128, 32>(a, st);
+      case 1: return launch_tap<float, 64, 32>(a, st);
+      case 2: return launch_tap<float, 32, 64>(a, st);
+      case 3: return launch_tap<float, 16, 64>(a, st);
+    }
+  }
+  return SV_E_BADARG;
+}

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers over the C ABI (include/splitvae.h).
+
+torch is plumbing only: it owns device memory and the HIP stream; every computation below is a
+call into libsplitvae_hip.so with raw pointers.  All tensors must live on a HIP device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SV_BF16, SV_F32, ConvDesc, LGVaeDesc, StepArgs, check
+
+_TORCH_DT = {SV_BF16: torch.bfloat16, SV_F32: torch.float32}
+_SV_DT = {torch.bfloat16: SV_BF16, torch.float32: SV_F32}
+
+
+def sv_dtype(dt):
+    if isinstance(dt, str):
+        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
+              "float32": torch.float32}[dt]
+    if isinstance(dt, int):
+        return dt
+    return _SV_DT[dt]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "split_vae_amd ops need device tensors (HIP); got a CPU tensor"
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ A1 scramble (augmentation.py:43-57)
+def random_perm(B, n_patch, seed, step=0, sample_offset=0, device="cuda"):
+    perm = torch.empty((B, n_patch), dtype=torch.int32, device=device)
+    check(_lib.load().sv_random_perm(_p(perm), B, n_patch, seed, step, sample_offset, _stream()), "sv_random_perm")
+    return perm
+
+
+def scramble_gather(x, perm, patch):
+    """x[B,H,W,3] fp32, perm[B,(H/patch)^2] int32 -> [B,H,W,6] = concat([x, x_aug], axis=-1)."""
+    B, H, W, Cc = x.shape
+    assert Cc == 3 and x.dtype == torch.float32 and perm.dtype == torch.int32
+    assert perm.shape == (B, (H // patch) * (W // patch))
+    out = torch.empty((B, H, W, 6), dtype=torch.float32, device=x.device)
+    check(_lib.load().sv_scramble_gather(_p(x), _p(perm), _p(out), B, H, W, patch, _stream()), "sv_scramble_gather")
+    return out
+
+
+# ------------------------------------------------------------------ A6 discretised logistic (vae/trainer.py:21-38)
+def dlogistic_nll(images6, ch_off, out6, grad_dtype=None, grad_scale=1.0):
+    B, H, W, _ = images6.shape
+    lib = _lib.load()
+    nll = torch.empty((B,), dtype=torch.float32, device=images6.device)
+    ws = torch.empty((lib.sv_dlogistic_nll_workspace_bytes(B, H, W) // 4,), dtype=torch.float32, device=images6.device)
+    grad = None
+    gdt = 0
+    if grad_dtype is not None:
+        gdt = sv_dtype(grad_dtype)
+        grad = torch.empty((B, H, W, 8), dtype=_TORCH_DT[gdt], device=images6.device)
+    check(lib.sv_dlogistic_nll(_p(images6), ch_off, _p(out6), _p(nll), _p(grad), gdt, grad_scale, B, H, W, _p(ws),
+                               _stream()), "sv_dlogistic_nll")
+    return nll, grad
+
+
+# ------------------------------------------------------------------ A4/A7 reparam + KL
+def reparam_kl_fwd(pre, bias, eps=None, z_dtype=torch.bfloat16, seed=0, step=0, stream_id=0, sample_offset=0):
+    B, L2 = pre.shape
+    L = L2 // 2
+    dev = pre.device
+    z_mean = torch.empty((B, L), dtype=torch.float32, device=dev)
+    z_sig = torch.empty_like(z_mean)
+    z = torch.empty_like(z_mean)
+    eps_out = torch.empty_like(z_mean)
+    kl = torch.empty((B,), dtype=torch.float32, device=dev)
+    z_lp = torch.empty((B, L), dtype=z_dtype, device=dev)
+    check(_lib.load().sv_reparam_kl_fwd(_p(pre), _p(bias), _p(eps), _p(eps_out), _p(z_mean), _p(z_sig), _p(z),
+                                        _p(z_lp), sv_dtype(z_dtype), L, 0, _p(kl), B, L, seed, step, stream_id,
+                                        sample_offset, _stream()), "sv_reparam_kl_fwd")
+    return z_mean, z_sig, z, z_lp, kl, eps_out
+
+
+def reparam_kl_bwd(dz, z_mean, z_sig, eps, kl_scale, g_dtype=torch.bfloat16, dz2=None):
+    B, L = z_mean.shape
+    g = torch.empty((B, 2 * L), dtype=g_dtype, device=dz.device)
+    check(_lib.load().sv_reparam_kl_bwd(_p(dz), dz.shape[1], _p(dz2), 0 if dz2 is None else dz2.shape[1],
+                                        _p(z_mean), _p(z_sig), _p(eps), kl_scale, _p(g), sv_dtype(g_dtype), B, L,
+                                        _stream()), "sv_reparam_kl_bwd")
+    return g
+
+
+# ------------------------------------------------------------------ K14 Keras Adam (vae/main.py:65)
+def adam_step(p, g, m, v, t, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    check(_lib.load().sv_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, t, grad_scale,
+                                   _stream()), "sv_adam_step")
+
+
+# ------------------------------------------------------------------ K10a bilinear 2x (vae/model.py:163-167)
+def upsample2x_fwd(x):
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+    check(_lib.load().sv_upsample2x_fwd(_p(x), _p(out), sv_dtype(x.dtype), B, H, W, Cc, _stream()), "sv_upsample2x_fwd")
+    return out
+
+
+def upsample2x_bwd(g_hi, y_lo_mask=None):
+    B, H2, W2, Cc = g_hi.shape
+    out = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=g_hi.dtype, device=g_hi.device)
+    check(_lib.load().sv_upsample2x_bwd(_p(g_hi), _p(y_lo_mask), _p(out), sv_dtype(g_hi.dtype), B, H2 // 2, W2 // 2,
+                                        Cc, _stream()), "sv_upsample2x_bwd")
+    return out
+
+
+# ------------------------------------------------------------------ K3-K10 conv (vae/model.py:36-38,:153-156)
+class Conv2D:
+    """One Conv2D(padding='same') layer instance on the MFMA path (forward, dgrad, wgrad)."""
+
+    def __init__(self, B, H, W, Cin, Cout, k, stride, act=None, dtype=torch.bfloat16, y_f32=False):
+        r8 = lambda v: (v + 7) // 8 * 8
+        self.dtype = dtype
+        self.desc = ConvDesc(B, H, W, Cin, Cout, k, k, stride, 1 if act == "relu" else 0, sv_dtype(dtype),
+                             r8(Cin), Cout if y_f32 else r8(Cout), 1 if y_f32 else 0)
+        self.OH, self.OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        lib = _lib.load()
+        nf = lib.sv_conv2d_wprep_elems(C.byref(self.desc), 0)
+        nd = lib.sv_conv2d_wprep_elems(C.byref(self.desc), 1)
+        if nf < 0 or nd < 0:
+            raise _lib.SplitVaeError("unsupported conv geometry")
+        self.nf, self.nd = nf, nd
+        self.w_fwd = self.w_dgrad = None
+
+    def prep(self, w_hwio):
+        dev = w_hwio.device
+        self.w_fwd = torch.empty((self.nf,), dtype=self.dtype, device=dev)
+        self.w_dgrad = torch.empty((self.nd,), dtype=self.dtype, device=dev)
+        check(_lib.load().sv_conv2d_prep_weights(C.byref(self.desc), _p(w_hwio), _p(self.w_fwd), _p(self.w_dgrad),
+                                                 _stream()), "sv_conv2d_prep_weights")
+
+    def fwd(self, x, bias):
+        d = self.desc
+        y = torch.empty((d.B, self.OH, self.OW, d.ldy), dtype=torch.float32 if d.y_f32 else self.dtype, device=x.device)
+        check(_lib.load().sv_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(self.w_fwd), _p(bias), _p(y), _stream()),
+              "sv_conv2d_nhwc_fwd")
+        return y
+
+    def dgrad(self, dy, relu_mask=None, f32_atomic=False):
+        d = self.desc
+        if f32_atomic:
+            dx = torch.zeros((d.B, d.H, d.W, d.ldx), dtype=torch.float32, device=dy.device)
+        else:
+            dx = torch.zeros((d.B, d.H, d.W, d.ldx), dtype=self.dtype, device=dy.device)
+        check(_lib.load().sv_conv2d_nhwc_dgrad(C.byref(d), _p(dy), _p(self.w_dgrad), _p(relu_mask), _p(dx),
+                                               1 if f32_atomic else 0, _stream()), "sv_conv2d_nhwc_dgrad")
+        return dx
+
+    def wgrad(self, x, dy):
+        d = self.desc
+        dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+        db = torch.zeros((d.Cout,), dtype=torch.float32, device=x.device)
+        check(_lib.load().sv_conv2d_nhwc_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream()),
+              "sv_conv2d_nhwc_wgrad")
+        return dw, db
+
+
+# ------------------------------------------------------------------ the whole-step plan
+class LGVaePlan:
+    """Native launch plan for LGVae.call / train_step_lg_vae (vae/model.py:189-200, vae/trainer.py:120-144)."""
+
+    def __init__(self, B, H, W, global_latent=128, local_latent=128, beta=40.0, dtype=torch.bfloat16, device="cuda"):
+        lib = _lib.load()
+        self.lib = lib
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.desc = LGVaeDesc(B, H, W, global_latent, local_latent, sv_dtype(dtype), float(beta))
+        h = C.c_void_p()
+        check(lib.sv_lgvae_plan_create(C.byref(self.desc), C.byref(h)), "sv_lgvae_plan_create")
+        self.handle = h
+        self.n_params = lib.sv_lgvae_param_count(C.byref(self.desc))
+        self.param_table = param_table(self.desc)
+        nbytes = lib.sv_lgvae_workspace_bytes(h)
+        self.workspace = torch.zeros((nbytes,), dtype=torch.uint8, device=self.device)
+        check(lib.sv_lgvae_plan_bind(h, _p(self.workspace), nbytes, _stream()), "sv_lgvae_plan_bind")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.sv_lgvae_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def buffer(self, name, dtype, shape):
+        off, nb = C.c_int64(), C.c_int64()
+        check(self.lib.sv_lgvae_buffer(self.handle, name.encode(), C.byref(off), C.byref(nb)), "sv_lgvae_buffer " + name)
+        return self.workspace[off.value: off.value + nb.value].view(dtype).view(*shape)
+
+    def step(self, phases, params=None, grads=None, adam_m=None, adam_v=None, images6=None, eps_x=None,
+             eps_x_hat=None, seed=0, step=0, sample_offset=0, lr=1e-4, beta1=0.9, beta2=0.999, adam_eps=1e-7, t=1,
+             grad_scale=1.0, accumulate_metrics=False):
+        a = StepArgs()
+        for name, tns in (("params", params), ("grads", grads), ("adam_m", adam_m), ("adam_v", adam_v),
+                          ("images6", images6), ("eps_x", eps_x), ("eps_x_hat", eps_x_hat)):
+            setattr(a, name, None if tns is None else _p(tns).value)
+        a.seed, a.step, a.sample_offset = seed, step, sample_offset
+        a.lr, a.beta1, a.beta2, a.adam_eps, a.t = lr, beta1, beta2, adam_eps, t
+        a.grad_scale, a.phases, a.accumulate_metrics = grad_scale, phases, 1 if accumulate_metrics else 0
+        check(self.lib.sv_lgvae_step(self.handle, C.byref(a), _stream()), "sv_lgvae_step")
+
+    def profile_enable(self, on=True):
+        check(self.lib.sv_lgvae_profile_enable(self.handle, 1 if on else 0), "sv_lgvae_profile_enable")
+
+    def profile_read(self, max_entries=128):
+        names = ((C.c_char * 64) * max_entries)()
+        ms = (C.c_double * max_entries)()
+        n_l = (C.c_int32 * max_entries)()
+        fl = (C.c_double * max_entries)()
+        by = (C.c_double * max_entries)()
+        n = self.lib.sv_lgvae_profile_read(self.handle, max_entries, names, ms, n_l, fl, by)
+        if n < 0:
+            check(n, "sv_lgvae_profile_read")
+        return [dict(name=names[i].value.decode(), total_ms=ms[i], launches=n_l[i], flops=fl[i], bytes=by[i])
+                for i in range(n)]
+
+
+def param_table(desc):
+    """[(name, offset, shape)] of the 40 variables in Keras creation order."""
+    lib = _lib.load()
+    out = []
+    for i in range(40):
+        off, nd = C.c_int64(), C.c_int32()
+        shp = (C.c_int64 * 4)()
+        name = C.create_string_buffer(96)
+        check(lib.sv_lgvae_param_info(C.byref(desc), i, C.byref(off), C.byref(nd), C.byref(shp), name), "sv_lgvae_param_info")
+        out.append((name.value.decode(), off.value, tuple(shp[k] for k in range(nd.value))))
+    return out

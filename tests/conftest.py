@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    """Build (if stale) the HIP library once per session; hipcc cross-compiles gfx950 without a GPU."""
+    from split_vae_amd import build
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        build.build(verbose=False)
+    return build.LIB

@@ -1,0 +1,322 @@
+"""GPU parity: every HIP kernel family, called through the C ABI, against the oracle on the same
+seeded inputs.  Bit-exact for the index bookkeeping (scramble); stated fp32 / bf16 tolerances
+for floating point."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import np_ref, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+# fp32 path: exact-f32 MFMA / fp32 pointwise vs the fp32 oracle -- only summation order differs
+F32_RTOL, F32_ATOL = 1e-4, 1e-5
+# bf16 path: operands rounded to 8 significant bits, fp32 accumulate
+BF16_RTOL, BF16_ATOL = 3e-2, 3e-2
+
+
+@pytest.fixture(scope="module")
+def ops(lib_built):
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from split_vae_amd import ops as o
+    return o
+
+
+def levels(rng, shape):
+    """the reference's data domain: x/255*2-1 (vae/data.py:52)"""
+    return (rng.integers(0, 256, size=shape) / 255.0 * 2 - 1).astype(np.float32)
+
+
+# ------------------------------------------------------------------ scramble: bit exact
+@pytest.mark.parametrize("H,patch", [(32, 1), (32, 4), (64, 8), (64, 64), (32, 2)])
+def test_scramble_bit_exact(ops, H, patch):
+    rng = np.random.default_rng(0)
+    B = 5
+    x = levels(rng, (B, H, H, 3))
+    G2 = (H // patch) ** 2
+    perm = np.stack([rng.permutation(G2) for _ in range(B)]).astype(np.int32)
+    want = np_ref.scramble_batch(x, perm, patch)
+    got = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), patch).cpu().numpy()
+    assert got.dtype == np.float32
+    assert np.array_equal(got, want.astype(np.float32))          # every bit
+    assert np.array_equal(got[..., :3], x)                        # channels 0-2 are the input
+
+
+def test_scramble_identity_and_multiset(ops):
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(levels(rng, (3, 32, 32, 3))).cuda()
+    ident = torch.arange(64, dtype=torch.int32).repeat(3, 1).cuda()
+    out = ops.scramble_gather(x, ident, 4)
+    assert torch.equal(out[..., 3:], x)
+    perm = ops.random_perm(3, 64, seed=7)
+    out = ops.scramble_gather(x, perm, 4)
+    for b in range(3):
+        for c in range(3):
+            assert torch.equal(out[b, :, :, 3 + c].flatten().sort().values, x[b, :, :, c].flatten().sort().values)
+
+
+def test_random_perm_properties(ops):
+    p = ops.random_perm(64, 1024, seed=123, step=5).cpu().numpy()
+    for row in p:
+        assert np.array_equal(np.sort(row), np.arange(1024))
+    assert len({tuple(r) for r in p}) == 64
+    p2 = ops.random_perm(64, 1024, seed=123, step=5).cpu().numpy()
+    assert np.array_equal(p, p2)                                   # counter-based: reproducible
+    # data-parallel invariance: rank r's rows == rows [off, off+n) of the single-process draw
+    shard = ops.random_perm(16, 1024, seed=123, step=5, sample_offset=32).cpu().numpy()
+    assert np.array_equal(shard, p[32:48])
+    assert not np.array_equal(ops.random_perm(64, 1024, seed=123, step=6).cpu().numpy(), p)
+
+
+# ------------------------------------------------------------------ discretised logistic NLL
+def _dll_inputs(rng, B, H):
+    x6 = levels(rng, (B, H, H, 6))
+    x6[0, 0, :, :] = -1.0           # edge bins (vae/trainer.py:37: x < -0.999 / x > 0.999)
+    x6[0, 1, :, :] = 1.0
+    out6 = rng.standard_normal((B, H, H, 6)).astype(np.float32)
+    out6[..., 3:] = rng.uniform(-6.0, 1.0, size=(B, H, H, 3))    # log-scales incl. very sharp ones
+    out6[1, :4, :, 3:] = 3.0                                     # wide: cdf_delta <= 1e-5 branch needs tiny inv_stdv
+    out6[1, 4:8, :, 3:] = 9.0
+    return x6, out6
+
+
+@pytest.mark.parametrize("ch_off", [0, 3])
+def test_dlogistic_nll_and_grad(ops, ch_off):
+    rng = np.random.default_rng(2)
+    B, H = 4, 32
+    x6, out6 = _dll_inputs(rng, B, H)
+    xt = torch.from_numpy(x6).double()
+    ot = torch.from_numpy(out6).double().requires_grad_(True)
+    nll_ref = torch_ref.discretised_logistic_loss(xt[..., ch_off:ch_off + 3], ot[..., :3], ot[..., 3:]).sum(dim=(1, 2, 3))
+    (nll_ref.mean()).backward()
+    nll, grad = ops.dlogistic_nll(torch.from_numpy(x6).cuda(), ch_off, torch.from_numpy(out6).cuda(),
+                                  grad_dtype=torch.float32, grad_scale=1.0 / B)
+    torch.testing.assert_close(nll.cpu().double(), nll_ref.detach(), rtol=2e-5, atol=1e-3)
+    g = grad.cpu().double()
+    assert torch.count_nonzero(g[..., 6:]) == 0
+    torch.testing.assert_close(g[..., :6], ot.grad, rtol=2e-4, atol=2e-6)
+    # bf16 gradient output = rounded fp32 gradient
+    _, gb = ops.dlogistic_nll(torch.from_numpy(x6).cuda(), ch_off, torch.from_numpy(out6).cuda(),
+                              grad_dtype=torch.bfloat16, grad_scale=1.0 / B)
+    torch.testing.assert_close(gb.float().cpu(), grad.cpu().bfloat16().float(), rtol=1e-2, atol=1e-7)
+
+
+def test_dlogistic_sums_to_one(ops):
+    """KAT: sum over the 256 bins of exp(-nll) == 1 for any (m, log_scale)."""
+    ks = (np.arange(256) / 255.0 * 2 - 1).astype(np.float32)
+    for m, ls in [(0.1, -2.0), (-0.7, -5.0), (0.9, -1.0), (0.0, -3.5)]:
+        x6 = np.zeros((1, 16, 16, 6), np.float32)
+        x6[0, :, :, 0] = ks.reshape(16, 16)
+        out6 = np.zeros((1, 16, 16, 6), np.float32)
+        out6[..., 0] = m
+        out6[..., 3] = ls
+        # per-pixel nll is needed: use gradient-free path on single-pixel images via B = 256
+        x6b = np.zeros((256, 8, 8, 6), np.float32)
+        out6b = np.zeros((256, 8, 8, 6), np.float32)
+        out6b[..., 3:] = 0.0
+        x6b[:, 0, 0, 0] = ks
+        out6b[:, 0, 0, 0] = m
+        out6b[:, 0, 0, 3] = ls
+        nll, _ = ops.dlogistic_nll(torch.from_numpy(x6b).cuda(), 0, torch.from_numpy(out6b).cuda())
+        # subtract the contribution of the 191 other (identical) elements of each image
+        base_elem = float(torch_ref.discretised_logistic_loss(torch.zeros(1), torch.zeros(1), torch.zeros(1)))
+        per = nll.cpu().double().numpy() - base_elem * (8 * 8 * 3 - 1)
+        assert abs(np.exp(-per).sum() - 1.0) < 2e-3
+
+
+# ------------------------------------------------------------------ reparam + KL
+def test_reparam_kl_fwd_bwd(ops):
+    rng = np.random.default_rng(3)
+    B, L = 6, 128
+    pre = rng.standard_normal((B, 2 * L)).astype(np.float32) * 2
+    bias = rng.standard_normal((2 * L,)).astype(np.float32) * 0.1
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    z_mean, z_sig, z, z_lp, kl, eps_out = ops.reparam_kl_fwd(torch.from_numpy(pre).cuda(), torch.from_numpy(bias).cuda(),
+                                                             torch.from_numpy(eps).cuda(), z_dtype=torch.float32)
+    pt = torch.from_numpy(pre).double().requires_grad_(True)
+    bt = torch.from_numpy(bias).double()
+    mu = pt[:, :L] + bt[:L]
+    sg = F.softplus(pt[:, L:] + bt[L:])
+    zz = mu + sg * torch.from_numpy(eps).double()
+    kl_ref = -0.5 * torch.sum(1 + torch.log(sg ** 2) - mu ** 2 - torch.exp(torch.log(sg ** 2)), dim=1)
+    torch.testing.assert_close(z_mean.cpu().double(), mu.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(z_sig.cpu().double(), sg.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(z.cpu().double(), zz.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(z_lp.cpu().double(), zz.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(kl.cpu().double(), kl_ref.detach(), rtol=1e-4, atol=1e-3)
+    assert torch.equal(eps_out.cpu(), torch.from_numpy(eps))
+    # KAT: kl(0,1) == 0 ; kl(mu,1) = 0.5|mu|^2
+    pre0 = np.zeros((2, 2 * L), np.float32)
+    pre0[:, L:] = math.log(math.e - 1)            # softplus^-1(1)
+    pre0[1, :L] = 0.5
+    _, s1, _, _, kl0, _ = ops.reparam_kl_fwd(torch.from_numpy(pre0).cuda(), torch.zeros(2 * L).cuda(),
+                                             torch.zeros(2, L).cuda(), z_dtype=torch.float32)
+    assert abs(float(kl0[0])) < 1e-4 and abs(float(kl0[1]) - 0.5 * L * 0.25) < 1e-3
+    # backward
+    dz = rng.standard_normal((B, L)).astype(np.float32)
+    dz2 = rng.standard_normal((B, L)).astype(np.float32)
+    beta = 40.0
+    loss = (zz * torch.from_numpy(dz + dz2).double()).sum() + beta * kl_ref.mean()
+    loss.backward()
+    g = ops.reparam_kl_bwd(torch.from_numpy(dz).cuda(), z_mean, z_sig, eps_out, beta / B, g_dtype=torch.float32,
+                           dz2=torch.from_numpy(dz2).cuda())
+    torch.testing.assert_close(g.cpu().double(), pt.grad, rtol=2e-4, atol=2e-5)
+
+
+def test_reparam_philox_normal(ops):
+    B, L = 512, 128
+    pre = torch.zeros((B, 2 * L), device="cuda")
+    bias = torch.zeros((2 * L,), device="cuda")
+    *_, e1 = ops.reparam_kl_fwd(pre, bias, None, z_dtype=torch.float32, seed=11, step=3)
+    *_, e2 = ops.reparam_kl_fwd(pre, bias, None, z_dtype=torch.float32, seed=11, step=3)
+    assert torch.equal(e1, e2)
+    e = e1.cpu().double()
+    assert abs(float(e.mean())) < 0.02 and abs(float(e.std()) - 1.0) < 0.02
+    assert abs(float((e ** 4).mean()) - 3.0) < 0.15
+    *_, sh = ops.reparam_kl_fwd(pre[:64], bias, None, z_dtype=torch.float32, seed=11, step=3, sample_offset=128)
+    assert torch.equal(sh, e1[128:192])                            # 1-GPU == N-GPU samples
+    *_, e3 = ops.reparam_kl_fwd(pre, bias, None, z_dtype=torch.float32, seed=11, step=3, stream_id=1)
+    assert not torch.equal(e3, e1)
+
+
+# ------------------------------------------------------------------ Keras Adam
+def test_adam_matches_keras_formula(ops):
+    rng = np.random.default_rng(4)
+    n = 10007 * 4
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p = torch.from_numpy(p0.copy()).cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    rp = [torch.from_numpy(p0.copy()).double()]
+    rm, rv = [torch.zeros(n).double()], [torch.zeros(n).double()]
+    for t in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * 10 ** rng.uniform(-6, 1)
+        ops.adam_step(p, torch.from_numpy(g).cuda(), m, v, t, lr=1e-4)
+        torch_ref.keras_adam_(rp, [torch.from_numpy(g).double()], rm, rv, t, lr=1e-4)
+        torch.testing.assert_close(p.cpu().double(), rp[0], rtol=1e-6, atol=1e-7)
+    # KAT: first step from zero state ~ -lr*sign(g)
+    p = torch.zeros(8, device="cuda"); m = torch.zeros(8, device="cuda"); v = torch.zeros(8, device="cuda")
+    g = torch.tensor([1., -1., 5., -5., 1e-2, -1e-2, 3., -3.], device="cuda")
+    ops.adam_step(p, g, m, v, 1, lr=1e-4)
+    torch.testing.assert_close(p.cpu(), -1e-4 * torch.sign(g.cpu()), rtol=1e-3, atol=0)
+
+
+# ------------------------------------------------------------------ bilinear 2x
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_upsample_fwd_bwd(ops, dtype, tol):
+    rng = np.random.default_rng(5)
+    B, H, C = 2, 8, 32
+    x = torch.from_numpy(rng.standard_normal((B, H, H, C)).astype(np.float32)).to(dtype)
+    xr = x.double().requires_grad_(True)
+    up = torch_ref.resize_bilinear_2x(xr)
+    got = ops.upsample2x_fwd(x.cuda())
+    torch.testing.assert_close(got.cpu().double(), up.detach(), rtol=tol, atol=tol)
+    ghi = torch.from_numpy(rng.standard_normal((B, 2 * H, 2 * H, C)).astype(np.float32)).to(dtype)
+    up.backward(ghi.double())
+    mask = torch.from_numpy(rng.standard_normal((B, H, H, C)).astype(np.float32)).to(dtype)
+    glo = ops.upsample2x_bwd(ghi.cuda(), mask.cuda())
+    want = xr.grad * (mask.double() > 0)
+    torch.testing.assert_close(glo.cpu().double(), want, rtol=tol, atol=4 * tol)
+    glo2 = ops.upsample2x_bwd(ghi.cuda(), None)
+    torch.testing.assert_close(glo2.cpu().double(), xr.grad, rtol=tol, atol=4 * tol)
+
+
+def test_upsample_stencil_kat(ops):
+    """tf.image.resize half-pixel stencil on i^2: [0, .25, .75, 1.75, ...]."""
+    H = 8
+    v = (torch.arange(H, dtype=torch.float32) ** 2)
+    x = v[None, :, None, None].expand(1, H, H, 4).contiguous().cuda()
+    up = ops.upsample2x_fwd(x)[0, :, 0, 0].cpu()
+    want = torch.tensor([0, .25, .75, 1.75, 3.25, 5.25, 7.75, 10.75, 14.25, 18.25, 22.75, 27.75, 33.25, 39.25, 45.75, 49.0])
+    torch.testing.assert_close(up, want, rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------ conv layers: every geometry of the model
+LAYERS = [  # name, H, Cin, Cout, k, stride, act, y_f32
+    ("e1", 32, 3, 32, 6, 2, "relu", False),
+    ("e2", 16, 32, 64, 6, 2, "relu", False),
+    ("e3", 8, 64, 128, 4, 2, "relu", False),
+    ("d2", 4, 128, 128, 4, 1, "relu", False),
+    ("d3", 8, 128, 64, 4, 1, "relu", False),
+    ("d4", 16, 64, 32, 6, 1, "relu", False),
+    ("d5", 32, 32, 6, 6, 1, None, True),
+    ("e1_64", 64, 3, 32, 6, 2, "relu", False),
+    ("d5_64", 64, 32, 6, 6, 1, None, True),
+]
+
+
+def _pad_c(t, c):
+    if t.shape[-1] == c:
+        return t
+    out = torch.zeros(t.shape[:-1] + (c,), dtype=t.dtype)
+    out[..., :t.shape[-1]] = t
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_fwd_dgrad_wgrad(ops, layer, dtype):
+    name, H, Cin, Cout, k, s, act, yf32 = layer
+    rng = np.random.default_rng(sum(map(ord, name)))
+    B = 3
+    rtol, atol = (F32_RTOL, F32_ATOL) if dtype == torch.float32 else (BF16_RTOL, BF16_ATOL)
+    x = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)).to(dtype)
+    fan = k * k * (Cin + Cout)
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / fan)
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=dtype, y_f32=yf32)
+    conv.prep(w.cuda())
+    xg = _pad_c(x, conv.desc.ldx).cuda()
+    y = conv.fwd(xg, b.cuda())
+    # reference in fp64 from the SAME (rounded) operands
+    wr = w.to(dtype).double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = torch_ref.conv2d_same(xr, wr, br, s, act)
+    scale = float(yr.abs().max())
+    torch.testing.assert_close(y[..., :Cout].double().cpu(), yr.detach(), rtol=rtol, atol=atol * scale)
+    # backward: dy is the gradient w.r.t. the pre-activation (ReLU mask already applied upstream)
+    OH = yr.shape[1]
+    dy = torch.from_numpy(rng.standard_normal((B, OH, OH, Cout)).astype(np.float32)).to(dtype)
+    pre = torch_ref.conv2d_same(xr, wr, br, s, None)
+    pre.backward(dy.double())
+    dyg = _pad_c(dy, (Cout + 7) // 8 * 8).cuda()
+    dw, db = conv.wgrad(xg, dyg)
+    torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=rtol, atol=atol * float(wr.grad.abs().max()))
+    torch.testing.assert_close(db.double().cpu(), br.grad, rtol=rtol, atol=atol * float(br.grad.abs().max()))
+    if name.startswith("e1"):
+        return   # first conv: no data gradient in the model
+    mask = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)).to(dtype)
+    dx = conv.dgrad(dyg, relu_mask=_pad_c(mask, conv.desc.ldx).cuda())
+    want = xr.grad * (mask.double() > 0)
+    torch.testing.assert_close(dx[..., :Cin].double().cpu(), want, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
+    dx2 = conv.dgrad(dyg, f32_atomic=True)
+    torch.testing.assert_close(dx2[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K,N", [(2048, 256), (256, 2048), (128, 8192), (8192, 256)])
+def test_dense_as_conv(ops, K, N, dtype):
+    """Dense layers (vae/model.py:41-42,:152) are the 1x1 / H=W=1 instance of the same kernels."""
+    rng = np.random.default_rng(K + N)
+    B = 37     # ragged: not a multiple of the 128-row tile
+    rtol, atol = (F32_RTOL, F32_ATOL) if dtype == torch.float32 else (BF16_RTOL, BF16_ATOL)
+    x = torch.from_numpy(rng.standard_normal((B, 1, 1, K)).astype(np.float32)).to(dtype)
+    w = (torch.from_numpy(rng.uniform(-1, 1, (1, 1, K, N)).astype(np.float32)) * math.sqrt(6.0 / (K + N)))
+    b = torch.from_numpy(rng.standard_normal((N,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, 1, 1, K, N, 1, 1, act="relu", dtype=dtype)
+    conv.prep(w.cuda())
+    y = conv.fwd(x.cuda(), b.cuda())
+    wr = w.to(dtype).double()[0, 0].requires_grad_(True)
+    xr = x.double()[:, 0, 0].requires_grad_(True)
+    pre = xr @ wr + b.double()
+    torch.testing.assert_close(y[:, 0, 0].double().cpu(), F.relu(pre).detach(), rtol=rtol, atol=atol * float(pre.abs().max()))
+    dy = torch.from_numpy(rng.standard_normal((B, 1, 1, N)).astype(np.float32)).to(dtype)
+    pre.backward(dy.double()[:, 0, 0])
+    dw, db = conv.wgrad(x.cuda(), dy.cuda())
+    torch.testing.assert_close(dw[0, 0].double().cpu(), wr.grad, rtol=rtol, atol=atol * float(wr.grad.abs().max()))
+    dx = conv.dgrad(dy.cuda(), f32_atomic=True)
+    torch.testing.assert_close(dx[:, 0, 0].double().cpu(), xr.grad, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
