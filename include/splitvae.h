@@ -143,8 +143,15 @@ int sv_lgvae_plan_bind(sv_lgvae_plan* plan, void* workspace, int64_t bytes, void
 /* byte offset/size of a named workspace buffer (for zero-copy views of outputs); <0 if unknown */
 int sv_lgvae_buffer(const sv_lgvae_plan* plan, const char* name, int64_t* offset, int64_t* bytes);
 
-enum { SV_PHASE_PREP = 1, SV_PHASE_FORWARD = 2, SV_PHASE_LOSS = 4, SV_PHASE_BWD_DECODERS = 8,
-       SV_PHASE_BWD_ENCODERS = 16, SV_PHASE_ADAM = 32, SV_PHASE_ALL = 63 };
+enum { SV_PHASE_PREP = 1,           /* fp32 master weights -> MFMA-ready images */
+       SV_PHASE_FWD_ENCODERS = 2,   /* split/pad, e1-e3, heads, reparameterisation + KL */
+       SV_PHASE_FWD_DECODERS = 4,   /* d1-d5 of both decoders from the latents in `zcat` */
+       SV_PHASE_LOSS = 8,           /* ELBO terms (+ their gradients and grad zeroing when grads != NULL) */
+       SV_PHASE_BWD_DECODERS = 16,  /* fills the decoder_x / decoder_x_hat gradient ranges */
+       SV_PHASE_BWD_ENC_HEADS = 32, /* reparam adjoint, e4_mean/e4_sd gradients, dgrad into a3 */
+       SV_PHASE_BWD_ENC_CONVS = 64, /* e3, e2, e1 gradients */
+       SV_PHASE_ADAM = 128,
+       SV_PHASE_FORWARD = 6, SV_PHASE_BACKWARD = 112, SV_PHASE_ALL = 255 };
 
 typedef struct {
   float* params;            /* flat fp32 [param_count] */
@@ -167,6 +174,8 @@ int sv_lgvae_step(sv_lgvae_plan* plan, const sv_lgvae_step_args* a, void* stream
 
 /* per-kernel hipEvent timing (bench roofline): enable, run steps, read average ms per launch */
 int sv_lgvae_profile_enable(sv_lgvae_plan* plan, int32_t enable);
+/* restrict the event brackets to launches whose label equals `name` (NULL or "" = all launches) */
+int sv_lgvae_profile_filter(sv_lgvae_plan* plan, const char* name);
 int sv_lgvae_profile_read(sv_lgvae_plan* plan, int32_t max_entries, char names[][64],
                           double* total_ms, int32_t* launches, double* flops_per_launch,
                           double* bytes_per_launch);

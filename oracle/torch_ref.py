@@ -157,7 +157,7 @@ class RefTrainer:
         fwd, losses, g = self.grads(images, eps_x, eps_x_hat)
         self.t += 1
         keras_adam_(self.params, g, self.m, self.v, self.t, self.lr)
-        return {k: float(val) for k, val in losses.items()}, g
+        return {k: float(val.detach()) for k, val in losses.items()}, g
 
 
 def scramble_batch(x, perm, size):

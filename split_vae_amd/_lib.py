@@ -11,8 +11,9 @@ LIB_PATH = os.path.join(_HERE, "libsplitvae_hip.so")
 
 SV_F32, SV_BF16 = 0, 1
 SV_ACT_NONE, SV_ACT_RELU = 0, 1
-PHASE_PREP, PHASE_FORWARD, PHASE_LOSS, PHASE_BWD_DECODERS, PHASE_BWD_ENCODERS, PHASE_ADAM = 1, 2, 4, 8, 16, 32
-PHASE_ALL = 63
+PHASE_PREP, PHASE_FWD_ENCODERS, PHASE_FWD_DECODERS, PHASE_LOSS = 1, 2, 4, 8
+PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM = 16, 32, 64, 128
+PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
 PHASE_INFER = PHASE_PREP | PHASE_FORWARD
 
 STATUS = {0: "SV_OK", -1: "SV_E_BADARG", -2: "SV_E_UNSUPPORTED", -3: "SV_E_WORKSPACE", -4: "SV_E_STATE"}
@@ -70,6 +71,7 @@ SYMBOLS = {
     "sv_lgvae_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "sv_lgvae_step": (C.c_int, [_vp, C.POINTER(StepArgs), _vp]),
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
+    "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),
     "sv_lgvae_profile_read": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 

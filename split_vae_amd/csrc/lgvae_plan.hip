@@ -100,6 +100,7 @@ struct sv_lgvae_plan {
   int64_t arena_elems;
   // profiling
   bool prof_on;
+  std::string prof_filter;
   std::vector<ProfEntry> prof;
   std::map<std::string, int> profidx;
   std::vector<ProfPending> pending;
@@ -126,6 +127,7 @@ namespace {
 struct Scope {   // hipEvent bracket around one launch when profiling is on
   sv_lgvae_plan* p; hipStream_t st; int entry; hipEvent_t a, b; bool on;
   Scope(sv_lgvae_plan* p_, hipStream_t st_, const std::string& name, double flops, double bytes) : p(p_), st(st_), on(p_->prof_on) {
+    if (on && !p->prof_filter.empty() && p->prof_filter != name) on = false;
     if (!on) return;
     auto it = p->profidx.find(name);
     if (it == p->profidx.end()) {
@@ -136,15 +138,15 @@ struct Scope {   // hipEvent bracket around one launch when profiling is on
     auto get = [&]() {
       hipEvent_t e;
       if (!p->event_pool.empty()) { e = p->event_pool.back(); p->event_pool.pop_back(); }
-      else hipEventCreate(&e);
+      else (void)hipEventCreate(&e);
       return e;
     };
     a = get(); b = get();
-    hipEventRecord(a, st);
+    (void)hipEventRecord(a, st);
   }
   ~Scope() {
     if (!on) return;
-    hipEventRecord(b, st);
+    (void)hipEventRecord(b, st);
     p->pending.push_back(ProfPending{entry, a, b});
   }
 };
@@ -360,16 +362,16 @@ static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
                           (int)p->jobs.size(), p->prep_blocks, st);
 }
 
-static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_enc, bool do_dec, hipStream_t st) {
   const sv_lgvae_desc& d = p->d;
   const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
   const char* en[2] = {"x", "xh"};
-  {
+  if (do_enc) {
     Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
     SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
   }
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
     const int L = e == 0 ? Lg : Ll;
     SV_TRY(run_fwd_layer(p, p->enc[e][0], p->bp("in8_" + sfx), s->params, p->bp("a1_" + sfx), st));
@@ -400,7 +402,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStrea
                                  (float*)p->bp("kl_" + sfx), B, L, s->seed, s->step, e, s->sample_offset, st));
     }
   }
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2 && do_dec; ++k) {
     const std::string sfx = en[k];
     const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
     SV_TRY(run_fwd_layer(p, p->dec[k][0], zin, s->params, p->bp("h1_" + sfx), st));
@@ -481,13 +483,13 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
   return SV_OK;
 }
 
-static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_heads, bool do_convs, hipStream_t st) {
   const sv_lgvae_desc& d = p->d;
   const int B = d.B, dt = d.dtype;
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
   const char* en[2] = {"x", "xh"};
   const float kl_scale = d.beta / (float)B;
-  {
+  if (do_heads) {
     Scope sc(p, st, "reparam_kl_bwd", 0, 0);
     SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x"), Lc, nullptr, 0, (const float*)p->bp("z_mean_x"),
                              (const float*)p->bp("z_sig_x"), (const float*)p->bp("eps_x"), kl_scale, p->bp("ghead_x"),
@@ -501,7 +503,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     Layer* L = p->enc[e];
     const int Lh = e == 0 ? Lg : Ll;
     // head: two Keras kernels/biases -> two wgrad launches on column halves of ghead
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2 && do_heads; ++h) {
       WgradArgs a;
       svg_wgrad_args(&L[3].d, &a);
       a.A = p->bp("a3_" + sfx);
@@ -512,7 +514,8 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
       Scope sc(p, st, "wgrad.head", conv_flops(L[3].d) / 2, 0);
       SV_TRY(svk_wgrad(a, dt, svg_pick_cfg(Lh), st));
     }
-    SV_TRY(run_dgrad_layer(p, L[3], p->bp("ghead_" + sfx), p->bp("a3_" + sfx), p->bp("ga3_" + sfx), false, st));
+    if (do_heads) SV_TRY(run_dgrad_layer(p, L[3], p->bp("ghead_" + sfx), p->bp("a3_" + sfx), p->bp("ga3_" + sfx), false, st));
+    if (!do_convs) continue;
     SV_TRY(run_wgrad_layer(p, L[2], p->bp("a2_" + sfx), p->bp("ga3_" + sfx), s->grads, st));
     SV_TRY(run_dgrad_layer(p, L[2], p->bp("ga3_" + sfx), p->bp("a2_" + sfx), p->bp("ga2_" + sfx), false, st));
     SV_TRY(run_wgrad_layer(p, L[1], p->bp("a1_" + sfx), p->bp("ga2_" + sfx), s->grads, st));
@@ -568,8 +571,8 @@ extern "C" int sv_lgvae_plan_create(const sv_lgvae_desc* d, sv_lgvae_plan** out)
 
 extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   if (!p) return;
-  for (auto& pe : p->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
-  for (auto e : p->event_pool) hipEventDestroy(e);
+  for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+  for (auto e : p->event_pool) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -605,12 +608,12 @@ extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void
   if (!p->bound) return SV_E_STATE;
   hipStream_t st = (hipStream_t)stream;
   const int ph = s->phases;
-  const bool train = ph & (SV_PHASE_BWD_DECODERS | SV_PHASE_BWD_ENCODERS);
-  if ((ph & (SV_PHASE_PREP | SV_PHASE_FORWARD | SV_PHASE_ADAM | SV_PHASE_BWD_DECODERS | SV_PHASE_BWD_ENCODERS)) && !s->params) return SV_E_BADARG;
-  if ((ph & (SV_PHASE_FORWARD | SV_PHASE_LOSS)) && !s->images6) return SV_E_BADARG;
+  const bool train = ph & SV_PHASE_BACKWARD;
+  if ((ph & (SV_PHASE_PREP | SV_PHASE_FORWARD | SV_PHASE_ADAM | SV_PHASE_BACKWARD)) && !s->params) return SV_E_BADARG;
+  if ((ph & (SV_PHASE_FWD_ENCODERS | SV_PHASE_LOSS)) && !s->images6) return SV_E_BADARG;
   if (train && !s->grads) return SV_E_BADARG;
   if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
-  if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, st));
+  if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, ph & SV_PHASE_FWD_ENCODERS, ph & SV_PHASE_FWD_DECODERS, st));
   if (ph & SV_PHASE_LOSS) {
     if (s->grads) {
       Scope sc(p, st, "zero_grads", 0, (double)p->nparams * 4);
@@ -619,7 +622,8 @@ extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void
     SV_TRY(phase_loss(p, s, s->grads != nullptr, st));
   }
   if (ph & SV_PHASE_BWD_DECODERS) SV_TRY(phase_bwd_decoders(p, s, st));
-  if (ph & SV_PHASE_BWD_ENCODERS) SV_TRY(phase_bwd_encoders(p, s, st));
+  if (ph & (SV_PHASE_BWD_ENC_HEADS | SV_PHASE_BWD_ENC_CONVS))
+    SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st));
   if (ph & SV_PHASE_ADAM) {
     if (!s->grads || !s->adam_m || !s->adam_v) return SV_E_BADARG;
     Scope sc(p, st, "adam_step", 0, (double)p->nparams * 28);
@@ -641,11 +645,17 @@ extern "C" int sv_lgvae_profile_enable(sv_lgvae_plan* p, int32_t enable) {
   return SV_OK;
 }
 
+extern "C" int sv_lgvae_profile_filter(sv_lgvae_plan* p, const char* name) {
+  if (!p) return SV_E_BADARG;
+  p->prof_filter = name ? name : "";
+  return SV_OK;
+}
+
 extern "C" int sv_lgvae_profile_read(sv_lgvae_plan* p, int32_t max_entries, char names[][64], double* total_ms,
                                      int32_t* launches, double* flops_per_launch, double* bytes_per_launch) {
   if (!p) return SV_E_BADARG;
   for (auto& pe : p->pending) {
-    hipEventSynchronize(pe.b);
+    (void)hipEventSynchronize(pe.b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
       p->prof[pe.entry].total_ms += ms;

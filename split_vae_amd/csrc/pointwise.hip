@@ -117,12 +117,17 @@ __device__ __forceinline__ void dll_elem(float x, float m, float ls, float& nll,
     dm = -s * sq;
     dls = -q * sq;
   } else {
-    const float delta = sp - sq;
+    // cdf_delta = sigmoid(p) - sigmoid(q) without cancellation: with d = p - q = 2*s/255 > 0,
+    //   sigmoid(p) - sigmoid(q) = sigmoid(p) * (1 - sigmoid(q)) * (1 - exp(-d))
+    // (every factor is computed to full relative precision; the reference's direct difference of two
+    // fp32 sigmoids loses up to ~1e-3 relative in the saturated tails).
+    const float d = s * (2.f / 255.f);
+    const float delta = sp * sqc * (-expm1f(-d));
     if (delta > 1e-5f) {
-      const float inv = 1.f / delta;   // max(delta,1e-12) == delta here
-      nll = -logf(delta);
-      dm = s * (dsp - dsq) * inv;
-      dls = (p * dsp - q * dsq) * inv;
+      nll = -logf(delta);              // max(delta,1e-12) == delta here
+      // d/dm log(delta) = s*(sigmoid(q) - (1-sigmoid(p))) ; d/dls = -p(1-sig(p)) + q sig(q) - d/expm1(d)
+      dm = s * (spc - sq);
+      dls = p * spc - q * sq + d / expm1f(d);
     } else {                      // log_pdf_mid - log(127.5)
       const float mid = s * c;
       float sm, smc, dsm;

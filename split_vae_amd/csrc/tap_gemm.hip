@@ -185,7 +185,7 @@ static int launch_tap(const TapGemmArgs& a, hipStream_t st) {
   const size_t lds = 2 * BM * 128 + 2 * BN * 128 + SV_MAX_TAPS * 3 * sizeof(int);
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation (idempotent)
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, a);

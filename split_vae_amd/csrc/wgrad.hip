@@ -204,7 +204,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   dim3 grid((a.Nrows + BR - 1) / BR, (a.N + BNW - 1) / BNW, (a.M + a.msplit - 1) / a.msplit), block(256);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)wgrad_kernel<T, WR, WC, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WR, WC, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_kernel<T, WR, WC, CF>), grid, block, lds, st, a);

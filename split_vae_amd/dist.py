@@ -1,0 +1,90 @@
+"""Data parallelism for the SPLIT-VAE step: one process per GPU, gradients averaged with
+all-reduce over RCCL/xGMI (torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" on CPU tests).
+
+The reference has no distributed code.  The step shards over the batch axis: every
+per-image quantity is independent and the loss is a batch mean (vae/trainer.py:13,:127-128), so
+the global-batch gradient is the mean of equal-sized shard gradients.  The flat fp32 gradient
+buffer is reduced in buckets that follow backward completion order, each launched on RCCL's own
+stream as soon as the phase that fills it has been enqueued, so the transfers overlap the rest of
+the backward pass.  The 1/world factor is applied inside the Adam kernel (grad_scale).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(global_batch, rank, world):
+    """Contiguous equal slices of the global batch; sample_offset keys the per-sample RNG so a
+    1-GPU run and an N-GPU run draw identical eps / permutations for the same global sample."""
+    if global_batch % world:
+        raise ValueError("global batch %d is not divisible by world size %d (equal shards are what makes "
+                         "mean-of-shard-gradients == global-batch gradient)" % (global_batch, world))
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def param_buckets(param_table, n_params):
+    """Element ranges of the flat buffer in backward-completion order:
+    [decoder_x + decoder_x_hat] -> [both encoder heads (e4_mean, e4_sd)] -> [encoder convs]."""
+    def span(pred):
+        rs = []
+        for i, (name, off, shape) in enumerate(param_table):
+            if not pred(name):
+                continue
+            end = param_table[i + 1][1] if i + 1 < len(param_table) else n_params
+            if rs and rs[-1][1] == off:
+                rs[-1] = (rs[-1][0], end)
+            else:
+                rs.append((off, end))
+        return rs
+    dec = span(lambda n: n.startswith("decoder"))
+    heads = span(lambda n: n.startswith("encoder") and "/e4_" in n)
+    convs = span(lambda n: n.startswith("encoder") and "/e4_" not in n)
+    covered = sum(e - b for rs in (dec, heads, convs) for b, e in rs)
+    assert covered == n_params, (covered, n_params)
+    return {"decoders": dec, "enc_heads": heads, "enc_convs": convs}
+
+
+class GradReducer:
+    """Bucketed asynchronous all-reduce(sum) of a flat gradient buffer."""
+
+    def __init__(self, param_table, n_params, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        self.buckets = param_buckets(param_table, n_params)
+        self._pending = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def launch(self, flat, bucket):
+        """Enqueue the all-reduce of one bucket (call right after the phase that produced it)."""
+        if self.world == 1:
+            return
+        for b, e in self.buckets[bucket]:
+            self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Make the compute stream wait for every outstanding bucket (no host sync on nccl)."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []

@@ -214,6 +214,9 @@ class LGVaePlan:
     def profile_enable(self, on=True):
         check(self.lib.sv_lgvae_profile_enable(self.handle, 1 if on else 0), "sv_lgvae_profile_enable")
 
+    def profile_filter(self, name=None):
+        check(self.lib.sv_lgvae_profile_filter(self.handle, (name or "").encode()), "sv_lgvae_profile_filter")
+
     def profile_read(self, max_entries=128):
         names = ((C.c_char * 64) * max_entries)()
         ms = (C.c_double * max_entries)()

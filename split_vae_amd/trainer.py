@@ -1,0 +1,149 @@
+"""Host-side mirror of vae/trainer.py for the SPLIT-VAE path: train_step_lg_vae / test_step_lg_vae
+(vae/trainer.py:120-144, :199-233) and the loop of train_local_global_autoencoder (:72-421).
+
+The step itself (forward, ELBO, backward, Keras-Adam, the 5 running means of :140-144) is one
+native call into libsplitvae_hip.so; with torch.distributed initialised the call is split at the
+phase boundaries so the RCCL gradient all-reduce overlaps the remaining backward work.
+"""
+import os
+import time
+from datetime import datetime
+
+import torch
+
+from . import dist as svdist
+from ._lib import (PHASE_ADAM, PHASE_ALL, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS,
+                   PHASE_FORWARD, PHASE_LOSS, PHASE_PREP)
+from .model import LGVae
+
+METRIC_NAMES = ["x_recon_loss", "x_kl_loss", "x_hat_recon_loss", "x_hat_kl_loss", "total_kl_loss"]
+
+
+class StepMetrics:
+    """The five tf.keras.metrics.Mean of vae/trainer.py:99-113 that train_step_lg_vae updates;
+    sums and count live on the device and are read back only by result()."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    def _acc(self):
+        return self.plan.buffer("metric_acc", torch.float32, (8,))
+
+    def result(self):
+        a = self._acc().cpu()
+        n = max(float(a[5]), 1.0)
+        return {k: float(a[i]) / n for i, k in enumerate(METRIC_NAMES)}
+
+    def reset_states(self, names=None):
+        a = self._acc()
+        if names is None:
+            a.zero_()
+        else:   # the reference resets only some of its means (vae/trainer.py:405-414)
+            for n in names:
+                a[METRIC_NAMES.index(n)] = 0
+
+
+def last_losses(plan):
+    """x_recon, x_kl, x_hat_recon, x_hat_kl, total_kl, total of the most recent step (device -> host)."""
+    l = plan.buffer("losses", torch.float32, (8,)).cpu()
+    return {k: float(l[i]) for i, k in enumerate(METRIC_NAMES + ["total_loss"])}
+
+
+def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0, accumulate_metrics=True):
+    """train_step_lg_vae (vae/trainer.py:120-144): forward, total = recon_x + recon_x_hat +
+    beta*KL, gradients of the 40 variables, Adam update, metric update.  `images` [B,H,W,6] fp32
+    on the device.  eps=(eps_x, eps_x_hat) pins the Sampling noise; default = Philox stream."""
+    if not isinstance(model, LGVae):
+        raise NotImplementedError("only LGVae (SPLIT-VAE) is on this path; LGGMVae/GMVae are next rows (SURVEY 8f)")
+    B = images.shape[0]
+    plan = model.plan(B)
+    m, v = optimizer.slots(model.flat)
+    lr = optimizer.lr()
+    optimizer.iterations += 1
+    ex, eh = (None, None) if eps is None else eps
+    kw = dict(params=model.flat, grads=model.grad_flat, adam_m=m, adam_v=v, images6=images, eps_x=ex, eps_x_hat=eh,
+              seed=model.seed, step=model._calls, sample_offset=sample_offset, lr=lr, beta1=optimizer.beta_1,
+              beta2=optimizer.beta_2, adam_eps=optimizer.epsilon, t=optimizer.iterations,
+              accumulate_metrics=accumulate_metrics)
+    model._calls += 1
+    if reducer is None or reducer.world == 1:
+        plan.step(PHASE_ALL, **kw)
+        return plan
+    # data parallel: launch each bucket's all-reduce as soon as the phase that fills it is enqueued
+    plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS, **kw)
+    reducer.launch(model.grad_flat, "decoders")
+    plan.step(PHASE_BWD_ENC_HEADS, **kw)
+    reducer.launch(model.grad_flat, "enc_heads")
+    plan.step(PHASE_BWD_ENC_CONVS, **kw)
+    reducer.launch(model.grad_flat, "enc_convs")
+    reducer.wait()
+    plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
+    return plan
+
+
+def test_step(model, images, labels=None, eps=None):
+    """test_step_lg_vae (vae/trainer.py:199-233) without the classifier branches (:213-226: the
+    probe classifier's weights are not in the reference repo, .MISSING_LARGE_BLOBS:1)."""
+    if labels is not None:
+        raise NotImplementedError("classifier-based metrics need svhn_classifier_weights.h5 (missing upstream)")
+    B = images.shape[0]
+    plan = model.plan(B)
+    ex, eh = (None, None) if eps is None else eps
+    plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS, params=model.flat, images6=images, eps_x=ex, eps_x_hat=eh,
+              seed=model.seed ^ 0x7e57, step=model._calls)
+    model._calls += 1
+    return last_losses(plan)
+
+
+test_step.__test__ = False   # not a pytest test
+
+
+def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, test_dataset, config):
+    """Loop of vae/trainer.py:72-421 for LGVae: train; every 10 000 steps (incl. step 0) evaluate
+    on the test set and print the reference's report; stop after training_steps; save weights.
+    The PNG grids of vae/visualizer.py are outside the path."""
+    RUN_NAME = datetime.now().strftime("%Y%m%d-%H%M%S")
+    model.beta = float(config.beta)
+    os.makedirs("models", exist_ok=True)
+    metrics = None
+    start = time.time()
+    log_every = int(config.get("log_every") or 10000)
+    for step, train_data in enumerate(train_dataset):
+        images = train_data[0] if config.label else train_data
+        plan = train_step(model, images, optimizer)
+        if metrics is None:
+            metrics = StepMetrics(plan)
+        if step % log_every == 0:
+            torch.cuda.synchronize()
+            print('Training time: {:.2f}'.format(time.time() - start))
+            start = time.time()
+            sums, n = dict.fromkeys(METRIC_NAMES, 0.0), 0
+            for test_data in test_dataset:
+                timg = test_data[0] if config.label else test_data
+                l = test_step(model, timg)
+                for k in METRIC_NAMES:
+                    sums[k] += l[k]
+                n += 1
+            te = {k: sums[k] / max(n, 1) for k in METRIC_NAMES}
+            print('Testing time: {:.2f}'.format(time.time() - start))
+            tr = metrics.result()
+            template = ('Training step {}\n'
+                        '            X Recon Loss: {:.4f}, X KLD loss: {:.4f}, Total X loss: {:.4f} \n'
+                        '            X hat Recon Loss: {:.4f}, X hat KLD loss: {:.4f}, Total X hat loss: {:.4f} \n'
+                        '            Test X Recon Loss: {:.4f}, Test X KLD loss: {:.4f}, Test Total X loss: {:.4f} \n'
+                        '            Test X hat Recon Loss: {:.4f}, Test X hat KLD loss: {:.4f}, Test Total X hat loss: {:.4f}\n'
+                        '            Total KL train loss: {:.4f}, Total KL test loss: {:.4f}')
+            print(template.format(step, tr["x_recon_loss"], tr["x_kl_loss"], tr["x_recon_loss"] + tr["x_kl_loss"],
+                                  tr["x_hat_recon_loss"], tr["x_hat_kl_loss"], tr["x_hat_recon_loss"] + tr["x_hat_kl_loss"],
+                                  te["x_recon_loss"], te["x_kl_loss"], te["x_recon_loss"] + te["x_kl_loss"],
+                                  te["x_hat_recon_loss"], te["x_hat_kl_loss"], te["x_hat_recon_loss"] + te["x_hat_kl_loss"],
+                                  tr["total_kl_loss"], te["total_kl_loss"]))
+            # vae/trainer.py:405-414 resets x_recon / x_kl / total_kl but never the x_hat_* means
+            metrics.reset_states(["x_recon_loss", "x_kl_loss", "total_kl_loss"])
+            start = time.time()
+        if step >= config.training_steps:
+            print('Training done!')
+            break
+    path = 'models/' + RUN_NAME
+    model.save_weights(path)
+    return path + ".npz"
