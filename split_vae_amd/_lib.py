@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsplitvae_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("SV_LIB_NAME", "libsplitvae_hip.so"))   # override: kernel A/B builds
 
 SV_F32, SV_BF16 = 0, 1
 SV_ACT_NONE, SV_ACT_RELU = 0, 1

@@ -6,8 +6,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsplitvae_hip.so")
-SOURCES = ["pointwise.hip", "tap_gemm.hip", "wgrad.hip", "conv_api.hip", "lgvae_plan.hip"]
+LIB = os.path.join(HERE, os.environ.get("SV_LIB_NAME", "libsplitvae_hip.so"))
+OBJ_TAG = os.environ.get("SV_OBJ_TAG", "")          # build variants side by side (kernel A/B experiments)
+EXTRA = os.environ.get("SV_EXTRA_FLAGS", "").split()
+SOURCES = ["pointwise.hip", "tap_gemm.hip", "tile_conv.hip", "wgrad.hip", "wgrad_tile.hip", "conv_api.hip", "lgvae_plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=off"]
 
@@ -26,10 +28,10 @@ def build(force=False, verbose=True):
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", OBJ_TAG + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -13,13 +13,47 @@
 template <typename T>
 __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
                                            T* __restrict__ arena, int block_in_job) {
-  const int64_t total = (int64_t)j.rows * j.ntaps * j.inner;
-  const int64_t idx = (int64_t)block_in_job * 256 + threadIdx.x;
+  if (j.ntaps == 1 && !j.transpose) {
+    // dense forward image dst[co][ci] = src[ci][co]: 32x32 tiles through LDS so that both the fp32
+    // reads (contiguous in co) and the low-precision writes (contiguous in ci) are coalesced
+    __shared__ float tile[32][33];
+    const int tr = (j.rows + 31) / 32;
+    const int r0 = (block_in_job % tr) * 32, c0 = (block_in_job / tr) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, row = r0 + tx;
+      tile[ty + 8 * k][tx] = (row < j.Cout && c < j.Cin) ? params[j.src_off + (int64_t)c * j.Cout + row] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = r0 + ty + 8 * k, c = c0 + tx;
+      if (row < j.rows && c < j.inner)
+        arena[j.dst_off + (int64_t)row * j.inner_ld + j.inner_off + c] = from_f32<T>(tile[tx][ty + 8 * k]);
+    }
+    return;
+  }
+  if (j.transpose && !(j.inner & 3) && !(j.Cout & 3) && !(j.inner_off & 3) && !(j.inner_ld & 3)) {
+    // dgrad images are contiguous in co on both sides: 4 channels per thread (one 16-B fp32 load)
+    const int q4 = j.inner >> 2;
+    const int total4 = j.rows * j.ntaps * q4;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int c = (idx % q4) << 2, t2 = idx / q4, t = t2 % j.ntaps, row = t2 / j.ntaps;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < j.Cin && c < j.Cout) v = *(const float4*)(params + j.src_off + ((int64_t)j.srctap[t] * j.Cin + row) * j.Cout + c);
+    T* d = arena + j.dst_off + ((int64_t)row * j.ntaps + t) * j.inner_ld + j.inner_off + c;
+    d[0] = from_f32<T>(v.x); d[1] = from_f32<T>(v.y); d[2] = from_f32<T>(v.z); d[3] = from_f32<T>(v.w);
+    return;
+  }
+  const int total = j.rows * j.ntaps * j.inner;
+  const int idx = block_in_job * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int c = (int)(idx % j.inner);
-  const int64_t t2 = idx / j.inner;
-  const int t = (int)(t2 % j.ntaps);
-  const int row = (int)(t2 / j.ntaps);
+  const int c = idx % j.inner;
+  const int t2 = idx / j.inner;
+  const int t = t2 % j.ntaps;
+  const int row = t2 / j.ntaps;
   float v = 0.f;
   const int st = j.srctap[t];
   if (!j.transpose) {
@@ -198,7 +232,7 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
   j->inner_ld = j->inner; j->inner_off = 0;
   j->transpose = 0;
   for (int t = 0; t < j->ntaps; ++t) j->srctap[t] = (uint8_t)t;
-  j->nblocks = (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+  j->nblocks = svg_prep_nblocks(j);
 }
 
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
@@ -212,7 +246,7 @@ void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
   j->inner = svg_gdy(d);
   j->inner_ld = j->inner; j->inner_off = 0;
   j->transpose = 1;
-  j->nblocks = (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+  j->nblocks = svg_prep_nblocks(j);
 }
 
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
@@ -264,7 +298,7 @@ extern "C" int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const vo
   TapGemmArgs a;
   svg_fwd_args(d, &a);
   a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
-  return svk_tap_gemm(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
 }
 
 extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
@@ -284,7 +318,7 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
       a.out_f32 = 1;
       a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
     }
-    rc = svk_tap_gemm(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
+    rc = svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
     if (rc) return rc;
     off += svg_wprep_elems_class(d, 1, c);
   }
@@ -299,5 +333,5 @@ extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const 
   WgradArgs a;
   svg_wgrad_args(d, &a);
   a.A = x; a.dY = dy; a.dW = dw; a.dbias = dbias;
-  return svk_wgrad(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  return svk_wgrad_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
 }

@@ -37,6 +37,12 @@ static inline int svg_choose_splitk(int M, int N, int nk) {
   return s < 1 ? 1 : s;
 }
 
+// blocks of 256 threads for one weight-preparation job (dense forward images use 32x32 LDS tiles)
+static inline int svg_prep_nblocks(const PrepJob* j) {
+  if (j->ntaps == 1 && !j->transpose) return ((j->rows + 31) / 32) * ((j->inner + 31) / 32);
+  return (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+}
+
 int svg_check(const sv_conv_desc* d);
 void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a);
 int svg_dgrad_classes(const sv_conv_desc* d);

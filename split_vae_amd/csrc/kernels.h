@@ -31,6 +31,26 @@ struct TapGemmArgs {
 // cfg: 0 = 128x128 tile, 1 = 128x64, 2 = 256x32, 3 = 256x16
 int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st);
 
+// ---- direct conv with the input tile resident in LDS (tile_conv.hip); planned from a TapGemmArgs
+struct TileConvArgs {
+  const void* A; const void* Wt; const float* bias; void* out; const void* mask;
+  int B, IH, IW, lda;
+  int cl2, P, Ktot, S;
+  int lTW, lTH, lNB;          // log2 tile width / height (iteration-grid pixels) / images per tile
+  int OY, OX, tilesX, tilesY, ntiles;
+  int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
+  int PS;                     // bytes per pixel in the LDS tile
+  int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
+  int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
+  int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
+  int8_t dy[SV_MAX_TAPS];
+  int8_t dx[SV_MAX_TAPS];
+};
+bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out);
+int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st);
+// picks the direct kernel when the problem fits it, the im2col tap GEMM otherwise
+int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st);
+
 // ---- weight gradient: dW[(t,ci)][co] += sum_m A[pix(m)+tap t, ci] * dY[m, co]; dbias += colsum(dY)
 struct WgradArgs {
   const void* A;      // [B, IH, IW, lda]
@@ -47,6 +67,22 @@ struct WgradArgs {
 };
 // cfg: 0 = 64 wrows x 128 cols, 1 = 128 x 64, 2 = 256 x 32, 3 = 256 x 16
 int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st);
+
+// ---- weight gradient with LDS-resident input/dY tiles (wgrad_tile.hip, bf16); planned from WgradArgs
+struct WgradTileArgs {
+  const void* A; const void* dY; float* dW; float* dbias;
+  int B, IH, IW, lda, cl2, S;
+  int lTW, lTH, lNB, OY, OX, tilesX, tilesY, ntiles;
+  int TIW, TIH, y_lo, x_lo, PS;
+  int ldy, YS, lycp;        // dY channels per pixel; bytes per dY pixel in LDS; log2(16-B pieces per dY pixel)
+  int in_bytes, dy_bytes;
+  int Cin_real, N, ntaps;
+  int8_t dy[SV_MAX_TAPS];
+  int8_t dx[SV_MAX_TAPS];
+};
+int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
+// tile kernel when the layer has an instantiation (bf16), im2col kernel otherwise
+int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st);
 
 // ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
 struct PrepJob {

@@ -226,7 +226,7 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
         j.ntaps = 1; j.Cin = F; j.Cout = Lh; j.rows = Lh; j.inner = F; j.inner_ld = F; j.inner_off = 0;
         j.transpose = 0; j.srctap[0] = 0;
         j.dst_off = arena + (int64_t)h * Lh * F;
-        j.nblocks = (int)(((int64_t)j.rows * j.inner + 255) / 256);
+        j.nblocks = svg_prep_nblocks(&j);
         push(j);
       }
       arena += (int64_t)L2 * F;
@@ -238,7 +238,7 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
         j.ntaps = 1; j.Cin = F; j.Cout = Lh; j.rows = F; j.inner = Lh; j.inner_ld = L2; j.inner_off = h * Lh;
         j.transpose = 1; j.srctap[0] = 0;
         j.dst_off = arena;
-        j.nblocks = (int)(((int64_t)j.rows * j.inner + 255) / 256);
+        j.nblocks = svg_prep_nblocks(&j);
         push(j);
       }
       arena += (int64_t)F * L2;
@@ -323,7 +323,7 @@ static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float*
   a.bias = params + p->params[L.bparam].off;
   a.out = y;
   Scope sc(p, st, "fwd." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
-  return svk_tap_gemm(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+  return svk_conv_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
 }
 
 static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const void* mask, void* dx, bool f32_atomic,
@@ -341,7 +341,7 @@ static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const voi
       a.out_f32 = 1;
       a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
     }
-    SV_TRY(svk_tap_gemm(a, L.d.dtype, svg_pick_cfg(L.d.Cin), st));
+    SV_TRY(svk_conv_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cin), st));
   }
   return SV_OK;
 }
@@ -353,7 +353,7 @@ static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void
   a.dW = grads + p->params[L.kparam].off;
   a.dbias = grads + p->params[L.bparam].off;
   Scope sc(p, st, "wgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
-  return svk_wgrad(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+  return svk_wgrad_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
 }
 
 static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {

@@ -1,0 +1,336 @@
+// Direct NHWC convolution on the gfx950 matrix cores with the input tile resident in LDS.
+//
+// The im2col "tap GEMM" (tap_gemm.hip) re-gathers every input pixel once per tap (16-36x) through
+// L2.  Here a workgroup stages its input SPATIAL tile (+ halo, SAME padding zero-filled) into LDS
+// ONCE with coalesced 16-B loads and every tap's MFMA A-fragment is a shifted window of that tile:
+//     A-frag(lane) = lds[ lane_pixel_base + piece_offset[p] ],   p = (tap, 16-B channel chunk)
+// so the only per-K-step global traffic is the (L2-resident) weight tile.  Rows of the implicit
+// GEMM are the pixels of a TH x TW patch of NB images (TW = min(W,16) so a 16-row MFMA fragment is
+// 16 neighbouring pixels); input stride 1 (decoder convs, all dgrads) or 2 (encoder forwards);
+// outputs may be scattered with stride/offset (parity classes of a stride-2 dgrad).
+//
+// Weight pipeline: K advances in 128-byte (8-piece) steps, weight tile of step ks+1 prefetched
+// global -> registers during step ks and written to the other LDS buffer.  (A 3-slot ring with a
+// two-step prefetch was measured SLOWER: its extra 4-8 KB of LDS drops the big-tile layers from
+// two resident workgroups per CU to one, and that overlap is worth more than the latency cover.)
+#include "common.hip.h"
+#include "kernels.h"
+#include <stdlib.h>
+#include <string.h>
+
+template <typename T> struct MmaOpT;
+template <> struct MmaOpT<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaOpT<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    const float4 af = __builtin_bit_cast(float4, a), bf = __builtin_bit_cast(float4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int MF>
+__global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvArgs g) {
+  constexpr int WM = 16 * MF, BM = 4 * WM, NF = BN / 16;
+  constexpr int BRN = BN >= 32 ? BN / 32 : 1;       // weight pieces per thread per step
+  constexpr int PPS = 8;                             // 16-B pieces of K per step (128 B per channel)
+  constexpr int EPP = ElemTraits<T>::EPP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sB = smem;                                   // [2][BN][128 B], XOR-swizzled
+  int* sOff = (int*)(smem + 2 * BN * 128);           // piece offsets, padded to a multiple of 8
+  char* sIn = smem + 2 * BN * 128 + g.off_bytes;     // input tile [NB][TIH][TIW] pixels of PS bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- which tile
+  int t = blockIdx.x;
+  const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
+  const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
+  const int b0 = t << g.lNB;
+  const int n0 = blockIdx.y * BN;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB;
+  const int cpp = 1 << g.cl2;                         // 16-B chunks per pixel
+
+  // ---- weight-tile pipeline: global -> one of two register sets -> LDS ring
+  const T* __restrict__ Wb = (const T*)g.Wt;
+  const int pp = tid & 7, r0 = tid >> 3;
+  uint4 rbA[BRN];
+  auto load_b = [&](int ks, uint4 (&rb)[BRN]) {
+    const int p = ks * 8 + pp;
+    const bool pv = p < g.P;
+#pragma unroll
+    for (int i = 0; i < BRN; ++i) {
+      const int n = r0 + 32 * i;
+      rb[i] = (pv && n < BN) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * g.Ktot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto write_b = [&](int slot, const uint4 (&rb)[BRN]) {
+#pragma unroll
+    for (int i = 0; i < BRN; ++i) {
+      const int n = r0 + 32 * i;
+      if (n < BN) *(uint4*)(sB + slot * (BN * 128) + n * 128 + ((pp ^ (n & 7)) << 4)) = rb[i];
+    }
+  };
+  const int nk = (g.dbg & 2) ? 0 : (g.P + 7) >> 3;
+  load_b(0, rbA);                                     // in flight while the input tile is staged
+
+  // ---- piece-offset table
+  const int nkp = ((g.P + 7) >> 3) << 3;
+  for (int p = tid; p < nkp; p += 256) {
+    int off = 0;
+    if (p < g.P) {
+      const int tap = p >> g.cl2, c = p & (cpp - 1);
+      off = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * g.PS + c * 16;
+    }
+    sOff[p] = off;
+  }
+  // ---- stage the input tile (zero-filled outside the image)
+  if (!(g.dbg & 1)) {
+    const T* __restrict__ Ab = (const T*)g.A;
+    // LPR lanes sweep one tile row (no integer division); 4 independent 16-B loads in flight per lane
+    const int ppr = g.TIW * cpp;                      // pieces per tile row
+    const int LPR = ppr > 160 ? 64 : 32, lLPR = ppr > 160 ? 6 : 5;
+    const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = 256 >> lLPR;
+    const int nrows = NB * g.TIH;
+    const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
+    for (int row = srow; row < nrows; row += rows_pp) {
+      int bl = 0, iyl = row;
+      while (iyl >= g.TIH) { iyl -= g.TIH; ++bl; }
+      const int iy = iy_base + iyl, b = b0 + bl;
+      const bool rok = b < g.B && (unsigned)iy < (unsigned)g.IH;
+      const T* src = Ab + ((int64_t)(b * g.IH + iy) * g.IW) * g.lda;
+      char* drow = sIn + row * g.TIW * g.PS;
+      for (int pc0 = slane; pc0 < ppr; pc0 += LPR * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pc = pc0 + u * LPR;
+          const int ixl = pc >> g.cl2, c = pc & (cpp - 1), ix = ix_base + ixl;
+          v[u] = make_uint4(0, 0, 0, 0);
+          if (pc < ppr && rok && (unsigned)ix < (unsigned)g.IW) v[u] = *(const uint4*)(src + (int64_t)ix * g.lda + c * EPP);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pc = pc0 + u * LPR;
+          if (pc < ppr) *(uint4*)(drow + (pc >> g.cl2) * g.PS + (pc & (cpp - 1)) * 16) = v[u];
+        }
+      }
+    }
+  }
+  // ---- per-lane pixel bases of this wave's MF row fragments
+  const int lr = lane & 15, lg = lane >> 4;
+  int lbase[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int r = wave * WM + i * 16 + lr;
+    const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+    lbase[i] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.S) * g.PS;
+  }
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int ks, int slot) {
+    const char* cB = sB + slot * (BN * 128);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int off = sOff[ks * 8 + kk * 4 + lg];
+      uint4 af[MF], bfr[NF];
+#pragma unroll
+      for (int i = 0; i < MF; ++i) af[i] = *(const uint4*)(sIn + lbase[i] + off);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int n = j * 16 + lr;
+        bfr[j] = *(const uint4*)(cB + n * 128 + (((kk * 4 + lg) ^ (n & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) MmaOpT<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+  };
+  write_b(0, rbA);
+  __syncthreads();                                    // input tile, offsets and weight tile 0 visible
+  for (int ks = 0; ks < nk; ++ks) {
+    const bool more = ks + 1 < nk;
+    if (more) load_b(ks + 1, rbA);
+    compute(ks, ks & 1);
+    if (more) write_b((ks & 1) ^ 1, rbA);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  The MFMA D layout (col = lane&15 channel, row = (lane>>4)*4 + reg pixel) would
+  // store 2-byte scalars; instead the bias/activation'd tile is transposed through LDS and written
+  // with 16-byte (8-byte for the 6-channel fp32 head) row-contiguous stores, ReLU mask applied there.
+  const int ncols = min(BN, g.N - n0);                  // real channels of this column tile
+  const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
+  const int rowb = ncols * oesz;                        // output bytes per pixel from this tile
+  const int srow = ((rowb + 15) & ~15) + 16;            // LDS row pitch (padded)
+  char* sC = smem;                                      // reuse: every LDS read finished at the loop's last barrier
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = wave * WM + i * 16 + lg * 4 + r4;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int nl = j * 16 + lr;
+        if (nl >= ncols) continue;
+        float v = acc[i][j][r4];
+        if (g.bias) v += g.bias[n0 + nl];
+        if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
+        if (g.out_f32) *(float*)(sC + r * srow + nl * 4) = v;
+        else *(T*)(sC + r * srow + nl * (int)sizeof(T)) = from_f32<T>(v);
+      }
+    }
+  __syncthreads();
+  if (g.dbg & 4) return;
+  const int psz = (rowb & 15) ? 8 : 16;                 // piece size; rowb is a multiple of 8
+  const int ppr_o = rowb / psz;
+  for (int q = tid; q < BM * ppr_o; q += 256) {
+    const int r = q / ppr_o, c = q - r * ppr_o;
+    const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+    const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
+    if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
+    const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+    const int64_t ob = (pix * g.ldo + n0) * oesz + c * psz;   // byte offset in the output tensor
+    if (psz == 16) {
+      uint4 v = *(const uint4*)(sC + r * srow + c * 16);
+      if (g.mask) {                                     // mask tensor has the output's type and indexing (never fp32)
+        const uint4 mv = *(const uint4*)((const char*)g.mask + ob);
+        T ve[EPP], me[EPP];
+        *(uint4*)ve = v; *(uint4*)me = mv;
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) ve[e] = to_f32(me[e]) > 0.f ? ve[e] : from_f32<T>(0.f);
+        v = *(uint4*)ve;
+      }
+      *(uint4*)((char*)g.out + ob) = v;
+    } else {
+      *(uint2*)((char*)g.out + ob) = *(const uint2*)(sC + r * srow + c * 8);
+    }
+  }
+}
+
+static inline size_t tile_lds_bytes(int BN, int MF, const TileConvArgs& a, size_t esz) {
+  size_t lds = 2 * BN * 128 + a.off_bytes + a.in_bytes;
+  const size_t epi = (size_t)(64 * MF) * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
+  return lds < epi ? epi : lds;
+}
+
+template <typename T, int BN, int MF>
+static int launch_tile(const TileConvArgs& a, hipStream_t st) {
+  const int Npad = round_up(a.N, BN);
+  dim3 grid(a.ntiles, Npad / BN), block(256);
+  const size_t lds = tile_lds_bytes(BN, MF, a, sizeof(T));
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF>), grid, block, lds, st, a);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+// Plans the tiling for a tap-GEMM problem; returns false when the problem does not fit the
+// direct kernel (dense layers, huge channel counts, K-split needed) and the caller should use
+// the im2col kernel instead.
+bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out) {
+  if (t.splitk != 1) return false;
+  const int OY = 1 << t.lOY, OX = 1 << t.lOX;
+  if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
+  const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
+  const int cin = (1 << t.cl2) * epp;
+  // N tile
+  int BN, cfgN;
+  if (t.N % 128 == 0) { BN = 128; cfgN = 0; }
+  else if (t.N % 64 == 0) { BN = 64; cfgN = 1; }
+  else if (t.N % 32 == 0) { BN = 32; cfgN = 2; }
+  else if (t.N <= 16) { BN = 16; cfgN = 3; }
+  else return false;
+  int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
+  for (int i = 0; i < t.ntaps; ++i) {
+    y_lo = t.dy[i] < y_lo ? t.dy[i] : y_lo; y_hi = t.dy[i] > y_hi ? t.dy[i] : y_hi;
+    x_lo = t.dx[i] < x_lo ? t.dx[i] : x_lo; x_hi = t.dx[i] > x_hi ? t.dx[i] : x_hi;
+  }
+  // LDS bytes per pixel: +32 B makes PS an odd multiple of 32, which spreads the 16 pixels of a
+  // ds_read_b128 fragment over all 64 banks (linear 64/128/256-B pixels are 2/4/8-way conflicted).
+  // Measured: pays for >= 128-B pixels at stride 1; for 64-B pixels the extra LDS costs more in
+  // occupancy than the 2-way conflict, and at stride 2 no padding can make 2*PS/32 odd.
+  const int PS = cin * esz + ((cin * esz >= 128 && t.S == 1) ? 32 : 0);
+  const int lTW = OX >= 16 ? 4 : t.lOX;
+  const int off_bytes = (((t.P + 7) / 8 * 8) * 4 + 15) / 16 * 16;
+  // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
+  for (int MF = 4; MF >= 2; MF -= 2) {
+    if (MF == 4 && BN == 128) continue;
+    if (MF == 2 && BN < 64) return false;
+    const int BM = 64 * MF;
+    int lTH = 0;
+    while ((1 << (lTW + lTH)) < BM && (1 << lTH) < OY) ++lTH;
+    int lNB = 0;
+    while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
+    const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
+    const int TIW = (TW - 1) * t.S + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
+    const int64_t in_bytes = (int64_t)NB * TIH * TIW * PS;
+    const int64_t lds = 2 * BN * 128 + off_bytes + in_bytes;
+    if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
+    if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
+    memset(a, 0, sizeof(*a));
+    a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
+    a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
+    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S;
+    a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
+    a->OY = OY; a->OX = OX;
+    a->tilesX = OX / TW; a->tilesY = OY / TH;
+    a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
+    a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS;
+    a->off_bytes = off_bytes; a->in_bytes = (int)in_bytes;
+    a->N = t.N; a->OHF = t.OHF; a->OWF = t.OWF; a->OS = t.OS; a->ooy = t.ooy; a->oox = t.oox; a->ldo = t.ldo;
+    a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps;
+    memcpy(a->dy, t.dy, sizeof(a->dy));
+    memcpy(a->dx, t.dx, sizeof(a->dx));
+    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1);
+    return true;
+  }
+  return false;
+}
+
+int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) {
+  if (dtype == SV_BF16) {
+    switch (cfg) {
+      case 1: return launch_tile<bf16_t, 128, 2>(a, st);
+      case 2: return launch_tile<bf16_t, 64, 4>(a, st);
+      case 3: return launch_tile<bf16_t, 64, 2>(a, st);
+      case 4: return launch_tile<bf16_t, 32, 4>(a, st);
+      case 6: return launch_tile<bf16_t, 16, 4>(a, st);
+    }
+  } else if (dtype == SV_F32) {
+    switch (cfg) {
+      case 1: return launch_tile<float, 128, 2>(a, st);
+      case 2: return launch_tile<float, 64, 4>(a, st);
+      case 3: return launch_tile<float, 64, 2>(a, st);
+      case 4: return launch_tile<float, 32, 4>(a, st);
+      case 6: return launch_tile<float, 16, 4>(a, st);
+    }
+  }
+  return SV_E_BADARG;
+}
+
+int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st) {
+  static const bool force_tap = getenv("SV_FORCE_IM2COL") != nullptr;   // A/B switch for tests and profiling
+  static const int dbg = getenv("SV_TC_DBG") ? atoi(getenv("SV_TC_DBG")) : 0;
+  TileConvArgs a;
+  int cfg;
+  if (!force_tap && svk_tile_conv_plan(t, dtype, t.M >> (t.lOY + t.lOX), &a, &cfg)) {
+    a.dbg = dbg;
+    return svk_tile_conv(a, dtype, cfg, st);
+  }
+  return svk_tap_gemm(t, dtype, tap_cfg, st);
+}
