@@ -17,6 +17,7 @@ PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
 PHASE_INFER = PHASE_PREP | PHASE_FORWARD
 
 STATUS = {0: "SV_OK", -1: "SV_E_BADARG", -2: "SV_E_UNSUPPORTED", -3: "SV_E_WORKSPACE", -4: "SV_E_STATE"}
+STATUS_BADARG, STATUS_UNSUPPORTED, STATUS_WORKSPACE, STATUS_STATE = -1, -2, -3, -4
 
 
 class SplitVaeError(RuntimeError):

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/splitvae.h
+declares, and validates arguments without touching a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import np_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "splitvae.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib_built):
+    from split_vae_amd import _lib
+    declared = header_functions()
+    assert len(declared) >= 25
+    assert sorted(_lib.SYMBOLS) == declared          # the ctypes table binds exactly the header's functions
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.sv_version()
+
+
+def test_library_is_gfx950_code_object(lib_built):
+    data = open(lib_built, "rb").read()
+    assert b"gfx950" in data and b"tile_conv_kernel" in data and b"wgrad_tile_kernel" in data
+
+
+def test_param_table_matches_reference_order(lib_built):
+    from split_vae_amd import _lib, ops
+    for H in (32, 64):
+        desc = _lib.LGVaeDesc(8, H, H, 128, 128, _lib.SV_BF16, 40.0)
+        table = ops.param_table(desc)
+        want = np_ref.param_shapes(H, H)
+        assert [n for n, _, _ in table] == [n for n, _ in want]
+        assert [tuple(s) for _, _, s in table] == [tuple(s) for _, s in want]
+        offs = [o for _, o, _ in table]
+        assert offs == sorted(offs) and all(o % 4 == 0 for o in offs)      # 16-byte aligned tensors
+        n = _lib.load().sv_lgvae_param_count(C.byref(desc))
+        assert n >= sum(int(np.prod(s)) for _, s in want) and n % 4 == 0
+
+
+def test_plan_geometry_without_gpu(lib_built):
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    desc = _lib.LGVaeDesc(512, 64, 64, 128, 128, _lib.SV_BF16, 120.0)
+    h = C.c_void_p()
+    assert lib.sv_lgvae_plan_create(C.byref(desc), C.byref(h)) == 0
+    ws = lib.sv_lgvae_workspace_bytes(h)
+    assert 1 << 30 < ws < 8 << 30           # ~1.6 GB of activations for B=512: fits 288 GB many times over
+    off, nb = C.c_int64(), C.c_int64()
+    assert lib.sv_lgvae_buffer(h, b"out6_x", C.byref(off), C.byref(nb)) == 0
+    assert nb.value == 512 * 64 * 64 * 6 * 4 and off.value % 256 == 0
+    assert lib.sv_lgvae_buffer(h, b"no_such_buffer", C.byref(off), C.byref(nb)) == _lib.STATUS_BADARG
+    # stepping an unbound plan is refused, not undefined behaviour
+    a = _lib.StepArgs()
+    a.phases = _lib.PHASE_ALL
+    assert lib.sv_lgvae_step(h, C.byref(a), None) == _lib.STATUS_STATE
+    lib.sv_lgvae_plan_destroy(h)
+
+
+@pytest.mark.parametrize("bad", [dict(H=48), dict(H=64, W=32), dict(gl=100), dict(dtype=7), dict(B=0)])
+def test_plan_rejects_unsupported(lib_built, bad):
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    H = bad.get("H", 64)
+    desc = _lib.LGVaeDesc(bad.get("B", 8), H, bad.get("W", H), bad.get("gl", 128), 128, bad.get("dtype", 1), 1.0)
+    h = C.c_void_p()
+    assert lib.sv_lgvae_plan_create(C.byref(desc), C.byref(h)) < 0
+    assert lib.sv_lgvae_param_count(C.byref(desc)) < 0
+
+
+def test_kernel_entry_points_validate_arguments(lib_built):
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    assert lib.sv_scramble_gather(None, None, None, 1, 32, 32, 4, None) == _lib.STATUS_BADARG
+    assert lib.sv_random_perm(None, 1, 16, 0, 0, 0, None) == _lib.STATUS_BADARG
+    assert lib.sv_adam_step(None, None, None, None, 16, 1e-4, .9, .999, 1e-7, 1, 1.0, None) == _lib.STATUS_BADARG
+    d = _lib.ConvDesc(4, 24, 24, 32, 32, 4, 4, 1, 0, 1, 32, 32, 0)       # 24 is not a power of two
+    assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) < 0
+    d = _lib.ConvDesc(4, 32, 32, 32, 6, 6, 6, 1, 0, 1, 32, 6, 1)
+    assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) == 16 * 36 * 32       # Cout 6 -> one 16-row MFMA column block
+    assert lib.sv_conv2d_wprep_elems(C.byref(d), 1) == 32 * 36 * 8        # dgrad contracts over Cout padded to 8
+    assert lib.sv_dlogistic_nll_workspace_bytes(8, 64, 64) == 8 * 4 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """The product path must not fall back to anything when the HIP extension is absent."""
+    from split_vae_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.SplitVaeError):
+        _lib.load()

@@ -1,0 +1,82 @@
+"""CPU: host-side mirror of the reference's Python surface (flags, dotdict, optimizer schedule,
+augmentor selection, data-parallel bookkeeping) -- everything that needs no device."""
+import numpy as np
+import pytest
+
+from oracle import np_ref
+
+
+def test_cli_flags_match_reference():
+    """vae/main.py:15-31: same names, types and defaults."""
+    from split_vae_amd.main import build_parser
+    a = build_parser().parse_args([])
+    want = dict(viz=False, global_latent_dims=128, local_latent_dims=128, learning_rate=1e-4, beta=40, dataset='svhn',
+                training_steps=1000000, batch_size=64, patch_size=1, augmentation='scramble', no_label=False,
+                model='lgvae', y_size=30, tau=0.4, alpha=40, allow_growth=False)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    b = build_parser().parse_args("--beta 120 --patch_size 8 --dataset celeba64 -no_label".split())   # README.md:37
+    assert (b.beta, b.patch_size, b.dataset, b.no_label) == (120.0, 8, "celeba64", True)
+    assert isinstance(b.beta, float) and isinstance(b.patch_size, int)
+
+
+def test_dotdict_missing_key_is_none():
+    from split_vae_amd.utils import dotdict
+    d = dotdict({"a": 1})
+    assert d.a == 1 and d.bg_model is None        # vae/utils.py:3-7 (dict.get semantics)
+    d.b = 2
+    assert d["b"] == 2
+    del d.a
+    assert "a" not in d
+
+
+def test_augmentator_selection():
+    from split_vae_amd.augmentation import Augmentator
+    a = Augmentator("scramble", size=8)
+    assert a.augment == a.scramble and a.size == 8
+    assert Augmentator("no_op").augment("x") == "x"
+    for t in ("mix_scramble", "blur", "high_low_pass"):
+        with pytest.raises(NotImplementedError):
+            Augmentator(t)
+    with pytest.raises(ValueError):
+        Augmentator("nope")
+
+
+def test_exponential_decay_schedule():
+    from split_vae_amd.optimizer import Adam, ExponentialDecay
+    s = ExponentialDecay(1e-4, decay_steps=1000000, decay_rate=0.4, staircase=True)      # vae/main.py:67
+    assert s(0) == 1e-4 and s(999999) == 1e-4 and abs(s(1000000) - 4e-5) < 1e-18 and abs(s(2500000) - 1.6e-5) < 1e-18
+    o = Adam(learning_rate=s)
+    assert o.lr() == 1e-4 and (o.beta_1, o.beta_2, o.epsilon) == (0.9, 0.999, 1e-7)      # Keras defaults
+
+
+def test_shard_bounds_and_buckets(lib_built):
+    import ctypes as C
+    from split_vae_amd import _lib, dist, ops
+    assert dist.shard_bounds(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        dist.shard_bounds(100, 0, 8)
+    desc = _lib.LGVaeDesc(8, 64, 64, 128, 128, 1, 1.0)
+    table = ops.param_table(desc)
+    n = _lib.load().sv_lgvae_param_count(C.byref(desc))
+    b = dist.param_buckets(table, n)
+    # decoders are one contiguous tail; heads and convs interleave per encoder
+    assert len(b["decoders"]) == 1 and b["decoders"][0][1] == n
+    assert len(b["enc_heads"]) == 2 and len(b["enc_convs"]) == 2
+    cover = np.zeros(n, int)
+    for rs in b.values():
+        for lo, hi in rs:
+            cover[lo:hi] += 1
+    assert np.all(cover == 1)
+    sizes = {k: sum(hi - lo for lo, hi in v) for k, v in b.items()}
+    assert sizes["enc_heads"] > 4_000_000 and sizes["decoders"] > 4_000_000 and sizes["enc_convs"] < 500_000
+
+
+def test_synthetic_data_domain_and_shard_invariance():
+    from split_vae_amd import data
+    full = data.synthetic_images(8, 32, 32, seed=0, device="cpu")
+    part = data.synthetic_images(3, 32, 32, seed=0, device="cpu", sample_offset=4)
+    assert np.array_equal(part.numpy(), full[4:7].numpy())
+    v = np.unique(np.round((full.numpy() + 1) * 127.5).astype(int))
+    assert v.min() >= 0 and v.max() <= 255 and full.dtype.is_floating_point      # vae/data.py:52 domain
+    assert np.allclose((np.round((full.numpy() + 1) * 127.5) / 127.5 - 1), full.numpy(), atol=1e-6)
