@@ -37,7 +37,9 @@ def cpu_baseline(H, patch, beta, seconds_budget=20.0):
     definition on a bounded sample of the workload (a 128-image batch instead of 512)."""
     import numpy as np
     from oracle import np_ref, torch_ref
-    cores = os.cpu_count() or 1
+    # measured on the GPU box (256 hardware threads): the oneDNN/ATen step peaks at 16 threads
+    # (8: 320, 16: 499, 32: 460, 64: 208, 128: 96, 256: 1.5 images/s), so 16 is what is used and reported
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     Bc = 128
     rng = np.random.Generator(np.random.PCG64(0))

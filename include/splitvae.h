@@ -117,6 +117,12 @@ int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dg
  * zero them first). */
 int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
                          float* dbias, void* stream);
+/* Same with a caller-owned partial-sum workspace (sv_conv2d_wgrad_workspace_bytes): the tile kernel
+ * then writes per-split slabs and reduces them in a fixed order -- faster than atomics and
+ * bitwise reproducible.  dw is still accumulated into (zero it first). */
+int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d);
+int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
+                            float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- A2/A3/A5/A8: the whole LGVae step
  * Replaces LGVae.call (vae/model.py:189-200) and train_step_lg_vae (vae/trainer.py:120-144)

@@ -62,6 +62,8 @@ SYMBOLS = {
     "sv_conv2d_nhwc_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sv_conv2d_nhwc_dgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp]),
     "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "sv_conv2d_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
+    "sv_conv2d_nhwc_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sv_lgvae_param_count": (_i64, [C.POINTER(LGVaeDesc)]),
     "sv_lgvae_param_info": (C.c_int, [C.POINTER(LGVaeDesc), _i32, C.POINTER(_i64), C.POINTER(_i32),
                                       C.POINTER(_i64 * 4), C.c_char_p]),

@@ -18,6 +18,7 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
     // reads (contiguous in co) and the low-precision writes (contiguous in ci) are coalesced
     __shared__ float tile[32][33];
     const int tr = (j.rows + 31) / 32;
+    if (block_in_job >= tr * ((j.inner + 31) / 32)) return;    // uniform per block
     const int r0 = (block_in_job % tr) * 32, c0 = (block_in_job / tr) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -32,6 +33,7 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
       if (row < j.rows && c < j.inner)
         arena[j.dst_off + (int64_t)row * j.inner_ld + j.inner_off + c] = from_f32<T>(tile[tx][ty + 8 * k]);
     }
+    __syncthreads();                                           // the tile is reused by the block's next unit
     return;
   }
   if (j.transpose && !(j.inner & 3) && !(j.Cout & 3) && !(j.inner_off & 3) && !(j.inner_ld & 3)) {
@@ -74,13 +76,14 @@ __global__ __launch_bounds__(256) void prep_table_kernel(const float* __restrict
     if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PrepJob j = jobs[lo];
-  prep_block<T>(j, params, arena, (int)blockIdx.x - j.first_block);
+  // SV_PREP_UNITS units of 256 threads' work per block amortise the job lookup (dependent global loads)
+  for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, ((int)blockIdx.x - j.first_block) * SV_PREP_UNITS + u);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void prep_single_kernel(const float* __restrict__ params, T* __restrict__ arena,
                                                           const PrepJob j) {
-  prep_block<T>(j, params, arena, (int)blockIdx.x);
+  for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, (int)blockIdx.x * SV_PREP_UNITS + u);
 }
 
 int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
@@ -333,5 +336,22 @@ extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const 
   WgradArgs a;
   svg_wgrad_args(d, &a);
   a.A = x; a.dY = dy; a.dW = dw; a.dbias = dbias;
+  return svk_wgrad_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+}
+
+extern "C" int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d) {
+  if (svg_check(d) != SV_OK) return -1;
+  return SV_WGRAD_WS_BYTES;
+}
+
+extern "C" int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!x || !dy || !dw) return SV_E_BADARG;
+  WgradArgs a;
+  svg_wgrad_args(d, &a);
+  a.A = x; a.dY = dy; a.dW = dw; a.dbias = dbias;
+  a.ws = (float*)workspace; a.ws_bytes = workspace ? workspace_bytes : 0;
   return svk_wgrad_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
 }

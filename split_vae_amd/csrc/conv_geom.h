@@ -38,9 +38,14 @@ static inline int svg_choose_splitk(int M, int N, int nk) {
 }
 
 // blocks of 256 threads for one weight-preparation job (dense forward images use 32x32 LDS tiles)
+#define SV_PREP_UNITS 8
 static inline int svg_prep_nblocks(const PrepJob* j) {
-  if (j->ntaps == 1 && !j->transpose) return ((j->rows + 31) / 32) * ((j->inner + 31) / 32);
-  return (int)(((int64_t)j->rows * j->ntaps * j->inner + 255) / 256);
+  int64_t units;
+  if (j->ntaps == 1 && !j->transpose) units = (int64_t)((j->rows + 31) / 32) * ((j->inner + 31) / 32);
+  else if (j->transpose && !(j->inner & 3) && !(j->Cout & 3) && !(j->inner_off & 3) && !(j->inner_ld & 3))
+    units = ((int64_t)j->rows * j->ntaps * (j->inner >> 2) + 255) / 256;          // 4 channels per thread
+  else units = ((int64_t)j->rows * j->ntaps * j->inner + 255) / 256;
+  return (int)((units + SV_PREP_UNITS - 1) / SV_PREP_UNITS);
 }
 
 int svg_check(const sv_conv_desc* d);

@@ -62,6 +62,8 @@ struct WgradArgs {
   int cl2;            // log2(pieces per tap)
   int Cin_pad, Cin_real, N, Nrows;   // Nrows = ntaps*Cin_pad (padded wrow count)
   int ntaps, msplit;  // msplit = rows of m per blockIdx.z slice (multiple of the m-step)
+  float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
+  int64_t ws_bytes;
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -71,11 +73,14 @@ int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st);
 // ---- weight gradient with LDS-resident input/dY tiles (wgrad_tile.hip, bf16); planned from WgradArgs
 struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
+  float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
   int B, IH, IW, lda, cl2, S;
   int lTW, lTH, lNB, OY, OX, tilesX, tilesY, ntiles;
   int TIW, TIH, y_lo, x_lo, PS;
   int ldy, YS, lycp;        // dY channels per pixel; bytes per dY pixel in LDS; log2(16-B pieces per dY pixel)
   int in_bytes, dy_bytes;
+  int dbg;                  // ablation: 1 = skip the atomic flush
+  int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
@@ -83,6 +88,7 @@ struct WgradTileArgs {
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
 // tile kernel when the layer has an instantiation (bf16), im2col kernel otherwise
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st);
+#define SV_WGRAD_WS_BYTES (512LL * 36 * 4 * 256 * 4)   // 512 workgroups x 36 fragments x 4 waves x 256 floats
 
 // ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
 struct PrepJob {

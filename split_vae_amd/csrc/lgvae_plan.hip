@@ -260,6 +260,7 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->ws_bytes = 0;
   p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
   p->add_buf("warena", p->arena_elems * es);
+  p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES);
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
   p->add_buf("zcat", B * Lc * es);
@@ -352,6 +353,7 @@ static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void
   a.A = x; a.dY = dy;
   a.dW = grads + p->params[L.kparam].off;
   a.dbias = grads + p->params[L.bparam].off;
+  a.ws = (float*)p->bp("wgrad_ws"); a.ws_bytes = p->bbytes("wgrad_ws");
   Scope sc(p, st, "wgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
   return svk_wgrad_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
 }

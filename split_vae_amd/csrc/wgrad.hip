@@ -20,8 +20,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   constexpr int BR = 64 * WR;             // wrows (tap, ci) per block
   constexpr int BNW = 16 * CF * WC;       // output channels per block
   constexpr int MS = 128 / (int)sizeof(T);  // m rows per K-step (64 bf16 / 32 fp32)
-  constexpr int SA = BR * (int)sizeof(T) + 16;    // LDS row strides (bytes)
-  constexpr int SB = BNW * (int)sizeof(T) + 16;
+  // LDS row pitches: an odd multiple of 32 B (bf16) so that the 8 consecutive m-rows touched by one
+  // lane-half of a transposed read start on 8 different 32-B bank groups (see wgrad_tile.hip)
+  constexpr int SA = BR * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+  constexpr int SB = BNW * (int)sizeof(T) + (sizeof(T) == 2 && BNW >= 32 ? 32 : 16);
   constexpr int PPRA = BR / EPP, PPRB = BNW / EPP;
   constexpr int APT = (MS * PPRA + 255) / 256;     // A pieces per thread
   constexpr int BPT = (MS * PPRB + 255) / 256;
@@ -123,18 +125,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int kk = 0; kk < MS / 32; ++kk) {
-        const int mrow = kk * 32 + 8 * lg + lq;     // rows of this lane's 4x16 transpose blocks
+        // K index k = 8g + 4h + q  <->  m-row 16h + 4g + q (same permutation on both operands)
+        const int mrow = kk * 32 + 4 * lg + lq;
         short8_t af[4], bfr[CF];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const char* p = cA + mrow * SA + (wr * 64 + i * 16 + 4 * lp) * 2;
-          const short4_t lo = lds_tr16_b64(p), hi = lds_tr16_b64(p + 4 * SA);
+          const short4_t lo = lds_tr16_b64(p), hi = lds_tr16_b64(p + 16 * SA);
           af[i] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int j = 0; j < CF; ++j) {
           const char* p = cB + mrow * SB + ((wc * CF + j) * 16 + 4 * lp) * 2;
-          const short4_t lo = lds_tr16_b64(p), hi = lds_tr16_b64(p + 4 * SB);
+          const short4_t lo = lds_tr16_b64(p), hi = lds_tr16_b64(p + 16 * SB);
           bfr[j] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 template <typename T, int WR, int WC, int CF>
 static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   constexpr int BR = 64 * WR, BNW = 16 * CF * WC, MS = 128 / (int)sizeof(T);
-  constexpr int SA = BR * (int)sizeof(T) + 16, SB = BNW * (int)sizeof(T) + 16;
+  constexpr int SA = BR * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+  constexpr int SB = BNW * (int)sizeof(T) + (sizeof(T) == 2 && BNW >= 32 ? 32 : 16);
   const size_t lds = 2 * MS * SA + 2 * MS * SB + SV_MAX_TAPS * 3 * sizeof(int);
   dim3 grid((a.Nrows + BR - 1) / BR, (a.N + BNW - 1) / BNW, (a.M + a.msplit - 1) / a.msplit), block(256);
   static bool attr_set = false;

@@ -1,19 +1,19 @@
 // Weight gradient with LDS-resident tiles (bf16):  dW[t][ci][co] += sum_pixels X[pix + tap t][ci] * dY[pix][co]
 //
-// A workgroup owns one TAP GROUP (all input channels, all output channels of those taps) and walks
-// a strided subset of the spatial tiles.  Per tile it stages, once, the input patch with its halo
-// and the matching dY patch in their natural NHWC layout (coalesced 16-B loads); every tap's
-// k-major MFMA operand is then a SHIFTED WINDOW of the same LDS patch, read transposed with
-// ds_read_b64_tr_b16 (pixels are the MFMA K dimension).  The im2col form (wgrad.hip) re-gathers
-// the input once per tap through L2; here the re-use factor is the tap-group size, which is made
-// as large as the accumulator registers allow (up to 36 fragments = 144 VGPRs per wave).
-// Accumulators stay in registers across all of the workgroup's tiles and are flushed once with
-// fp32 atomics.  Waves split the tap group (WT) and/or the input-channel fragments (WC).
+// The im2col GEMM form (wgrad.hip) re-gathers the input once per tap through L2 and its tiles have
+// an arithmetic intensity of ~43 FLOP/B: L2-bound.  Here a workgroup owns a CHANNEL SLICE of the
+// input (CW = 16 or 32 channels) x a tap group (all taps when the accumulators fit) x all output
+// channels, and walks a strided subset of the spatial tiles.  Per tile it stages, once, the input
+// patch slice with its halo and the matching dY patch (coalesced 16-B loads, natural NHWC order);
+// every tap's k-major MFMA operand is then a SHIFTED WINDOW of the same LDS patch, read transposed
+// with ds_read_b64_tr_b16 (pixels are the MFMA K dimension).  The four waves split the taps.
+// Accumulators (up to 36 fragments = 144 VGPRs per wave) stay in registers across all of the
+// workgroup's tiles and are flushed once with fp32 atomics.
 //
-// LDS layout: pixel records of PS = Cin*2 + 32 bytes (dY: Cout*2 + 32).  With PS/32 odd, eight
-// consecutive pixels start on eight different 32-B bank groups, and the MFMA K index is mapped to
-// pixels as k = 8g + 4h + q  <->  pixel 16h + 4g + q so that the two lane-halves of each
-// transposed read touch 8 consecutive pixels: conflict-free.
+// LDS layout: pixel records of PS bytes with PS/32 odd (32-B slices as they are, 64-B slices padded
+// to 96; dY 64 -> 96, 128 -> 160, 256 -> 288), and the MFMA K index is mapped to pixels as
+// k = 8g + 4h + q  <->  pixel 16h + 4g + q, so the two lane-halves of each transposed read touch
+// 8 consecutive pixels on 8 different 32-B bank groups: conflict-free.
 #include <stdlib.h>
 #include <string.h>
 #include "common.hip.h"
@@ -27,19 +27,19 @@ __device__ __forceinline__ short4_t tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
 }
 
-// TPW taps per wave, CIF ci-fragments (16 channels) per wave, COF co-fragments (all of Cout_pad16),
-// WT x WC = 4 waves over (taps, ci-fragments); KC = 32-pixel K chunks per tile (BM = 32*KC pixels)
-template <int TPW, int CIF, int COF, int WT, int WC, int KC>
+// TPW taps per wave (4 waves: tap group = 4*TPW taps), CIF ci-fragments (16 channels) per
+// workgroup slice, COF co-fragments (all of Cout_pad16), KC = 32-pixel K chunks per tile.
+template <int TPW, int CIF, int COF, int KC>
 __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs g) {
-  static_assert(WT * WC == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sIn = smem;                       // [NB][TIH][TIW] pixels of PS bytes (+ slack)
   char* sDy = smem + g.in_bytes;          // [BM] pixels of YS bytes (+ slack)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wt = wave / WC, wc = wave % WC;
-  const int tap0 = blockIdx.y * (TPW * WT) + wt * TPW;      // this wave's first tap
+  const int tg = blockIdx.y / g.ncg, cg = blockIdx.y - tg * g.ncg;   // tap group, channel slice
+  const int tap0 = tg * (4 * TPW) + wave * TPW;                       // this wave's first tap
+  const int ci0 = cg * g.CW;                                          // first input channel of the slice
   const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB;
-  const int cpp = 1 << g.cl2;
+  const int cpp = 1 << g.cl2;                                         // 16-B chunks per pixel IN THE SLICE
   const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3, lr = lane & 15;
 
   // per-lane LDS byte offsets for the transposed reads: read h of chunk kc -> tile pixel
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     for (int h = 0; h < 2; ++h) {
       const int r = kc * 32 + 16 * h + 4 * lg + lq;
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
-      inb[kc][h] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.S) * g.PS + (wc * CIF * 16 + 4 * lp) * 2;
+      inb[kc][h] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.S) * g.PS + 4 * lp * 2;
       dyb[kc][h] = r * g.YS + 4 * lp * 2;
     }
   int tapoff[TPW];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
   const int ycols = g.ldy;                          // dY channels per pixel (power of two >= 8)
   const int bcol = tid & (ycols - 1), bgrp = tid / ycols, nbg = 256 / ycols;
 
-  const bf16_t* __restrict__ Ab = (const bf16_t*)g.A;
+  const bf16_t* __restrict__ Ab = (const bf16_t*)g.A + ci0;
   const bf16_t* __restrict__ Yb = (const bf16_t*)g.dY;
   // staging geometry: LPR lanes sweep one tile row (no integer division anywhere)
   const int ppr = g.TIW * cpp;                      // 16-B pieces per input-tile row
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
     const int b0 = t << g.lNB;
     __syncthreads();                                // previous tile fully consumed
-    // ---- stage input patch (+halo, zero outside the image)
+    // ---- stage input patch slice (+halo, zero outside the image)
     {
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
       for (int row = srow; row < nrows; row += rows_pp) {
@@ -164,7 +164,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     }
   }
 
-  // ---- flush: D row = ci (lane>>4)*4+reg within the fragment, col = co lane&15
+  // ---- flush.  With a partial-sum slab (two-stage, deterministic): every accumulator register goes
+  // out as one fully coalesced 256-B store in fragment order; wgrad_reduce_kernel sums the slabs in
+  // a fixed order.  (fp32 atomics straight into dW run at ~1.3 TB/s chip-wide and were 40-60 % of
+  // this kernel's time: SV_WT_NOFLUSH ablation.)
+  if (g.slab) {
+    if (g.dbg) return;
+    float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * CIF * COF)) * 256 + lane;
+#pragma unroll
+    for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+      for (int i = 0; i < CIF; ++i)
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) sl[(((t2 * CIF + i) * COF + j) * 4 + r4) * 64] = acc[t2][i][j][r4];
+  } else
+  // atomics: D row = ci (lane>>4)*4+reg within the fragment, col = co lane&15
 #pragma unroll
   for (int t2 = 0; t2 < TPW; ++t2) {
     const int tap = tap0 + t2;
@@ -173,12 +189,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     for (int i = 0; i < CIF; ++i)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int ci = (wc * CIF + i) * 16 + lg * 4 + r4;
-        if (ci >= g.Cin_real) continue;
+        const int ci = ci0 + i * 16 + lg * 4 + r4;
+        if (ci >= g.Cin_real || i * 16 + lg * 4 + r4 >= g.CW) continue;
 #pragma unroll
         for (int j = 0; j < COF; ++j) {
           const int co = j * 16 + lr;
-          if (co < g.N) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + co, acc[t2][i][j][r4]);
+          if (co < g.N && !g.dbg) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + co, acc[t2][i][j][r4]);
         }
       }
   }
@@ -195,49 +211,87 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
   }
 }
 
-template <int TPW, int CIF, int COF, int WT, int WC, int KC>
+// second stage of the slab path: dW[...] += sum over the m-splits, in split order (deterministic)
+template <int TPW, int CIF, int COF>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
+                                                           int msplit, int groups, int ncg, int CW, int Cin_real,
+                                                           int N, int ntaps) {
+  constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
+  const int y = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= PER) return;
+  const int wave = e / (NFR * 256), rem = e - wave * (NFR * 256), f = rem >> 8, r4 = (rem >> 6) & 3, lane = rem & 63;
+  const int t2 = f / (CIF * COF), i = (f / COF) % CIF, j = f % COF;
+  const int tg = y / ncg, cg = y - tg * ncg;
+  const int tap = tg * 4 * TPW + wave * TPW + t2;
+  const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = cg * CW + cl, co = j * 16 + (lane & 15);
+  if (tap >= ntaps || cl >= CW || ci >= Cin_real || co >= N) return;
+  const float* p = slab + (int64_t)y * PER + e;
+  float s = 0.f;
+  for (int x = 0; x < msplit; ++x) s += p[(int64_t)x * groups * PER];
+  dW[((int64_t)(tap * Cin_real + ci)) * N + co] += s;
+}
+
+template <int TPW, int CIF, int COF, int KC>
 static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
   const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, WT, WC, KC>,
+    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  // resident workgroups per CU by LDS, capped at 3 (accumulator-heavy waves)
+  // resident workgroups per CU: LDS, and 2 waves per SIMD (accumulator-heavy waves)
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 3) per_cu = 3;
+  if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
+  static const int force_pc = getenv("SV_WT_PERCU") ? atoi(getenv("SV_WT_PERCU")) : 0;   // profiling knob
+  if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
+  static const bool no_flush = getenv("SV_WT_NOFLUSH") != nullptr;                       // ablation: skip the atomic flush
+  const_cast<WgradTileArgs&>(a).dbg = no_flush ? 1 : 0;
   int msplit = (256 * per_cu + groups - 1) / groups;
   if (msplit > a.ntiles) msplit = a.ntiles;
   dim3 grid(msplit, groups), block(256);
-  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, WT, WC, KC>), grid, block, lds, st, a);
+  constexpr int PER = 4 * TPW * CIF * COF * 256;
+  WgradTileArgs b = a;
+  b.dbg = a.dbg;
+  const int64_t need = (int64_t)msplit * groups * PER * 4;
+  static const bool no_slab = getenv("SV_WT_ATOMICS") != nullptr;
+  b.slab = (a.ws && a.ws_bytes >= need && !no_slab) ? a.ws : nullptr;
+  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, b);
   SV_LAUNCH_CHECK();
+  if (b.slab && !b.dbg) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3((PER + 255) / 256, groups), dim3(256), 0, st,
+                       (const float*)b.slab, b.dW, msplit, groups, b.ncg, b.CW, b.Cin_real, b.N, b.ntaps);
+    SV_LAUNCH_CHECK();
+  }
   return SV_OK;
 }
 
 // Returns SV_E_UNSUPPORTED when the layer shape has no tile instantiation (caller falls back to
-// the im2col wgrad).  Shapes: conv layers of the SPLIT-VAE encoder/decoder with few channels and
-// many taps, where tap re-use from LDS pays; the wide (Cin = 128) layers stay on the im2col GEMM.
+// the im2col wgrad).  Shapes: the seven conv layers of the SPLIT-VAE encoder/decoder.
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   static const bool force_old = getenv("SV_FORCE_IM2COL") != nullptr;
-  static const char* only = getenv("SV_WGRAD_TILE_IDS");    // e.g. "0145": restrict to these ids (profiling A/B)
+  static const char* skip = getenv("SV_WGRAD_IM2COL_IDS");    // e.g. "23": these layer ids use the im2col kernel (A/B)
   if (force_old) return SV_E_UNSUPPORTED;
   const int OY = 1 << w.lOY, OX = 1 << w.lOX;
   if (OY * OX < 16 || w.ycols != w.ldy) return SV_E_UNSUPPORTED;
   const int cin = w.Cin_pad, cout = w.ldy, nt = w.ntaps;
-  int id = -1, BM = 0, groups = 0;
-  if (nt == 36 && cin == 32 && cout == 8) { id = 0; BM = 256; groups = 1; }         // d5
-  else if (nt == 36 && cin == 64 && cout == 32) { id = 1; BM = 128; groups = 2; }   // d4
-  else if (nt == 16 && cin == 128 && cout == 64) { id = 2; BM = 128; groups = 4; }  // d3
-  else if (nt == 16 && cin == 128 && cout == 128) { id = 3; BM = 64; groups = 8; }  // d2
-  else if (nt == 16 && cin == 64 && cout == 128) { id = 4; BM = 64; groups = 4; }   // e3
-  else if (nt == 36 && cin == 32 && cout == 64) { id = 5; BM = 64; groups = 2; }    // e2
-  else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; groups = 1; }    // e1
+  // id, pixels per tile, channel slice width, taps per group
+  int id = -1, BM = 0, CW = 0, TT = 0;
+  if (nt == 36 && cin == 32 && cout == 8) { id = 0; BM = 256; CW = 32; TT = 36; }          // d5
+  else if (nt == 36 && cin == 64 && cout == 32) { id = 1; BM = 256; CW = 32; TT = 36; }    // d4
+  else if (nt == 16 && cin == 128 && cout == 64) { id = 2; BM = 256; CW = 32; TT = 16; }   // d3
+  else if (nt == 16 && cin == 128 && cout == 128) { id = 3; BM = 128; CW = 16; TT = 16; }  // d2
+  else if (nt == 16 && cin == 64 && cout == 128) { id = 4; BM = 128; CW = 16; TT = 16; }   // e3
+  else if (nt == 36 && cin == 32 && cout == 64) { id = 5; BM = 128; CW = 16; TT = 36; }    // e2
+  else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1
   else return SV_E_UNSUPPORTED;
-  if (only && !strchr(only, '0' + id)) return SV_E_UNSUPPORTED;
-  if (!only && (id == 2 || id == 3 || id == 4 || id == 5)) return SV_E_UNSUPPORTED;   // measured: im2col GEMM is faster there
-  if (OY * OX < BM && (BM % (OY * OX))) return SV_E_UNSUPPORTED;
+  if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
+  if (!skip && (id == 4 || id == 5)) return SV_E_UNSUPPORTED;   // measured: e2 / e3 are faster on the im2col GEMM
+  // d5 (6 of 16 columns real) and e1 (3 of 16 rows real): the slabs would carry 3-5x padding, atomics win
+  const bool allow_slab = !(id == 0 || id == 6);
+  while (OY * OX < BM && (BM % (OY * OX))) BM >>= 1;
+  if (BM < 64) return SV_E_UNSUPPORTED;
   int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
   for (int i = 0; i < nt; ++i) {
     y_lo = w.dy[i] < y_lo ? w.dy[i] : y_lo; y_hi = w.dy[i] > y_hi ? w.dy[i] : y_hi;
@@ -253,29 +307,39 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   WgradTileArgs a;
   memset(&a, 0, sizeof(a));
   a.A = w.A; a.dY = w.dY; a.dW = w.dW; a.dbias = w.dbias;
-  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.cl2 = w.cl2; a.S = w.S;
+  a.ws = allow_slab ? w.ws : nullptr; a.ws_bytes = allow_slab ? w.ws_bytes : 0;
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S;
+  a.CW = CW; a.ncg = cin / CW;
+  a.cl2 = ilog2_exact(CW / 8);
   a.lTW = lTW; a.lTH = lTH; a.lNB = lNB; a.OY = OY; a.OX = OX;
   a.tilesX = OX / TW; a.tilesY = OY / TH;
   a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
   a.TIW = (TW - 1) * w.S + (x_hi - x_lo) + 1; a.TIH = (TH - 1) * w.S + (y_hi - y_lo) + 1;
   a.y_lo = y_lo; a.x_lo = x_lo;
-  a.PS = cin * 2 + (cin >= 32 ? 32 : 0);            // +32 B: odd multiple of 32 -> conflict-free transposed reads
+  a.PS = CW * 2 + (CW == 32 ? 32 : 0);              // 16 / 32 / 96 B: PS/32 odd (or a single 16-B chunk)
   a.ldy = cout; a.YS = cout * 2 + (cout >= 32 ? 32 : 0);
   a.lycp = ilog2_exact(cout / 8);
   a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;   // slack: 16-column transposed reads of narrow pixels
-  a.dy_bytes = (BM * a.YS + 64 + 15) / 16 * 16;
+  a.dy_bytes = ((32 * (BM / 32)) * a.YS + 64 + 15) / 16 * 16;
   if (a.in_bytes + a.dy_bytes > 150 * 1024) return SV_E_UNSUPPORTED;
   a.Cin_real = w.Cin_real; a.N = w.N; a.ntaps = nt;
   memcpy(a.dy, w.dy, sizeof(a.dy));
   memcpy(a.dx, w.dx, sizeof(a.dx));
+  const int groups = a.ncg * ((nt + TT - 1) / TT);
+  const int KC = BM / 32;
+  // <TPW, CIF, COF, KC>
   switch (id) {
-    case 0: return launch_wt<9, 2, 1, 4, 1, 8>(a, groups, st);
-    case 1: return launch_wt<18, 1, 2, 1, 4, 4>(a, groups, st);
-    case 2: return launch_wt<4, 2, 4, 1, 4, 4>(a, groups, st);
-    case 3: return launch_wt<2, 2, 8, 1, 4, 2>(a, groups, st);
-    case 4: return launch_wt<4, 1, 8, 1, 4, 2>(a, groups, st);
-    case 5: return launch_wt<9, 1, 4, 2, 2, 2>(a, groups, st);
-    case 6: return launch_wt<9, 1, 2, 4, 1, 8>(a, groups, st);
+    case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(a, groups, st); break;
+    case 1: if (KC == 8) return launch_wt<9, 2, 2, 8>(a, groups, st); break;
+    case 2: if (KC == 8) return launch_wt<4, 2, 4, 8>(a, groups, st);
+            if (KC == 2) return launch_wt<4, 2, 4, 2>(a, groups, st); break;
+    case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(a, groups, st);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(a, groups, st); break;
+    case 4: if (KC == 4) return launch_wt<4, 1, 8, 4>(a, groups, st);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(a, groups, st); break;
+    case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(a, groups, st);
+            if (KC == 2) return launch_wt<9, 1, 4, 2>(a, groups, st); break;
+    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(a, groups, st); break;
   }
   return SV_E_UNSUPPORTED;
 }

@@ -158,12 +158,19 @@ class Conv2D:
                                                1 if f32_atomic else 0, _stream()), "sv_conv2d_nhwc_dgrad")
         return dx
 
-    def wgrad(self, x, dy):
+    def wgrad(self, x, dy, workspace=False):
         d = self.desc
         dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
         db = torch.zeros((d.Cout,), dtype=torch.float32, device=x.device)
-        check(_lib.load().sv_conv2d_nhwc_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream()),
-              "sv_conv2d_nhwc_wgrad")
+        if workspace:
+            n = _lib.load().sv_conv2d_wgrad_workspace_bytes(C.byref(d))
+            if getattr(self, "_ws", None) is None or self._ws.numel() < n:
+                self._ws = torch.empty((n,), dtype=torch.uint8, device=x.device)
+            check(_lib.load().sv_conv2d_nhwc_wgrad_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(self._ws), n, _stream()),
+                  "sv_conv2d_nhwc_wgrad_ws")
+        else:
+            check(_lib.load().sv_conv2d_nhwc_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream()),
+                  "sv_conv2d_nhwc_wgrad")
         return dw, db
 
 

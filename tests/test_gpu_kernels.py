@@ -291,6 +291,12 @@ def test_conv_fwd_dgrad_wgrad(ops, layer, dtype):
     dw, db = conv.wgrad(xg, dyg)
     torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=rtol, atol=atol * float(wr.grad.abs().max()))
     torch.testing.assert_close(db.double().cpu(), br.grad, rtol=rtol, atol=atol * float(br.grad.abs().max()))
+    # two-stage (slab + fixed-order reduce) flush: same numbers, and bitwise reproducible
+    dw2, db2 = conv.wgrad(xg, dyg, workspace=True)
+    torch.testing.assert_close(dw2.double().cpu(), wr.grad, rtol=rtol, atol=atol * float(wr.grad.abs().max()))
+    dw3, _ = conv.wgrad(xg, dyg, workspace=True)
+    if dtype == torch.bfloat16 and name in ("d2", "d3", "d4"):     # layers on the slab path (others keep atomics)
+        assert torch.equal(dw2, dw3)
     if name.startswith("e1"):
         return   # first conv: no data gradient in the model
     mask = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)).to(dtype)
