@@ -99,6 +99,9 @@ typedef struct {
   int32_t ldx;              /* channels per input pixel in memory  (>= Cin, multiple of 8) */
   int32_t ldy;              /* channels per output pixel in memory (>= Cout; multiple of 8 unless y_f32) */
   int32_t y_f32;            /* forward output written as fp32 (decoder head) */
+  int32_t ups_in;           /* x is the LOW-RES tensor [B,H/2,W/2,ldx] and the layer input is its 2x bilinear
+                               upsample (tf.image.resize, vae/model.py:163-167), produced on the fly while the
+                               tile is staged: forward and wgrad only, stride 1, tile kernels (else SV_E_UNSUPPORTED) */
 } sv_conv_desc;
 
 /* element counts (of `dtype`) of the prepared forward / dgrad weight images */

@@ -26,7 +26,7 @@ class SplitVaeError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "act", "dtype", "ldx", "ldy", "y_f32")]
+                ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "act", "dtype", "ldx", "ldy", "y_f32", "ups_in")]
 
 
 class LGVaeDesc(C.Structure):

@@ -120,6 +120,7 @@ int svg_check(const sv_conv_desc* d) {
   if (ilog2_exact(svg_cin_pad(d)) < 0 || ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
   if (d->ldy < d->Cout) return SV_E_BADARG;
   if (!d->y_f32 && d->ldy % 8) return SV_E_BADARG;
+  if (d->ups_in && (d->stride != 1 || (d->H & 1) || (d->W & 1))) return SV_E_UNSUPPORTED;
   if ((int64_t)d->B * d->H * d->W * d->ldx >= (1LL << 31)) return SV_E_UNSUPPORTED;
   if ((int64_t)d->B * svg_oh(d) * svg_ow(d) * svg_gdy(d) >= (1LL << 31)) return SV_E_UNSUPPORTED;
   return SV_OK;
@@ -141,7 +142,7 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   a->S = d->stride;
   a->N = d->Cout;
   a->OHF = OH; a->OWF = OW; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldy;
-  a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1;
+  a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1; a->ups = d->ups_in;
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) {
       a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
@@ -206,7 +207,7 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   a->ldy = svg_gdy(d);
   a->ycols = svg_gdy(d);
   a->cl2 = ilog2_exact(cpad / epp);
-  a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout;
+  a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout; a->ups = d->ups_in;
   a->ntaps = d->KH * d->KW;
   a->Nrows = a->ntaps * cpad;
   for (int kh = 0; kh < d->KH; ++kh)

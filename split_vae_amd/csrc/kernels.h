@@ -25,6 +25,7 @@ struct TapGemmArgs {
   int N;                // real output channels
   int OHF, OWF, OS, ooy, oox, ldo;   // out pixel = ((b*OHF + oy*OS+ooy)*OWF + ox*OS+oox), ldo channels
   int act, out_f32, splitk, ntaps;
+  int ups;              // A is the LOW-RES tensor [B, IH/2, IW/2, lda]; the conv sees its 2x bilinear upsample
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -43,6 +44,7 @@ struct TileConvArgs {
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
   int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
+  int ups;                    // input tile staged through the fused 2x bilinear upsample
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -62,6 +64,7 @@ struct WgradArgs {
   int cl2;            // log2(pieces per tap)
   int Cin_pad, Cin_real, N, Nrows;   // Nrows = ntaps*Cin_pad (padded wrow count)
   int ntaps, msplit;  // msplit = rows of m per blockIdx.z slice (multiple of the m-step)
+  int ups;            // A is the low-res tensor, the layer input is its 2x bilinear upsample (tile kernel only)
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
   int8_t dy[SV_MAX_TAPS];
@@ -80,6 +83,7 @@ struct WgradTileArgs {
   int ldy, YS, lycp;        // dY channels per pixel; bytes per dY pixel in LDS; log2(16-B pieces per dY pixel)
   int in_bytes, dy_bytes;
   int dbg;                  // ablation: 1 = skip the atomic flush
+  int ups;                  // fused 2x bilinear upsample of the input
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];

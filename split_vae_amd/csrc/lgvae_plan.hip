@@ -10,6 +10,7 @@
 #include <vector>
 #include <map>
 #include <stdio.h>
+#include <stdlib.h>
 #include "common.hip.h"
 #include "kernels.h"
 #include "conv_geom.h"
@@ -160,7 +161,7 @@ static void build_layers(sv_lgvae_plan* p) {
                 int ldy, int yf32, int kparam, bool need_dgrad) {
     Layer L;
     L.name = name;
-    L.d = sv_conv_desc{B, h, w, cin, cout, k, k, s, act, d.dtype, ldx, ldy, yf32};
+    L.d = sv_conv_desc{B, h, w, cin, cout, k, k, s, act, d.dtype, ldx, ldy, yf32, 0};
     L.kparam = kparam; L.bparam = kparam + 1; L.need_dgrad = need_dgrad;
     L.wf_off = 0;
     for (int i = 0; i < 4; ++i) L.wd_off[i] = 0;
@@ -185,6 +186,11 @@ static void build_layers(sv_lgvae_plan* p) {
     p->dec[k][2] = mk(pre + "d3", H / 4, W / 4, 128, 64, 4, 1, SV_ACT_RELU, 128, 64, 0, pb + 4, true);
     p->dec[k][3] = mk(pre + "d4", H / 2, W / 2, 64, 32, 6, 1, SV_ACT_RELU, 64, 32, 0, pb + 6, true);
     p->dec[k][4] = mk(pre + "d5", H, W, 32, 6, 6, 1, SV_ACT_NONE, 32, 6, 1, pb + 8, true);
+    // bf16: the three bilinear resizes are fused into the staging of d3/d4/d5's forward and wgrad
+    // tiles (needs >= 16 output pixels per image for the tile kernels: any H >= 16 here)
+    static const bool no_fuse = getenv("SV_NO_FUSED_UPSAMPLE") != nullptr;
+    if (d.dtype == SV_BF16 && !no_fuse && H >= 16)
+      for (int l = 2; l <= 4; ++l) p->dec[k][l].d.ups_in = 1;
   }
 }
 
@@ -409,21 +415,22 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
     SV_TRY(run_fwd_layer(p, p->dec[k][0], zin, s->params, p->bp("h1_" + sfx), st));
     SV_TRY(run_fwd_layer(p, p->dec[k][1], p->bp("h1_" + sfx), s->params, p->bp("h2_" + sfx), st));
-    {
-      Scope sc(p, st, "upsample_fwd", 0, 0);
-      SV_TRY(sv_upsample2x_fwd(p->bp("h2_" + sfx), p->bp("u2_" + sfx), dt, B, H / 8, W / 8, 128, st));
+    // d3..d5 consume the 2x bilinear upsample of the previous activation (vae/model.py:163-167).
+    // Fused (bf16): the conv/wgrad tile staging interpolates from the low-res tensor, u2/u3/u4 are
+    // never written.  Materialised (fp32 parity path, whose wgrad runs on the im2col kernel).
+    static const char* lo_name[3] = {"h2_", "h3_", "h4_"};
+    static const char* hi_name[3] = {"u2_", "u3_", "u4_"};
+    static const char* out_name[3] = {"h3_", "h4_", "out6_"};
+    for (int l = 0; l < 3; ++l) {
+      const Layer& L = p->dec[k][2 + l];
+      const void* in = p->bp(lo_name[l] + sfx);
+      if (!L.d.ups_in) {
+        Scope sc(p, st, "upsample_fwd", 0, 0);
+        SV_TRY(sv_upsample2x_fwd(in, p->bp(hi_name[l] + sfx), dt, B, L.d.H / 2, L.d.W / 2, L.d.Cin, st));
+        in = p->bp(hi_name[l] + sfx);
+      }
+      SV_TRY(run_fwd_layer(p, p->dec[k][2 + l], in, s->params, p->bp(out_name[l] + sfx), st));
     }
-    SV_TRY(run_fwd_layer(p, p->dec[k][2], p->bp("u2_" + sfx), s->params, p->bp("h3_" + sfx), st));
-    {
-      Scope sc(p, st, "upsample_fwd", 0, 0);
-      SV_TRY(sv_upsample2x_fwd(p->bp("h3_" + sfx), p->bp("u3_" + sfx), dt, B, H / 4, W / 4, 64, st));
-    }
-    SV_TRY(run_fwd_layer(p, p->dec[k][3], p->bp("u3_" + sfx), s->params, p->bp("h4_" + sfx), st));
-    {
-      Scope sc(p, st, "upsample_fwd", 0, 0);
-      SV_TRY(sv_upsample2x_fwd(p->bp("h4_" + sfx), p->bp("u4_" + sfx), dt, B, H / 2, W / 2, 32, st));
-    }
-    SV_TRY(run_fwd_layer(p, p->dec[k][4], p->bp("u4_" + sfx), s->params, p->bp("out6_" + sfx), st));
   }
   return SV_OK;
 }
@@ -454,17 +461,17 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     const std::string sfx = en[k];
     Layer* L = p->dec[k];
     // d5
-    SV_TRY(run_wgrad_layer(p, L[4], p->bp("u4_" + sfx), p->bp("g5_" + sfx), s->grads, st));
+    SV_TRY(run_wgrad_layer(p, L[4], p->bp((L[4].d.ups_in ? "h4_" : "u4_") + sfx), p->bp("g5_" + sfx), s->grads, st));
     SV_TRY(run_dgrad_layer(p, L[4], p->bp("g5_" + sfx), nullptr, p->bp("gu4_" + sfx), false, st));
     { Scope sc(p, st, "upsample_bwd", 0, 0);
       SV_TRY(sv_upsample2x_bwd(p->bp("gu4_" + sfx), p->bp("h4_" + sfx), p->bp("g4_" + sfx), dt, B, H / 2, W / 2, 32, st)); }
     // d4
-    SV_TRY(run_wgrad_layer(p, L[3], p->bp("u3_" + sfx), p->bp("g4_" + sfx), s->grads, st));
+    SV_TRY(run_wgrad_layer(p, L[3], p->bp((L[3].d.ups_in ? "h3_" : "u3_") + sfx), p->bp("g4_" + sfx), s->grads, st));
     SV_TRY(run_dgrad_layer(p, L[3], p->bp("g4_" + sfx), nullptr, p->bp("gu3_" + sfx), false, st));
     { Scope sc(p, st, "upsample_bwd", 0, 0);
       SV_TRY(sv_upsample2x_bwd(p->bp("gu3_" + sfx), p->bp("h3_" + sfx), p->bp("g3_" + sfx), dt, B, H / 4, W / 4, 64, st)); }
     // d3
-    SV_TRY(run_wgrad_layer(p, L[2], p->bp("u2_" + sfx), p->bp("g3_" + sfx), s->grads, st));
+    SV_TRY(run_wgrad_layer(p, L[2], p->bp((L[2].d.ups_in ? "h2_" : "u2_") + sfx), p->bp("g3_" + sfx), s->grads, st));
     SV_TRY(run_dgrad_layer(p, L[2], p->bp("g3_" + sfx), nullptr, p->bp("gu2_" + sfx), false, st));
     { Scope sc(p, st, "upsample_bwd", 0, 0);
       SV_TRY(sv_upsample2x_bwd(p->bp("gu2_" + sfx), p->bp("h2_" + sfx), p->bp("g2_" + sfx), dt, B, H / 8, W / 8, 128, st)); }

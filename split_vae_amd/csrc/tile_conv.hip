@@ -15,6 +15,7 @@
 // two resident workgroups per CU to one, and that overlap is worth more than the latency cover.)
 #include "common.hip.h"
 #include "kernels.h"
+#include "tile_stage.hip.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -90,36 +91,10 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvArgs g) {
   }
   // ---- stage the input tile (zero-filled outside the image)
   if (!(g.dbg & 1)) {
-    const T* __restrict__ Ab = (const T*)g.A;
-    // LPR lanes sweep one tile row (no integer division); 4 independent 16-B loads in flight per lane
-    const int ppr = g.TIW * cpp;                      // pieces per tile row
-    const int LPR = ppr > 160 ? 64 : 32, lLPR = ppr > 160 ? 6 : 5;
-    const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = 256 >> lLPR;
-    const int nrows = NB * g.TIH;
+    const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
-    for (int row = srow; row < nrows; row += rows_pp) {
-      int bl = 0, iyl = row;
-      while (iyl >= g.TIH) { iyl -= g.TIH; ++bl; }
-      const int iy = iy_base + iyl, b = b0 + bl;
-      const bool rok = b < g.B && (unsigned)iy < (unsigned)g.IH;
-      const T* src = Ab + ((int64_t)(b * g.IH + iy) * g.IW) * g.lda;
-      char* drow = sIn + row * g.TIW * g.PS;
-      for (int pc0 = slane; pc0 < ppr; pc0 += LPR * 4) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int pc = pc0 + u * LPR;
-          const int ixl = pc >> g.cl2, c = pc & (cpp - 1), ix = ix_base + ixl;
-          v[u] = make_uint4(0, 0, 0, 0);
-          if (pc < ppr && rok && (unsigned)ix < (unsigned)g.IW) v[u] = *(const uint4*)(src + (int64_t)ix * g.lda + c * EPP);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int pc = pc0 + u * LPR;
-          if (pc < ppr) *(uint4*)(drow + (pc >> g.cl2) * g.PS + (pc & (cpp - 1)) * 16) = v[u];
-        }
-      }
-    }
+    if (g.ups) stage_tile_upsampled<T>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
+    else stage_tile_plain<T>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
   }
   // ---- per-lane pixel bases of this wave's MF row fragments
   const int lr = lane & 15, lg = lane >> 4;
@@ -245,6 +220,7 @@ static int launch_tile(const TileConvArgs& a, hipStream_t st) {
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out) {
   if (t.splitk != 1) return false;
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
+  if (t.ups && t.S != 1) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
   const int cin = (1 << t.cl2) * epp;
@@ -268,9 +244,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   const int lTW = OX >= 16 ? 4 : t.lOX;
   const int off_bytes = (((t.P + 7) / 8 * 8) * 4 + 15) / 16 * 16;
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
+  static const char* mf2 = getenv("SV_TC_MF2");       // tuning knob: BN values (as letters a=16,b=32,c=64) forced to 128-row tiles
   for (int MF = 4; MF >= 2; MF -= 2) {
     if (MF == 4 && BN == 128) continue;
-    if (MF == 2 && BN < 64) return false;
+    if (MF == 4 && mf2 && strchr(mf2, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) continue;
+    if (MF == 4 && BN == 32 && OY * OX <= 256 && t.OS == 2) continue;   // measured: e2's dgrad parity classes (16x16 grids) run 20 % faster on 128-row tiles
     const int BM = 64 * MF;
     int lTH = 0;
     while ((1 << (lTW + lTH)) < BM && (1 << lTH) < OY) ++lTH;
@@ -293,7 +271,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS;
     a->off_bytes = off_bytes; a->in_bytes = (int)in_bytes;
     a->N = t.N; a->OHF = t.OHF; a->OWF = t.OWF; a->OS = t.OS; a->ooy = t.ooy; a->oox = t.oox; a->ldo = t.ldo;
-    a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps;
+    a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;
     memcpy(a->dy, t.dy, sizeof(a->dy));
     memcpy(a->dx, t.dx, sizeof(a->dx));
     *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1);
@@ -309,6 +287,8 @@ int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) {
       case 2: return launch_tile<bf16_t, 64, 4>(a, st);
       case 3: return launch_tile<bf16_t, 64, 2>(a, st);
       case 4: return launch_tile<bf16_t, 32, 4>(a, st);
+      case 5: return launch_tile<bf16_t, 32, 2>(a, st);
+      case 7: return launch_tile<bf16_t, 16, 2>(a, st);
       case 6: return launch_tile<bf16_t, 16, 4>(a, st);
     }
   } else if (dtype == SV_F32) {
@@ -317,6 +297,8 @@ int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) {
       case 2: return launch_tile<float, 64, 4>(a, st);
       case 3: return launch_tile<float, 64, 2>(a, st);
       case 4: return launch_tile<float, 32, 4>(a, st);
+      case 5: return launch_tile<float, 32, 2>(a, st);
+      case 7: return launch_tile<float, 16, 2>(a, st);
       case 6: return launch_tile<float, 16, 4>(a, st);
     }
   }
@@ -332,5 +314,6 @@ int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t 
     a.dbg = dbg;
     return svk_tile_conv(a, dtype, cfg, st);
   }
+  if (t.ups) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor
   return svk_tap_gemm(t, dtype, tap_cfg, st);
 }

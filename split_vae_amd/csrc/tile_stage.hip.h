@@ -1,0 +1,112 @@
+// Shared LDS staging of an input spatial tile (+halo) for tile_conv.hip and wgrad_tile.hip.
+//
+//   stage_tile_plain      : tile pixels copied from the NHWC tensor, zero outside the image (SAME pad)
+//   stage_tile_upsampled  : the conv's logical input is the 2x bilinear upsample (tf.image.resize,
+//                           half-pixel centres, edge clamp: vae/model.py:163-167) of a LOW-RES tensor;
+//                           the hi-res tile is produced on the fly and the hi-res tensor never exists.
+//                           Hi-res rows {2i+1, 2i+2} both interpolate low-res rows i and i+1, so one
+//                           thread turns 4 low-res 16-B pieces into a 2x2 block of hi-res pieces: the
+//                           load count equals the plain path's, the bytes fetched are 4x fewer.
+//                           Same blend order as upsample2x_fwd_kernel -> bitwise the same values.
+#pragma once
+#include "common.hip.h"
+
+struct TileStageGeom {
+  int B, IH, IW, lda;       // logical (hi-res when upsampled) input extent; lda = channels per pixel in memory
+  int cl2;                  // log2(16-B chunks per pixel staged)
+  int TIW, TIH, PS;         // LDS tile extent in pixels, bytes per pixel record
+  int NB;                   // images per tile
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
+                                                 int ix_base, char* sIn, int tid) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  const int cpp = 1 << s.cl2;
+  // LPR lanes sweep one tile row (no integer division); 4 independent 16-B loads in flight per lane
+  const int ppr = s.TIW * cpp;                      // pieces per tile row
+  const int LPR = ppr > 160 ? 64 : 32, lLPR = ppr > 160 ? 6 : 5;
+  const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = 256 >> lLPR;
+  const int nrows = s.NB * s.TIH;
+  for (int row = srow; row < nrows; row += rows_pp) {
+    int bl = 0, iyl = row;
+    while (iyl >= s.TIH) { iyl -= s.TIH; ++bl; }
+    const int iy = iy_base + iyl, b = b0 + bl;
+    const bool rok = b < s.B && (unsigned)iy < (unsigned)s.IH;
+    const T* src = Ab + ((int64_t)(b * s.IH + iy) * s.IW) * s.lda;
+    char* drow = sIn + row * s.TIW * s.PS;
+    for (int pc0 = slane; pc0 < ppr; pc0 += LPR * 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = pc0 + u * LPR;
+        const int ixl = pc >> s.cl2, c = pc & (cpp - 1), ix = ix_base + ixl;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (pc < ppr && rok && (unsigned)ix < (unsigned)s.IW) v[u] = *(const uint4*)(src + (int64_t)ix * s.lda + c * EPP);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = pc0 + u * LPR;
+        if (pc < ppr) *(uint4*)(drow + (pc >> s.cl2) * s.PS + (pc & (cpp - 1)) * 16) = v[u];
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 blend4(const uint4& a00, const uint4& a01, const uint4& a10, const uint4& a11, float fx, float fy) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  T v00[EPP], v01[EPP], v10[EPP], v11[EPP], r[EPP];
+  *(uint4*)v00 = a00; *(uint4*)v01 = a01; *(uint4*)v10 = a10; *(uint4*)v11 = a11;
+#pragma unroll
+  for (int e = 0; e < EPP; ++e) {
+    const float top = to_f32(v00[e]) + (to_f32(v01[e]) - to_f32(v00[e])) * fx;
+    const float bot = to_f32(v10[e]) + (to_f32(v11[e]) - to_f32(v10[e])) * fx;
+    r[e] = from_f32<T>(top + (bot - top) * fy);
+  }
+  return *(uint4*)r;
+}
+
+// Ab: LOW-RES tensor [B, IH/2, IW/2, lda]; geometry (IH, IW, iy_base, ix_base, tile) in HI-RES pixels.
+template <typename T>
+__device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
+                                                     int ix_base, char* sIn, int tid) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  const int cpp = 1 << s.cl2;
+  const int LH = s.IH >> 1, LW = s.IW >> 1;
+  // block row i covers hi-res rows 2i+1, 2i+2 (i = (Y-1)>>1): low-res rows i, i+1 (clamped)
+  const int i_lo = (iy_base - 1) >> 1, nbi = ((iy_base + s.TIH - 2) >> 1) - i_lo + 1;
+  const int j_lo = (ix_base - 1) >> 1, nbj = ((ix_base + s.TIW - 2) >> 1) - j_lo + 1;
+  const int per_img = nbi * nbj * cpp, total = s.NB * per_img;
+  for (int q = tid; q < total; q += 256) {
+    const int bl = q / per_img, r1 = q - bl * per_img;
+    const int c = r1 & (cpp - 1), r2 = r1 >> s.cl2;
+    const int bi = r2 / nbj, bj = r2 - bi * nbj;
+    const int i = i_lo + bi, j = j_lo + bj, b = b0 + bl;
+    const int y0 = min(max(i, 0), LH - 1), y1 = min(max(i + 1, 0), LH - 1);
+    const int x0 = min(max(j, 0), LW - 1), x1 = min(max(j + 1, 0), LW - 1);
+    uint4 a00 = make_uint4(0, 0, 0, 0), a01 = a00, a10 = a00, a11 = a00;
+    if (b < s.B) {
+      const T* img = Ab + (int64_t)b * LH * LW * s.lda + c * EPP;
+      a00 = *(const uint4*)(img + ((int64_t)y0 * LW + x0) * s.lda);
+      a01 = *(const uint4*)(img + ((int64_t)y0 * LW + x1) * s.lda);
+      a10 = *(const uint4*)(img + ((int64_t)y1 * LW + x0) * s.lda);
+      a11 = *(const uint4*)(img + ((int64_t)y1 * LW + x1) * s.lda);
+    }
+#pragma unroll
+    for (int dyb = 0; dyb < 2; ++dyb) {
+      const int Y = 2 * i + 1 + dyb, ty = Y - iy_base;
+      if ((unsigned)ty >= (unsigned)s.TIH) continue;
+      const float fy = dyb ? 0.75f : 0.25f;             // weight of the second (y1) row: odd Y .25, even Y .75
+#pragma unroll
+      for (int dxb = 0; dxb < 2; ++dxb) {
+        const int X = 2 * j + 1 + dxb, tx = X - ix_base;
+        if ((unsigned)tx >= (unsigned)s.TIW) continue;
+        const float fx = dxb ? 0.75f : 0.25f;
+        uint4 v = make_uint4(0, 0, 0, 0);               // SAME padding lives in hi-res space
+        if (b < s.B && (unsigned)Y < (unsigned)s.IH && (unsigned)X < (unsigned)s.IW) v = blend4<T>(a00, a01, a10, a11, fx, fy);
+        *(uint4*)(sIn + ((bl * s.TIH + ty) * s.TIW + tx) * s.PS + c * 16) = v;
+      }
+    }
+  }
+}

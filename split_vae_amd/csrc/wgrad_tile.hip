@@ -18,6 +18,7 @@
 #include <string.h>
 #include "common.hip.h"
 #include "kernels.h"
+#include "tile_stage.hip.h"
 
 #ifndef SV_WT_PF
 #define SV_WT_PF 4      // LDS prefetch depth (fragments) of the transposed A-operand reads
@@ -75,11 +76,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
 
   const bf16_t* __restrict__ Ab = (const bf16_t*)g.A + ci0;
   const bf16_t* __restrict__ Yb = (const bf16_t*)g.dY;
-  // staging geometry: LPR lanes sweep one tile row (no integer division anywhere)
-  const int ppr = g.TIW * cpp;                      // 16-B pieces per input-tile row
-  const int LPR = ppr > 160 ? 64 : 32, lLPR = ppr > 160 ? 6 : 5;
-  const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = 256 >> lLPR;
-  const int nrows = NB * g.TIH;
   const int lycp = g.lycp;                          // log2(16-B pieces per dY pixel)
   const int dy_total = (32 * KC) << lycp;
 
@@ -89,32 +85,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
     const int b0 = t << g.lNB;
     __syncthreads();                                // previous tile fully consumed
-    // ---- stage input patch slice (+halo, zero outside the image)
+    // ---- stage input patch slice (+halo, zero outside the image; optionally through the fused upsample)
     {
+      const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
-      for (int row = srow; row < nrows; row += rows_pp) {
-        int bl = 0, iyl = row;
-        while (iyl >= g.TIH) { iyl -= g.TIH; ++bl; }
-        const int iy = iy_base + iyl, b = b0 + bl;
-        const bool rok = b < g.B && (unsigned)iy < (unsigned)g.IH;
-        const bf16_t* src = Ab + ((int64_t)(b * g.IH + iy) * g.IW) * g.lda;
-        char* drow = sIn + row * g.TIW * g.PS;
-        for (int pc0 = slane; pc0 < ppr; pc0 += LPR * 4) {
-          uint4 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int pc = pc0 + u * LPR;
-            const int ixl = pc >> g.cl2, c = pc & (cpp - 1), ix = ix_base + ixl;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (pc < ppr && rok && (unsigned)ix < (unsigned)g.IW) v[u] = *(const uint4*)(src + (int64_t)ix * g.lda + c * 8);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int pc = pc0 + u * LPR;
-            if (pc < ppr) *(uint4*)(drow + (pc >> g.cl2) * g.PS + (pc & (cpp - 1)) * 16) = v[u];
-          }
-        }
-      }
+      if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
+      else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
     }
     // ---- stage dY patch
     for (int q = tid; q < dy_total; q += 256) {
@@ -274,7 +250,7 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   static const char* skip = getenv("SV_WGRAD_IM2COL_IDS");    // e.g. "23": these layer ids use the im2col kernel (A/B)
   if (force_old) return SV_E_UNSUPPORTED;
   const int OY = 1 << w.lOY, OX = 1 << w.lOX;
-  if (OY * OX < 16 || w.ycols != w.ldy) return SV_E_UNSUPPORTED;
+  if (OY * OX < 16 || w.ycols != w.ldy || (w.ups && w.S != 1)) return SV_E_UNSUPPORTED;
   const int cin = w.Cin_pad, cout = w.ldy, nt = w.ntaps;
   // id, pixels per tile, channel slice width, taps per group
   int id = -1, BM = 0, CW = 0, TT = 0;
@@ -308,7 +284,7 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.A = w.A; a.dY = w.dY; a.dW = w.dW; a.dbias = w.dbias;
   a.ws = allow_slab ? w.ws : nullptr; a.ws_bytes = allow_slab ? w.ws_bytes : 0;
-  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S;
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.ups = w.ups;
   a.CW = CW; a.ncg = cin / CW;
   a.cl2 = ilog2_exact(CW / 8);
   a.lTW = lTW; a.lTH = lTH; a.lNB = lNB; a.OY = OY; a.OX = OX;
@@ -349,5 +325,6 @@ int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st) {
     const int rc = svk_wgrad_tile(w, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
+  if (w.ups) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor
   return svk_wgrad(w, dtype, cfg, st);
 }

@@ -120,11 +120,11 @@ def upsample2x_bwd(g_hi, y_lo_mask=None):
 class Conv2D:
     """One Conv2D(padding='same') layer instance on the MFMA path (forward, dgrad, wgrad)."""
 
-    def __init__(self, B, H, W, Cin, Cout, k, stride, act=None, dtype=torch.bfloat16, y_f32=False):
+    def __init__(self, B, H, W, Cin, Cout, k, stride, act=None, dtype=torch.bfloat16, y_f32=False, ups_in=False):
         r8 = lambda v: (v + 7) // 8 * 8
         self.dtype = dtype
         self.desc = ConvDesc(B, H, W, Cin, Cout, k, k, stride, 1 if act == "relu" else 0, sv_dtype(dtype),
-                             r8(Cin), Cout if y_f32 else r8(Cout), 1 if y_f32 else 0)
+                             r8(Cin), Cout if y_f32 else r8(Cout), 1 if y_f32 else 0, 1 if ups_in else 0)
         self.OH, self.OW = (H + stride - 1) // stride, (W + stride - 1) // stride
         lib = _lib.load()
         nf = lib.sv_conv2d_wprep_elems(C.byref(self.desc), 0)

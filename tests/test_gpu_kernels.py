@@ -307,6 +307,36 @@ def test_conv_fwd_dgrad_wgrad(ops, layer, dtype):
     torch.testing.assert_close(dx2[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("layer", [l for l in LAYERS if l[0] in ("d3", "d4", "d5", "d5_64")], ids=lambda l: l[0])
+def test_conv_fused_upsample_equals_materialised(ops, layer):
+    """ups_in: the tile staging interpolates from the low-res tensor.  Same blend order as the
+    stand-alone resize kernel -> the forward output is BITWISE the unfused result; the weight
+    gradient agrees to accumulation order."""
+    name, H, Cin, Cout, k, s, act, yf32 = layer
+    rng = np.random.default_rng(sum(map(ord, name)) + 1)
+    B = 3
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16().cuda()
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)).cuda() * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)).cuda() * 0.1
+    plain = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.bfloat16, y_f32=yf32)
+    fused = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.bfloat16, y_f32=yf32, ups_in=True)
+    plain.prep(w); fused.prep(w)
+    x_hi = ops.upsample2x_fwd(x_lo)
+    # the resize itself against the oracle (tf.image.resize semantics)
+    ref_hi = torch_ref.resize_bilinear_2x(x_lo.float().cpu().double())
+    torch.testing.assert_close(x_hi.float().cpu().double(), ref_hi, rtol=1e-2, atol=1e-2)
+    y0 = plain.fwd(x_hi, b)
+    y1 = fused.fwd(x_lo, b)
+    assert torch.equal(y0, y1)
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, (Cout + 7) // 8 * 8)).astype(np.float32)).bfloat16().cuda()
+    if Cout % 8:
+        dy[..., Cout:] = 0
+    dw0, db0 = plain.wgrad(x_hi, dy, workspace=True)
+    dw1, db1 = fused.wgrad(x_lo, dy, workspace=True)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-4, atol=1e-5 * float(dw0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * float(db0.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K,N", [(2048, 256), (256, 2048), (128, 8192), (8192, 256)])
 def test_dense_as_conv(ops, K, N, dtype):
