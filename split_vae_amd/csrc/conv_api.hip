@@ -4,6 +4,7 @@
 #include "common.hip.h"
 #include "kernels.h"
 #include "conv_geom.h"
+#include <stdlib.h>
 
 // ============================================================================ weight preparation
 // dst[(row*ntaps + t)*inner_ld + inner_off + c]:
@@ -219,7 +220,10 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   static const int BRt[4] = {64, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
   const int ms = d->dtype == SV_BF16 ? 64 : 32;
   const int tiles = ((a->Nrows + BRt[cfg] - 1) / BRt[cfg]) * ((a->N + BNt[cfg] - 1) / BNt[cfg]);
-  int z = 1024 / (tiles > 0 ? tiles : 1);
+  // m-splits: every split adds one atomic pass over dW (~1.3 TB/s chip-wide), so use only as many
+  // as it takes to put ~2 workgroups on each of the 256 CUs (SV_WGRAD_WGS overrides for tuning)
+  static const int target_wgs = getenv("SV_WGRAD_WGS") ? atoi(getenv("SV_WGRAD_WGS")) : 512;
+  int z = target_wgs / (tiles > 0 ? tiles : 1);
   const int maxz = (a->M + ms - 1) / ms;
   if (z < 1) z = 1;
   if (z > maxz) z = maxz;

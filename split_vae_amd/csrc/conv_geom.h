@@ -1,5 +1,6 @@
 // Host-side geometry helpers shared by conv_api.hip and lgvae_plan.hip.
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/splitvae.h"
 #include "kernels.h"
@@ -32,7 +33,8 @@ static inline int svg_choose_splitk(int M, int N, int nk) {
   const int cfg = svg_pick_cfg(N);
   const int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
   if (tiles >= 128) return 1;
-  int s = (256 + tiles - 1) / tiles;
+  static const int target = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 128;   // measured best of 64/128/256/512 on the heads and d1
+  int s = (target + tiles - 1) / tiles;
   if (s > nk / 2) s = nk / 2;
   return s < 1 ? 1 : s;
 }

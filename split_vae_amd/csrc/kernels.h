@@ -42,6 +42,7 @@ struct TileConvArgs {
   int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
   int PS;                     // bytes per pixel in the LDS tile
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
+  int buf_bytes;              // persistent kernel: bytes of each of its two input-tile buffers
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
   int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
   int ups;                    // input tile staged through the fused 2x bilinear upsample

@@ -149,6 +149,57 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
 
   // ---- epilogue: C/D layout col = lane&15 (n), row = (lane>>4)*4 + reg (m)
   const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
+  if (g.splitk == 1) {
+    // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores, as tile_conv.hip
+    const int ncols = min(BN, g.N - n0);
+    const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
+    const int rowb = ncols * oesz;
+    if (!(rowb & 7)) {
+      const int srow = ((rowb + 15) & ~15) + 16;
+      char* sC = smem;                         // all LDS reads finished at the loop's last barrier
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = wave * WM + i * 16 + lg * 4 + r;
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int nl = j * 16 + lr;
+            if (nl >= ncols) continue;
+            float v = acc[i][j][r];
+            if (g.bias) v += g.bias[n0 + nl];
+            if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
+            if (g.out_f32) *(float*)(sC + rl * srow + nl * 4) = v;
+            else *(T*)(sC + rl * srow + nl * (int)sizeof(T)) = from_f32<T>(v);
+          }
+        }
+      __syncthreads();
+      const int psz = (rowb & 15) ? 8 : 16, ppr_o = rowb / psz;
+      for (int q = tid; q < BM * ppr_o; q += 256) {
+        const int rl = q / ppr_o, c = q - rl * ppr_o;
+        const int m = m0 + rl;
+        if (m >= g.M) continue;
+        const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+        const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+        const int64_t ob = (pix * g.ldo + n0) * oesz + c * psz;
+        if (psz == 16) {
+          uint4 v = *(const uint4*)(sC + rl * srow + c * 16);
+          if (g.mask) {
+            const uint4 mv = *(const uint4*)((const char*)g.mask + ob);
+            T ve[EPP], me[EPP];
+            *(uint4*)ve = v; *(uint4*)me = mv;
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) ve[e] = to_f32(me[e]) > 0.f ? ve[e] : from_f32<T>(0.f);
+            v = *(uint4*)ve;
+          }
+          *(uint4*)((char*)g.out + ob) = v;
+        } else {
+          *(uint2*)((char*)g.out + ob) = *(const uint2*)(sC + rl * srow + c * 8);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
 #pragma unroll
@@ -182,11 +233,13 @@ static int launch_tap(const TapGemmArgs& a, hipStream_t st) {
   constexpr int BM = 4 * WM;
   const int Npad = round_up(a.N, BN);
   dim3 grid((a.M + BM - 1) / BM, Npad / BN, a.splitk), block(256);
-  const size_t lds = 2 * BM * 128 + 2 * BN * 128 + SV_MAX_TAPS * 3 * sizeof(int);
-  static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation (idempotent)
-  if (!attr_set) {
+  size_t lds = 2 * BM * 128 + 2 * BN * 128 + SV_MAX_TAPS * 3 * sizeof(int);
+  const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : sizeof(T)) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
+  if (lds < epi) lds = epi;
+  static size_t attr_set = 0;   // raise the dynamic-LDS cap when a launch needs more than any before it
+  if (lds > attr_set) {
     (void)hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set = lds;
   }
   hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, a);
   SV_LAUNCH_CHECK();

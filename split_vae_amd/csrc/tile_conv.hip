@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvArgs g) {
   write_b(0, rbA);
   __syncthreads();                                    // input tile, offsets and weight tile 0 visible
   for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk;
+    const bool more = ks + 1 < nk && !(g.dbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
     if (more) load_b(ks + 1, rbA);
     compute(ks, ks & 1);
     if (more) write_b((ks & 1) ^ 1, rbA);
-    __syncthreads();
+    if (!(g.dbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
   }
 
   // ---- epilogue.  The MFMA D layout (col = lane&15 channel, row = (lane>>4)*4 + reg pixel) would
@@ -281,6 +281,10 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
 }
 
 int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) {
+  // (A persistent variant that staged tile t+1 in per-K-step slices into a second LDS buffer was
+  // built and measured 2-2.5x SLOWER: CDNA's vmcnt retires in order, so every K-step's weight-tile
+  // wait also waited for that step's HBM slice loads, and the second buffer halved the resident
+  // workgroups.  Overlap needs producer waves with their own load queue, not in-loop slices.)
   if (dtype == SV_BF16) {
     switch (cfg) {
       case 1: return launch_tile<bf16_t, 128, 2>(a, st);
