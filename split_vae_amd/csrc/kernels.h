@@ -49,7 +49,11 @@ struct TileConvArgs {
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
+#define SV_MAX_MULTI 8
+struct TileConvMulti { TileConvArgs a[SV_MAX_MULTI]; };   // kernel argument: blockIdx.z selects the problem
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out);
+int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStream_t st);
+int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg, hipStream_t st);
 int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st);
 // picks the direct kernel when the problem fits it, the im2col tap GEMM otherwise
 int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st);

@@ -322,35 +322,58 @@ static double conv_flops(const sv_conv_desc& d) {
     if (rc__) return rc__;   \
   } while (0)
 
+// The x and x-hat networks have twin layers of identical geometry: n of them go out as ONE launch
+// (blockIdx.z picks the problem), which halves the per-launch fixed cost that dominates at B<=512.
+static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const float* params,
+                          void* const* y, hipStream_t st) {
+  TapGemmArgs a[2];
+  double fl = 0;
+  for (int i = 0; i < n; ++i) {
+    svg_fwd_args(&L[i]->d, &a[i]);
+    a[i].A = x[i];
+    a[i].Wt = (char*)p->bp("warena") + L[i]->wf_off * p->esz();
+    a[i].bias = params + p->params[L[i]->bparam].off;
+    a[i].out = y[i];
+    fl += conv_flops(L[i]->d);
+  }
+  Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  return svk_conv_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
+}
 static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float* params, void* y, hipStream_t st) {
-  TapGemmArgs a;
-  svg_fwd_args(&L.d, &a);
-  a.A = x;
-  a.Wt = (char*)p->bp("warena") + L.wf_off * p->esz();
-  a.bias = params + p->params[L.bparam].off;
-  a.out = y;
-  Scope sc(p, st, "fwd." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
-  return svk_conv_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+  Layer* Lp = &L;
+  return run_fwd_layers(p, 1, &Lp, &x, params, &y, st);
 }
 
+// all parity classes of all n twin layers in one launch (stride 2: 4 classes x 2 networks = 8 problems)
+static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* dy, const void* const* mask,
+                            void* const* dx, bool f32_atomic, hipStream_t st) {
+  TapGemmArgs a[SV_MAX_MULTI];
+  double fl = 0;
+  int m = 0;
+  const int ncls = svg_dgrad_classes(&L[0]->d);
+  for (int i = 0; i < n; ++i) {
+    fl += conv_flops(L[i]->d);
+    for (int c = 0; c < ncls; ++c, ++m) {
+      uint8_t srctap[SV_MAX_TAPS];
+      svg_dgrad_args(&L[i]->d, c, &a[m], srctap);
+      a[m].A = dy[i];
+      a[m].Wt = (char*)p->bp("warena") + L[i]->wd_off[c] * p->esz();
+      a[m].out = dx[i];
+      a[m].mask = mask[i];
+      if (f32_atomic) {
+        a[m].out_f32 = 1;
+        a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8);
+      }
+    }
+  }
+  Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  // the classes of a stride-2 layer have different tap counts but plan to the same tile grid
+  return svk_conv_dispatch_multi(a, m, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cin), st);
+}
 static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const void* mask, void* dx, bool f32_atomic,
                            hipStream_t st) {
-  Scope sc(p, st, "dgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
-  for (int c = 0; c < svg_dgrad_classes(&L.d); ++c) {
-    TapGemmArgs a;
-    uint8_t srctap[SV_MAX_TAPS];
-    svg_dgrad_args(&L.d, c, &a, srctap);
-    a.A = dy;
-    a.Wt = (char*)p->bp("warena") + L.wd_off[c] * p->esz();
-    a.out = dx;
-    a.mask = mask;
-    if (f32_atomic) {
-      a.out_f32 = 1;
-      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
-    }
-    SV_TRY(svk_conv_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cin), st));
-  }
-  return SV_OK;
+  Layer* Lp = &L;
+  return run_dgrad_layers(p, 1, &Lp, &dy, &mask, &dx, f32_atomic, st);
 }
 
 static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void* dy, float* grads, hipStream_t st) {
@@ -379,12 +402,19 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
     SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
   }
+  if (do_enc) {
+    static const char* in_name[3] = {"in8_", "a1_", "a2_"};
+    static const char* out_name[3] = {"a1_", "a2_", "a3_"};
+    for (int l = 0; l < 3; ++l) {
+      Layer* Ls[2] = {&p->enc[0][l], &p->enc[1][l]};
+      const void* xs[2] = {p->bp(std::string(in_name[l]) + "x"), p->bp(std::string(in_name[l]) + "xh")};
+      void* ys[2] = {p->bp(std::string(out_name[l]) + "x"), p->bp(std::string(out_name[l]) + "xh")};
+      SV_TRY(run_fwd_layers(p, 2, Ls, xs, s->params, ys, st));
+    }
+  }
   for (int e = 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
     const int L = e == 0 ? Lg : Ll;
-    SV_TRY(run_fwd_layer(p, p->enc[e][0], p->bp("in8_" + sfx), s->params, p->bp("a1_" + sfx), st));
-    SV_TRY(run_fwd_layer(p, p->enc[e][1], p->bp("a1_" + sfx), s->params, p->bp("a2_" + sfx), st));
-    SV_TRY(run_fwd_layer(p, p->enc[e][2], p->bp("a2_" + sfx), s->params, p->bp("a3_" + sfx), st));
     // head: split-K GEMM into the zeroed fp32 pre-activation; bias + softplus live in reparam_kl_fwd
     {
       Layer& Lh = p->enc[e][3];
@@ -410,11 +440,16 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
                                  (float*)p->bp("kl_" + sfx), B, L, s->seed, s->step, e, s->sample_offset, st));
     }
   }
-  for (int k = 0; k < 2 && do_dec; ++k) {
-    const std::string sfx = en[k];
-    const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
-    SV_TRY(run_fwd_layer(p, p->dec[k][0], zin, s->params, p->bp("h1_" + sfx), st));
-    SV_TRY(run_fwd_layer(p, p->dec[k][1], p->bp("h1_" + sfx), s->params, p->bp("h2_" + sfx), st));
+  if (do_dec) {
+    const void* zin[2] = {p->bp("zcat"), (const char*)p->bp("zcat") + (size_t)Lg * p->esz()};
+    for (int k = 0; k < 2; ++k)   // d1 differs between the twins (zcat vs local-only input)
+      SV_TRY(run_fwd_layer(p, p->dec[k][0], zin[k], s->params, p->bp(std::string("h1_") + en[k]), st));
+    {
+      Layer* Ls[2] = {&p->dec[0][1], &p->dec[1][1]};
+      const void* xs[2] = {p->bp("h1_x"), p->bp("h1_xh")};
+      void* ys[2] = {p->bp("h2_x"), p->bp("h2_xh")};
+      SV_TRY(run_fwd_layers(p, 2, Ls, xs, s->params, ys, st));
+    }
     // d3..d5 consume the 2x bilinear upsample of the previous activation (vae/model.py:163-167).
     // Fused (bf16): the conv/wgrad tile staging interpolates from the low-res tensor, u2/u3/u4 are
     // never written.  Materialised (fp32 parity path, whose wgrad runs on the im2col kernel).
@@ -422,14 +457,20 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     static const char* hi_name[3] = {"u2_", "u3_", "u4_"};
     static const char* out_name[3] = {"h3_", "h4_", "out6_"};
     for (int l = 0; l < 3; ++l) {
-      const Layer& L = p->dec[k][2 + l];
-      const void* in = p->bp(lo_name[l] + sfx);
-      if (!L.d.ups_in) {
-        Scope sc(p, st, "upsample_fwd", 0, 0);
-        SV_TRY(sv_upsample2x_fwd(in, p->bp(hi_name[l] + sfx), dt, B, L.d.H / 2, L.d.W / 2, L.d.Cin, st));
-        in = p->bp(hi_name[l] + sfx);
+      Layer* Ls[2] = {&p->dec[0][2 + l], &p->dec[1][2 + l]};
+      const void* xs[2];
+      void* ys[2];
+      for (int k = 0; k < 2; ++k) {
+        const std::string sfx = en[k];
+        xs[k] = p->bp(lo_name[l] + sfx);
+        ys[k] = p->bp(out_name[l] + sfx);
+        if (!Ls[k]->d.ups_in) {
+          Scope sc(p, st, "upsample_fwd", 0, 0);
+          SV_TRY(sv_upsample2x_fwd(xs[k], p->bp(hi_name[l] + sfx), dt, B, Ls[k]->d.H / 2, Ls[k]->d.W / 2, Ls[k]->d.Cin, st));
+          xs[k] = p->bp(hi_name[l] + sfx);
+        }
       }
-      SV_TRY(run_fwd_layer(p, p->dec[k][2 + l], in, s->params, p->bp(out_name[l] + sfx), st));
+      SV_TRY(run_fwd_layers(p, 2, Ls, xs, s->params, ys, st));
     }
   }
   return SV_OK;
@@ -457,27 +498,38 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
   const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
   const int Lg = d.global_latent;
   const char* en[2] = {"x", "xh"};
+  auto both = [&](const char* n, const void** out) { out[0] = p->bp(std::string(n) + "x"); out[1] = p->bp(std::string(n) + "xh"); };
+  const void* none[2] = {nullptr, nullptr};
+  static const char* gy_name[3] = {"g5_", "g4_", "g3_"};       // gradient at the layer output
+  static const char* gu_name[3] = {"gu4_", "gu3_", "gu2_"};    // gradient at the (virtual) upsampled input
+  static const char* lo_name[3] = {"h4_", "h3_", "h2_"};       // low-res activation feeding the upsample
+  static const char* hi_name[3] = {"u4_", "u3_", "u2_"};
+  static const char* gl_name[3] = {"g4_", "g3_", "g2_"};       // gradient at the low-res activation
+  for (int l = 0; l < 3; ++l) {                                // d5, d4, d3
+    const int li = 4 - l;
+    Layer* Ls[2] = {&p->dec[0][li], &p->dec[1][li]};
+    const void *gy[2], *gu[2];
+    both(gy_name[l], gy); both(gu_name[l], gu);
+    for (int k = 0; k < 2; ++k)
+      SV_TRY(run_wgrad_layer(p, *Ls[k], p->bp(std::string(Ls[k]->d.ups_in ? lo_name[l] : hi_name[l]) + en[k]), gy[k], s->grads, st));
+    SV_TRY(run_dgrad_layers(p, 2, Ls, gy, none, (void* const*)gu, false, st));
+    for (int k = 0; k < 2; ++k) {
+      Scope sc(p, st, "upsample_bwd", 0, 0);
+      SV_TRY(sv_upsample2x_bwd(gu[k], p->bp(std::string(lo_name[l]) + en[k]), p->bp(std::string(gl_name[l]) + en[k]), dt, B,
+                               (H / 2) >> l, (W / 2) >> l, 32 << l, st));
+    }
+  }
+  {
+    // d2 (input h1 = relu(d1): mask fused in the dgrad epilogue)
+    Layer* Ls[2] = {&p->dec[0][1], &p->dec[1][1]};
+    const void *g2[2], *h1[2], *g1[2];
+    both("g2_", g2); both("h1_", h1); both("g1_", g1);
+    for (int k = 0; k < 2; ++k) SV_TRY(run_wgrad_layer(p, *Ls[k], h1[k], g2[k], s->grads, st));
+    SV_TRY(run_dgrad_layers(p, 2, Ls, g2, h1, (void* const*)g1, false, st));
+  }
   for (int k = 0; k < 2; ++k) {
     const std::string sfx = en[k];
     Layer* L = p->dec[k];
-    // d5
-    SV_TRY(run_wgrad_layer(p, L[4], p->bp((L[4].d.ups_in ? "h4_" : "u4_") + sfx), p->bp("g5_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[4], p->bp("g5_" + sfx), nullptr, p->bp("gu4_" + sfx), false, st));
-    { Scope sc(p, st, "upsample_bwd", 0, 0);
-      SV_TRY(sv_upsample2x_bwd(p->bp("gu4_" + sfx), p->bp("h4_" + sfx), p->bp("g4_" + sfx), dt, B, H / 2, W / 2, 32, st)); }
-    // d4
-    SV_TRY(run_wgrad_layer(p, L[3], p->bp((L[3].d.ups_in ? "h3_" : "u3_") + sfx), p->bp("g4_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[3], p->bp("g4_" + sfx), nullptr, p->bp("gu3_" + sfx), false, st));
-    { Scope sc(p, st, "upsample_bwd", 0, 0);
-      SV_TRY(sv_upsample2x_bwd(p->bp("gu3_" + sfx), p->bp("h3_" + sfx), p->bp("g3_" + sfx), dt, B, H / 4, W / 4, 64, st)); }
-    // d3
-    SV_TRY(run_wgrad_layer(p, L[2], p->bp((L[2].d.ups_in ? "h2_" : "u2_") + sfx), p->bp("g3_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[2], p->bp("g3_" + sfx), nullptr, p->bp("gu2_" + sfx), false, st));
-    { Scope sc(p, st, "upsample_bwd", 0, 0);
-      SV_TRY(sv_upsample2x_bwd(p->bp("gu2_" + sfx), p->bp("h2_" + sfx), p->bp("g2_" + sfx), dt, B, H / 8, W / 8, 128, st)); }
-    // d2 (input h1 = relu(d1): mask fused in the dgrad epilogue)
-    SV_TRY(run_wgrad_layer(p, L[1], p->bp("h1_" + sfx), p->bp("g2_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[1], p->bp("g2_" + sfx), p->bp("h1_" + sfx), p->bp("g1_" + sfx), false, st));
     // d1 (dense): dz accumulated in fp32 over split K
     const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
     SV_TRY(run_wgrad_layer(p, L[0], zin, p->bp("g1_" + sfx), s->grads, st));
@@ -524,12 +576,20 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       SV_TRY(svk_wgrad(a, dt, svg_pick_cfg(Lh), st));
     }
     if (do_heads) SV_TRY(run_dgrad_layer(p, L[3], p->bp("ghead_" + sfx), p->bp("a3_" + sfx), p->bp("ga3_" + sfx), false, st));
-    if (!do_convs) continue;
-    SV_TRY(run_wgrad_layer(p, L[2], p->bp("a2_" + sfx), p->bp("ga3_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[2], p->bp("ga3_" + sfx), p->bp("a2_" + sfx), p->bp("ga2_" + sfx), false, st));
-    SV_TRY(run_wgrad_layer(p, L[1], p->bp("a1_" + sfx), p->bp("ga2_" + sfx), s->grads, st));
-    SV_TRY(run_dgrad_layer(p, L[1], p->bp("ga2_" + sfx), p->bp("a1_" + sfx), p->bp("ga1_" + sfx), false, st));
-    SV_TRY(run_wgrad_layer(p, L[0], p->bp("in8_" + sfx), p->bp("ga1_" + sfx), s->grads, st));
+  }
+  if (do_convs) {
+    auto both = [&](const char* n, const void** out) { out[0] = p->bp(std::string(n) + "x"); out[1] = p->bp(std::string(n) + "xh"); };
+    static const char* act_name[3] = {"in8_", "a1_", "a2_"};
+    static const char* g_name[3] = {"ga1_", "ga2_", "ga3_"};
+    for (int l = 2; l >= 0; --l) {
+      Layer* Ls[2] = {&p->enc[0][l], &p->enc[1][l]};
+      const void *x[2], *gy[2], *gx[2];
+      both(act_name[l], x); both(g_name[l], gy);
+      for (int k = 0; k < 2; ++k) SV_TRY(run_wgrad_layer(p, *Ls[k], x[k], gy[k], s->grads, st));
+      if (l == 0) break;
+      both(g_name[l - 1], gx);
+      SV_TRY(run_dgrad_layers(p, 2, Ls, gy, x, (void* const*)gx, false, st));
+    }
   }
   return SV_OK;
 }

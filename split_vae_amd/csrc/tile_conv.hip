@@ -36,7 +36,11 @@ template <> struct MmaOpT<float> {
 };
 
 template <typename T, int BN, int MF>
-__global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvArgs g) {
+__global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) {
+  // blockIdx.z picks one of up to 8 problems of identical geometry (the x / x_hat twin networks and
+  // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
+  // workgroups instead of paying the ~10 us fixed latency of a launch each
+  const TileConvArgs& g = mg.a[blockIdx.z];
   constexpr int WM = 16 * MF, BM = 4 * WM, NF = BN / 16;
   constexpr int BRN = BN >= 32 ? BN / 32 : 1;       // weight pieces per thread per step
   constexpr int PPS = 8;                             // 16-B pieces of K per step (128 B per channel)
@@ -200,16 +204,22 @@ static inline size_t tile_lds_bytes(int BN, int MF, const TileConvArgs& a, size_
 }
 
 template <typename T, int BN, int MF>
-static int launch_tile(const TileConvArgs& a, hipStream_t st) {
-  const int Npad = round_up(a.N, BN);
-  dim3 grid(a.ntiles, Npad / BN), block(256);
-  const size_t lds = tile_lds_bytes(BN, MF, a, sizeof(T));
+static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
+  const int Npad = round_up(a[0].N, BN);
+  dim3 grid(a[0].ntiles, Npad / BN, n), block(256);
+  size_t lds = 0;
+  TileConvMulti m;
+  for (int i = 0; i < n; ++i) {
+    m.a[i] = a[i];
+    const size_t l = tile_lds_bytes(BN, MF, a[i], sizeof(T));
+    if (l > lds) lds = l;
+  }
   static size_t attr_set = 0;
   if (lds > attr_set) {
     (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -280,44 +290,72 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   return false;
 }
 
-int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) {
+// n problems of identical geometry (same cfg / tile grid / N) in one launch
+int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStream_t st) {
   // (A persistent variant that staged tile t+1 in per-K-step slices into a second LDS buffer was
   // built and measured 2-2.5x SLOWER: CDNA's vmcnt retires in order, so every K-step's weight-tile
   // wait also waited for that step's HBM slice loads, and the second buffer halved the resident
   // workgroups.  Overlap needs producer waves with their own load queue, not in-loop slices.)
+  if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
   if (dtype == SV_BF16) {
     switch (cfg) {
-      case 1: return launch_tile<bf16_t, 128, 2>(a, st);
-      case 2: return launch_tile<bf16_t, 64, 4>(a, st);
-      case 3: return launch_tile<bf16_t, 64, 2>(a, st);
-      case 4: return launch_tile<bf16_t, 32, 4>(a, st);
-      case 5: return launch_tile<bf16_t, 32, 2>(a, st);
-      case 7: return launch_tile<bf16_t, 16, 2>(a, st);
-      case 6: return launch_tile<bf16_t, 16, 4>(a, st);
+      case 1: return launch_tile<bf16_t, 128, 2>(a, n, st);
+      case 2: return launch_tile<bf16_t, 64, 4>(a, n, st);
+      case 3: return launch_tile<bf16_t, 64, 2>(a, n, st);
+      case 4: return launch_tile<bf16_t, 32, 4>(a, n, st);
+      case 5: return launch_tile<bf16_t, 32, 2>(a, n, st);
+      case 7: return launch_tile<bf16_t, 16, 2>(a, n, st);
+      case 6: return launch_tile<bf16_t, 16, 4>(a, n, st);
     }
   } else if (dtype == SV_F32) {
     switch (cfg) {
-      case 1: return launch_tile<float, 128, 2>(a, st);
-      case 2: return launch_tile<float, 64, 4>(a, st);
-      case 3: return launch_tile<float, 64, 2>(a, st);
-      case 4: return launch_tile<float, 32, 4>(a, st);
-      case 5: return launch_tile<float, 32, 2>(a, st);
-      case 7: return launch_tile<float, 16, 2>(a, st);
-      case 6: return launch_tile<float, 16, 4>(a, st);
+      case 1: return launch_tile<float, 128, 2>(a, n, st);
+      case 2: return launch_tile<float, 64, 4>(a, n, st);
+      case 3: return launch_tile<float, 64, 2>(a, n, st);
+      case 4: return launch_tile<float, 32, 4>(a, n, st);
+      case 5: return launch_tile<float, 32, 2>(a, n, st);
+      case 7: return launch_tile<float, 16, 2>(a, n, st);
+      case 6: return launch_tile<float, 16, 4>(a, n, st);
     }
   }
   return SV_E_BADARG;
 }
 
-int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st) {
+int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) { return svk_tile_conv_multi(&a, 1, dtype, cfg, st); }
+
+// n tap-GEMM problems of the same shape: one multi launch of the tile kernel when they all plan
+// to the same configuration, individual launches otherwise
+int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg, hipStream_t st) {
   static const bool force_tap = getenv("SV_FORCE_IM2COL") != nullptr;   // A/B switch for tests and profiling
+  static const bool no_multi = getenv("SV_NO_MULTI") != nullptr;        // A/B: one launch per problem
   static const int dbg = getenv("SV_TC_DBG") ? atoi(getenv("SV_TC_DBG")) : 0;
-  TileConvArgs a;
-  int cfg;
-  if (!force_tap && svk_tile_conv_plan(t, dtype, t.M >> (t.lOY + t.lOX), &a, &cfg)) {
-    a.dbg = dbg;
-    return svk_tile_conv(a, dtype, cfg, st);
+  if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
+  TileConvArgs a[SV_MAX_MULTI];
+  int cfg[SV_MAX_MULTI];
+  bool all_tile = !force_tap;
+  for (int i = 0; i < n && all_tile; ++i) {
+    all_tile = svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &a[i], &cfg[i]);
+    a[i].dbg = dbg;
+    if (all_tile && i > 0 && (cfg[i] != cfg[0] || a[i].ntiles != a[0].ntiles || a[i].N != a[0].N)) all_tile = false;
   }
-  if (t.ups) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor
-  return svk_tap_gemm(t, dtype, tap_cfg, st);
+  if (all_tile && !no_multi) return svk_tile_conv_multi(a, n, dtype, cfg[0], st);
+  for (int i = 0; i < n; ++i) {
+    int rc;
+    TileConvArgs b;
+    int c;
+    if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &b, &c)) {
+      b.dbg = dbg;
+      rc = svk_tile_conv(b, dtype, c, st);
+    } else if (t[i].ups) {
+      rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor
+    } else {
+      rc = svk_tap_gemm(t[i], dtype, tap_cfg, st);
+    }
+    if (rc) return rc;
+  }
+  return SV_OK;
+}
+
+int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st) {
+  return svk_conv_dispatch_multi(&t, 1, dtype, tap_cfg, st);
 }
