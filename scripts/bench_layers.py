@@ -38,10 +38,12 @@ def main():
     which = os.environ.get("SV_BENCH_OPS", "fwd,dgrad,wgrad").split(",")
     for name in names:
         H, Cin, Cout, k, s, act, yf32 = LAYERS[name]
-        conv = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.bfloat16, y_f32=yf32)
+        ups = name in ("d3", "d4", "d5") and not os.environ.get("SV_NO_FUSED_UPSAMPLE")   # as the training plan runs them
+        conv = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.bfloat16, y_f32=yf32, ups_in=ups)
         w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
         conv.prep(w)
-        x = torch.randn(B, H, H, conv.desc.ldx, device="cuda").to(torch.bfloat16)
+        HI = H // 2 if ups else H
+        x = torch.randn(B, HI, HI, conv.desc.ldx, device="cuda").to(torch.bfloat16)
         bias = torch.zeros(Cout, device="cuda")
         OH = conv.OH
         dy = torch.randn(B, OH, OH, (Cout + 7) // 8 * 8, device="cuda").to(torch.bfloat16)
@@ -62,7 +64,9 @@ def main():
             t = timeit(lambda: lib.sv_conv2d_nhwc_dgrad(C.byref(conv.desc), P(dy), P(conv.w_dgrad), None, P(dx), 0, st()))
             res.append("dgrad %7.1f us %6.0f TF/s" % (t, flops / t / 1e6))
         if "wgrad" in which:
-            t = timeit(lambda: lib.sv_conv2d_nhwc_wgrad(C.byref(conv.desc), P(x), P(dy), P(dw), P(db), st()))
+            n = lib.sv_conv2d_wgrad_workspace_bytes(C.byref(conv.desc))
+            ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+            t = timeit(lambda: lib.sv_conv2d_nhwc_wgrad_ws(C.byref(conv.desc), P(x), P(dy), P(dw), P(db), P(ws), C.c_int64(n), st()))
             res.append("wgrad %7.1f us %6.0f TF/s" % (t, flops / t / 1e6))
         print("%-3s B=%d  %s" % (name, B, "  |  ".join(res)), flush=True)
 

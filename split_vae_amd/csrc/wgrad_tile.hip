@@ -89,11 +89,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
-      if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
+      if (g.dbg & 2) {}
+      else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
       else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
     }
     // ---- stage dY patch
-    for (int q = tid; q < dy_total; q += 256) {
+    for (int q = tid; q < dy_total && !(g.dbg & 4); q += 256) {
       const int r = q >> lycp, c = q & ((1 << lycp) - 1);
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
     }
     __syncthreads();
     // ---- MFMA: K = pixels
+    if (!(g.dbg & 8))
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       short8_t bfr[COF];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
   // a fixed order.  (fp32 atomics straight into dW run at ~1.3 TB/s chip-wide and were 40-60 % of
   // this kernel's time: SV_WT_NOFLUSH ablation.)
   if (g.slab) {
-    if (g.dbg) return;
+    if (g.dbg & 1) return;
     float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * CIF * COF)) * 256 + lane;
 #pragma unroll
     for (int t2 = 0; t2 < TPW; ++t2)
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
 #pragma unroll
         for (int j = 0; j < COF; ++j) {
           const int co = j * 16 + lr;
-          if (co < g.N && !g.dbg) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + co, acc[t2][i][j][r4]);
+          if (co < g.N && !(g.dbg & 1)) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + co, acc[t2][i][j][r4]);
         }
       }
   }
@@ -187,24 +189,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
   }
 }
 
-// second stage of the slab path: dW[...] += sum over the m-splits, in split order (deterministic)
+// second stage of the slab path: dW[...] += sum over the m-splits (fixed order: deterministic).
+// A block sums 32 float4 columns; its 8 thread rows take the splits x = row, row+8, ... with 16-B
+// loads (many in flight: the first version, one scalar column per thread, ran at 1.2 TB/s) and are
+// combined through LDS in row order.
 template <int TPW, int CIF, int COF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
                                                            int msplit, int groups, int ncg, int CW, int Cin_real,
                                                            int N, int ntaps) {
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
-  const int y = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= PER) return;
+  __shared__ float4 part[8][32];
+  const int y = blockIdx.y, col = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const int e = (blockIdx.x * 32 + col) * 4;                     // first of this thread's 4 floats (PER % 128 == 0)
+  const float* p = slab + (int64_t)y * PER + e;
+  const int64_t xs = (int64_t)groups * PER;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int x = row; x < msplit; x += 8) {
+    const float4 v = *(const float4*)(p + x * xs);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[row][col] = s;
+  __syncthreads();
+  if (row) return;
+#pragma unroll
+  for (int r = 1; r < 8; ++r) {
+    const float4 v = part[r][col];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  // e = ((wave*NFR + f)*4 + r4)*64 + lane: four consecutive lanes = four consecutive output channels
   const int wave = e / (NFR * 256), rem = e - wave * (NFR * 256), f = rem >> 8, r4 = (rem >> 6) & 3, lane = rem & 63;
   const int t2 = f / (CIF * COF), i = (f / COF) % CIF, j = f % COF;
   const int tg = y / ncg, cg = y - tg * ncg;
   const int tap = tg * 4 * TPW + wave * TPW + t2;
   const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = cg * CW + cl, co = j * 16 + (lane & 15);
-  if (tap >= ntaps || cl >= CW || ci >= Cin_real || co >= N) return;
-  const float* p = slab + (int64_t)y * PER + e;
-  float s = 0.f;
-  for (int x = 0; x < msplit; ++x) s += p[(int64_t)x * groups * PER];
-  dW[((int64_t)(tap * Cin_real + ci)) * N + co] += s;
+  if (tap >= ntaps || cl >= CW || ci >= Cin_real) return;
+  float* d = dW + ((int64_t)(tap * Cin_real + ci)) * N + co;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (co + k < N) d[k] += sv[k];
 }
 
 template <int TPW, int CIF, int COF, int KC>
@@ -222,8 +246,9 @@ static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
   if (per_cu < 1) per_cu = 1;
   static const int force_pc = getenv("SV_WT_PERCU") ? atoi(getenv("SV_WT_PERCU")) : 0;   // profiling knob
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
-  static const bool no_flush = getenv("SV_WT_NOFLUSH") != nullptr;                       // ablation: skip the atomic flush
-  const_cast<WgradTileArgs&>(a).dbg = no_flush ? 1 : 0;
+  // ablation bits: 1 skip the flush (+reduce), 2 skip input staging, 4 skip dY staging, 8 skip the MFMA loop
+  static const int dbg = getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0);
+  const_cast<WgradTileArgs&>(a).dbg = dbg;
   int msplit = (256 * per_cu + groups - 1) / groups;
   if (msplit > a.ntiles) msplit = a.ntiles;
   dim3 grid(msplit, groups), block(256);
@@ -235,8 +260,8 @@ static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
   b.slab = (a.ws && a.ws_bytes >= need && !no_slab) ? a.ws : nullptr;
   hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, b);
   SV_LAUNCH_CHECK();
-  if (b.slab && !b.dbg) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3((PER + 255) / 256, groups), dim3(256), 0, st,
+  if (b.slab && !(b.dbg & 1)) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups), dim3(256), 0, st,
                        (const float*)b.slab, b.dW, msplit, groups, b.ncg, b.CW, b.Cin_real, b.N, b.ntaps);
     SV_LAUNCH_CHECK();
   }
@@ -263,6 +288,9 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1
   else return SV_E_UNSUPPORTED;
   if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
+  static const char* cw16 = getenv("SV_WT_CW16");             // A/B: 16-channel slices for these layer ids (half the slab traffic)
+  const bool narrow = cw16 && strchr(cw16, '0' + id) && (id == 1 || id == 2);
+  if (narrow) CW = 16;
   if (!skip && (id == 4 || id == 5)) return SV_E_UNSUPPORTED;   // measured: e2 / e3 are faster on the im2col GEMM
   // d5 (6 of 16 columns real) and e1 (3 of 16 rows real): the slabs would carry 3-5x padding, atomics win
   const bool allow_slab = !(id == 0 || id == 6);
@@ -306,8 +334,10 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   // <TPW, CIF, COF, KC>
   switch (id) {
     case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(a, groups, st); break;
-    case 1: if (KC == 8) return launch_wt<9, 2, 2, 8>(a, groups, st); break;
-    case 2: if (KC == 8) return launch_wt<4, 2, 4, 8>(a, groups, st);
+    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(a, groups, st);
+            if (KC == 8) return launch_wt<9, 2, 2, 8>(a, groups, st); break;
+    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(a, groups, st);
+            if (KC == 8) return launch_wt<4, 2, 4, 8>(a, groups, st);
             if (KC == 2) return launch_wt<4, 2, 4, 2>(a, groups, st); break;
     case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(a, groups, st);
             if (KC == 2) return launch_wt<4, 1, 8, 2>(a, groups, st); break;
