@@ -94,7 +94,12 @@ struct WgradTileArgs {
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
+#define SV_WGRAD_MAX_MULTI 2
+struct WgradTileMulti { WgradTileArgs a[SV_WGRAD_MAX_MULTI]; };     // blockIdx.z selects the problem
+struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; };
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
+int svk_wgrad_tile_multi(const WgradArgs* w, int n, hipStream_t st);   // n twin layers, one launch (own ws each)
+int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st);
 // tile kernel when the layer has an instantiation (bf16), im2col kernel otherwise
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st);
 #define SV_WGRAD_WS_BYTES (512LL * 36 * 4 * 256 * 4)   // 512 workgroups x 36 fragments x 4 waves x 256 floats

@@ -266,7 +266,7 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->ws_bytes = 0;
   p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
   p->add_buf("warena", p->arena_elems * es);
-  p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES);
+  p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI);
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
   p->add_buf("zcat", B * Lc * es);
@@ -376,15 +376,25 @@ static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const voi
   return run_dgrad_layers(p, 1, &Lp, &dy, &mask, &dx, f32_atomic, st);
 }
 
+static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const void* const* dy,
+                            float* grads, hipStream_t st) {
+  WgradArgs a[SV_WGRAD_MAX_MULTI];
+  double fl = 0;
+  const int64_t wsb = p->bbytes("wgrad_ws") / SV_WGRAD_MAX_MULTI;      // one partial-sum slab region per problem
+  for (int i = 0; i < n; ++i) {
+    svg_wgrad_args(&L[i]->d, &a[i]);
+    a[i].A = x[i]; a[i].dY = dy[i];
+    a[i].dW = grads + p->params[L[i]->kparam].off;
+    a[i].dbias = grads + p->params[L[i]->bparam].off;
+    a[i].ws = (float*)((char*)p->bp("wgrad_ws") + i * wsb); a[i].ws_bytes = wsb;
+    fl += conv_flops(L[i]->d);
+  }
+  Scope sc(p, st, "wgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
+}
 static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void* dy, float* grads, hipStream_t st) {
-  WgradArgs a;
-  svg_wgrad_args(&L.d, &a);
-  a.A = x; a.dY = dy;
-  a.dW = grads + p->params[L.kparam].off;
-  a.dbias = grads + p->params[L.bparam].off;
-  a.ws = (float*)p->bp("wgrad_ws"); a.ws_bytes = p->bbytes("wgrad_ws");
-  Scope sc(p, st, "wgrad." + L.name.substr(L.name.find('.') + 1), conv_flops(L.d), 0);
-  return svk_wgrad_dispatch(a, L.d.dtype, svg_pick_cfg(L.d.Cout), st);
+  Layer* Lp = &L;
+  return run_wgrad_layers(p, 1, &Lp, &x, &dy, grads, st);
 }
 
 static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
@@ -510,8 +520,9 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     Layer* Ls[2] = {&p->dec[0][li], &p->dec[1][li]};
     const void *gy[2], *gu[2];
     both(gy_name[l], gy); both(gu_name[l], gu);
-    for (int k = 0; k < 2; ++k)
-      SV_TRY(run_wgrad_layer(p, *Ls[k], p->bp(std::string(Ls[k]->d.ups_in ? lo_name[l] : hi_name[l]) + en[k]), gy[k], s->grads, st));
+    const void* xin[2];
+    for (int k = 0; k < 2; ++k) xin[k] = p->bp(std::string(Ls[k]->d.ups_in ? lo_name[l] : hi_name[l]) + en[k]);
+    SV_TRY(run_wgrad_layers(p, 2, Ls, xin, gy, s->grads, st));
     SV_TRY(run_dgrad_layers(p, 2, Ls, gy, none, (void* const*)gu, false, st));
     for (int k = 0; k < 2; ++k) {
       Scope sc(p, st, "upsample_bwd", 0, 0);
@@ -524,7 +535,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     Layer* Ls[2] = {&p->dec[0][1], &p->dec[1][1]};
     const void *g2[2], *h1[2], *g1[2];
     both("g2_", g2); both("h1_", h1); both("g1_", g1);
-    for (int k = 0; k < 2; ++k) SV_TRY(run_wgrad_layer(p, *Ls[k], h1[k], g2[k], s->grads, st));
+    SV_TRY(run_wgrad_layers(p, 2, Ls, h1, g2, s->grads, st));
     SV_TRY(run_dgrad_layers(p, 2, Ls, g2, h1, (void* const*)g1, false, st));
   }
   for (int k = 0; k < 2; ++k) {
@@ -585,7 +596,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       Layer* Ls[2] = {&p->enc[0][l], &p->enc[1][l]};
       const void *x[2], *gy[2], *gx[2];
       both(act_name[l], x); both(g_name[l], gy);
-      for (int k = 0; k < 2; ++k) SV_TRY(run_wgrad_layer(p, *Ls[k], x[k], gy[k], s->grads, st));
+      SV_TRY(run_wgrad_layers(p, 2, Ls, x, gy, s->grads, st));
       if (l == 0) break;
       both(g_name[l - 1], gx);
       SV_TRY(run_dgrad_layers(p, 2, Ls, gy, x, (void* const*)gx, false, st));

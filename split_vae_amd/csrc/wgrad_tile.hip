@@ -31,7 +31,8 @@ __device__ __forceinline__ short4_t tr16(const char* p) {
 // TPW taps per wave (4 waves: tap group = 4*TPW taps), CIF ci-fragments (16 channels) per
 // workgroup slice, COF co-fragments (all of Cout_pad16), KC = 32-pixel K chunks per tile.
 template <int TPW, int CIF, int COF, int KC>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs g) {
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti mg) {
+  const WgradTileArgs& g = mg.a[blockIdx.z];      // twin layers (x / x-hat networks) share one launch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sIn = smem;                       // [NB][TIH][TIW] pixels of PS bytes (+ slack)
   char* sDy = smem + g.in_bytes;          // [BM] pixels of YS bytes (+ slack)
@@ -194,9 +195,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileArgs 
 // loads (many in flight: the first version, one scalar column per thread, ran at 1.2 TB/s) and are
 // combined through LDS in row order.
 template <int TPW, int CIF, int COF>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW,
-                                                           int msplit, int groups, int ncg, int CW, int Cin_real,
-                                                           int N, int ntaps) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMulti m, int msplit, int groups, int ncg,
+                                                           int CW, int Cin_real, int N, int ntaps) {
+  const float* __restrict__ slab = m.slab[blockIdx.z];
+  float* __restrict__ dW = m.dW[blockIdx.z];
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
   __shared__ float4 part[8][32];
   const int y = blockIdx.y, col = threadIdx.x & 31, row = threadIdx.x >> 5;
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <int TPW, int CIF, int COF, int KC>
-static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
-  const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st) {
+  const size_t lds = (size_t)a[0].in_bytes + a[0].dy_bytes;
   static size_t attr_set = 0;
   if (lds > attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC>,
@@ -248,21 +250,27 @@ static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
   // ablation bits: 1 skip the flush (+reduce), 2 skip input staging, 4 skip dY staging, 8 skip the MFMA loop
   static const int dbg = getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0);
-  const_cast<WgradTileArgs&>(a).dbg = dbg;
   int msplit = (256 * per_cu + groups - 1) / groups;
-  if (msplit > a.ntiles) msplit = a.ntiles;
-  dim3 grid(msplit, groups), block(256);
+  if (msplit > a[0].ntiles) msplit = a[0].ntiles;
+  dim3 grid(msplit, groups, n), block(256);
   constexpr int PER = 4 * TPW * CIF * COF * 256;
-  WgradTileArgs b = a;
-  b.dbg = a.dbg;
   const int64_t need = (int64_t)msplit * groups * PER * 4;
   static const bool no_slab = getenv("SV_WT_ATOMICS") != nullptr;
-  b.slab = (a.ws && a.ws_bytes >= need && !no_slab) ? a.ws : nullptr;
-  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, b);
+  WgradTileMulti m;
+  WgradReduceMulti r;
+  bool slab = !no_slab;
+  for (int i = 0; i < n; ++i) slab = slab && a[i].ws && a[i].ws_bytes >= need;
+  for (int i = 0; i < n; ++i) {
+    m.a[i] = a[i];
+    m.a[i].dbg = dbg;
+    m.a[i].slab = slab ? a[i].ws : nullptr;
+    r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW;
+  }
+  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
-  if (b.slab && !(b.dbg & 1)) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups), dim3(256), 0, st,
-                       (const float*)b.slab, b.dW, msplit, groups, b.ncg, b.CW, b.Cin_real, b.N, b.ntaps);
+  if (slab && !(dbg & 1)) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
+                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps);
     SV_LAUNCH_CHECK();
   }
   return SV_OK;
@@ -270,7 +278,9 @@ static int launch_wt(const WgradTileArgs& a, int groups, hipStream_t st) {
 
 // Returns SV_E_UNSUPPORTED when the layer shape has no tile instantiation (caller falls back to
 // the im2col wgrad).  Shapes: the seven conv layers of the SPLIT-VAE encoder/decoder.
-int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
+int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
+  if (n < 1 || n > SV_WGRAD_MAX_MULTI) return SV_E_BADARG;
+  const WgradArgs& w = wv[0];                       // the n problems share one geometry, pointers differ
   static const bool force_old = getenv("SV_FORCE_IM2COL") != nullptr;
   static const char* skip = getenv("SV_WGRAD_IM2COL_IDS");    // e.g. "23": these layer ids use the im2col kernel (A/B)
   if (force_old) return SV_E_UNSUPPORTED;
@@ -308,10 +318,9 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
   const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
   const int B = w.M >> (w.lOY + w.lOX);
-  WgradTileArgs a;
+  WgradTileArgs av[SV_WGRAD_MAX_MULTI];
+  WgradTileArgs& a = av[0];
   memset(&a, 0, sizeof(a));
-  a.A = w.A; a.dY = w.dY; a.dW = w.dW; a.dbias = w.dbias;
-  a.ws = allow_slab ? w.ws : nullptr; a.ws_bytes = allow_slab ? w.ws_bytes : 0;
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.ups = w.ups;
   a.CW = CW; a.ncg = cin / CW;
   a.cl2 = ilog2_exact(CW / 8);
@@ -331,23 +340,43 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) {
   memcpy(a.dx, w.dx, sizeof(a.dx));
   const int groups = a.ncg * ((nt + TT - 1) / TT);
   const int KC = BM / 32;
+  for (int i = n - 1; i >= 0; --i) {
+    av[i] = a;
+    av[i].A = wv[i].A; av[i].dY = wv[i].dY; av[i].dW = wv[i].dW; av[i].dbias = wv[i].dbias;
+    av[i].ws = allow_slab ? wv[i].ws : nullptr; av[i].ws_bytes = allow_slab ? wv[i].ws_bytes : 0;
+  }
   // <TPW, CIF, COF, KC>
   switch (id) {
-    case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(a, groups, st); break;
-    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(a, groups, st);
-            if (KC == 8) return launch_wt<9, 2, 2, 8>(a, groups, st); break;
-    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(a, groups, st);
-            if (KC == 8) return launch_wt<4, 2, 4, 8>(a, groups, st);
-            if (KC == 2) return launch_wt<4, 2, 4, 2>(a, groups, st); break;
-    case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(a, groups, st);
-            if (KC == 2) return launch_wt<4, 1, 8, 2>(a, groups, st); break;
-    case 4: if (KC == 4) return launch_wt<4, 1, 8, 4>(a, groups, st);
-            if (KC == 2) return launch_wt<4, 1, 8, 2>(a, groups, st); break;
-    case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(a, groups, st);
-            if (KC == 2) return launch_wt<9, 1, 4, 2>(a, groups, st); break;
-    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(a, groups, st); break;
+    case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(av, n, groups, st); break;
+    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(av, n, groups, st);
+            if (KC == 8) return launch_wt<9, 2, 2, 8>(av, n, groups, st); break;
+    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(av, n, groups, st);
+            if (KC == 8) return launch_wt<4, 2, 4, 8>(av, n, groups, st);
+            if (KC == 2) return launch_wt<4, 2, 4, 2>(av, n, groups, st); break;
+    case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st); break;
+    case 4: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st); break;
+    case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st);
+            if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st); break;
+    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st); break;
   }
   return SV_E_UNSUPPORTED;
+}
+
+int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) { return svk_wgrad_tile_multi(&w, 1, st); }
+
+int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st) {
+  static const bool no_multi = getenv("SV_NO_MULTI") != nullptr;
+  if (dtype == SV_BF16 && !no_multi) {
+    const int rc = svk_wgrad_tile_multi(w, n, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = svk_wgrad_dispatch(w[i], dtype, cfg, st);
+    if (rc) return rc;
+  }
+  return SV_OK;
 }
 
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st) {
