@@ -127,3 +127,6 @@ int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* b
                         float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
                         int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
                         int64_t sample_offset, hipStream_t st);
+int svk_dlogistic_nll_multi(const float* images6, int ch_off, const float* out6, int64_t zs_out, float* nll,
+                            int64_t zs_nll, void* grad, int64_t zs_grad, int grad_dtype, float grad_scale, int B,
+                            int H, int W, float* partial_ws, int64_t zs_part, int nets, hipStream_t st);

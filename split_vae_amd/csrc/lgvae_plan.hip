@@ -270,46 +270,47 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
   p->add_buf("zcat", B * Lc * es);
-  const char* en[2] = {"x", "xh"};
-  for (int e = 0; e < 2; ++e) {
-    const std::string s = en[e];
-    const int64_t L = e == 0 ? Lg : Ll;
-    p->add_buf("in8_" + s, B * H * W * 8 * es);
-    p->add_buf("a1_" + s, B * (H / 2) * (W / 2) * 32 * es);
-    p->add_buf("a2_" + s, B * (H / 4) * (W / 4) * 64 * es);
-    p->add_buf("a3_" + s, B * F * es);
-    p->add_buf("pre_" + s, B * 2 * L * 4);
-    p->add_buf("z_mean_" + s, B * L * 4);
-    p->add_buf("z_sig_" + s, B * L * 4);
-    p->add_buf("z_" + s, B * L * 4);
-    p->add_buf("eps_" + s, B * L * 4);
-    p->add_buf("kl_" + s, B * 4);
-    p->add_buf("ghead_" + s, B * 2 * L * es);
-    p->add_buf("ga3_" + s, B * F * es);
-    p->add_buf("ga2_" + s, B * (H / 4) * (W / 4) * 64 * es);
-    p->add_buf("ga1_" + s, B * (H / 2) * (W / 2) * 32 * es);
-    // decoder k == e
-    const int64_t Lz = e == 0 ? Lc : Ll;
-    p->add_buf("h1_" + s, B * F * es);
-    p->add_buf("h2_" + s, B * F * es);
-    p->add_buf("u2_" + s, B * (H / 4) * (W / 4) * 128 * es);
-    p->add_buf("h3_" + s, B * (H / 4) * (W / 4) * 64 * es);
-    p->add_buf("u3_" + s, B * (H / 2) * (W / 2) * 64 * es);
-    p->add_buf("h4_" + s, B * (H / 2) * (W / 2) * 32 * es);
-    p->add_buf("u4_" + s, B * H * W * 32 * es);
-    p->add_buf("out6_" + s, B * H * W * 6 * 4);
-    p->add_buf("nll_" + s, B * 4);
-    p->add_buf("nllpart_" + s, sv_dlogistic_nll_workspace_bytes((int)B, (int)H, (int)W));
-    p->add_buf("g5_" + s, B * H * W * 8 * es);
-    p->add_buf("gu4_" + s, B * H * W * 32 * es);
-    p->add_buf("g4_" + s, B * (H / 2) * (W / 2) * 32 * es);
-    p->add_buf("gu3_" + s, B * (H / 2) * (W / 2) * 64 * es);
-    p->add_buf("g3_" + s, B * (H / 4) * (W / 4) * 64 * es);
-    p->add_buf("gu2_" + s, B * (H / 4) * (W / 4) * 128 * es);
-    p->add_buf("g2_" + s, B * F * es);
-    p->add_buf("g1_" + s, B * F * es);
-    p->add_buf("gz_" + s, B * Lz * 4);
-  }
+  // per-network buffers: the x and x-hat twins of one kind are adjacent (x-hat exactly `bytes` after x
+  // when the size is a multiple of 256 B), so pointwise kernels can take both as one batch of 2B
+  auto twin = [&](const char* kind, int64_t bytes_x, int64_t bytes_xh) {
+    p->add_buf(std::string(kind) + "x", bytes_x);
+    p->add_buf(std::string(kind) + "xh", bytes_xh);
+  };
+  auto same = [&](const char* kind, int64_t bytes) { twin(kind, bytes, bytes); };
+  same("in8_", B * H * W * 8 * es);
+  same("a1_", B * (H / 2) * (W / 2) * 32 * es);
+  same("a2_", B * (H / 4) * (W / 4) * 64 * es);
+  same("a3_", B * F * es);
+  twin("pre_", B * 2 * Lg * 4, B * 2 * Ll * 4);
+  twin("z_mean_", B * Lg * 4, B * Ll * 4);
+  twin("z_sig_", B * Lg * 4, B * Ll * 4);
+  twin("z_", B * Lg * 4, B * Ll * 4);
+  twin("eps_", B * Lg * 4, B * Ll * 4);
+  same("kl_", B * 4);
+  twin("ghead_", B * 2 * Lg * es, B * 2 * Ll * es);
+  same("ga3_", B * F * es);
+  same("ga2_", B * (H / 4) * (W / 4) * 64 * es);
+  same("ga1_", B * (H / 2) * (W / 2) * 32 * es);
+  // decoders
+  same("h1_", B * F * es);
+  same("h2_", B * F * es);
+  same("u2_", B * (H / 4) * (W / 4) * 128 * es);
+  same("h3_", B * (H / 4) * (W / 4) * 64 * es);
+  same("u3_", B * (H / 2) * (W / 2) * 64 * es);
+  same("h4_", B * (H / 2) * (W / 2) * 32 * es);
+  same("u4_", B * H * W * 32 * es);
+  same("out6_", B * H * W * 6 * 4);
+  same("nll_", B * 4);
+  same("nllpart_", sv_dlogistic_nll_workspace_bytes((int)B, (int)H, (int)W));
+  same("g5_", B * H * W * 8 * es);
+  same("gu4_", B * H * W * 32 * es);
+  same("g4_", B * (H / 2) * (W / 2) * 32 * es);
+  same("gu3_", B * (H / 2) * (W / 2) * 64 * es);
+  same("g3_", B * (H / 4) * (W / 4) * 64 * es);
+  same("gu2_", B * (H / 4) * (W / 4) * 128 * es);
+  same("g2_", B * F * es);
+  same("g1_", B * F * es);
+  twin("gz_", B * Lc * 4, B * Ll * 4);
 }
 
 static double conv_flops(const sv_conv_desc& d) {
@@ -489,13 +490,15 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
 static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_grad, hipStream_t st) {
   const sv_lgvae_desc& d = p->d;
   const char* en[2] = {"x", "xh"};
-  for (int k = 0; k < 2; ++k) {
-    const std::string sfx = en[k];
-    // algorithmic bytes: read x, m, log_scale (12 B/element) + write dm, dls (2 * esz B/element)
-    Scope sc(p, st, "dlogistic_nll", 0, (double)d.B * d.H * d.W * 3 * (12.0 + (with_grad ? 2.0 * p->esz() : 0.0)));
-    SV_TRY(sv_dlogistic_nll(s->images6, k == 0 ? 0 : 3, (const float*)p->bp("out6_" + sfx), (float*)p->bp("nll_" + sfx),
-                            with_grad ? p->bp("g5_" + sfx) : nullptr, d.dtype, 1.0f / (float)d.B, d.B, d.H, d.W,
-                            (float*)p->bp("nllpart_" + sfx), st));
+  {
+    // algorithmic bytes: read x, m, log_scale (12 B/element) + write dm, dls (2 * esz B/element); both networks
+    Scope sc(p, st, "dlogistic_nll", 0, 2.0 * d.B * d.H * d.W * 3 * (12.0 + (with_grad ? 2.0 * p->esz() : 0.0)));
+    auto zs = [&](const char* kind, int64_t esz) {
+      return (int64_t)((char*)p->bp(std::string(kind) + "xh") - (char*)p->bp(std::string(kind) + "x")) / esz;
+    };
+    SV_TRY(svk_dlogistic_nll_multi(s->images6, 0, (const float*)p->bp("out6_x"), zs("out6_", 4), (float*)p->bp("nll_x"),
+                                   zs("nll_", 4), with_grad ? p->bp("g5_x") : nullptr, zs("g5_", (int64_t)p->esz()), d.dtype,
+                                   1.0f / (float)d.B, d.B, d.H, d.W, (float*)p->bp("nllpart_x"), zs("nllpart_", 4), 2, st));
   }
   SV_TRY(svk_finalize_losses((const float*)p->bp("nll_x"), (const float*)p->bp("nll_xh"), (const float*)p->bp("kl_x"),
                              (const float*)p->bp("kl_xh"), d.B, d.beta, (float*)p->bp("losses"),
@@ -524,10 +527,17 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     for (int k = 0; k < 2; ++k) xin[k] = p->bp(std::string(Ls[k]->d.ups_in ? lo_name[l] : hi_name[l]) + en[k]);
     SV_TRY(run_wgrad_layers(p, 2, Ls, xin, gy, s->grads, st));
     SV_TRY(run_dgrad_layers(p, 2, Ls, gy, none, (void* const*)gu, false, st));
-    for (int k = 0; k < 2; ++k) {
-      Scope sc(p, st, "upsample_bwd", 0, 0);
-      SV_TRY(sv_upsample2x_bwd(gu[k], p->bp(std::string(lo_name[l]) + en[k]), p->bp(std::string(gl_name[l]) + en[k]), dt, B,
-                               (H / 2) >> l, (W / 2) >> l, 32 << l, st));
+    {
+      const void *lo[2], *gl[2];
+      both(lo_name[l], lo); both(gl_name[l], gl);
+      const int h = (H / 2) >> l, w = (W / 2) >> l, c = 32 << l;
+      const int64_t lo_bytes = (int64_t)B * h * w * c * p->esz();
+      const bool contig = (const char*)gu[1] == (const char*)gu[0] + 4 * lo_bytes &&
+                          (const char*)lo[1] == (const char*)lo[0] + lo_bytes && (const char*)gl[1] == (const char*)gl[0] + lo_bytes;
+      Scope sc(p, st, std::string("upsample_bwd.") + lo_name[l][1], 0, 2.0 * 6 * lo_bytes);   // read g_hi (4x) + mask, write g_lo; both networks
+      if (contig) SV_TRY(sv_upsample2x_bwd(gu[0], lo[0], (void*)gl[0], dt, 2 * B, h, w, c, st));
+      else
+        for (int k = 0; k < 2; ++k) SV_TRY(sv_upsample2x_bwd(gu[k], lo[k], (void*)gl[k], dt, B, h, w, c, st));
     }
   }
   {

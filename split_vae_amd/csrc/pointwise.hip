@@ -145,7 +145,13 @@ __global__ __launch_bounds__(256) void dlogistic_kernel(const float* __restrict_
                                                         const float* __restrict__ out6,
                                                         TG* __restrict__ grad, float gscale,
                                                         float* __restrict__ partial, int HW,
-                                                        int pix_per_block) {
+                                                        int pix_per_block, int64_t zs_out, int64_t zs_grad,
+                                                        int64_t zs_part) {
+  // blockIdx.z = network (x / x-hat twin launch): channel triple 3z of images6, buffers one net stride apart
+  ch_off += 3 * blockIdx.z;
+  out6 += blockIdx.z * zs_out;
+  if (GRAD) grad += blockIdx.z * zs_grad;
+  partial += blockIdx.z * zs_part;
   const int part = blockIdx.x, b = blockIdx.y, P = gridDim.x;
   const int64_t base = (int64_t)b * HW;
   const int p0 = part * pix_per_block;
@@ -185,7 +191,10 @@ __global__ __launch_bounds__(256) void dlogistic_kernel(const float* __restrict_
   if (threadIdx.x == 0) partial[(int64_t)b * P + part] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void rowsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ nll, int B, int P) {
+__global__ void rowsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ nll, int B, int P,
+                                       int64_t zs_part, int64_t zs_nll) {
+  partial += blockIdx.y * zs_part;
+  nll += blockIdx.y * zs_nll;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float s = 0.f;
@@ -199,30 +208,39 @@ extern "C" int64_t sv_dlogistic_nll_workspace_bytes(int32_t B, int32_t H, int32_
   return (int64_t)B * dll_parts(H * W) * sizeof(float);
 }
 
+// nets = 1: plain call.  nets = 2: the x and x-hat reconstructions in one launch (channel triples
+// ch_off and ch_off+3 of images6; out6 / nll / grad / partial_ws of the second net one stride further)
+int svk_dlogistic_nll_multi(const float* images6, int ch_off, const float* out6, int64_t zs_out, float* nll,
+                            int64_t zs_nll, void* grad, int64_t zs_grad, int grad_dtype, float grad_scale, int B,
+                            int H, int W, float* partial_ws, int64_t zs_part, int nets, hipStream_t st) {
+  const int HW = H * W, P = dll_parts(HW);
+  const int ppb = (HW + P - 1) / P;
+  dim3 grid(P, B, nets), block(256);
+  if (!grad)
+    hipLaunchKernelGGL((dlogistic_kernel<float, false>), grid, block, 0, st, images6, ch_off, out6,
+                       (float*)nullptr, 0.f, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
+  else if (grad_dtype == SV_BF16)
+    hipLaunchKernelGGL((dlogistic_kernel<bf16_t, true>), grid, block, 0, st, images6, ch_off, out6,
+                       (bf16_t*)grad, grad_scale, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
+  else if (grad_dtype == SV_F32)
+    hipLaunchKernelGGL((dlogistic_kernel<float, true>), grid, block, 0, st, images6, ch_off, out6,
+                       (float*)grad, grad_scale, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
+  else
+    return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rowsum_partials_kernel, dim3((B + 255) / 256, nets), dim3(256), 0, st, partial_ws, nll, B, P,
+                     zs_part, zs_nll);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_dlogistic_nll(const float* images6, int32_t ch_off, const float* out6, float* nll,
                                 void* grad, int32_t grad_dtype, float grad_scale, int32_t B,
                                 int32_t H, int32_t W, float* partial_ws, void* stream) {
   if (!images6 || !out6 || !nll || !partial_ws || B <= 0 || H <= 0 || W <= 0) return SV_E_BADARG;
   if (ch_off != 0 && ch_off != 3) return SV_E_BADARG;
-  const int HW = H * W, P = dll_parts(HW);
-  const int ppb = (HW + P - 1) / P;
-  dim3 grid(P, B), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (!grad)
-    hipLaunchKernelGGL((dlogistic_kernel<float, false>), grid, block, 0, st, images6, ch_off, out6,
-                       (float*)nullptr, 0.f, partial_ws, HW, ppb);
-  else if (grad_dtype == SV_BF16)
-    hipLaunchKernelGGL((dlogistic_kernel<bf16_t, true>), grid, block, 0, st, images6, ch_off, out6,
-                       (bf16_t*)grad, grad_scale, partial_ws, HW, ppb);
-  else if (grad_dtype == SV_F32)
-    hipLaunchKernelGGL((dlogistic_kernel<float, true>), grid, block, 0, st, images6, ch_off, out6,
-                       (float*)grad, grad_scale, partial_ws, HW, ppb);
-  else
-    return SV_E_BADARG;
-  SV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rowsum_partials_kernel, dim3((B + 255) / 256), dim3(256), 0, st, partial_ws, nll, B, P);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
+  return svk_dlogistic_nll_multi(images6, ch_off, out6, 0, nll, 0, grad, 0, grad_dtype, grad_scale, B, H, W, partial_ws,
+                                 0, 1, (hipStream_t)stream);
 }
 
 // ============================================================================ A4 + A7 reparam / KL
