@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
 #pragma unroll
       for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) MmaOpT<T>::run(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NF; ++j) MmaOpT<T>::run(bfr[j], af[i], acc[i][j]);   // D = W x pixels: a lane ends up with 4 CHANNELS of one pixel
     }
   };
   write_b(0, rbA);
@@ -145,30 +145,46 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
     if (!(g.dbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
   }
 
-  // ---- epilogue.  The MFMA D layout (col = lane&15 channel, row = (lane>>4)*4 + reg pixel) would
-  // store 2-byte scalars; instead the bias/activation'd tile is transposed through LDS and written
-  // with 16-byte (8-byte for the 6-channel fp32 head) row-contiguous stores, ReLU mask applied there.
+  // ---- epilogue.  The operands are swapped (D rows = output channels, cols = pixels), so a lane
+  // holds 4 consecutive channels (lane>>4)*4.. of pixel lane&15 per fragment: bias (one 16-B load per
+  // column fragment) + activation, then ONE 8-byte (bf16) / 16-byte (fp32) LDS store per fragment into
+  // a pixel-major tile that is written out with 16-byte row-contiguous stores (8-byte for the
+  // 6-channel fp32 head), ReLU mask applied there.  (The first version stored 2-byte scalars and
+  // re-loaded the bias per element behind a branch: 32 dependent global loads per tile, a 35 us floor.)
   const int ncols = min(BN, g.N - n0);                  // real channels of this column tile
   const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
   const int rowb = ncols * oesz;                        // output bytes per pixel from this tile
   const int srow = ((rowb + 15) & ~15) + 16;            // LDS row pitch (padded)
   char* sC = smem;                                      // reuse: every LDS read finished at the loop's last barrier
+  float bv[NF][4];
 #pragma unroll
-  for (int i = 0; i < MF; ++i)
+  for (int j = 0; j < NF; ++j)
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int r = wave * WM + i * 16 + lg * 4 + r4;
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int nl = j * 16 + lr;
-        if (nl >= ncols) continue;
-        float v = acc[i][j][r4];
-        if (g.bias) v += g.bias[n0 + nl];
-        if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
-        if (g.out_f32) *(float*)(sC + r * srow + nl * 4) = v;
-        else *(T*)(sC + r * srow + nl * (int)sizeof(T)) = from_f32<T>(v);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int nl = j * 16 + lg * 4 + e;
+      bv[j][e] = (g.bias && nl < ncols) ? g.bias[n0 + nl] : 0.f;
     }
+  const bool relu = g.act == SV_ACT_RELU;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int r = wave * WM + i * 16 + lr;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int nl = j * 16 + lg * 4;
+      if (nl >= ncols) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][j][e] + bv[j][e];
+        if (relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (g.out_f32) *(float4*)(sC + r * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      else if constexpr (sizeof(T) == 2) {
+        T pk[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+        *(uint2*)(sC + r * srow + nl * 2) = *(uint2*)pk;
+      } else *(float4*)(sC + r * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
   __syncthreads();
   if (g.dbg & 4) return;
   const int psz = (rowb & 15) ? 8 : 16;                 // piece size; rowb is a multiple of 8
