@@ -141,38 +141,52 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
 #pragma unroll
       for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) MmaOp<T>::run(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NF; ++j) MmaOp<T>::run(bfr[j], af[i], acc[i][j]);   // D = W x rows: a lane gets 4 channels of one row
     }
     if (more) write_stage(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&15 (n), row = (lane>>4)*4 + reg (m)
+  // ---- epilogue.  Operands swapped: D rows = channels, cols = GEMM rows, so a lane holds channels
+  // n0 + j*16 + (lane>>4)*4 + {0..3} of row lane&15 of each fragment (see tile_conv.hip).
   const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
+  const int ncols = min(BN, g.N - n0);
   if (g.splitk == 1) {
-    // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores, as tile_conv.hip
-    const int ncols = min(BN, g.N - n0);
+    // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores
     const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
     const int rowb = ncols * oesz;
     if (!(rowb & 7)) {
       const int srow = ((rowb + 15) & ~15) + 16;
       char* sC = smem;                         // all LDS reads finished at the loop's last barrier
+      float bv[NF][4];
 #pragma unroll
-      for (int i = 0; i < MF; ++i)
+      for (int j = 0; j < NF; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rl = wave * WM + i * 16 + lg * 4 + r;
-#pragma unroll
-          for (int j = 0; j < NF; ++j) {
-            const int nl = j * 16 + lr;
-            if (nl >= ncols) continue;
-            float v = acc[i][j][r];
-            if (g.bias) v += g.bias[n0 + nl];
-            if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
-            if (g.out_f32) *(float*)(sC + rl * srow + nl * 4) = v;
-            else *(T*)(sC + rl * srow + nl * (int)sizeof(T)) = from_f32<T>(v);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int nl = j * 16 + lg * 4 + e;
+          bv[j][e] = (g.bias && nl < ncols) ? g.bias[n0 + nl] : 0.f;
         }
+      const bool relu = g.act == SV_ACT_RELU;
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int rl = wave * WM + i * 16 + lr;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int nl = j * 16 + lg * 4;
+          if (nl >= ncols) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][j][e] + bv[j][e];
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (g.out_f32) *(float4*)(sC + rl * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          else if constexpr (sizeof(T) == 2) {
+            T pk[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+            *(uint2*)(sC + rl * srow + nl * 2) = *(uint2*)pk;
+          } else *(float4*)(sC + rl * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
       __syncthreads();
       const int psz = (rowb & 15) ? 8 : 16, ppr_o = rowb / psz;
       for (int q = tid; q < BM * ppr_o; q += 256) {
@@ -200,19 +214,20 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
       return;
     }
   }
+  // split-K partial sums (fp32 atomics) and odd row widths: straight from the registers
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wave * WM + i * 16 + lr;
+    if (m >= g.M) continue;
+    const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+    const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wave * WM + i * 16 + lg * 4 + r;
-      if (m >= g.M) continue;
-      const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
-      const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        const int n = n0 + j * 16 + lr;
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + j * 16 + lg * 4 + e;
         if (n >= g.N) continue;
-        float v = acc[i][j][r];
+        float v = acc[i][j][e];
         const int64_t o = pix * g.ldo + n;
         if (g.splitk > 1) {
           atomicAdd((float*)g.out + o, v);
@@ -224,7 +239,6 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
         if (g.out_f32) ((float*)g.out)[o] = v;
         else ((T*)g.out)[o] = from_f32<T>(v);
       }
-    }
   }
 }
 

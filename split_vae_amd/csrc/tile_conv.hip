@@ -61,16 +61,19 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
   const int cpp = 1 << g.cl2;                         // 16-B chunks per pixel
 
   // ---- weight-tile pipeline: global -> one of two register sets -> LDS ring
+  // (kernarg fields used in the K loop are copied to locals: through the reference hipcc re-issued
+  // their scalar loads, with an lgkmcnt(0) wait each, in every K step)
   const T* __restrict__ Wb = (const T*)g.Wt;
+  const int gP = g.P, gKtot = g.Ktot, gdbg = g.dbg;
   const int pp = tid & 7, r0 = tid >> 3;
   uint4 rbA[BRN];
   auto load_b = [&](int ks, uint4 (&rb)[BRN]) {
     const int p = ks * 8 + pp;
-    const bool pv = p < g.P;
+    const bool pv = p < gP;
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + 32 * i;
-      rb[i] = (pv && n < BN) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * g.Ktot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
+      rb[i] = (pv && n < BN) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * gKtot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
     }
   };
   auto write_b = [&](int slot, const uint4 (&rb)[BRN]) {
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
       if (n < BN) *(uint4*)(sB + slot * (BN * 128) + n * 128 + ((pp ^ (n & 7)) << 4)) = rb[i];
     }
   };
-  const int nk = (g.dbg & 2) ? 0 : (g.P + 7) >> 3;
+  const int nk = (gdbg & 2) ? 0 : (gP + 7) >> 3;
   load_b(0, rbA);                                     // in flight while the input tile is staged
 
   // ---- piece-offset table
@@ -138,11 +141,11 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
   write_b(0, rbA);
   __syncthreads();                                    // input tile, offsets and weight tile 0 visible
   for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk && !(g.dbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
+    const bool more = ks + 1 < nk && !(gdbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
     if (more) load_b(ks + 1, rbA);
     compute(ks, ks & 1);
     if (more) write_b((ks & 1) ^ 1, rbA);
-    if (!(g.dbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
+    if (!(gdbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
   }
 
   // ---- epilogue.  The operands are swapped (D rows = output channels, cols = pixels), so a lane
@@ -266,7 +269,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // ds_read_b128 fragment over all 64 banks (linear 64/128/256-B pixels are 2/4/8-way conflicted).
   // Measured: pays for >= 128-B pixels at stride 1; for 64-B pixels the extra LDS costs more in
   // occupancy than the 2-way conflict, and at stride 2 no padding can make 2*PS/32 odd.
-  const int PS = cin * esz + ((cin * esz >= 128 && t.S == 1) ? 32 : 0);
+  // At stride 2 the fragment's pixels are 2*PS apart: +16 B makes 2*PS an odd multiple of 32 (linear
+  // 64/128-B pixels are 4/8-way conflicted there).  scripts/lds_bank_model.py has the lane-group model.
+  static const bool s2pad = getenv("SV_TC_NO_S2PAD") == nullptr, p64 = getenv("SV_TC_PAD64") != nullptr;
+  const int pb = cin * esz;
+  const int PS = pb + (t.S == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
   const int lTW = OX >= 16 ? 4 : t.lOX;
   const int off_bytes = (((t.P + 7) / 8 * 8) * 4 + 15) / 16 * 16;
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
