@@ -22,6 +22,44 @@ template <> struct ElemTraits<bf16_t> { static constexpr int EPP = 8; };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// ---- 16-B piece <-> packed fp32 pairs (v_pk_* VALU ops take two floats per instruction)
+template <typename T> struct Piece;
+template <> struct Piece<bf16_t> {
+  static constexpr int NP = 4;   // f32x2 pairs per piece
+  static __device__ __forceinline__ void unpack(const uint4& u, f32x2 (&f)[4]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (f32x2){__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ uint4 pack(const f32x2 (&f)[4]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x2 b = __builtin_convertvector(f[i], bf16x2);   // v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
+      w[i] = __builtin_bit_cast(uint32_t, b);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <> struct Piece<float> {
+  static constexpr int NP = 2;
+  static __device__ __forceinline__ void unpack(const uint4& u, f32x2 (&f)[2]) {
+    f[0] = (f32x2){__uint_as_float(u.x), __uint_as_float(u.y)};
+    f[1] = (f32x2){__uint_as_float(u.z), __uint_as_float(u.w)};
+  }
+  static __device__ __forceinline__ uint4 pack(const f32x2 (&f)[2]) {
+    return make_uint4(__float_as_uint(f[0][0]), __float_as_uint(f[0][1]), __float_as_uint(f[1][0]), __float_as_uint(f[1][1]));
+  }
+};
+// a + (b - a) * w as one subtract and one fused multiply-add per pair: THE interpolation arithmetic of
+// the 2x bilinear resize, shared by upsample2x_fwd_kernel and the fused tile staging (bitwise equal)
+__device__ __forceinline__ f32x2 lerp2(f32x2 a, f32x2 b, float w) {
+  return __builtin_elementwise_fma(b - a, (f32x2){w, w}, a);
+}
+
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }

@@ -419,18 +419,16 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
     const float fy = (oy & 1) ? 0.25f : 0.75f;   // weight of the second (y1) sample
     const float fx = (ox & 1) ? 0.25f : 0.75f;
     const T* base = in + (int64_t)b * H * W * C + c * EPP;
-    T v00[EPP], v01[EPP], v10[EPP], v11[EPP], r[EPP];
-    *(uint4*)v00 = *(const uint4*)(base + ((int64_t)y0 * W + x0) * C);
-    *(uint4*)v01 = *(const uint4*)(base + ((int64_t)y0 * W + x1) * C);
-    *(uint4*)v10 = *(const uint4*)(base + ((int64_t)y1 * W + x0) * C);
-    *(uint4*)v11 = *(const uint4*)(base + ((int64_t)y1 * W + x1) * C);
+    constexpr int NP = Piece<T>::NP;
+    f32x2 v00[NP], v01[NP], v10[NP], v11[NP], r[NP];
+    Piece<T>::unpack(*(const uint4*)(base + ((int64_t)y0 * W + x0) * C), v00);
+    Piece<T>::unpack(*(const uint4*)(base + ((int64_t)y0 * W + x1) * C), v01);
+    Piece<T>::unpack(*(const uint4*)(base + ((int64_t)y1 * W + x0) * C), v10);
+    Piece<T>::unpack(*(const uint4*)(base + ((int64_t)y1 * W + x1) * C), v11);
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) {
-      const float top = to_f32(v00[e]) + (to_f32(v01[e]) - to_f32(v00[e])) * fx;
-      const float bot = to_f32(v10[e]) + (to_f32(v11[e]) - to_f32(v10[e])) * fx;
-      r[e] = from_f32<T>(top + (bot - top) * fy);
-    }
-    *(uint4*)(out + (((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + c * EPP) = *(uint4*)r;
+    for (int e = 0; e < NP; ++e) r[e] = lerp2(lerp2(v00[e], v01[e], fx), lerp2(v10[e], v11[e], fx), fy);   // as tile_stage.hip.h blend2x2
+    const uint4 rp = Piece<T>::pack(r);
+    *(uint4*)(out + (((int64_t)b * 2 * H + oy) * 2 * W + ox) * C + c * EPP) = rp;
   }
 }
 

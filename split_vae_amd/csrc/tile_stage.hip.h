@@ -53,18 +53,28 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
   }
 }
 
+// the 2x2 hi-res block {2i+1, 2i+2} x {2j+1, 2j+2} from the low-res 2x2 neighbourhood: horizontal
+// interpolation first (shared by the two rows), packed fp32 math (56 v_pk ops per 16-B piece quad
+// instead of ~200 scalar ones: the blend, not the MFMAs, was the busiest user of the issue slots)
 template <typename T>
-__device__ __forceinline__ uint4 blend4(const uint4& a00, const uint4& a01, const uint4& a10, const uint4& a11, float fx, float fy) {
-  constexpr int EPP = ElemTraits<T>::EPP;
-  T v00[EPP], v01[EPP], v10[EPP], v11[EPP], r[EPP];
-  *(uint4*)v00 = a00; *(uint4*)v01 = a01; *(uint4*)v10 = a10; *(uint4*)v11 = a11;
+__device__ __forceinline__ void blend2x2(const uint4& a00, const uint4& a01, const uint4& a10, const uint4& a11, uint4 (&out)[2][2]) {
+  constexpr int NP = Piece<T>::NP;
+  f32x2 v00[NP], v01[NP], v10[NP], v11[NP];
+  Piece<T>::unpack(a00, v00); Piece<T>::unpack(a01, v01); Piece<T>::unpack(a10, v10); Piece<T>::unpack(a11, v11);
 #pragma unroll
-  for (int e = 0; e < EPP; ++e) {
-    const float top = to_f32(v00[e]) + (to_f32(v01[e]) - to_f32(v00[e])) * fx;
-    const float bot = to_f32(v10[e]) + (to_f32(v11[e]) - to_f32(v10[e])) * fx;
-    r[e] = from_f32<T>(top + (bot - top) * fy);
+  for (int dxb = 0; dxb < 2; ++dxb) {
+    const float fx = dxb ? 0.75f : 0.25f;               // weight of the second (x1) column: odd X .25, even X .75
+    f32x2 top[NP], bot[NP], r0[NP], r1[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      top[e] = lerp2(v00[e], v01[e], fx);
+      bot[e] = lerp2(v10[e], v11[e], fx);
+      r0[e] = lerp2(top[e], bot[e], 0.25f);             // odd Y
+      r1[e] = lerp2(top[e], bot[e], 0.75f);             // even Y
+    }
+    out[0][dxb] = Piece<T>::pack(r0);
+    out[1][dxb] = Piece<T>::pack(r1);
   }
-  return *(uint4*)r;
 }
 
 // Ab: LOW-RES tensor [B, IH/2, IW/2, lda]; geometry (IH, IW, iy_base, ix_base, tile) in HI-RES pixels.
@@ -78,10 +88,13 @@ __device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, c
   const int i_lo = (iy_base - 1) >> 1, nbi = ((iy_base + s.TIH - 2) >> 1) - i_lo + 1;
   const int j_lo = (ix_base - 1) >> 1, nbj = ((ix_base + s.TIW - 2) >> 1) - j_lo + 1;
   const int per_img = nbi * nbj * cpp, total = s.NB * per_img;
+  // q / per_img and r2 / nbj by reciprocal multiplication: exact for these small operands
+  // ((n + 0.5) / d is never within 2^-20 of an integer), 3 VALU ops instead of a ~25-op integer division
+  const float inv_img = 1.0f / (float)per_img, inv_nbj = 1.0f / (float)nbj;
   for (int q = tid; q < total; q += 256) {
-    const int bl = q / per_img, r1 = q - bl * per_img;
+    const int bl = (int)(((float)q + 0.5f) * inv_img), r1 = q - bl * per_img;
     const int c = r1 & (cpp - 1), r2 = r1 >> s.cl2;
-    const int bi = r2 / nbj, bj = r2 - bi * nbj;
+    const int bi = (int)(((float)r2 + 0.5f) * inv_nbj), bj = r2 - bi * nbj;
     const int i = i_lo + bi, j = j_lo + bj, b = b0 + bl;
     const int y0 = min(max(i, 0), LH - 1), y1 = min(max(i + 1, 0), LH - 1);
     const int x0 = min(max(j, 0), LW - 1), x1 = min(max(j + 1, 0), LW - 1);
@@ -93,19 +106,19 @@ __device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, c
       a10 = *(const uint4*)(img + ((int64_t)y1 * LW + x0) * s.lda);
       a11 = *(const uint4*)(img + ((int64_t)y1 * LW + x1) * s.lda);
     }
+    uint4 blk[2][2];
+    blend2x2<T>(a00, a01, a10, a11, blk);
 #pragma unroll
     for (int dyb = 0; dyb < 2; ++dyb) {
       const int Y = 2 * i + 1 + dyb, ty = Y - iy_base;
       if ((unsigned)ty >= (unsigned)s.TIH) continue;
-      const float fy = dyb ? 0.75f : 0.25f;             // weight of the second (y1) row: odd Y .25, even Y .75
 #pragma unroll
       for (int dxb = 0; dxb < 2; ++dxb) {
         const int X = 2 * j + 1 + dxb, tx = X - ix_base;
         if ((unsigned)tx >= (unsigned)s.TIW) continue;
-        const float fx = dxb ? 0.75f : 0.25f;
-        uint4 v = make_uint4(0, 0, 0, 0);               // SAME padding lives in hi-res space
-        if (b < s.B && (unsigned)Y < (unsigned)s.IH && (unsigned)X < (unsigned)s.IW) v = blend4<T>(a00, a01, a10, a11, fx, fy);
-        *(uint4*)(sIn + ((bl * s.TIH + ty) * s.TIW + tx) * s.PS + c * 16) = v;
+        // SAME padding lives in hi-res space
+        const bool in = b < s.B && (unsigned)Y < (unsigned)s.IH && (unsigned)X < (unsigned)s.IW;
+        *(uint4*)(sIn + ((bl * s.TIH + ty) * s.TIW + tx) * s.PS + c * 16) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
       }
     }
   }
