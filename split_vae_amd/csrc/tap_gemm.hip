@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
   // n0 + j*16 + (lane>>4)*4 + {0..3} of row lane&15 of each fragment (see tile_conv.hip).
   const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
   const int ncols = min(BN, g.N - n0);
-  if (g.splitk == 1) {
-    // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores
+  {
+    // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores; split-K
+    // partial sums take the same route so that their fp32 atomics are issued row-contiguously
     const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
     const int rowb = ncols * oesz;
     if (!(rowb & 7)) {
@@ -188,6 +189,20 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
         }
       }
       __syncthreads();
+      if (g.splitk > 1) {
+        // fp32 partial sums (no bias / activation / mask: checked at launch): one dword per lane,
+        // consecutive lanes on consecutive channels, so an atomic instruction covers whole 128-B lines
+        const float rinv = 1.0f / (float)ncols;
+        for (int q = tid; q < BM * ncols; q += 256) {
+          const int rl = (int)(((float)q + 0.5f) * rinv), n = q - rl * ncols;
+          const int m = m0 + rl;
+          if (m >= g.M) continue;
+          const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+          const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+          atomicAdd((float*)g.out + pix * g.ldo + n0 + n, *(const float*)(sC + rl * srow + n * 4));
+        }
+        return;
+      }
       const int psz = (rowb & 15) ? 8 : 16, ppr_o = rowb / psz;
       for (int q = tid; q < BM * ppr_o; q += 256) {
         const int rl = q / ppr_o, c = q - rl * ppr_o;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
       return;
     }
   }
-  // split-K partial sums (fp32 atomics) and odd row widths: straight from the registers
+  // odd row widths: straight from the registers
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int m = m0 + wave * WM + i * 16 + lr;
