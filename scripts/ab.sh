@@ -1,6 +1,5 @@
-export SV_BENCH_OPS=${SV_BENCH_OPS:-fwd,wgrad}
-L="d5 d4 d3"
-echo "--- np (previous)";  SV_LIB_NAME=libsplitvae_np.so python scripts/bench_layers.py 512 $L
+export SV_BENCH_OPS=wgrad
+L="d5 e1 e2"
 echo "--- cur"; python scripts/bench_layers.py 512 $L
-echo "--- np (previous)";  SV_LIB_NAME=libsplitvae_np.so python scripts/bench_layers.py 512 $L
-echo "--- cur"; python scripts/bench_layers.py 512 $L
+echo "--- SLAB_ALL"; SV_WT_SLAB_ALL=1 python scripts/bench_layers.py 512 $L
+for d in 1 2 4 8; do echo "--- DBG=$d"; SV_WT_DBG=$d python scripts/bench_layers.py 512 d5 e1; done

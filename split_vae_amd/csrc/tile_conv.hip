@@ -35,14 +35,17 @@ template <> struct MmaOpT<float> {
   }
 };
 
-template <typename T, int BN, int MF>
-__global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) {
+// NW waves per workgroup: 4, or 8 (same tile, half the row fragments per wave) where the LDS tile
+// limits a CU to two workgroups -- the kernel is latency-bound and wants waves
+template <typename T, int BN, int MF, int NW>
+__global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti mg) {
   // blockIdx.z picks one of up to 8 problems of identical geometry (the x / x_hat twin networks and
   // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
   // workgroups instead of paying the ~10 us fixed latency of a launch each
   const TileConvArgs& g = mg.a[blockIdx.z];
-  constexpr int WM = 16 * MF, BM = 4 * WM, NF = BN / 16;
-  constexpr int BRN = BN >= 32 ? BN / 32 : 1;       // weight pieces per thread per step
+  constexpr int NT = 64 * NW, WM = 16 * MF, BM = NW * WM, NF = BN / 16;
+  constexpr int RPP = NT / 8;                        // weight rows loaded per pass (8 threads per 128-B row)
+  constexpr int BRN = BN >= RPP ? BN / RPP : 1;      // weight pieces per thread per step
   constexpr int PPS = 8;                             // 16-B pieces of K per step (128 B per channel)
   constexpr int EPP = ElemTraits<T>::EPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,14 +75,14 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
     const bool pv = p < gP;
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
-      const int n = r0 + 32 * i;
+      const int n = r0 + RPP * i;
       rb[i] = (pv && n < BN) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * gKtot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
     }
   };
   auto write_b = [&](int slot, const uint4 (&rb)[BRN]) {
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
-      const int n = r0 + 32 * i;
+      const int n = r0 + RPP * i;
       if (n < BN) *(uint4*)(sB + slot * (BN * 128) + n * 128 + ((pp ^ (n & 7)) << 4)) = rb[i];
     }
   };
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
 
   // ---- piece-offset table
   const int nkp = ((g.P + 7) >> 3) << 3;
-  for (int p = tid; p < nkp; p += 256) {
+  for (int p = tid; p < nkp; p += NT) {
     int off = 0;
     if (p < g.P) {
       const int tap = p >> g.cl2, c = p & (cpp - 1);
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
   if (!(g.dbg & 1)) {
     const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
-    if (g.ups) stage_tile_upsampled<T>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
-    else stage_tile_plain<T>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
+    if (g.ups) stage_tile_upsampled<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
+    else stage_tile_plain<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
   }
   // ---- per-lane pixel bases of this wave's MF row fragments
   const int lr = lane & 15, lg = lane >> 4;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
   if (g.dbg & 4) return;
   const int psz = (rowb & 15) ? 8 : 16;                 // piece size; rowb is a multiple of 8
   const int ppr_o = rowb / psz;
-  for (int q = tid; q < BM * ppr_o; q += 256) {
+  for (int q = tid; q < BM * ppr_o; q += NT) {
     const int r = q / ppr_o, c = q - r * ppr_o;
     const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
     const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
@@ -216,29 +219,29 @@ __global__ __launch_bounds__(256) void tile_conv_kernel(const TileConvMulti mg) 
   }
 }
 
-static inline size_t tile_lds_bytes(int BN, int MF, const TileConvArgs& a, size_t esz) {
+static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_t esz) {
   size_t lds = 2 * BN * 128 + a.off_bytes + a.in_bytes;
-  const size_t epi = (size_t)(64 * MF) * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
+  const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
   return lds < epi ? epi : lds;
 }
 
-template <typename T, int BN, int MF>
+template <typename T, int BN, int MF, int NW = 4>
 static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   const int Npad = round_up(a[0].N, BN);
-  dim3 grid(a[0].ntiles, Npad / BN, n), block(256);
+  dim3 grid(a[0].ntiles, Npad / BN, n), block(64 * NW);
   size_t lds = 0;
   TileConvMulti m;
   for (int i = 0; i < n; ++i) {
     m.a[i] = a[i];
-    const size_t l = tile_lds_bytes(BN, MF, a[i], sizeof(T));
+    const size_t l = tile_lds_bytes(BN, NW * 16 * MF, a[i], sizeof(T));
     if (l > lds) lds = l;
   }
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF>), grid, block, lds, st, m);
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -308,6 +311,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     memcpy(a->dy, t.dy, sizeof(a->dy));
     memcpy(a->dx, t.dx, sizeof(a->dx));
     *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1);
+    // 256-row tiles that leave room for at most two workgroups per CU: 8 waves share the tile
+    static const char* nw8 = getenv("SV_TC_NW8");       // tuning knob: BN classes (a=16, b=32, c=64) run with 8-wave workgroups
+    if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) *cfg_out = 16 + cfgN;
     return true;
   }
   return false;
@@ -329,6 +335,9 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
       case 5: return launch_tile<bf16_t, 32, 2>(a, n, st);
       case 7: return launch_tile<bf16_t, 16, 2>(a, n, st);
       case 6: return launch_tile<bf16_t, 16, 4>(a, n, st);
+      case 17: return launch_tile<bf16_t, 64, 2, 8>(a, n, st);
+      case 18: return launch_tile<bf16_t, 32, 2, 8>(a, n, st);
+      case 19: return launch_tile<bf16_t, 16, 2, 8>(a, n, st);
     }
   } else if (dtype == SV_F32) {
     switch (cfg) {

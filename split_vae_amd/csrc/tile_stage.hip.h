@@ -18,7 +18,7 @@ struct TileStageGeom {
   int NB;                   // images per tile
 };
 
-template <typename T>
+template <typename T, int NT = 256>   // NT = threads of the workgroup
 __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
                                                  int ix_base, char* sIn, int tid) {
   constexpr int EPP = ElemTraits<T>::EPP;
@@ -26,7 +26,7 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
   // LPR lanes sweep one tile row (no integer division); 4 independent 16-B loads in flight per lane
   const int ppr = s.TIW * cpp;                      // pieces per tile row
   const int LPR = ppr > 160 ? 64 : 32, lLPR = ppr > 160 ? 6 : 5;
-  const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = 256 >> lLPR;
+  const int srow = tid >> lLPR, slane = tid & (LPR - 1), rows_pp = NT >> lLPR;
   const int nrows = s.NB * s.TIH;
   for (int row = srow; row < nrows; row += rows_pp) {
     int bl = 0, iyl = row;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void blend2x2(const uint4& a00, const uint4& a01, con
 }
 
 // Ab: LOW-RES tensor [B, IH/2, IW/2, lda]; geometry (IH, IW, iy_base, ix_base, tile) in HI-RES pixels.
-template <typename T>
+template <typename T, int NT = 256>
 __device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
                                                      int ix_base, char* sIn, int tid) {
   constexpr int EPP = ElemTraits<T>::EPP;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, c
   // q / per_img and r2 / nbj by reciprocal multiplication: exact for these small operands
   // ((n + 0.5) / d is never within 2^-20 of an integer), 3 VALU ops instead of a ~25-op integer division
   const float inv_img = 1.0f / (float)per_img, inv_nbj = 1.0f / (float)nbj;
-  for (int q = tid; q < total; q += 256) {
+  for (int q = tid; q < total; q += NT) {
     const int bl = (int)(((float)q + 0.5f) * inv_img), r1 = q - bl * per_img;
     const int c = r1 & (cpp - 1), r2 = r1 >> s.cl2;
     const int bi = (int)(((float)r2 + 0.5f) * inv_nbj), bj = r2 - bi * nbj;

@@ -301,9 +301,10 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   static const char* cw16 = getenv("SV_WT_CW16");             // A/B: 16-channel slices for these layer ids (half the slab traffic)
   const bool narrow = cw16 && strchr(cw16, '0' + id) && (id == 1 || id == 2);
   if (narrow) CW = 16;
-  if (!skip && (id == 4 || id == 5)) return SV_E_UNSUPPORTED;   // measured: e2 / e3 are faster on the im2col GEMM
-  // d5 (6 of 16 columns real) and e1 (3 of 16 rows real): the slabs would carry 3-5x padding, atomics win
-  const bool allow_slab = !(id == 0 || id == 6);
+  if (!skip && id == 4) return SV_E_UNSUPPORTED;   // measured: e3 (8x8 output grid) is no faster here than on the im2col GEMM
+  // every layer takes the two-stage flush when a workspace is given: even d5 (6 of 16 slab columns
+  // real) and e1 (3 of 16 rows real) beat the fp32 atomics (d5: 183 -> 133 us) since the reduce runs at HBM speed
+  const bool allow_slab = true;
   while (OY * OX < BM && (BM % (OY * OX))) BM >>= 1;
   if (BM < 64) return SV_E_UNSUPPORTED;
   int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
