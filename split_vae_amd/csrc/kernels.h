@@ -72,6 +72,7 @@ struct WgradArgs {
   int ups;            // A is the low-res tensor, the layer input is its 2x bilinear upsample (tile kernel only)
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
+  hipEvent_t ev_mid[2];   // profiling: when set, both are recorded after the main kernel, before the slab reduce
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };

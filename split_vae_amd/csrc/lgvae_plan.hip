@@ -126,29 +126,47 @@ struct sv_lgvae_plan {
 namespace {
 
 struct Scope {   // hipEvent bracket around one launch when profiling is on
-  sv_lgvae_plan* p; hipStream_t st; int entry; hipEvent_t a, b; bool on;
+  sv_lgvae_plan* p; hipStream_t st; int entry = -1, entry2 = -1; hipEvent_t a = nullptr, b = nullptr, m1 = nullptr, m2 = nullptr;
+  bool on, on2 = false;
+  hipEvent_t get() {
+    hipEvent_t e;
+    if (!p->event_pool.empty()) { e = p->event_pool.back(); p->event_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  }
+  int find(const std::string& name, double flops, double bytes) {
+    auto it = p->profidx.find(name);
+    if (it != p->profidx.end()) return it->second;
+    const int e = (int)p->prof.size();
+    p->profidx[name] = e;
+    p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0});
+    return e;
+  }
   Scope(sv_lgvae_plan* p_, hipStream_t st_, const std::string& name, double flops, double bytes) : p(p_), st(st_), on(p_->prof_on) {
     if (on && !p->prof_filter.empty() && p->prof_filter != name) on = false;
     if (!on) return;
-    auto it = p->profidx.find(name);
-    if (it == p->profidx.end()) {
-      entry = (int)p->prof.size();
-      p->profidx[name] = entry;
-      p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0});
-    } else entry = it->second;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!p->event_pool.empty()) { e = p->event_pool.back(); p->event_pool.pop_back(); }
-      else (void)hipEventCreate(&e);
-      return e;
-    };
+    entry = find(name, flops, bytes);
     a = get(); b = get();
     (void)hipEventRecord(a, st);
   }
+  // a launch with a second stage (wgrad tile kernel -> slab reduce): the callee records ev[0], ev[1] between
+  // the two, and the second stage is booked under its own name
+  void split(const std::string& name2, double bytes2, hipEvent_t ev[2]) {
+    ev[0] = ev[1] = nullptr;
+    if (!p->prof_on) return;
+    on2 = p->prof_filter.empty() || p->prof_filter == name2;
+    if (!on && !on2) return;
+    if (on2) entry2 = find(name2, 0, bytes2);
+    m1 = ev[0] = get(); m2 = ev[1] = get();
+    if (!b) b = get();
+  }
   ~Scope() {
-    if (!on) return;
+    if (!b) return;
     (void)hipEventRecord(b, st);
-    p->pending.push_back(ProfPending{entry, a, b});
+    if (!m1) { p->pending.push_back(ProfPending{entry, a, b}); return; }
+    if (on) p->pending.push_back(ProfPending{entry, a, m1}); else p->event_pool.push_back(m1);
+    if (on2) p->pending.push_back(ProfPending{entry2, m2, b});
+    else { p->event_pool.push_back(m2); p->event_pool.push_back(b); }
   }
 };
 
@@ -390,7 +408,9 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     a[i].ws = (float*)((char*)p->bp("wgrad_ws") + i * wsb); a[i].ws_bytes = wsb;
     fl += conv_flops(L[i]->d);
   }
-  Scope sc(p, st, "wgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  const std::string nm = "wgrad." + L[0]->name.substr(L[0]->name.find('.') + 1);
+  Scope sc(p, st, nm, fl, 0);
+  sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
 static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void* dy, float* grads, hipStream_t st) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
 }
 
 template <int TPW, int CIF, int COF, int KC>
-static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st) {
+static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
   const size_t lds = (size_t)a[0].in_bytes + a[0].dy_bytes;
   static size_t attr_set = 0;
   if (lds > attr_set) {
@@ -268,6 +268,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st) 
   }
   hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
+  if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
     hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
                        a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps);
@@ -348,19 +349,19 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   }
   // <TPW, CIF, COF, KC>
   switch (id) {
-    case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(av, n, groups, st); break;
-    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(av, n, groups, st);
-            if (KC == 8) return launch_wt<9, 2, 2, 8>(av, n, groups, st); break;
-    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(av, n, groups, st);
-            if (KC == 8) return launch_wt<4, 2, 4, 8>(av, n, groups, st);
-            if (KC == 2) return launch_wt<4, 2, 4, 2>(av, n, groups, st); break;
-    case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st);
-            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st); break;
-    case 4: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st);
-            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st); break;
-    case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st);
-            if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st); break;
-    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st); break;
+    case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 8) return launch_wt<9, 2, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 8) return launch_wt<4, 2, 4, 8>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 2) return launch_wt<4, 2, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
+    case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st, wv[0].ev_mid); break;
+    case 4: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st, wv[0].ev_mid); break;
+    case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
+    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
   }
   return SV_E_UNSUPPORTED;
 }
@@ -374,9 +375,12 @@ int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipS
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
   for (int i = 0; i < n; ++i) {
-    const int rc = svk_wgrad_dispatch(w[i], dtype, cfg, st);
+    WgradArgs wi = w[i];
+    wi.ev_mid[0] = wi.ev_mid[1] = nullptr;
+    const int rc = svk_wgrad_dispatch(wi, dtype, cfg, st);
     if (rc) return rc;
   }
+  if (w[0].ev_mid[0]) { (void)hipEventRecord(w[0].ev_mid[0], st); (void)hipEventRecord(w[0].ev_mid[1], st); }   // no second stage on this path
   return SV_OK;
 }
 
