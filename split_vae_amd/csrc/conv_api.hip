@@ -322,11 +322,12 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
     uint8_t srctap[SV_MAX_TAPS];
     svg_dgrad_args(d, c, &a, srctap);
     a.A = dy; a.Wt = (const char*)w_dgrad + off * esz; a.out = dx; a.mask = relu_mask;
+    int cfg = svg_pick_cfg(d->Cin);
     if (dx_f32_atomic) {
       a.out_f32 = 1;
-      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
+      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
     }
-    rc = svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
+    rc = svk_conv_dispatch(a, d->dtype, cfg, (hipStream_t)stream);
     if (rc) return rc;
     off += svg_wprep_elems_class(d, 1, c);
   }

@@ -27,14 +27,20 @@ static inline int svg_pick_cfg(int N) {
   if (N % 32 == 0) return 2;
   return 3;
 }
-// split K across workgroups when the M x N tile grid cannot fill 256 CUs
-static inline int svg_choose_splitk(int M, int N, int nk) {
+// split K across workgroups when the M x N tile grid cannot fill 256 CUs.  *cfg (optional) is the
+// tap-GEMM tile: a split-K problem on 128-column tiles drops to 64 columns (twice the workgroups for
+// the same number of atomic passes; prepared weight rows are padded to 128, so either tile fits).
+static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr) {
   static const int BMt[4] = {128, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
-  const int cfg = svg_pick_cfg(N);
-  const int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
+  static const bool narrow = getenv("SV_SPLITK_NO_NARROW") == nullptr;
+  int cfg = svg_pick_cfg(N);
+  int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
   if (tiles >= 128) return 1;
+  if (cfg == 0 && cfg_io && narrow) { cfg = 1; tiles *= 2; }
+  if (cfg_io) *cfg_io = cfg;
   static const int target = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 128;   // measured best of 64/128/256/512 on the heads and d1
-  int s = (target + tiles - 1) / tiles;
+  const int tgt = cfg_io && narrow && cfg == 1 && svg_pick_cfg(N) == 0 ? 2 * target : target;
+  int s = (tgt + tiles - 1) / tiles;
   if (s > nk / 2) s = nk / 2;
   return s < 1 ? 1 : s;
 }

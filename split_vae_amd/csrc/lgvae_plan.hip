@@ -368,7 +368,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
                             void* const* dx, bool f32_atomic, hipStream_t st) {
   TapGemmArgs a[SV_MAX_MULTI];
   double fl = 0;
-  int m = 0;
+  int m = 0, tap_cfg = svg_pick_cfg(L[0]->d.Cin);
   const int ncls = svg_dgrad_classes(&L[0]->d);
   for (int i = 0; i < n; ++i) {
     fl += conv_flops(L[i]->d);
@@ -381,13 +381,13 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       a[m].mask = mask[i];
       if (f32_atomic) {
         a[m].out_f32 = 1;
-        a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8);
+        a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8, &tap_cfg);
       }
     }
   }
   Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
   // the classes of a stride-2 layer have different tap counts but plan to the same tile grid
-  return svk_conv_dispatch_multi(a, m, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cin), st);
+  return svk_conv_dispatch_multi(a, m, L[0]->d.dtype, tap_cfg, st);
 }
 static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const void* mask, void* dx, bool f32_atomic,
                            hipStream_t st) {
@@ -455,9 +455,10 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       a.A = p->bp("a3_" + sfx);
       a.Wt = (char*)p->bp("warena") + Lh.wf_off * p->esz();
       a.bias = nullptr; a.out = p->bp("pre_" + sfx); a.out_f32 = 1;
-      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8);
+      int cfg = svg_pick_cfg(Lh.d.Cout);
+      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
       Scope sc(p, st, "fwd.head", conv_flops(Lh.d), 0);
-      SV_TRY(svk_tap_gemm(a, dt, svg_pick_cfg(Lh.d.Cout), st));
+      SV_TRY(svk_tap_gemm(a, dt, cfg, st));
     }
     {
       Scope sc(p, st, "reparam_kl_fwd", 0, (double)B * L * 16);
