@@ -14,6 +14,19 @@
 template <typename T>
 __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
                                            T* __restrict__ arena, int block_in_job) {
+  if (j.packx_kw) {
+    const int total = j.rows * j.ntaps * j.inner;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % j.inner, t2 = idx / j.inner, t = t2 % j.ntaps, row = t2 / j.ntaps;
+    const int px = row >> 3, co = row & 7, ky = t / (j.packx_kw + 1), tx = t - ky * (j.packx_kw + 1);
+    const int kx = tx - px;
+    float v = 0.f;
+    if (co < j.Cout && c < j.Cin && (unsigned)kx < (unsigned)j.packx_kw)
+      v = params[j.src_off + ((int64_t)(ky * j.packx_kw + kx) * j.Cin + c) * j.Cout + co];
+    arena[j.dst_off + ((int64_t)row * j.ntaps + t) * j.inner_ld + j.inner_off + c] = from_f32<T>(v);
+    return;
+  }
   if (j.ntaps == 1 && !j.transpose) {
     // dense forward image dst[co][ci] = src[ci][co]: 32x32 tiles through LDS so that both the fp32
     // reads (contiguous in co) and the low-precision writes (contiguous in ci) are coalesced
@@ -140,10 +153,25 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   a->ntaps = d->KH * d->KW;
   a->Ktot = a->ntaps * cpad;
   a->P = a->Ktot / epp;
-  a->S = d->stride;
+  a->S = d->stride; a->SX = d->stride;
   a->N = d->Cout;
   a->OHF = OH; a->OWF = OW; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldy;
   a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1; a->ups = d->ups_in;
+  if (svg_packx(d)) {
+    // rows = output pixel pairs (y, 2X .. 2X+1); tap (ky, tx) reads input pixel (y + ky - pt, 2X + tx - pl)
+    a->M = d->B * OH * (OW / 2);
+    a->lOX = ilog2_exact(OW / 2);
+    a->ntaps = d->KH * (d->KW + 1);
+    a->Ktot = a->ntaps * cpad;
+    a->P = a->Ktot / epp;
+    a->SX = 2; a->N = 16; a->d2s = d->Cout;
+    for (int ky = 0; ky < d->KH; ++ky)
+      for (int tx = 0; tx <= d->KW; ++tx) {
+        a->dy[ky * (d->KW + 1) + tx] = (int8_t)(ky - pt);
+        a->dx[ky * (d->KW + 1) + tx] = (int8_t)(tx - pl);
+      }
+    return;
+  }
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) {
       a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
@@ -166,7 +194,7 @@ void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srct
   a->lOY = ilog2_exact(gy); a->lOX = ilog2_exact(gx);
   a->IH = OH; a->IW = OW; a->lda = gdy;
   a->cl2 = ilog2_exact(gdy / epp);
-  a->S = 1;
+  a->S = 1; a->SX = 1;
   a->N = d->Cin;
   a->OHF = d->H; a->OWF = d->W; a->OS = s; a->ooy = ph; a->oox = pw; a->ldo = d->ldx;
   a->act = SV_ACT_NONE; a->out_f32 = 0; a->splitk = 1;
@@ -239,6 +267,11 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
   j->inner = svg_cin_pad(d);
   j->inner_ld = j->inner; j->inner_off = 0;
   j->transpose = 0;
+  if (svg_packx(d)) {
+    j->ntaps = d->KH * (d->KW + 1);
+    j->rows = 16;
+    j->packx_kw = d->KW;
+  }
   for (int t = 0; t < j->ntaps; ++t) j->srctap[t] = (uint8_t)t;
   j->nblocks = svg_prep_nblocks(j);
 }

@@ -20,6 +20,19 @@ static inline void svg_pads(const sv_conv_desc* d, int* pt, int* pl) {
   *pt = ph / 2;
   *pl = pw / 2;
 }
+// x-pixel packing of a thin-output stride-1 conv (the 6-channel decoder head d5).  With N = Cout <= 8
+// an MFMA tile is 10/16 padding and every A fragment read from LDS feeds a single MFMA.  Written
+// for PAIRS of output pixels (y, 2X+px) the same conv has x-stride 2, KW+1 taps in x and 2*8 = 16
+// output columns n = px*8 + co with W'[ky][tx][ci][n] = W[ky][tx-px][ci][co] (zero outside the kernel):
+// (KW+1)/(2*KW) = 0.58x the MFMAs, A/B fragment reads and K steps for the same LDS tile per output.
+// Its dY is the ordinary [B,H,W,8] gradient viewed as [B,H,W/2,16].  Forward (tile_conv.hip, depth-to-
+// space stores) and wgrad (wgrad_tile.hip, folded reduce) use it; the dgrad keeps the direct form.
+static inline int svg_packx(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_PACKX") != nullptr;
+  return !off && d->dtype == SV_BF16 && d->stride == 1 && d->Cout <= 8 && !(d->Cout & 1) && d->y_f32 &&
+         d->ldy == d->Cout && d->KH * (d->KW + 1) <= SV_MAX_TAPS && d->W >= 32 && d->H >= 16 &&
+         svg_cin_pad(d) >= 16 && svg_cin_pad(d) <= 64;
+}
 // N tile selection of the tap GEMM: 0: 128, 1: 64, 2: 32, 3: 16 columns
 static inline int svg_pick_cfg(int N) {
   if (N % 128 == 0) return 0;
@@ -49,7 +62,8 @@ static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr)
 #define SV_PREP_UNITS 8
 static inline int svg_prep_nblocks(const PrepJob* j) {
   int64_t units;
-  if (j->ntaps == 1 && !j->transpose) units = (int64_t)((j->rows + 31) / 32) * ((j->inner + 31) / 32);
+  if (j->packx_kw) units = ((int64_t)j->rows * j->ntaps * j->inner + 255) / 256;
+  else if (j->ntaps == 1 && !j->transpose) units = (int64_t)((j->rows + 31) / 32) * ((j->inner + 31) / 32);
   else if (j->transpose && !(j->inner & 3) && !(j->Cout & 3) && !(j->inner_off & 3) && !(j->inner_ld & 3))
     units = ((int64_t)j->rows * j->ntaps * (j->inner >> 2) + 255) / 256;          // 4 channels per thread
   else units = ((int64_t)j->rows * j->ntaps * j->inner + 255) / 256;

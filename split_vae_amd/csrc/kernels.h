@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define SV_MAX_TAPS 36
+#define SV_MAX_TAPS 42      // 6 x 7: the x-pixel-packed form of a 6x6 stride-1 conv (conv_geom.h svg_packx)
 
 // ---- generic "tap GEMM": out[m, n] = sum_{t, c} A[pix(m) + tap t, c] * Wt[n][t][c]
 // rows m enumerate (b, oy, ox) over a power-of-two OY x OX grid; taps are (dy, dx) offsets on an
@@ -21,11 +21,13 @@ struct TapGemmArgs {
   int cl2;              // log2(16-byte pieces per tap) ; Cin = (1<<cl2)*EPP
   int P;                // total 16-byte pieces along K
   int Ktot;             // ntaps*Cin  (row length of Wt in elements)
-  int S;                // input coordinate = o*S + d
+  int S, SX;            // input coordinate = oy*S + dy, ox*SX + dx  (SX = S except for the x-packed conv)
   int N;                // real output channels
   int OHF, OWF, OS, ooy, oox, ldo;   // out pixel = ((b*OHF + oy*OS+ooy)*OWF + ox*OS+oox), ldo channels
   int act, out_f32, splitk, ntaps;
   int ups;              // A is the LOW-RES tensor [B, IH/2, IW/2, lda]; the conv sees its 2x bilinear upsample
+  int d2s;              // > 0: x-pixel-packed conv: column n = px*8 + co holds channel co < d2s of output pixel
+                        // (oy, 2*ox + px); out is the unpacked [B, OHF, OWF, ldo] tensor
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -36,7 +38,7 @@ int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st);
 struct TileConvArgs {
   const void* A; const void* Wt; const float* bias; void* out; const void* mask;
   int B, IH, IW, lda;
-  int cl2, P, Ktot, S;
+  int cl2, P, Ktot, S, SX;
   int lTW, lTH, lNB;          // log2 tile width / height (iteration-grid pixels) / images per tile
   int OY, OX, tilesX, tilesY, ntiles;
   int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
@@ -46,6 +48,7 @@ struct TileConvArgs {
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
   int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
   int ups;                    // input tile staged through the fused 2x bilinear upsample
+  int d2s;                    // depth-to-space (x) epilogue of the pixel-packed conv: real channels per sub-pixel
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -114,6 +117,8 @@ struct PrepJob {
   int32_t rows, inner; // destination [rows][ntaps][inner] ...
   int32_t inner_ld, inner_off; // ... stored with row pitch inner_ld at column offset inner_off
   int32_t transpose;   // 0: rows=co, inner=ci (forward); 1: rows=ci, inner=co (dgrad)
+  int32_t packx_kw;    // > 0: forward image of the x-packed conv of a KH x packx_kw kernel: row n = px*8 + co,
+                       // tap (ky, tx) of KH x (KW+1) <- source tap (ky, tx - px), zero outside the kernel
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap

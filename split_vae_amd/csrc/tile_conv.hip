@@ -19,6 +19,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef SV_TC_PPS16
+#define SV_TC_PPS16 16    // K-step pieces of the 16-column kernel (build-time A/B knob)
+#endif
+static __host__ __device__ constexpr int tile_pps(int BN) { return BN == 16 ? SV_TC_PPS16 : 8; }
+
 template <typename T> struct MmaOpT;
 template <> struct MmaOpT<bf16_t> {
   static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
@@ -44,14 +49,16 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   // workgroups instead of paying the ~10 us fixed latency of a launch each
   const TileConvArgs& g = mg.a[blockIdx.z];
   constexpr int NT = 64 * NW, WM = 16 * MF, BM = NW * WM, NF = BN / 16;
-  constexpr int RPP = NT / 8;                        // weight rows loaded per pass (8 threads per 128-B row)
+  // 16-B pieces of K per step.  128 B per weight row normally; the 16-column kernel takes 512-B steps:
+  // its steps are otherwise 8 MFMAs per wave between two barriers (21 -> 6 steps for the packed d5)
+  constexpr int PPS = tile_pps(BN), RB = PPS * 16;   // RB = bytes per weight row per step
+  constexpr int RPP = NT / PPS;                      // weight rows loaded per pass (PPS threads per row)
   constexpr int BRN = BN >= RPP ? BN / RPP : 1;      // weight pieces per thread per step
-  constexpr int PPS = 8;                             // 16-B pieces of K per step (128 B per channel)
   constexpr int EPP = ElemTraits<T>::EPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sB = smem;                                   // [2][BN][128 B], XOR-swizzled
-  int* sOff = (int*)(smem + 2 * BN * 128);           // piece offsets, padded to a multiple of 8
-  char* sIn = smem + 2 * BN * 128 + g.off_bytes;     // input tile [NB][TIH][TIW] pixels of PS bytes
+  int* sOff = (int*)(smem + 2 * BN * RB);            // piece offsets, padded to a multiple of PPS
+  char* sIn = smem + 2 * BN * RB + g.off_bytes;      // input tile [NB][TIH][TIW] pixels of PS bytes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- which tile
@@ -68,10 +75,10 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   // their scalar loads, with an lgkmcnt(0) wait each, in every K step)
   const T* __restrict__ Wb = (const T*)g.Wt;
   const int gP = g.P, gKtot = g.Ktot, gdbg = g.dbg;
-  const int pp = tid & 7, r0 = tid >> 3;
+  const int pp = tid % PPS, r0 = tid / PPS;
   uint4 rbA[BRN];
   auto load_b = [&](int ks, uint4 (&rb)[BRN]) {
-    const int p = ks * 8 + pp;
+    const int p = ks * PPS + pp;
     const bool pv = p < gP;
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
@@ -83,14 +90,14 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + RPP * i;
-      if (n < BN) *(uint4*)(sB + slot * (BN * 128) + n * 128 + ((pp ^ (n & 7)) << 4)) = rb[i];
+      if (n < BN) *(uint4*)(sB + slot * (BN * RB) + n * RB + ((pp ^ (n & 7)) << 4)) = rb[i];   // XOR swizzle within each 8-piece group
     }
   };
-  const int nk = (gdbg & 2) ? 0 : (gP + 7) >> 3;
+  const int nk = (gdbg & 2) ? 0 : (gP + PPS - 1) / PPS;
   load_b(0, rbA);                                     // in flight while the input tile is staged
 
   // ---- piece-offset table
-  const int nkp = ((g.P + 7) >> 3) << 3;
+  const int nkp = (g.P + PPS - 1) / PPS * PPS;
   for (int p = tid; p < nkp; p += NT) {
     int off = 0;
     if (p < g.P) {
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   // ---- stage the input tile (zero-filled outside the image)
   if (!(g.dbg & 1)) {
     const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
-    const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
+    const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
     if (g.ups) stage_tile_upsampled<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
     else stage_tile_plain<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
   }
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   for (int i = 0; i < MF; ++i) {
     const int r = wave * WM + i * 16 + lr;
     const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
-    lbase[i] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.S) * g.PS;
+    lbase[i] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS;
   }
 
   f32x4 acc[MF][NF];
@@ -123,17 +130,17 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
     for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int ks, int slot) {
-    const char* cB = sB + slot * (BN * 128);
+    const char* cB = sB + slot * (BN * RB);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int off = sOff[ks * 8 + kk * 4 + lg];
+    for (int kk = 0; kk < PPS / 4; ++kk) {
+      const int off = sOff[ks * PPS + kk * 4 + lg];
       uint4 af[MF], bfr[NF];
 #pragma unroll
       for (int i = 0; i < MF; ++i) af[i] = *(const uint4*)(sIn + lbase[i] + off);
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const int n = j * 16 + lr;
-        bfr[j] = *(const uint4*)(cB + n * 128 + (((kk * 4 + lg) ^ (n & 7)) << 4));
+        bfr[j] = *(const uint4*)(cB + n * RB + (((kk * 4 + lg) ^ (n & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i)
@@ -159,7 +166,8 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   // re-loaded the bias per element behind a branch: 32 dependent global loads per tile, a 35 us floor.)
   const int ncols = min(BN, g.N - n0);                  // real channels of this column tile
   const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
-  const int rowb = ncols * oesz;                        // output bytes per pixel from this tile
+  // x-packed conv (fp32 head): the 16 columns (px, co<8) become 2*C contiguous floats of output pixels 2*ox, 2*ox+1
+  const int rowb = g.d2s ? 2 * g.d2s * 4 : ncols * oesz;   // output bytes per tile row
   const int srow = ((rowb + 15) & ~15) + 16;            // LDS row pitch (padded)
   char* sC = smem;                                      // reuse: every LDS read finished at the loop's last barrier
   float bv[NF][4];
@@ -168,7 +176,8 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int nl = j * 16 + lg * 4 + e;
-      bv[j][e] = (g.bias && nl < ncols) ? g.bias[n0 + nl] : 0.f;
+      const int bi = g.d2s ? (nl & 7) : n0 + nl;
+      bv[j][e] = (g.bias && nl < ncols && (!g.d2s || bi < g.d2s)) ? g.bias[bi] : 0.f;
     }
   const bool relu = g.act == SV_ACT_RELU;
 #pragma unroll
@@ -184,7 +193,12 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
         v[e] = acc[i][j][e] + bv[j][e];
         if (relu) v[e] = fmaxf(v[e], 0.f);
       }
-      if (g.out_f32) *(float4*)(sC + r * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      if (g.d2s) {                                      // n = px*8 + co -> column px*C + co (co < C)
+        const int px = nl >> 3, c0 = nl & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c0 + e < g.d2s) *(float*)(sC + r * srow + (px * g.d2s + c0 + e) * 4) = v[e];
+      } else if (g.out_f32) *(float4*)(sC + r * srow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
       else if constexpr (sizeof(T) == 2) {
         T pk[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
         *(uint2*)(sC + r * srow + nl * 2) = *(uint2*)pk;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
     const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
     const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
     if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
-    const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
+    const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * (g.d2s ? 2 : g.OS) + g.oox;
     const int64_t ob = (pix * g.ldo + n0) * oesz + c * psz;   // byte offset in the output tensor
     if (psz == 16) {
       uint4 v = *(const uint4*)(sC + r * srow + c * 16);
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
 }
 
 static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_t esz) {
-  size_t lds = 2 * BN * 128 + a.off_bytes + a.in_bytes;
+  size_t lds = 2 * BN * tile_pps(BN) * 16 + a.off_bytes + a.in_bytes;
   const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
   return lds < epi ? epi : lds;
 }
@@ -253,6 +267,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.splitk != 1) return false;
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
   if (t.ups && t.S != 1) return false;
+  if (t.d2s && (t.N != 16 || !t.out_f32)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
   const int cin = (1 << t.cl2) * epp;
@@ -276,9 +291,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // 64/128-B pixels are 4/8-way conflicted there).  scripts/lds_bank_model.py has the lane-group model.
   static const bool s2pad = getenv("SV_TC_NO_S2PAD") == nullptr, p64 = getenv("SV_TC_PAD64") != nullptr;
   const int pb = cin * esz;
-  const int PS = pb + (t.S == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
+  const int PS = pb + (t.SX == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
   const int lTW = OX >= 16 ? 4 : t.lOX;
-  const int off_bytes = (((t.P + 7) / 8 * 8) * 4 + 15) / 16 * 16;
+  const int off_bytes = (((t.P + 31) / 32 * 32) * 4 + 15) / 16 * 16;   // padded to the largest K step
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
   static const char* mf2 = getenv("SV_TC_MF2");       // tuning knob: BN values (as letters a=16,b=32,c=64) forced to 128-row tiles
   for (int MF = 4; MF >= 2; MF -= 2) {
@@ -291,15 +306,15 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     int lNB = 0;
     while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
     const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
-    const int TIW = (TW - 1) * t.S + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
+    const int TIW = (TW - 1) * t.SX + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
     const int64_t in_bytes = (int64_t)NB * TIH * TIW * PS;
-    const int64_t lds = 2 * BN * 128 + off_bytes + in_bytes;
+    const int64_t lds = 2 * BN * tile_pps(BN) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
     memset(a, 0, sizeof(*a));
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
-    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S;
+    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;
@@ -378,8 +393,8 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &b, &c)) {
       b.dbg = dbg;
       rc = svk_tile_conv(b, dtype, c, st);
-    } else if (t[i].ups) {
-      rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor
+    } else if (t[i].ups || t[i].d2s) {
+      rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor / has no depth-to-space store
     } else {
       rc = svk_tap_gemm(t[i], dtype, tap_cfg, st);
     }
