@@ -1,3 +1,4 @@
-export SV_BENCH_OPS=${SV_BENCH_OPS:-fwd}
-for lib in libsplitvae_p8.so libsplitvae_p16.so libsplitvae_hip.so; do
-echo "--- $lib packx / unpacked"; SV_LIB_NAME=$lib python scripts/bench_layers.py 512 d5;  SV_LIB_NAME=$lib SV_NO_PACKX=1 python scripts/bench_layers.py 512 d5; done
+export SV_BENCH_OPS=${SV_BENCH_OPS:-wgrad}
+echo "--- packx"; python scripts/bench_layers.py 512 d5
+echo "--- no packx"; SV_NO_PACKX=1 python scripts/bench_layers.py 512 d5
+for d in 1 2 4 8; do echo "--- packx DBG=$d"; SV_WT_DBG=$d python scripts/bench_layers.py 512 d5; done

@@ -232,13 +232,30 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   svg_pads(d, &pt, &pl);
   a->M = d->B * OH * OW;
   a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW);
-  a->IH = d->H; a->IW = d->W; a->lda = d->ldx; a->S = d->stride;
+  a->IH = d->H; a->IW = d->W; a->lda = d->ldx; a->S = d->stride; a->SX = d->stride;
   a->ldy = svg_gdy(d);
   a->ycols = svg_gdy(d);
   a->cl2 = ilog2_exact(cpad / epp);
   a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout; a->ups = d->ups_in;
   a->ntaps = d->KH * d->KW;
   a->Nrows = a->ntaps * cpad;
+  if (svg_packx(d)) {
+    // the x-packed conv's weight gradient: rows = pixel pairs, dY = the [B,H,W,8] gradient viewed as
+    // [B,H,W/2,16]; the tile kernel folds dW' back into the HWIO gradient (the im2col kernel cannot)
+    a->M = d->B * OH * (OW / 2);
+    a->lOX = ilog2_exact(OW / 2);
+    a->SX = 2; a->ldy = 16; a->ycols = 16; a->N = 16;
+    a->fold_kw = d->KW; a->fold_c = d->Cout;
+    a->ntaps = d->KH * (d->KW + 1);
+    a->Nrows = a->ntaps * cpad;
+    for (int ky = 0; ky < d->KH; ++ky)
+      for (int tx = 0; tx <= d->KW; ++tx) {
+        a->dy[ky * (d->KW + 1) + tx] = (int8_t)(ky - pt);
+        a->dx[ky * (d->KW + 1) + tx] = (int8_t)(tx - pl);
+      }
+    a->msplit = a->M;
+    return;
+  }
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) {
       a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);

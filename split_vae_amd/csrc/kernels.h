@@ -67,7 +67,8 @@ struct WgradArgs {
   const void* dY;     // [M, ldy]
   float* dW;          // [ntaps*Cin_real][N] fp32, atomically accumulated
   float* dbias;       // [N] or null
-  int M, lOY, lOX, IH, IW, lda, S;
+  int M, lOY, lOX, IH, IW, lda, S, SX;   // SX: x stride (= S except for the x-packed conv)
+  int fold_kw, fold_c;   // x-packed conv (svg_packx): dW'[(ky,tx)][ci][px*8+co] folds into dW[ky][tx-px][ci][co], co < fold_c
   int ldy, ycols;     // dY row stride and number of valid columns from the dY pointer (multiple of 8)
   int cl2;            // log2(pieces per tap)
   int Cin_pad, Cin_real, N, Nrows;   // Nrows = ntaps*Cin_pad (padded wrow count)
@@ -86,7 +87,7 @@ int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st);
 struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
-  int B, IH, IW, lda, cl2, S;
+  int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
   int lTW, lTH, lNB, OY, OX, tilesX, tilesY, ntiles;
   int TIW, TIH, y_lo, x_lo, PS;
   int ldy, YS, lycp;        // dY channels per pixel; bytes per dY pixel in LDS; log2(16-B pieces per dY pixel)

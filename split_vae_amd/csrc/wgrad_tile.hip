@@ -28,6 +28,15 @@ __device__ __forceinline__ short4_t tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
 }
 
+// index of (tap, ci, co) in the HWIO gradient; the x-packed conv (fold_kw > 0) has taps (ky, tx) of
+// KH x (KW+1) and columns co = px*8 + c, which fold onto tap (ky, tx - px), channel c.  -1: padding.
+__device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_real, int N, int fold_kw, int fold_c) {
+  if (!fold_kw) return ((int64_t)(tap * Cin_real + ci)) * N + co;
+  const int ky = tap / (fold_kw + 1), tx = tap - ky * (fold_kw + 1), px = co >> 3, c = co & 7, kx = tx - px;
+  if ((unsigned)kx >= (unsigned)fold_kw || c >= fold_c) return -1;
+  return ((int64_t)((ky * fold_kw + kx) * Cin_real + ci)) * fold_c + c;
+}
+
 // TPW taps per wave (4 waves: tap group = 4*TPW taps), CIF ci-fragments (16 channels) per
 // workgroup slice, COF co-fragments (all of Cout_pad16), KC = 32-pixel K chunks per tile.
 template <int TPW, int CIF, int COF, int KC>
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     for (int h = 0; h < 2; ++h) {
       const int r = kc * 32 + 16 * h + 4 * lg + lq;
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
-      inb[kc][h] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.S) * g.PS + 4 * lp * 2;
+      inb[kc][h] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS + 4 * lp * 2;
       dyb[kc][h] = r * g.YS + 4 * lp * 2;
     }
   int tapoff[TPW];
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     // ---- stage input patch slice (+halo, zero outside the image; optionally through the fused upsample)
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
-      const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.S + g.x_lo;
+      const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
       if (g.dbg & 2) {}
       else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
       else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
@@ -173,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
 #pragma unroll
         for (int j = 0; j < COF; ++j) {
           const int co = j * 16 + lr;
-          if (co < g.N && !(g.dbg & 1)) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + co, acc[t2][i][j][r4]);
+          const int64_t di = co < g.N ? dw_index(tap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
+          if (di >= 0 && !(g.dbg & 1)) atomicAdd(g.dW + di, acc[t2][i][j][r4]);
         }
       }
   }
@@ -182,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     float* red = (float*)smem;
     red[bgrp * ycols + bcol] = bsum;
     __syncthreads();
-    if (tid < ycols && tid < g.N) {
+    if (tid < ycols && tid < g.N && (!g.fold_kw || (tid & 7) < g.fold_c)) {
       float s = 0.f;
       for (int k = 0; k < nbg; ++k) s += red[k * ycols + tid];
-      atomicAdd(g.dbias + tid, s);
+      atomicAdd(g.dbias + (g.fold_kw ? (tid & 7) : tid), s);
     }
   }
 }
@@ -196,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
 // combined through LDS in row order.
 template <int TPW, int CIF, int COF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMulti m, int msplit, int groups, int ncg,
-                                                           int CW, int Cin_real, int N, int ntaps) {
+                                                           int CW, int Cin_real, int N, int ntaps, int fold_kw,
+                                                           int fold_c) {
   const float* __restrict__ slab = m.slab[blockIdx.z];
   float* __restrict__ dW = m.dW[blockIdx.z];
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
@@ -226,11 +237,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   const int tap = tg * 4 * TPW + wave * TPW + t2;
   const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = cg * CW + cl, co = j * 16 + (lane & 15);
   if (tap >= ntaps || cl >= CW || ci >= Cin_real) return;
-  float* d = dW + ((int64_t)(tap * Cin_real + ci)) * N + co;
   const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (co + k < N) d[k] += sv[k];
+  for (int k = 0; k < 4; ++k) {
+    if (co + k >= N) continue;
+    const int64_t di = dw_index(tap, ci, co + k, Cin_real, N, fold_kw, fold_c);
+    if (di < 0) continue;
+    // folded: the two pixel-parity columns of a tap pair land on one element from two threads; two
+    // atomic adds onto the zeroed gradient commute exactly, so the result is still run-to-run identical
+    if (fold_kw) atomicAdd(dW + di, sv[k]); else dW[di] += sv[k];
+  }
 }
 
 template <int TPW, int CIF, int COF, int KC>
@@ -271,7 +287,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
     hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
-                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps);
+                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c);
     SV_LAUNCH_CHECK();
   }
   return SV_OK;
@@ -297,6 +313,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   else if (nt == 16 && cin == 64 && cout == 128) { id = 4; BM = 128; CW = 16; TT = 16; }   // e3
   else if (nt == 36 && cin == 32 && cout == 64) { id = 5; BM = 128; CW = 16; TT = 36; }    // e2
   else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1
+  else if (nt == 42 && cin == 32 && cout == 16 && w.fold_kw) { id = 7; BM = 256; CW = 32; TT = 42; }   // d5, x-packed
   else return SV_E_UNSUPPORTED;
   if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
   static const char* cw16 = getenv("SV_WT_CW16");             // A/B: 16-channel slices for these layer ids (half the slab traffic)
@@ -323,15 +340,17 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   WgradTileArgs av[SV_WGRAD_MAX_MULTI];
   WgradTileArgs& a = av[0];
   memset(&a, 0, sizeof(a));
-  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.ups = w.ups;
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.ups = w.ups;
+  a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
   a.CW = CW; a.ncg = cin / CW;
   a.cl2 = ilog2_exact(CW / 8);
   a.lTW = lTW; a.lTH = lTH; a.lNB = lNB; a.OY = OY; a.OX = OX;
   a.tilesX = OX / TW; a.tilesY = OY / TH;
   a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
-  a.TIW = (TW - 1) * w.S + (x_hi - x_lo) + 1; a.TIH = (TH - 1) * w.S + (y_hi - y_lo) + 1;
+  a.TIW = (TW - 1) * w.SX + (x_hi - x_lo) + 1; a.TIH = (TH - 1) * w.S + (y_hi - y_lo) + 1;
   a.y_lo = y_lo; a.x_lo = x_lo;
-  a.PS = CW * 2 + (CW == 32 ? 32 : 0);              // 16 / 32 / 96 B: PS/32 odd (or a single 16-B chunk)
+  // 16 / 32 / 96 B: PS/32 odd (or a single 16-B chunk); at x stride 2 the K pixels are 2*PS apart: 80 B
+  a.PS = CW * 2 + (CW == 32 ? (w.SX == 2 ? 16 : 32) : 0);
   a.ldy = cout; a.YS = cout * 2 + (cout >= 32 ? 32 : 0);
   a.lycp = ilog2_exact(cout / 8);
   a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;   // slack: 16-column transposed reads of narrow pixels
@@ -362,6 +381,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
     case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
     case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 7: if (KC == 8) return launch_wt<11, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
   }
   return SV_E_UNSUPPORTED;
 }
@@ -389,6 +409,6 @@ int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st) {
     const int rc = svk_wgrad_tile(w, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
-  if (w.ups) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor
+  if (w.ups || w.fold_kw) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor / cannot fold
   return svk_wgrad(w, dtype, cfg, st);
 }
