@@ -27,40 +27,77 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
     arena[j.dst_off + ((int64_t)row * j.ntaps + t) * j.inner_ld + j.inner_off + c] = from_f32<T>(v);
     return;
   }
-  if (j.ntaps == 1 && !j.transpose) {
-    // dense forward image dst[co][ci] = src[ci][co]: 32x32 tiles through LDS so that both the fp32
-    // reads (contiguous in co) and the low-precision writes (contiguous in ci) are coalesced
-    __shared__ float tile[32][33];
-    const int tr = (j.rows + 31) / 32;
-    if (block_in_job >= tr * ((j.inner + 31) / 32)) return;    // uniform per block
-    const int r0 = (block_in_job % tr) * 32, c0 = (block_in_job / tr) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (!j.transpose) {
+    // forward images dst[co][tap][ci] = src[tap][ci][co] (dense: one tap): per tap a [ci][co] -> [co][ci]
+    // transpose in 64x64 tiles through LDS; fp32 reads are 16 B per thread along co (256-B row
+    // segments), low-precision writes 16 B per thread along ci.  (One element per thread read the
+    // HWIO master with a stride of Cout floats: the conv images took most of the kernel's time.)
+    constexpr int EPP = ElemTraits<T>::EPP;
+    __shared__ float tile[64][65];
+    const int tr = (j.rows + 63) / 64, tc = (j.inner + 63) / 64;
+    if (block_in_job >= j.ntaps * tr * tc) return;             // uniform per block
+    const int t = block_in_job / (tr * tc), rem = block_in_job - t * (tr * tc);
+    const int r0 = (rem % tr) * 64, c0 = (rem / tr) * 64;
+    const int64_t soff = j.src_off + (int64_t)j.srctap[t] * j.Cin * j.Cout;
+    const int64_t doff = j.dst_off + (int64_t)t * j.inner_ld + j.inner_off;
+    const int64_t dpitch = (int64_t)j.ntaps * j.inner_ld;
+    {
+      const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+      const int row = r0 + tx * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c0 + ty + 8 * k, row = r0 + tx;
-      tile[ty + 8 * k][tx] = (row < j.Cout && c < j.Cin) ? params[j.src_off + (int64_t)c * j.Cout + row] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int cl = ty + 16 * k, c = c0 + cl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < j.Cin) {
+          const float* sp = params + soff + (int64_t)c * j.Cout + row;
+          if (row + 3 < j.Cout && !(j.Cout & 3) && !(soff & 3)) v = *(const float4*)sp;
+          else {
+            if (row < j.Cout) v.x = sp[0];
+            if (row + 1 < j.Cout) v.y = sp[1];
+            if (row + 2 < j.Cout) v.z = sp[2];
+            if (row + 3 < j.Cout) v.w = sp[3];
+          }
+        }
+        tile[cl][tx * 4] = v.x; tile[cl][tx * 4 + 1] = v.y; tile[cl][tx * 4 + 2] = v.z; tile[cl][tx * 4 + 3] = v.w;
+      }
     }
     __syncthreads();
+    {
+      constexpr int TPR = 64 / EPP, RPP = 256 / TPR;            // threads per destination row, rows per pass
+      const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+      for (int rl = ty; rl < 64; rl += RPP) {
+        const int row = r0 + rl, c = c0 + tx * EPP;
+        if (row >= j.rows || c >= j.inner) continue;
+        T* dp = arena + doff + (int64_t)row * dpitch + c;
+        T v[EPP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = r0 + ty + 8 * k, c = c0 + tx;
-      if (row < j.rows && c < j.inner)
-        arena[j.dst_off + (int64_t)row * j.inner_ld + j.inner_off + c] = from_f32<T>(tile[tx][ty + 8 * k]);
+        for (int e = 0; e < EPP; ++e) v[e] = from_f32<T>(tile[tx * EPP + e][rl]);
+        if (c + EPP <= j.inner && !((doff + (int64_t)row * dpitch + c) % EPP)) *(uint4*)dp = *(uint4*)v;
+        else
+          for (int e = 0; e < EPP && c + e < j.inner; ++e) dp[e] = v[e];
+      }
     }
     __syncthreads();                                           // the tile is reused by the block's next unit
     return;
   }
-  if (j.transpose && !(j.inner & 3) && !(j.Cout & 3) && !(j.inner_off & 3) && !(j.inner_ld & 3)) {
-    // dgrad images are contiguous in co on both sides: 4 channels per thread (one 16-B fp32 load)
-    const int q4 = j.inner >> 2;
-    const int total4 = j.rows * j.ntaps * q4;
+  if (j.transpose && !(j.inner & 7) && !(j.Cout & 7) && !(j.inner_off & 7) && !(j.inner_ld & 7)) {
+    // dgrad images are contiguous in co on both sides: 8 channels per thread (two 16-B fp32 loads, one 16-B store
+    // for bf16).  Source tensors are 16-B aligned (parameter table / allocator) and images 128-element aligned.
+    const int q8 = j.inner >> 3;
+    const int total8 = j.rows * j.ntaps * q8;
     const int idx = block_in_job * 256 + threadIdx.x;
-    if (idx >= total4) return;
-    const int c = (idx % q4) << 2, t2 = idx / q4, t = t2 % j.ntaps, row = t2 / j.ntaps;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < j.Cin && c < j.Cout) v = *(const float4*)(params + j.src_off + ((int64_t)j.srctap[t] * j.Cin + row) * j.Cout + c);
+    if (idx >= total8) return;
+    const int c = (idx % q8) << 3, t2 = idx / q8, t = t2 % j.ntaps, row = t2 / j.ntaps;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < j.Cin && c < j.Cout) {
+      const float* sp = params + j.src_off + ((int64_t)j.srctap[t] * j.Cin + row) * j.Cout + c;
+      v0 = *(const float4*)sp; v1 = *(const float4*)(sp + 4);
+    }
     T* d = arena + j.dst_off + ((int64_t)row * j.ntaps + t) * j.inner_ld + j.inner_off + c;
-    d[0] = from_f32<T>(v.x); d[1] = from_f32<T>(v.y); d[2] = from_f32<T>(v.z); d[3] = from_f32<T>(v.w);
+    T v[8] = {from_f32<T>(v0.x), from_f32<T>(v0.y), from_f32<T>(v0.z), from_f32<T>(v0.w),
+              from_f32<T>(v1.x), from_f32<T>(v1.y), from_f32<T>(v1.z), from_f32<T>(v1.w)};
+    if constexpr (sizeof(T) == 2) *(uint4*)d = *(uint4*)v;
+    else { *(uint4*)d = *(uint4*)v; *(uint4*)(d + 4) = *(uint4*)(v + 4); }
     return;
   }
   const int total = j.rows * j.ntaps * j.inner;
@@ -89,7 +126,7 @@ __global__ __launch_bounds__(256) void prep_table_kernel(const float* __restrict
     const int mid = (lo + hi + 1) >> 1;
     if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const PrepJob j = jobs[lo];
+  const PrepJob& j = jobs[lo];   // by reference: uniform (scalar) loads, srctap[] indexed in memory
   // SV_PREP_UNITS units of 256 threads' work per block amortise the job lookup (dependent global loads)
   for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, ((int)blockIdx.x - j.first_block) * SV_PREP_UNITS + u);
 }

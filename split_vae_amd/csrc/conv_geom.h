@@ -63,9 +63,9 @@ static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr)
 static inline int svg_prep_nblocks(const PrepJob* j) {
   int64_t units;
   if (j->packx_kw) units = ((int64_t)j->rows * j->ntaps * j->inner + 255) / 256;
-  else if (j->ntaps == 1 && !j->transpose) units = (int64_t)((j->rows + 31) / 32) * ((j->inner + 31) / 32);
-  else if (j->transpose && !(j->inner & 3) && !(j->Cout & 3) && !(j->inner_off & 3) && !(j->inner_ld & 3))
-    units = ((int64_t)j->rows * j->ntaps * (j->inner >> 2) + 255) / 256;          // 4 channels per thread
+  else if (!j->transpose) units = (int64_t)j->ntaps * ((j->rows + 63) / 64) * ((j->inner + 63) / 64);
+  else if (j->transpose && !(j->inner & 7) && !(j->Cout & 7) && !(j->inner_off & 7) && !(j->inner_ld & 7))
+    units = ((int64_t)j->rows * j->ntaps * (j->inner >> 3) + 255) / 256;          // 8 channels per thread
   else units = ((int64_t)j->rows * j->ntaps * j->inner + 255) / 256;
   return (int)((units + SV_PREP_UNITS - 1) / SV_PREP_UNITS);
 }
