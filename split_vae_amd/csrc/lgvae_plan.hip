@@ -99,6 +99,7 @@ struct sv_lgvae_plan {
   std::vector<PrepJob> jobs;
   int prep_blocks;
   int64_t arena_elems;
+  bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
   // profiling
   bool prof_on;
   std::string prof_filter;
@@ -299,7 +300,9 @@ static void build_buffers(sv_lgvae_plan* p) {
   same("a1_", B * (H / 2) * (W / 2) * 32 * es);
   same("a2_", B * (H / 4) * (W / 4) * 64 * es);
   same("a3_", B * F * es);
+  // zeroed every step by ONE memset (split-K / atomic accumulation targets): pre_x .. gz_xh are adjacent
   twin("pre_", B * 2 * Lg * 4, B * 2 * Ll * 4);
+  twin("gz_", B * Lc * 4, B * Ll * 4);
   twin("z_mean_", B * Lg * 4, B * Ll * 4);
   twin("z_sig_", B * Lg * 4, B * Ll * 4);
   twin("z_", B * Lg * 4, B * Ll * 4);
@@ -328,7 +331,6 @@ static void build_buffers(sv_lgvae_plan* p) {
   same("gu2_", B * (H / 4) * (W / 4) * 128 * es);
   same("g2_", B * F * es);
   same("g1_", B * F * es);
-  twin("gz_", B * Lc * 4, B * Ll * 4);
 }
 
 static double conv_flops(const sv_conv_desc& d) {
@@ -430,6 +432,13 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
   const char* en[2] = {"x", "xh"};
   if (do_enc) {
+    // the head pre-activations (split-K partial sums) and dz (split-K dgrad of d1) accumulate with atomics
+    char* z0 = (char*)p->bp("pre_x");
+    char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
+    if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
+    p->gz_clean = true;
+  }
+  if (do_enc) {
     Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
     SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
   }
@@ -449,7 +458,6 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     // head: split-K GEMM into the zeroed fp32 pre-activation; bias + softplus live in reparam_kl_fwd
     {
       Layer& Lh = p->enc[e][3];
-      if (hipMemsetAsync(p->bp("pre_" + sfx), 0, p->bbytes("pre_" + sfx), st) != hipSuccess) return (int)hipGetLastError();
       TapGemmArgs a;
       svg_fwd_args(&Lh.d, &a);
       a.A = p->bp("a3_" + sfx);
@@ -528,6 +536,12 @@ static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_g
 }
 
 static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  if (!p->gz_clean) {   // a second backward over the same forward: re-zero the split-K dz accumulators
+    char* z0 = (char*)p->bp("gz_x");
+    char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
+    if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
+  }
+  p->gz_clean = false;
   const sv_lgvae_desc& d = p->d;
   const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
   const int Lg = d.global_latent;
@@ -575,7 +589,6 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     // d1 (dense): dz accumulated in fp32 over split K
     const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
     SV_TRY(run_wgrad_layer(p, L[0], zin, p->bp("g1_" + sfx), s->grads, st));
-    if (hipMemsetAsync(p->bp("gz_" + sfx), 0, p->bbytes("gz_" + sfx), st) != hipSuccess) return (int)hipGetLastError();
     {
       // dz has its own row pitch (Lz), not the zcat pitch: patch ldo after building the args
       Layer Ld = L[0];
