@@ -88,6 +88,8 @@ struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
   int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
+  int pairx;                // 8-channel pixels (e1): rows 8..15 of a fragment are the NEXT pixel = the next x tap;
+                            // the tap list holds every other x tap and accumulator row r means (tap 2u + (r>>3), channel r&7)
   int lTW, lTH, lNB, OY, OX, tilesX, tilesY, ntiles;
   int TIW, TIH, y_lo, x_lo, PS;
   int ldy, YS, lycp;        // dY channels per pixel; bytes per dY pixel in LDS; log2(16-B pieces per dY pixel)

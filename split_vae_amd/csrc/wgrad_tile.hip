@@ -177,12 +177,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     for (int i = 0; i < CIF; ++i)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int ci = ci0 + i * 16 + lg * 4 + r4;
-        if (ci >= g.Cin_real || i * 16 + lg * 4 + r4 >= g.CW) continue;
+        const int cl = i * 16 + lg * 4 + r4;
+        const int ci = g.pairx ? (cl & 7) : ci0 + cl;
+        if (ci >= g.Cin_real || (!g.pairx && cl >= g.CW)) continue;
 #pragma unroll
         for (int j = 0; j < COF; ++j) {
           const int co = j * 16 + lr;
-          const int64_t di = co < g.N ? dw_index(tap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
+          const int otap = g.pairx ? 2 * tap + (cl >> 3) : tap;
+          const int64_t di = co < g.N ? dw_index(otap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
           if (di >= 0 && !(g.dbg & 1)) atomicAdd(g.dW + di, acc[t2][i][j][r4]);
         }
       }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
 template <int TPW, int CIF, int COF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMulti m, int msplit, int groups, int ncg,
                                                            int CW, int Cin_real, int N, int ntaps, int fold_kw,
-                                                           int fold_c) {
+                                                           int fold_c, int pairx) {
   const float* __restrict__ slab = m.slab[blockIdx.z];
   float* __restrict__ dW = m.dW[blockIdx.z];
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
@@ -235,13 +237,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   const int t2 = f / (CIF * COF), i = (f / COF) % CIF, j = f % COF;
   const int tg = y / ncg, cg = y - tg * ncg;
   const int tap = tg * 4 * TPW + wave * TPW + t2;
-  const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = cg * CW + cl, co = j * 16 + (lane & 15);
-  if (tap >= ntaps || cl >= CW || ci >= Cin_real) return;
+  const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = pairx ? (cl & 7) : cg * CW + cl, co = j * 16 + (lane & 15);
+  if (tap >= ntaps || (!pairx && cl >= CW) || ci >= Cin_real) return;
+  const int otap = pairx ? 2 * tap + (cl >> 3) : tap;
   const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (co + k >= N) continue;
-    const int64_t di = dw_index(tap, ci, co + k, Cin_real, N, fold_kw, fold_c);
+    const int64_t di = dw_index(otap, ci, co + k, Cin_real, N, fold_kw, fold_c);
     if (di < 0) continue;
     // folded: the two pixel-parity columns of a tap pair land on one element from two threads; two
     // atomic adds onto the zeroed gradient commute exactly, so the result is still run-to-run identical
@@ -287,7 +290,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
     hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
-                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c);
+                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c, a[0].pairx);
     SV_LAUNCH_CHECK();
   }
   return SV_OK;
@@ -312,7 +315,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   else if (nt == 16 && cin == 128 && cout == 128) { id = 3; BM = 128; CW = 16; TT = 16; }  // d2
   else if (nt == 16 && cin == 64 && cout == 128) { id = 4; BM = 128; CW = 16; TT = 16; }   // e3
   else if (nt == 36 && cin == 32 && cout == 64) { id = 5; BM = 128; CW = 16; TT = 36; }    // e2
-  else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1
+  else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1 (taps halved below: pairx)
   else if (nt == 42 && cin == 32 && cout == 16 && w.fold_kw) { id = 7; BM = 256; CW = 32; TT = 42; }   // d5, x-packed
   else return SV_E_UNSUPPORTED;
   if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
@@ -359,7 +362,18 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   a.Cin_real = w.Cin_real; a.N = w.N; a.ntaps = nt;
   memcpy(a.dy, w.dy, sizeof(a.dy));
   memcpy(a.dx, w.dx, sizeof(a.dx));
-  const int groups = a.ncg * ((nt + TT - 1) / TT);
+  static const bool no_pairx = getenv("SV_WT_NO_PAIRX") != nullptr;   // A/B knob
+  const bool pairx = id == 6 && !no_pairx;
+  if (pairx) {
+    // 8-channel pixel records: fragment rows 8..15 (channel block 8..15 of the transposed read) are the next
+    // pixel in x, i.e. the operand of tap (ky, kx+1) -- one MFMA serves two taps.  Keep the even-kx taps
+    // (taps are ky-major, KW = 6 even, so original tap = 2 * kept index + (row >> 3)).
+    for (int u = 0; u < nt / 2; ++u) { a.dy[u] = w.dy[2 * u]; a.dx[u] = w.dx[2 * u]; }
+    a.ntaps = nt / 2;
+    a.pairx = 1;
+    TT = nt / 2;
+  }
+  const int groups = a.ncg * ((a.ntaps + TT - 1) / TT);
   const int KC = BM / 32;
   for (int i = n - 1; i >= 0; --i) {
     av[i] = a;
@@ -380,7 +394,8 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
             if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st, wv[0].ev_mid); break;
     case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
-    case 6: if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 6: if (KC == 8 && pairx) return launch_wt<5, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
     case 7: if (KC == 8) return launch_wt<11, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
   }
   return SV_E_UNSUPPORTED;
