@@ -29,6 +29,22 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+# plan scope -> HIP kernel symbol (as rocprofv3 prints it) for the launches that can be the dominant one
+SCOPE_KERNEL = {"fwd.d5": "_Z16tile_conv_kernelIDF16bLi16ELi4ELi4EEv13TileConvMulti",
+                "wgrad.d5": "void wgrad_tile_kernel<11, 2, 1, 8>(WgradTileMulti)",
+                "wgrad.d4": "void wgrad_tile_kernel<9, 2, 2, 8>(WgradTileMulti)",
+                "dgrad.d4": "_Z16tile_conv_kernelIDF16bLi64ELi4ELi4EEv13TileConvMulti"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_e_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
+
+
+def measured_traffic(scope):
+    """HBM bytes per launch of the scope's kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, gfx950 x2 read correction); None when that kernel was not measured."""
+    try:
+        k = json.load(open(TRAFFIC_FILE))["kernels"].get(SCOPE_KERNEL.get(scope, ""), None)
+        return None if k is None else k["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}   # BASELINE.md section 2
 
 
@@ -172,7 +188,9 @@ def main():
         ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         out["roofline"] = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(prof[0]["name"]),
+                           "traffic_source": "profiles/r01_e_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)",
+                           "hip_kernel": SCOPE_KERNEL.get(prof[0]["name"]),
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"]}
     if world == 1 and not args.no_cpu_baseline:
