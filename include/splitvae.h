@@ -23,7 +23,7 @@ extern "C" {
 
 typedef enum { SV_OK = 0, SV_E_BADARG = -1, SV_E_UNSUPPORTED = -2, SV_E_WORKSPACE = -3, SV_E_STATE = -4 } sv_status;
 typedef enum { SV_F32 = 0, SV_BF16 = 1 } sv_dtype;
-typedef enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1 } sv_act;
+typedef enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_ELU = 2 /* pointwise kernels of the GMVAE encoder only */ } sv_act;
 
 const char* sv_version(void);
 
@@ -127,6 +127,50 @@ int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d);
 int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
                             float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- A9: SPLIT-GMVAE global encoder glue
+ * The contractions of Encoder(type='gmvae') (vae/model.py:48-79, call_gmvae :116-135) run on the
+ * sv_conv2d_* kernels (dense layers = 1x1 convs on a 1x1 grid); these are the pointwise pieces between
+ * them.  `dtype` arguments are sv_dtype; "lp" tensors are in the contraction dtype with the row pitch
+ * the next MFMA layer reads (padding columns are written as zeros).
+ *
+ * sv_act_fwd: x[r,c] = dropout(act(a[r,c])), c < C  (Conv2D/Dense activation='elu' :50-52,:55,:57,:64,:73;
+ *   Dropout(rate) in training = x * keep / (1-rate) :56,:72 as called at :118,:129).  y_act (optional) receives
+ *   the pre-dropout activation (act' is recovered from it in the backward).  keep_in (optional, [rows*C] 0/1)
+ *   pins the mask; otherwise it is drawn from Philox keyed by (seed, step, stream_id, sample_offset + r /
+ *   rows_per_sample, column) and written to keep_out.
+ * sv_act_bwd: ga = (gx * keep/(1-rate) + gx2) * act'(y_act)   (gx2, y_act optional). */
+int sv_act_fwd(const void* a, int32_t a_dtype, int32_t lda, void* y_act, void* x, int32_t x_dtype, int32_t ldx,
+               int64_t rows, int32_t C, int32_t act, float drop_rate, const float* keep_in, float* keep_out,
+               uint64_t seed, uint64_t step, int32_t stream_id, int64_t sample_offset, int32_t rows_per_sample,
+               void* stream);
+int sv_act_bwd(const void* gx, int32_t gx_dtype, int32_t ldg, const void* gx2, int32_t gx2_dtype, int32_t ldg2,
+               const void* y_act, int32_t y_dtype, int32_t ldy, int32_t act, float drop_rate, const float* keep,
+               void* ga, int32_t ga_dtype, int32_t ldga, int64_t rows, int32_t C, void* stream);
+/* out = a + b (vae/model.py:130: h = h + h_top) */
+int sv_add(const void* a, const void* b, void* out, int32_t dtype, int64_t n, void* stream);
+/* Gumbel-softmax (vae/model.py:121-122): y = softmax((logits - log(-log u)) / tau, axis=1); u[B,K] (NULL: Philox,
+ * written to u_out).  y[B,K] fp32 and y_lp[B,ld_lp] (zero padded).  K, ld_lp <= 128. */
+int sv_gumbel_softmax_fwd(const float* logits, int32_t ld_logits, const float* u, float* u_out, float tau, float* y,
+                          void* y_lp, int32_t lp_dtype, int32_t ld_lp, int32_t B, int32_t K, uint64_t seed,
+                          uint64_t step, int64_t sample_offset, void* stream);
+/* its adjoint plus the categorical term of train_step_lg_gm_vae (vae/trainer.py:161-165):
+ * g_logits = (1/tau) y (gy - <y,gy>) + alpha_over_B * d/dlogits sum_k p_k (log(p_k + 1e-8) - log(1/K)), p = softmax(logits);
+ * y_kl[b] = that sum for image b.  g_logits NULL: only y_kl (evaluation). */
+int sv_gumbel_softmax_bwd(const float* gy, int32_t ldg, const float* y, const float* logits, int32_t ld_logits,
+                          float tau, float alpha_over_B, void* g_logits, int32_t g_dtype, int32_t ld_out,
+                          float* y_kl, int32_t B, int32_t K, void* stream);
+/* posterior and prior heads (vae/model.py:124-125,:131-133; Sampling :9-13) from the four fp32 pre-activations
+ * (bias included): z_mean = a_mean, z_sig = softplus(a_sig), z = z_mean + z_sig*eps, prior likewise; z_lp is the
+ * decoder input (columns [z_col, z_col+L) of `zcat`); kl2[b] = kl_divergence_two_gauss row sum (vae/trainer.py:17-18). */
+int sv_gm_head_fwd(const float* a_mean, const float* a_sig, const float* a_prior_mean, const float* a_prior_sig,
+                   const float* eps, float* eps_out, float* z_mean, float* z_sig, float* z, float* prior_mean,
+                   float* prior_sig, void* z_lp, int32_t lp_dtype, int32_t ldz, int32_t z_col, float* kl2,
+                   int32_t B, int32_t L, uint64_t seed, uint64_t step, int64_t sample_offset, void* stream);
+/* adjoint: dL/dz (decoder) + kl_scale * d kl2, through the two softplus heads, as the dY of the four Dense layers */
+int sv_gm_head_bwd(const float* dz, int32_t ld_dz, const float* z_mean, const float* z_sig, const float* prior_mean,
+                   const float* prior_sig, const float* eps, float kl_scale, void* g_a_mean, void* g_a_sig,
+                   void* g_a_prior_mean, void* g_a_prior_sig, int32_t g_dtype, int32_t B, int32_t L, void* stream);
+
 /* ---------------------------------------------------------------- A2/A3/A5/A8: the whole LGVae step
  * Replaces LGVae.call (vae/model.py:189-200) and train_step_lg_vae (vae/trainer.py:120-144)
  * with one native launch sequence on `stream` (captured into a hipGraph by the caller if wanted). */
@@ -135,6 +179,12 @@ typedef struct {
   int32_t global_latent, local_latent;   /* vae/main.py:16-17 (multiples of 8) */
   int32_t dtype;                         /* sv_dtype of the contractions */
   float beta;                            /* vae/main.py:19 */
+  int32_t external_global_encoder;       /* 1: SPLIT-GMVAE (LGGMVae, vae/model.py:221-246): encoder_x is the caller's
+                                            (type 'gmvae', :48-79).  The plan then skips encoder_x in every phase: the
+                                            caller stores z_x into columns [0, global_latent) of the `zcat` buffer between
+                                            FWD_ENCODERS and FWD_DECODERS and reads dL/dz_x from columns [0, global_latent)
+                                            of `gz_x` after BWD_DECODERS.  The encoder_x slots of the parameter table stay
+                                            (unused, zero gradient) so the flat layout is the same in both modes. */
 } sv_lgvae_desc;
 
 typedef struct sv_lgvae_plan sv_lgvae_plan;

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("SV_LIB_NAME", "libsplitvae_hip.so"))   # override: kernel A/B builds
 
 SV_F32, SV_BF16 = 0, 1
-SV_ACT_NONE, SV_ACT_RELU = 0, 1
+SV_ACT_NONE, SV_ACT_RELU, SV_ACT_ELU = 0, 1, 2
 PHASE_PREP, PHASE_FWD_ENCODERS, PHASE_FWD_DECODERS, PHASE_LOSS = 1, 2, 4, 8
 PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM = 16, 32, 64, 128
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
 
 class LGVaeDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("global_latent", C.c_int32),
-                ("local_latent", C.c_int32), ("dtype", C.c_int32), ("beta", C.c_float)]
+                ("local_latent", C.c_int32), ("dtype", C.c_int32), ("beta", C.c_float),
+                ("external_global_encoder", C.c_int32)]
 
 
 class StepArgs(C.Structure):
@@ -54,6 +55,16 @@ SYMBOLS = {
     "sv_reparam_kl_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32,
                                     _u64, _u64, _i32, _i64, _vp]),
     "sv_reparam_kl_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f, _vp, _i32, _i32, _i32, _vp]),
+    "sv_act_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _f, _vp, _vp, _u64, _u64, _i32, _i64,
+                             _i32, _vp]),
+    "sv_act_bwd": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f, _vp, _vp, _i32, _i32, _i64,
+                             _i32, _vp]),
+    "sv_add": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "sv_gumbel_softmax_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _f, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _u64, _i64, _vp]),
+    "sv_gumbel_softmax_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "sv_gm_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32,
+                                 _i32, _u64, _u64, _i64, _vp]),
+    "sv_gm_head_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "sv_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _f, _vp]),
     "sv_upsample2x_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_upsample2x_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -449,10 +449,11 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       Layer* Ls[2] = {&p->enc[0][l], &p->enc[1][l]};
       const void* xs[2] = {p->bp(std::string(in_name[l]) + "x"), p->bp(std::string(in_name[l]) + "xh")};
       void* ys[2] = {p->bp(std::string(out_name[l]) + "x"), p->bp(std::string(out_name[l]) + "xh")};
-      SV_TRY(run_fwd_layers(p, 2, Ls, xs, s->params, ys, st));
+      const int e0 = d.external_global_encoder ? 1 : 0;     // SPLIT-GMVAE: the caller runs its own encoder_x
+      SV_TRY(run_fwd_layers(p, 2 - e0, Ls + e0, xs + e0, s->params, ys + e0, st));
     }
   }
-  for (int e = 0; e < 2 && do_enc; ++e) {
+  for (int e = d.external_global_encoder ? 1 : 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
     const int L = e == 0 ? Lg : Ll;
     // head: split-K GEMM into the zeroed fp32 pre-activation; bias + softplus live in reparam_kl_fwd
@@ -605,16 +606,18 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
   const char* en[2] = {"x", "xh"};
   const float kl_scale = d.beta / (float)B;
+  const int e0 = d.external_global_encoder ? 1 : 0;
   if (do_heads) {
     Scope sc(p, st, "reparam_kl_bwd", 0, 0);
-    SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x"), Lc, nullptr, 0, (const float*)p->bp("z_mean_x"),
-                             (const float*)p->bp("z_sig_x"), (const float*)p->bp("eps_x"), kl_scale, p->bp("ghead_x"),
-                             dt, B, Lg, st));
+    if (!e0)
+      SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x"), Lc, nullptr, 0, (const float*)p->bp("z_mean_x"),
+                               (const float*)p->bp("z_sig_x"), (const float*)p->bp("eps_x"), kl_scale, p->bp("ghead_x"),
+                               dt, B, Lg, st));
     SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x") + Lg, Lc, (const float*)p->bp("gz_xh"), Ll,
                              (const float*)p->bp("z_mean_xh"), (const float*)p->bp("z_sig_xh"),
                              (const float*)p->bp("eps_xh"), kl_scale, p->bp("ghead_xh"), dt, B, Ll, st));
   }
-  for (int e = 0; e < 2; ++e) {
+  for (int e = e0; e < 2; ++e) {
     const std::string sfx = en[e];
     Layer* L = p->enc[e];
     const int Lh = e == 0 ? Lg : Ll;
@@ -640,10 +643,10 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       Layer* Ls[2] = {&p->enc[0][l], &p->enc[1][l]};
       const void *x[2], *gy[2], *gx[2];
       both(act_name[l], x); both(g_name[l], gy);
-      SV_TRY(run_wgrad_layers(p, 2, Ls, x, gy, s->grads, st));
+      SV_TRY(run_wgrad_layers(p, 2 - e0, Ls + e0, x + e0, gy + e0, s->grads, st));
       if (l == 0) break;
       both(g_name[l - 1], gx);
-      SV_TRY(run_dgrad_layers(p, 2, Ls, gy, x, (void* const*)gx, false, st));
+      SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gy + e0, x + e0, (void* const*)gx + e0, false, st));
     }
   }
   return SV_OK;

@@ -55,8 +55,15 @@ def main(argv=None):
         model = LGVae(global_latent_dims=config.global_latent_dims, local_latent_dims=config.local_latent_dims,
                       image_shape=input_shape, dtype=config.dtype, seed=config.seed)
         optimizer = Adam(learning_rate=config.learning_rate)
+    elif args.model == 'lggmvae':                                       # vae/main.py:66-69
+        from .gm import LGGMVae
+        from .optimizer import ExponentialDecay
+        lr_schedule = ExponentialDecay(config.learning_rate, decay_steps=1000000, decay_rate=0.4, staircase=True)
+        optimizer = Adam(learning_rate=lr_schedule)
+        model = LGGMVae(global_latent_dims=config.global_latent_dims, local_latent_dims=config.local_latent_dims,
+                        image_shape=input_shape, y_size=config.y_size, tau=config.tau, dtype=config.dtype, seed=config.seed)
     else:
-        raise NotImplementedError("--model %s: LGGMVae/GMVae are the next rows (SURVEY 8f F1)" % args.model)
+        raise NotImplementedError("--model %s: GMVae has no local branch and is outside the SPLIT path (SURVEY 8f)" % args.model)
     model.summary()
     print('Training local-global autoencoder')
     return trainer.train_local_global_autoencoder(model, optimizer, config.dataset, train_ds, test_batches, config=config)

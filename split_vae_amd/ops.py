@@ -141,16 +141,22 @@ class Conv2D:
         check(_lib.load().sv_conv2d_prep_weights(C.byref(self.desc), _p(w_hwio), _p(self.w_fwd), _p(self.w_dgrad),
                                                  _stream()), "sv_conv2d_prep_weights")
 
-    def fwd(self, x, bias):
+    def fwd(self, x, bias, out=None):
         d = self.desc
-        y = torch.empty((d.B, self.OH, self.OW, d.ldy), dtype=torch.float32 if d.y_f32 else self.dtype, device=x.device)
+        y = out if out is not None else torch.empty((d.B, self.OH, self.OW, d.ldy),
+                                                    dtype=torch.float32 if d.y_f32 else self.dtype, device=x.device)
         check(_lib.load().sv_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(self.w_fwd), _p(bias), _p(y), _stream()),
               "sv_conv2d_nhwc_fwd")
         return y
 
-    def dgrad(self, dy, relu_mask=None, f32_atomic=False):
+    def dgrad(self, dy, relu_mask=None, f32_atomic=False, out=None):
+        """out (f32_atomic only): an fp32 [B,H,W,ldx] tensor the partial sums are ADDED to (several layers
+        feeding one activation accumulate into the same buffer)."""
         d = self.desc
-        if f32_atomic:
+        if out is not None:
+            assert f32_atomic and out.dtype == torch.float32
+            dx = out
+        elif f32_atomic:
             dx = torch.zeros((d.B, d.H, d.W, d.ldx), dtype=torch.float32, device=dy.device)
         else:
             dx = torch.zeros((d.B, d.H, d.W, d.ldx), dtype=self.dtype, device=dy.device)
@@ -158,10 +164,13 @@ class Conv2D:
                                                1 if f32_atomic else 0, _stream()), "sv_conv2d_nhwc_dgrad")
         return dx
 
-    def wgrad(self, x, dy, workspace=False):
+    def wgrad(self, x, dy, workspace=False, dw=None, db=None):
+        """dw / db: zeroed fp32 views to accumulate into (e.g. slices of a flat gradient buffer)."""
         d = self.desc
-        dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
-        db = torch.zeros((d.Cout,), dtype=torch.float32, device=x.device)
+        if dw is None:
+            dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
+        if db is None:
+            db = torch.zeros((d.Cout,), dtype=torch.float32, device=x.device)
         if workspace:
             n = _lib.load().sv_conv2d_wgrad_workspace_bytes(C.byref(d))
             if getattr(self, "_ws", None) is None or self._ws.numel() < n:
@@ -178,12 +187,14 @@ class Conv2D:
 class LGVaePlan:
     """Native launch plan for LGVae.call / train_step_lg_vae (vae/model.py:189-200, vae/trainer.py:120-144)."""
 
-    def __init__(self, B, H, W, global_latent=128, local_latent=128, beta=40.0, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, B, H, W, global_latent=128, local_latent=128, beta=40.0, dtype=torch.bfloat16, device="cuda",
+                 external_global_encoder=False):
         lib = _lib.load()
         self.lib = lib
         self.device = torch.device(device)
         self.dtype = dtype
-        self.desc = LGVaeDesc(B, H, W, global_latent, local_latent, sv_dtype(dtype), float(beta))
+        self.desc = LGVaeDesc(B, H, W, global_latent, local_latent, sv_dtype(dtype), float(beta),
+                              1 if external_global_encoder else 0)
         h = C.c_void_p()
         check(lib.sv_lgvae_plan_create(C.byref(self.desc), C.byref(h)), "sv_lgvae_plan_create")
         self.handle = h
@@ -248,3 +259,62 @@ def param_table(desc):
         check(lib.sv_lgvae_param_info(C.byref(desc), i, C.byref(off), C.byref(nd), C.byref(shp), name), "sv_lgvae_param_info")
         out.append((name.value.decode(), off.value, tuple(shp[k] for k in range(nd.value))))
     return out
+
+
+# ------------------------------------------------------------------ A9 SPLIT-GMVAE glue (vae/model.py:48-79,:116-135)
+ACT = {None: _lib.SV_ACT_NONE, "relu": _lib.SV_ACT_RELU, "elu": _lib.SV_ACT_ELU}
+
+
+def act_fwd(a, C_, x, act=None, y_act=None, rate=0.0, keep_in=None, keep_out=None, seed=0, step=0, stream_id=0,
+            sample_offset=0, rows_per_sample=1):
+    """x[r, :C] = dropout(act(a[r, :C])), padding columns of x zeroed; a, x 2-D views [rows, ld]."""
+    rows = a.shape[0]
+    check(_lib.load().sv_act_fwd(_p(a), sv_dtype(a.dtype), a.shape[1], _p(y_act), _p(x), sv_dtype(x.dtype), x.shape[1], rows, C_,
+                                 ACT[act], float(rate), _p(keep_in), _p(keep_out), seed, step, stream_id, sample_offset,
+                                 rows_per_sample, _stream()), "sv_act_fwd")
+    return x
+
+
+def act_bwd(gx, C_, ga, y_act=None, act=None, rate=0.0, keep=None, gx2=None):
+    rows = gx.shape[0]
+    check(_lib.load().sv_act_bwd(_p(gx), sv_dtype(gx.dtype), gx.shape[1], _p(gx2), sv_dtype(gx2.dtype) if gx2 is not None else 0,
+                                 gx2.shape[1] if gx2 is not None else 0, _p(y_act),
+                                 sv_dtype(y_act.dtype) if y_act is not None else 0, y_act.shape[1] if y_act is not None else 0,
+                                 ACT[act], float(rate), _p(keep), _p(ga), sv_dtype(ga.dtype), ga.shape[1], rows, C_, _stream()),
+          "sv_act_bwd")
+    return ga
+
+
+def add(a, b, out):
+    check(_lib.load().sv_add(_p(a), _p(b), _p(out), sv_dtype(out.dtype), out.numel(), _stream()), "sv_add")
+    return out
+
+
+def gumbel_softmax_fwd(logits, K, tau, y, y_lp, u=None, u_out=None, seed=0, step=0, sample_offset=0):
+    B = logits.shape[0]
+    check(_lib.load().sv_gumbel_softmax_fwd(_p(logits), logits.shape[1], _p(u), _p(u_out), float(tau), _p(y), _p(y_lp),
+                                            sv_dtype(y_lp.dtype), y_lp.shape[1], B, K, seed, step, sample_offset, _stream()),
+          "sv_gumbel_softmax_fwd")
+
+
+def gumbel_softmax_bwd(gy, y, logits, K, tau, alpha_over_B, g_logits, y_kl):
+    B = logits.shape[0]
+    check(_lib.load().sv_gumbel_softmax_bwd(_p(gy), gy.shape[1] if gy is not None else 0, _p(y), _p(logits), logits.shape[1],
+                                            float(tau), float(alpha_over_B), _p(g_logits),
+                                            sv_dtype(g_logits.dtype) if g_logits is not None else 0,
+                                            g_logits.shape[1] if g_logits is not None else 0, _p(y_kl), B, K, _stream()),
+          "sv_gumbel_softmax_bwd")
+
+
+def gm_head_fwd(a_m, a_s, a_pm, a_ps, zm, zs, z, pm, ps, zcat, z_col, kl2, eps=None, eps_out=None, seed=0, step=0,
+                sample_offset=0):
+    B, L = a_m.shape
+    check(_lib.load().sv_gm_head_fwd(_p(a_m), _p(a_s), _p(a_pm), _p(a_ps), _p(eps), _p(eps_out), _p(zm), _p(zs), _p(z), _p(pm),
+                                     _p(ps), _p(zcat), sv_dtype(zcat.dtype), zcat.shape[1], z_col, _p(kl2), B, L, seed, step,
+                                     sample_offset, _stream()), "sv_gm_head_fwd")
+
+
+def gm_head_bwd(dz, zm, zs, pm, ps, eps, kl_scale, g_am, g_as, g_apm, g_aps):
+    B, L = zm.shape
+    check(_lib.load().sv_gm_head_bwd(_p(dz), dz.shape[1], _p(zm), _p(zs), _p(pm), _p(ps), _p(eps), float(kl_scale), _p(g_am),
+                                     _p(g_as), _p(g_apm), _p(g_aps), sv_dtype(g_am.dtype), B, L, _stream()), "sv_gm_head_bwd")

@@ -53,8 +53,11 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
     """train_step_lg_vae (vae/trainer.py:120-144): forward, total = recon_x + recon_x_hat +
     beta*KL, gradients of the 40 variables, Adam update, metric update.  `images` [B,H,W,6] fp32
     on the device.  eps=(eps_x, eps_x_hat) pins the Sampling noise; default = Philox stream."""
+    from .gm import LGGMVae
+    if isinstance(model, LGGMVae):
+        raise TypeError("LGGMVae trains with gm.train_step_lg_gm_vae (vae/trainer.py:297-299 picks the step by model class)")
     if not isinstance(model, LGVae):
-        raise NotImplementedError("only LGVae (SPLIT-VAE) is on this path; LGGMVae/GMVae are next rows (SURVEY 8f)")
+        raise NotImplementedError("GMVae (no local branch) is outside the SPLIT path (SURVEY 8f)")
     B = images.shape[0]
     plan = model.plan(B)
     m, v = optimizer.slots(model.flat)
@@ -102,6 +105,9 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
     """Loop of vae/trainer.py:72-421 for LGVae: train; every 10 000 steps (incl. step 0) evaluate
     on the test set and print the reference's report; stop after training_steps; save weights.
     The PNG grids of vae/visualizer.py are outside the path."""
+    from . import gm
+    if isinstance(model, gm.LGGMVae):               # vae/trainer.py:294-302: the step functions follow the model class
+        return _train_lggmvae(model, optimizer, train_dataset, test_dataset, config)
     RUN_NAME = datetime.now().strftime("%Y%m%d-%H%M%S")
     model.beta = float(config.beta)
     os.makedirs("models", exist_ok=True)
@@ -140,6 +146,49 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
                                   tr["total_kl_loss"], te["total_kl_loss"]))
             # vae/trainer.py:405-414 resets x_recon / x_kl / total_kl but never the x_hat_* means
             metrics.reset_states(["x_recon_loss", "x_kl_loss", "total_kl_loss"])
+            start = time.time()
+        if step >= config.training_steps:
+            print('Training done!')
+            break
+    path = 'models/' + RUN_NAME
+    model.save_weights(path)
+    return path + ".npz"
+
+
+def _train_lggmvae(model, optimizer, train_dataset, test_dataset, config):
+    """The same loop for LGGMVae (train_step_lg_gm_vae / test_step_lg_gm_vae, vae/trainer.py:146-173, :235-272): the five
+    training means + y_kl, evaluated every `log_every` steps; cluster accuracy needs labels and the probe classifier
+    (missing upstream) and is not reported."""
+    from . import gm
+    RUN_NAME = datetime.now().strftime("%Y%m%d-%H%M%S")
+    model.beta, model.alpha = float(config.beta), float(config.alpha)
+    os.makedirs("models", exist_ok=True)
+    acc, n_acc = None, 0
+    start = time.time()
+    log_every = int(config.get("log_every") or 10000)
+    for step, train_data in enumerate(train_dataset):
+        images = train_data[0] if config.label else train_data
+        m = gm.train_step_lg_gm_vae(model, images, optimizer)
+        acc = m.clone() if acc is None else acc + m
+        n_acc += 1
+        if step % log_every == 0:
+            torch.cuda.synchronize()
+            print('Training time: {:.2f}'.format(time.time() - start))
+            start = time.time()
+            te, n = None, 0
+            for test_data in test_dataset:
+                timg = test_data[0] if config.label else test_data
+                t = gm.test_step_lg_gm_vae(model, timg)
+                te = t.clone() if te is None else te + t
+                n += 1
+            print('Testing time: {:.2f}'.format(time.time() - start))
+            tr = (acc / n_acc).tolist()
+            te = (te / max(n, 1)).tolist() if te is not None else [float('nan')] * 6
+            print('Training step {}'.format(step))
+            for tag, v in (('', tr), ('Test ', te)):
+                print('            {}X Recon Loss: {:.4f}, {}X KLD loss: {:.4f}, {}X hat Recon Loss: {:.4f}, {}X hat KLD loss: {:.4f}, '
+                      '{}Y KL loss: {:.4f}'.format(tag, v[0], tag, v[1], tag, v[2], tag, v[3], tag, v[4]))
+            acc, n_acc = None, 0
             start = time.time()
         if step >= config.training_steps:
             print('Training done!')

@@ -80,3 +80,13 @@ def test_synthetic_data_domain_and_shard_invariance():
     v = np.unique(np.round((full.numpy() + 1) * 127.5).astype(int))
     assert v.min() >= 0 and v.max() <= 255 and full.dtype.is_floating_point      # vae/data.py:52 domain
     assert np.allclose((np.round((full.numpy() + 1) * 127.5) / 127.5 - 1), full.numpy(), atol=1e-6)
+
+
+def test_cli_selects_lggmvae_schedule():
+    """vae/main.py:66-69: --model lggmvae uses ExponentialDecay(lr, 1e6, 0.4, staircase=True) and the y_size/tau/alpha flags."""
+    from split_vae_amd.main import build_parser
+    from split_vae_amd.optimizer import ExponentialDecay
+    a = build_parser().parse_args(["--model", "lggmvae", "--patch_size", "4", "--beta", "40", "--alpha", "40"])
+    assert (a.model, a.y_size, a.tau, a.alpha) == ("lggmvae", 30, 0.4, 40)
+    sch = ExponentialDecay(1e-4, decay_steps=1000000, decay_rate=0.4, staircase=True)
+    assert sch(0) == 1e-4 and sch(999999) == 1e-4 and abs(sch(1000000) - 4e-5) < 1e-12

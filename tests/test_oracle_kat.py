@@ -148,3 +148,60 @@ def test_param_table_and_work_per_image():
     assert len(shapes) == 40 and sum(int(np.prod(s)) for _, s in shapes) == 8722060
     assert sum(int(np.prod(s)) for _, s in np_ref.param_shapes(32, 32)) == 3204748
     assert [n.split('/')[0] for n, _ in shapes[::10]] == ["encoder_x", "encoder_x_hat", "decoder_x", "decoder_x_hat"]
+
+
+# ------------------------------------------------------------------ SPLIT-GMVAE restatement (oracle/gm_ref.py)
+def test_gm_oracle_kats():
+    """Analytic pins of the LGGMVae loss pieces (SURVEY 8c pins (2) + the A9 additions)."""
+    import torch
+    from oracle import gm_ref, torch_ref
+    g = torch.Generator().manual_seed(0)
+    mu = torch.randn(5, 16, generator=g, dtype=torch.float64)
+    sig = torch.rand(5, 16, generator=g, dtype=torch.float64) + 0.3
+    # kl_two_gauss(mu, sig, 0, 1) == kl_divergence(mu, sig)   (vae/trainer.py:17-18 vs :11-15)
+    assert abs(float(gm_ref.kl_divergence_two_gauss(mu, sig, 0.0, 1.0)) - float(torch_ref.kl_divergence(mu, sig))) < 1e-12
+    # KL(q || q) = 0 ; KL >= 0
+    assert abs(float(gm_ref.kl_divergence_two_gauss(mu, sig, mu, sig))) < 1e-12
+    assert float(gm_ref.kl_divergence_two_gauss(mu, sig, mu + 1, sig * 2)) > 0
+    # categorical term: zero at uniform logits, -> log K at a one-hot limit (vae/trainer.py:161-162)
+    K = 30
+    assert abs(float(gm_ref.categorical_kl(torch.zeros(4, K, dtype=torch.float64), K))) < 1e-6
+    hot = torch.full((4, K), -50.0, dtype=torch.float64); hot[:, 3] = 50.0
+    assert abs(float(gm_ref.categorical_kl(hot, K)) - np.log(K)) < 1e-6
+    # Gumbel-softmax: rows sum to one; tau -> 0 picks argmax(logits + gumbel)
+    logits = torch.randn(6, K, generator=g, dtype=torch.float64)
+    u = torch.rand(6, K, generator=g, dtype=torch.float64).clamp(1e-6, 1 - 1e-6)
+    y = gm_ref.gumbel_softmax(logits, u, 0.4)
+    assert torch.allclose(y.sum(1), torch.ones(6, dtype=torch.float64))
+    y0 = gm_ref.gumbel_softmax(logits, u, 1e-3)
+    assert torch.equal(y0.argmax(1), (logits - torch.log(-torch.log(u))).argmax(1)) and float(y0.max(1).values.min()) > 0.99
+
+
+def test_gm_oracle_shapes_counts_and_fd_gradient():
+    import torch
+    from oracle import gm_ref
+    H, B, K = 32, 2, 30
+    shapes = gm_ref.gm_param_shapes(H, H, y_size=K)
+    assert len(shapes) == 54 and sum(int(np.prod(s)) for _, s in shapes) == 6775370     # SURVEY 8a A9: 6.78 M params
+    params = gm_ref.gm_glorot_init(H, H, seed=2, y_size=K, dtype=np.float64)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (B, H, H, 6)) / 255.0 * 2 - 1
+    F_ = (H // 8) ** 2 * 128
+    a = (rng.standard_normal((B, 128)), rng.standard_normal((B, 128)), rng.uniform(0.05, 0.95, (B, K)),
+         (rng.uniform(size=(B, 1024)) > 0.2) * 1.0, (rng.uniform(size=(B, F_)) > 0.2) * 1.0)
+    tr = gm_ref.GMRefTrainer(params, 40.0, 40.0, y_size=K, dtype=torch.float64)
+    _, losses, g = tr.grads(img, *a)
+    assert all(np.isfinite(float(v)) for v in losses.values())
+    # central finite differences on a few coordinates of representative tensors (conv, dense, prior head, bias)
+    for ti, idx in [(0, (1, 2, 0, 5)), (6, (100, 7)), (10, (3, 4)), (16, (2, 9)), (17, (4,)), (22, (11, 3)), (34, (7, 50))]:
+        h = 1e-5
+        base = tr.params[ti].detach().clone()
+        vals = []
+        for sgn in (+1, -1):
+            with torch.no_grad():
+                tr.params[ti].copy_(base); tr.params[ti][idx] += sgn * h
+            vals.append(float(tr.forward_losses(img, *a)[1]["total_loss"]))
+        with torch.no_grad():
+            tr.params[ti].copy_(base)
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - float(g[ti][idx])) <= 1e-5 * max(1.0, abs(fd)), (ti, idx, fd, float(g[ti][idx]))
