@@ -1,0 +1,43 @@
+"""Worker of tests/test_gpu_dist.py: one data-parallel rank of the SPLIT-VAE step on the (shared) GPU.
+usage: python tests/dp_worker.py <out.npz> <global_batch> <steps>   (RANK / WORLD_SIZE / MASTER_* in the env)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from split_vae_amd import data, dist as svdist, trainer   # noqa: E402
+from split_vae_amd.augmentation import Augmentator          # noqa: E402
+from split_vae_amd.model import LGVae                       # noqa: E402
+from split_vae_amd.optimizer import Adam                    # noqa: E402
+
+
+def main():
+    out, GB, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    rank, _, world = svdist.init_from_env()
+    torch.cuda.set_device(0)
+    H, patch = 32, 4
+    lo, hi = svdist.shard_bounds(GB, rank, world)
+    model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="f32", device="cuda", seed=3)
+    model.beta = 40.0
+    opt = Adam(learning_rate=1e-3)
+    aug = Augmentator("scramble", size=patch, seed=1)
+    x = data.synthetic_images(hi - lo, H, H, seed=0, device="cuda", sample_offset=lo)
+    reducer = svdist.GradReducer(model.param_table, model.n_params) if world > 1 else None
+    losses = []
+    for _ in range(steps):
+        img = aug.augment(x, sample_offset=lo)
+        plan = trainer.train_step(model, img, opt, reducer=reducer, sample_offset=lo)
+        torch.cuda.synchronize()
+        losses.append(plan.buffer("losses", torch.float32, (8,)).cpu().numpy().copy())
+    if rank == 0:
+        np.savez(out, params=model.flat.cpu().numpy(), grads=model.grad_flat.cpu().numpy(), losses=np.stack(losses))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
