@@ -1,7 +1,7 @@
 """Input side of the SPLIT-VAE path.  The metric runs on synthetic batches in the reference's data
-domain (vae/data.py:52: x/255*2-1, fp32 NHWC); the on-disk readers of vae/data.py (SVHN .mat,
-CelebA TFRecord) are the "next" row F3 of SURVEY 8f -- SVHN .mat loading is provided, CelebA
-TFRecord parsing is not."""
+domain (vae/data.py:52: x/255*2-1, fp32 NHWC); the on-disk formats of vae/data.py are
+read without TensorFlow: SVHN .mat here, the CelebA TFRecord-of-serialize_tensor files in tfrecord.py,
+both behind the 20 000-element shuffle buffer of vae/main.py:57-61."""
 import os
 
 import numpy as np
@@ -58,6 +58,29 @@ class ArrayDataset:
                 return
 
 
+class StreamDataset:
+    """shuffle(buffer).repeat().batch(B) over a re-iterable source of single images (vae/main.py:57-61)."""
+
+    def __init__(self, make_iter, batch_size, repeat, buffer_size=20000, seed=0, device="cuda"):
+        self.make_iter, self.bs, self.repeat, self.buffer_size, self.seed, self.device = make_iter, batch_size, repeat, buffer_size, seed, device
+
+    def __iter__(self):
+        from .tfrecord import shuffle_buffer
+        epoch = 0
+        while True:
+            batch = []
+            for x in shuffle_buffer(self.make_iter(), self.buffer_size, self.seed + epoch):
+                batch.append(x)
+                if len(batch) == self.bs:
+                    yield torch.from_numpy(np.stack(batch)).to(self.device)
+                    batch = []
+            if batch and not self.repeat:
+                yield torch.from_numpy(np.stack(batch)).to(self.device)      # Dataset.batch keeps the remainder
+            if not self.repeat:
+                return
+            epoch += 1
+
+
 def get_dataset(dataset="svhn", batch_size=64, synthetic=False, data_dir="data", device="cuda", test_batches=4):
     """vae/data.py:11-21 analogue -> (train_iterable, test_iterable, input_shape)."""
     if dataset not in SHAPES:
@@ -70,6 +93,13 @@ def get_dataset(dataset="svhn", batch_size=64, synthetic=False, data_dir="data",
         xtr, _ = load_svhn_mat(tr)
         xte, _ = load_svhn_mat(te)
         return ArrayDataset(xtr, batch_size, True, 0, device), ArrayDataset(xte, batch_size, False, 1, device), shape
+    if not synthetic and dataset.startswith("celeba"):               # vae/data.py:102-131
+        from .tfrecord import read_celeba_tfrec
+        tr = os.path.join(data_dir, "celeba", "train_%dx%d.tfrec" % (H, W))
+        te = os.path.join(data_dir, "celeba", "test_%dx%d.tfrec" % (H, W))
+        if os.path.exists(tr) and os.path.exists(te):
+            return (StreamDataset(lambda: read_celeba_tfrec(tr, H), batch_size, True, 20000, 0, device),
+                    StreamDataset(lambda: read_celeba_tfrec(te, H), batch_size, False, 20000, 1, device), shape)
     if not synthetic:
         raise FileNotFoundError("dataset files for %r not found under %r (no network here); pass --synthetic" % (dataset, data_dir))
     return (SyntheticDataset(H, W, batch_size, None, 0, device), SyntheticDataset(H, W, batch_size, test_batches, 77, device), shape)
