@@ -9,30 +9,29 @@ import argparse
 from .utils import dotdict
 
 
+# (flag, type, default) of vae/main.py:15-31 -- same names and defaults; the test suite checks the table
+# against the reference's list (tests/test_host_logic.py::test_cli_flags_match_reference)
+REFERENCE_SWITCHES = ["-viz", "-no_label", "-allow_growth"]
+REFERENCE_OPTIONS = [
+    ("--global_latent_dims", int, 128), ("--local_latent_dims", int, 128), ("--learning_rate", float, 1e-4),
+    ("--beta", float, 40), ("--dataset", str, "svhn"), ("--training_steps", int, 1000000), ("--batch_size", int, 64),
+    ("--patch_size", int, 1), ("--augmentation", str, "scramble"), ("--model", str, "lgvae"), ("--y_size", int, 30),
+    ("--tau", float, 0.4), ("--alpha", float, 40),
+]
+
+
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-viz', action='store_true')  # visualize results
-    parser.add_argument('--global_latent_dims', type=int, nargs='?', default=128)
-    parser.add_argument('--local_latent_dims', type=int, nargs='?', default=128)
-    parser.add_argument('--learning_rate', type=float, nargs='?', default=1e-4)
-    parser.add_argument('--beta', type=float, nargs='?', default=40)
-    parser.add_argument('--dataset', type=str, nargs='?', default='svhn')
-    parser.add_argument('--training_steps', type=int, nargs='?', default=1000000)
-    parser.add_argument('--batch_size', type=int, nargs='?', default=64)
-    parser.add_argument('--patch_size', type=int, nargs='?', default=1)
-    parser.add_argument('--augmentation', type=str, nargs='?', default='scramble')
-    parser.add_argument('-no_label', action='store_true')
-    parser.add_argument('--model', type=str, nargs='?', default='lgvae')
-    parser.add_argument('--y_size', type=int, nargs='?', default=30)
-    parser.add_argument('--tau', type=float, nargs='?', default=0.4)
-    parser.add_argument('--alpha', type=float, nargs='?', default=40)
-    parser.add_argument('-allow_growth', action='store_true')
-    # --- additions
-    parser.add_argument('--synthetic', action='store_true', help='synthetic batches in the reference data domain')
-    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f32'])
-    parser.add_argument('--seed', type=int, default=0)
-    parser.add_argument('--log_every', type=int, default=10000)
-    return parser
+    ap = argparse.ArgumentParser(description="SPLIT-VAE / SPLIT-GMVAE training on MI355X (flags of the reference's vae/main.py)")
+    for sw in REFERENCE_SWITCHES:
+        ap.add_argument(sw, action="store_true")
+    for flag, ty, default in REFERENCE_OPTIONS:
+        ap.add_argument(flag, type=ty, nargs="?", default=default)
+    # additions (not in the reference)
+    ap.add_argument("--synthetic", action="store_true", help="synthetic batches in the reference data domain")
+    ap.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--log_every", type=int, default=10000)
+    return ap
 
 
 def main(argv=None):
