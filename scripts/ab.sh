@@ -1,5 +1,5 @@
-export SV_BENCH_OPS=dgrad
-echo "--- default"; python scripts/bench_layers.py 512 d4
-echo "--- PAD64"; SV_TC_PAD64=1 python scripts/bench_layers.py 512 d4
-echo "--- default"; python scripts/bench_layers.py 512 d4
-echo "--- PAD64"; SV_TC_PAD64=1 python scripts/bench_layers.py 512 d4
+export SV_BENCH_OPS=fwd,dgrad
+echo "--- N split"; python scripts/bench_layers.py 512 e3 d2
+echo "--- no N split"; SV_TC_NO_NSPLIT=1 python scripts/bench_layers.py 512 e3 d2
+echo "--- N split"; python scripts/bench_layers.py 512 e3 d2
+echo "--- no N split"; SV_TC_NO_NSPLIT=1 python scripts/bench_layers.py 512 e3 d2

@@ -49,6 +49,15 @@ static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr)
   int cfg = svg_pick_cfg(N);
   int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
   if (tiles >= 128) return 1;
+  static const bool small = getenv("SV_SPLITK_SMALL") != nullptr;      // A/B knob: 64 x 32 tiles (tap-GEMM cfg 4)
+  if (small && cfg_io && (N % 32) == 0) {
+    static const int tgt_small = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 512;
+    const int t2 = ((M + 63) / 64) * (N / 32);
+    *cfg_io = 4;
+    int s2 = (tgt_small + t2 - 1) / t2;
+    if (s2 > nk / 2) s2 = nk / 2;
+    return s2 < 1 ? 1 : s2;
+  }
   if (cfg == 0 && cfg_io && narrow) { cfg = 1; tiles *= 2; }
   if (cfg_io) *cfg_io = cfg;
   static const int target = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 128;   // measured best of 64/128/256/512 on the heads and d1

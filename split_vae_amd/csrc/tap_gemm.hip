@@ -284,6 +284,7 @@ int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st) {
       case 1: return launch_tap<bf16_t, 64, 32>(a, st);
       case 2: return launch_tap<bf16_t, 32, 64>(a, st);
       case 3: return launch_tap<bf16_t, 16, 64>(a, st);
+      case 4: return launch_tap<bf16_t, 32, 16>(a, st);   // 64 x 32: skinny split-K problems (heads, d1 dgrad)
     }
   } else if (dtype == SV_F32) {
     switch (cfg) {
@@ -291,6 +292,7 @@ int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st) {
       case 1: return launch_tap<float, 64, 32>(a, st);
       case 2: return launch_tap<float, 32, 64>(a, st);
       case 3: return launch_tap<float, 16, 64>(a, st);
+      case 4: return launch_tap<float, 32, 16>(a, st);
     }
   }
   return SV_E_BADARG;
