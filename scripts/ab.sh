@@ -1,5 +1,3 @@
 export SV_BENCH_OPS=fwd,dgrad
-echo "--- N split"; python scripts/bench_layers.py 512 e3 d2
-echo "--- no N split"; SV_TC_NO_NSPLIT=1 python scripts/bench_layers.py 512 e3 d2
-echo "--- N split"; python scripts/bench_layers.py 512 e3 d2
-echo "--- no N split"; SV_TC_NO_NSPLIT=1 python scripts/bench_layers.py 512 e3 d2
+for lib in libsplitvae_hip.so libsplitvae_p32.so libsplitvae_hip.so libsplitvae_p32.so; do
+echo "--- $lib"; SV_LIB_NAME=$lib python scripts/bench_layers.py 512 d5 d4; done

@@ -43,6 +43,7 @@ struct TileConvArgs {
   int OY, OX, tilesX, tilesY, ntiles;
   int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
   int PS;                     // bytes per pixel in the LDS tile
+  int plane_bytes;            // > 0: planar tile (tile_stage.hip.h), PS = 32
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
   int buf_bytes;              // persistent kernel: bytes of each of its two input-tile buffers
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;

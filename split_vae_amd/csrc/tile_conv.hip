@@ -22,7 +22,10 @@
 #ifndef SV_TC_PPS16
 #define SV_TC_PPS16 16    // K-step pieces of the 16-column kernel (build-time A/B knob)
 #endif
-static __host__ __device__ constexpr int tile_pps(int BN) { return BN == 16 ? SV_TC_PPS16 : 8; }
+#ifndef SV_TC_PPS32
+#define SV_TC_PPS32 8     // K-step pieces of the 32-column kernel (build-time A/B knob)
+#endif
+static __host__ __device__ constexpr int tile_pps(int BN) { return BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8; }
 
 template <typename T> struct MmaOpT;
 template <> struct MmaOpT<bf16_t> {
@@ -102,13 +105,14 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
     int off = 0;
     if (p < g.P) {
       const int tap = p >> g.cl2, c = p & (cpp - 1);
-      off = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * g.PS + c * 16;
+      const int tp = ((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo);   // tap offset in tile pixels
+      off = g.plane_bytes ? tp * 32 + (c >> 1) * g.plane_bytes + (c & 1) * 16 : tp * g.PS + c * 16;
     }
     sOff[p] = off;
   }
   // ---- stage the input tile (zero-filled outside the image)
   if (!(g.dbg & 1)) {
-    const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
+    const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, g.plane_bytes};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
     if (g.ups) stage_tile_upsampled<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
     else stage_tile_plain<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
@@ -291,7 +295,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // 64/128-B pixels are 4/8-way conflicted there).  scripts/lds_bank_model.py has the lane-group model.
   static const bool s2pad = getenv("SV_TC_NO_S2PAD") == nullptr, p64 = getenv("SV_TC_PAD64") != nullptr;
   const int pb = cin * esz;
-  const int PS = pb + (t.SX == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
+  // Stride-1 tiles of >= 64-B pixels are PLANAR (32-B planes: conflict-free with no padding; SV_TC_NO_PLANAR = the
+  // padded linear layout for A/B)
+  static const bool planar_on = getenv("SV_TC_NO_PLANAR") == nullptr;
+  const bool planar = planar_on && t.SX == 1 && t.S == 1 && pb >= 64;
+  const int PS = planar ? 32 : pb + (t.SX == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
   const int lTW = OX >= 16 ? 4 : t.lOX;
   const int off_bytes = (((t.P + 31) / 32 * 32) * 4 + 15) / 16 * 16;   // padded to the largest K step
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
@@ -307,7 +315,8 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
     const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
     const int TIW = (TW - 1) * t.SX + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
-    const int64_t in_bytes = (int64_t)NB * TIH * TIW * PS;
+    const int plane_bytes = planar ? NB * TIH * TIW * 32 : 0;
+    const int64_t in_bytes = planar ? (int64_t)plane_bytes * (pb / 32) : (int64_t)NB * TIH * TIW * PS;
     const int64_t lds = 2 * BN * tile_pps(BN) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
@@ -319,7 +328,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
-    a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS;
+    a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
     a->off_bytes = off_bytes; a->in_bytes = (int)in_bytes;
     a->N = t.N; a->OHF = t.OHF; a->OWF = t.OWF; a->OS = t.OS; a->ooy = t.ooy; a->oox = t.oox; a->ldo = t.ldo;
     a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;

@@ -16,7 +16,13 @@ struct TileStageGeom {
   int cl2;                  // log2(16-B chunks per pixel staged)
   int TIW, TIH, PS;         // LDS tile extent in pixels, bytes per pixel record
   int NB;                   // images per tile
+  int plane_bytes;          // > 0: PLANAR tile -- the 16-B chunk c of a pixel lives in plane c>>1 (planes of 32-B
+                            // pixel records, PS = 32): the same conflict-free ds_read_b128 pattern as a 32-B pixel for
+                            // any channel count, without the +32 B padding of the linear layout
 };
+__device__ __forceinline__ int tile_piece_off(const TileStageGeom& s, int pixel, int c) {
+  return s.plane_bytes ? (c >> 1) * s.plane_bytes + pixel * 32 + (c & 1) * 16 : pixel * s.PS + c * 16;
+}
 
 template <typename T, int NT = 256>   // NT = threads of the workgroup
 __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
@@ -34,7 +40,7 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
     const int iy = iy_base + iyl, b = b0 + bl;
     const bool rok = b < s.B && (unsigned)iy < (unsigned)s.IH;
     const T* src = Ab + ((int64_t)(b * s.IH + iy) * s.IW) * s.lda;
-    char* drow = sIn + row * s.TIW * s.PS;
+    const int prow = row * s.TIW;                      // first tile pixel of this row
     for (int pc0 = slane; pc0 < ppr; pc0 += LPR * 4) {
       uint4 v[4];
 #pragma unroll
@@ -47,7 +53,7 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = pc0 + u * LPR;
-        if (pc < ppr) *(uint4*)(drow + (pc >> s.cl2) * s.PS + (pc & (cpp - 1)) * 16) = v[u];
+        if (pc < ppr) *(uint4*)(sIn + tile_piece_off(s, prow + (pc >> s.cl2), pc & (cpp - 1))) = v[u];
       }
     }
   }
@@ -118,7 +124,7 @@ __device__ __forceinline__ void stage_tile_upsampled(const T* __restrict__ Ab, c
         if ((unsigned)tx >= (unsigned)s.TIW) continue;
         // SAME padding lives in hi-res space
         const bool in = b < s.B && (unsigned)Y < (unsigned)s.IH && (unsigned)X < (unsigned)s.IW;
-        *(uint4*)(sIn + ((bl * s.TIH + ty) * s.TIW + tx) * s.PS + c * 16) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
+        *(uint4*)(sIn + tile_piece_off(s, (bl * s.TIH + ty) * s.TIW + tx, c)) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
       }
     }
   }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     __syncthreads();                                // previous tile fully consumed
     // ---- stage input patch slice (+halo, zero outside the image; optionally through the fused upsample)
     {
-      const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB};
+      const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
       if (g.dbg & 2) {}
       else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
