@@ -162,3 +162,30 @@ def test_step_forward_reproducible(ops):
                      plan.buffer("losses", torch.float32, (8,)).clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     torch.testing.assert_close(outs[0][1][:6], outs[1][1][:6], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("H,L", [(128, 128), (32, 64)])
+def test_other_geometries_match_oracle_losses(ops, H, L):
+    """celeba128 (vae/data.py:18) and a non-default latent width: the bf16 step's loss terms against the fp64
+    oracle, and a finite, non-zero gradient for every variable."""
+    B, patch, beta = 2, 8, 120.0
+    x, perm, _ = make_inputs(B, H, patch, seed=4)
+    eps = np.random.Generator(np.random.PCG64(8)).standard_normal((2, B, L)).astype(np.float32)
+    images = torch.from_numpy(np_ref.scramble_batch(x, perm, patch).astype(np.float32))
+    params_np = np_ref.glorot_init(H, H, seed=3, global_latent=L, local_latent=L)
+    ref = torch_ref.RefTrainer(params_np, beta, dtype=torch.float64)
+    _, loss_ref = ref.forward_losses(images.double(), eps[0], eps[1])
+    plan = ops.LGVaePlan(B, H, H, global_latent=L, local_latent=L, beta=beta, dtype=torch.bfloat16)
+    P = flat_params(plan, params_np)
+    G = torch.zeros_like(P)
+    from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM
+    plan.step(PHASE_ALL & ~PHASE_ADAM, params=P, grads=G, images6=images.cuda(), eps_x=torch.from_numpy(eps[0]).cuda(),
+              eps_x_hat=torch.from_numpy(eps[1]).cuda(), t=1)
+    torch.cuda.synchronize()
+    losses = plan.buffer("losses", torch.float32, (8,)).cpu()
+    for i, k in enumerate(LOSS_KEYS):
+        want = float(loss_ref[k])
+        assert abs(float(losses[i]) - want) <= 5e-3 * abs(want) + 5e-2, (k, float(losses[i]), want)
+    for name, off, shape in plan.param_table:
+        g = G[off:off + int(np.prod(shape))]
+        assert torch.isfinite(g).all() and float(g.abs().max()) > 0, name
