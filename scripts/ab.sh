@@ -1,3 +1,6 @@
-export SV_BENCH_OPS=fwd,dgrad
-for lib in libsplitvae_hip.so libsplitvae_p32.so libsplitvae_hip.so libsplitvae_p32.so; do
-echo "--- $lib"; SV_LIB_NAME=$lib python scripts/bench_layers.py 512 d5 d4; done
+export SV_BENCH_OPS=wgrad
+L="d5 d4 d3 d2 e1 e2"
+echo "--- contiguous"; python scripts/bench_layers.py 512 $L
+echo "--- strided"; SV_WT_STRIDED=1 python scripts/bench_layers.py 512 $L
+echo "--- contiguous"; python scripts/bench_layers.py 512 $L
+echo "--- strided"; SV_WT_STRIDED=1 python scripts/bench_layers.py 512 $L

@@ -44,6 +44,7 @@ struct TileConvArgs {
   int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
   int PS;                     // bytes per pixel in the LDS tile
   int plane_bytes;            // > 0: planar tile (tile_stage.hip.h), PS = 32
+  int xcd_chunk;              // > 0: XCD-aware tile order: workgroup id w runs tile (w & 7) * xcd_chunk + (w >> 3)
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
   int buf_bytes;              // persistent kernel: bytes of each of its two input-tile buffers
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
@@ -89,6 +90,7 @@ struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
   int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
+  int contig;               // tiles of a workgroup: contiguous run (1) or strided by the grid (0)
   int pairx;                // 8-channel pixels (e1): rows 8..15 of a fragment are the NEXT pixel = the next x tap;
                             // the tap list holds every other x tap and accumulator row r means (tap 2u + (r>>3), channel r&7)
   int lTW, lTH, lNB, OY, OX, tilesX, tilesY, ntiles;

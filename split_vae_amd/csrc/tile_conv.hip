@@ -65,7 +65,13 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- which tile
+  // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give XCD k a CONTIGUOUS range of
+  // tiles so that neighbouring tiles (shared halos, same image) meet in one L2 (g.xcd_chunk = ceil(ntiles/8), 0 = off)
   int t = blockIdx.x;
+  if (g.xcd_chunk) {
+    const int remapped = (t & 7) * g.xcd_chunk + (t >> 3);
+    t = remapped < g.ntiles && (g.ntiles & 7) == 0 ? remapped : t;
+  }
   const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
   const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
   const int b0 = t << g.lNB;
@@ -329,6 +335,10 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->tilesX = OX / TW; a->tilesY = OY / TH;
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
+    {
+      static const bool xcd = getenv("SV_TC_NO_XCD") == nullptr;
+      a->xcd_chunk = (xcd && a->ntiles >= 64 && (a->ntiles & 7) == 0) ? a->ntiles / 8 : 0;
+    }
     a->off_bytes = off_bytes; a->in_bytes = (int)in_bytes;
     a->N = t.N; a->OHF = t.OHF; a->OWF = t.OWF; a->OS = t.OS; a->ooy = t.ooy; a->oox = t.oox; a->ldo = t.ldo;
     a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;

@@ -89,7 +89,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
   const int lycp = g.lycp;                          // log2(16-B pieces per dY pixel)
   const int dy_total = (32 * KC) << lycp;
 
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+  // each workgroup walks a CONTIGUOUS run of tiles (neighbours share halos: the re-reads hit this XCD's L2)
+  const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_lo = g.contig ? (int)blockIdx.x * per_wg : (int)blockIdx.x;
+  const int tile_hi = g.contig ? min(g.ntiles, tile_lo + per_wg) : g.ntiles;
+  const int tile_step = g.contig ? 1 : (int)gridDim.x;
+  for (int tile = tile_lo; tile < tile_hi; tile += tile_step) {
     int t = tile;
     const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
     const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
@@ -345,6 +350,8 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
+  static const bool contig = getenv("SV_WT_STRIDED") == nullptr;
+  a.contig = contig ? 1 : 0;
   a.CW = CW; a.ncg = cin / CW;
   a.cl2 = ilog2_exact(CW / 8);
   a.lTW = lTW; a.lTH = lTH; a.lNB = lNB; a.OY = OY; a.OX = OX;
