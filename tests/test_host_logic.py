@@ -119,3 +119,25 @@ def test_tfrecord_codec_and_shuffle_buffer(tmp_path):
     assert sorted(out) == list(range(100)) and out != list(range(100))
     assert list(tfr.shuffle_buffer(range(20), 1, seed=0)) == list(range(20))
     assert all(v <= i + 10 for i, v in enumerate(out))                  # item v cannot be emitted before position v - buffer
+
+
+def test_svhn_mat_reader_and_array_dataset(tmp_path):
+    """vae/data.py:44-53: loadmat(...)['X'] is [32,32,3,N] uint8 -> [N,32,32,3] in [-1,1]; labels 10 -> 0."""
+    import scipy.io
+    from split_vae_amd import data
+    rng = np.random.default_rng(0)
+    X = rng.integers(0, 256, (32, 32, 3, 7), dtype=np.uint8)
+    y = np.array([[1], [10], [3], [10], [9], [2], [5]], dtype=np.uint8)
+    for name in ("train_32x32.mat", "test_32x32.mat"):
+        scipy.io.savemat(str(tmp_path / name), {"X": X, "y": y})
+    x, lab = data.load_svhn_mat(str(tmp_path / "train_32x32.mat"))
+    assert x.shape == (7, 32, 32, 3) and x.dtype == np.float32
+    assert np.array_equal(x[2], (X[..., 2].astype(np.float32) / 255.0 * 2 - 1))
+    assert lab.tolist() == [1, 0, 3, 0, 9, 2, 5]
+    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
+    tr, te, shape = data.get_dataset("svhn", batch_size=3, synthetic=False, data_dir=str(tmp_path), device="cpu")
+    assert shape == [-1, 32, 32, 3]
+    batches = list(te)                      # finite test iterator: 7 images -> two full batches of 3
+    assert len(batches) == 2 and tuple(batches[0].shape) == (3, 32, 32, 3)
+    it = iter(tr)                           # training iterator repeats
+    assert all(tuple(next(it).shape) == (3, 32, 32, 3) for _ in range(5))
