@@ -90,6 +90,7 @@ struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
   int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
+  int layer_id;             // instantiation id (tuning table of svk_wgrad_tile_multi)
   int contig;               // tiles of a workgroup: contiguous run (1) or strided by the grid (0)
   int pairx;                // 8-channel pixels (e1): rows 8..15 of a fragment are the NEXT pixel = the next x tap;
                             // the tap list holds every other x tap and accumulator row r means (tap 2u + (r>>3), channel r&7)

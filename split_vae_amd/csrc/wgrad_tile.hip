@@ -39,13 +39,18 @@ __device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_rea
 
 // TPW taps per wave (4 waves: tap group = 4*TPW taps), CIF ci-fragments (16 channels) per
 // workgroup slice, COF co-fragments (all of Cout_pad16), KC = 32-pixel K chunks per tile.
-template <int TPW, int CIF, int COF, int KC>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti mg) {
+// NG wave groups of 4 waves: with NG = 2 the workgroup has two tile buffers, each group walks every other tile of the
+// run with the SAME tap split, and group 1's accumulators are added to group 0's through LDS before the flush --
+// the same waves per SIMD as two 4-wave workgroups per CU, but half the partial-sum slabs to write and reduce
+// (the slab traffic was 25-40 % of these kernels).
+template <int TPW, int CIF, int COF, int KC, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void wgrad_tile_kernel(const WgradTileMulti mg) {
   const WgradTileArgs& g = mg.a[blockIdx.z];      // twin layers (x / x-hat networks) share one launch
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sIn = smem;                       // [NB][TIH][TIW] pixels of PS bytes (+ slack)
-  char* sDy = smem + g.in_bytes;          // [BM] pixels of YS bytes (+ slack)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
+  char* sIn = smem + grp * (g.in_bytes + g.dy_bytes);   // [NB][TIH][TIW] pixels of PS bytes (+ slack)
+  char* sDy = sIn + g.in_bytes;                         // [BM] pixels of YS bytes (+ slack)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // thread / wave WITHIN the group
   const int tg = blockIdx.y / g.ncg, cg = blockIdx.y - tg * g.ncg;   // tap group, channel slice
   const int tap0 = tg * (4 * TPW) + wave * TPW;                       // this wave's first tap
   const int ci0 = cg * g.CW;                                          // first input channel of the slice
@@ -94,8 +99,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
   const int tile_lo = g.contig ? (int)blockIdx.x * per_wg : (int)blockIdx.x;
   const int tile_hi = g.contig ? min(g.ntiles, tile_lo + per_wg) : g.ntiles;
   const int tile_step = g.contig ? 1 : (int)gridDim.x;
-  for (int tile = tile_lo; tile < tile_hi; tile += tile_step) {
-    int t = tile;
+  for (int tile0 = tile_lo; tile0 < tile_hi; tile0 += tile_step * NG) {
+    const int tile = tile0 + grp * tile_step;
+    const bool has = tile < tile_hi;                // the last pass of an odd run leaves group 1 idle
+    int t = has ? tile : tile_lo;
     const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
     const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
     const int b0 = t << g.lNB;
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
-      if (g.dbg & 2) {}
+      if ((g.dbg & 2) || !has) {}
       else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
       else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
     }
     // ---- stage dY patch
-    for (int q = tid; q < dy_total && !(g.dbg & 4); q += 256) {
+    for (int q = tid; q < dy_total && !(g.dbg & 4) && has; q += 256) {
       const int r = q >> lycp, c = q & ((1 << lycp) - 1);
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
     }
     __syncthreads();
     // ---- MFMA: K = pixels
-    if (!(g.dbg & 8))
+    if (!(g.dbg & 8) && has)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       short8_t bfr[COF];
@@ -152,17 +159,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
               __builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[j]), acc[u / CIF][u % CIF][j], 0, 0, 0);
       }
     }
-    if (do_bias) {
+    if (do_bias && has) {
       for (int r = bgrp; r < 32 * KC; r += nbg) bsum += (float)*(const bf16_t*)(sDy + r * g.YS + bcol * 2);
     }
   }
 
+  if constexpr (NG == 2) {
+    // group 1 -> group 0 through LDS, half of the fragments at a time (the tile buffers are free now)
+    constexpr int NFR_ = TPW * CIF * COF, HF = (NFR_ + 1) / 2;
+    float* xch = (float*)smem + (wave * HF * 4) * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      if (grp == 1) {
+#pragma unroll
+        for (int f = 0; f < NFR_; ++f)
+          if (f / HF == h)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) xch[((f - h * HF) * 4 + r4) * 64] = acc[f / (CIF * COF)][(f / COF) % CIF][f % COF][r4];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int f = 0; f < NFR_; ++f)
+          if (f / HF == h)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) acc[f / (CIF * COF)][(f / COF) % CIF][f % COF][r4] += xch[((f - h * HF) * 4 + r4) * 64];
+      }
+    }
+  }
+  const bool flusher = grp == 0;
   // ---- flush.  With a partial-sum slab (two-stage, deterministic): every accumulator register goes
   // out as one fully coalesced 256-B store in fragment order; wgrad_reduce_kernel sums the slabs in
   // a fixed order.  (fp32 atomics straight into dW run at ~1.3 TB/s chip-wide and were 40-60 % of
   // this kernel's time: SV_WT_NOFLUSH ablation.)
   if (g.slab) {
-    if (g.dbg & 1) return;
+    if ((g.dbg & 1) || !flusher) goto bias_part;
+    {
     float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * CIF * COF)) * 256 + lane;
 #pragma unroll
     for (int t2 = 0; t2 < TPW; ++t2)
@@ -172,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
         for (int j = 0; j < COF; ++j)
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) sl[(((t2 * CIF + i) * COF + j) * 4 + r4) * 64] = acc[t2][i][j][r4];
-  } else
+    }
+  } else if (flusher)
   // atomics: D row = ci (lane>>4)*4+reg within the fragment, col = co lane&15
 #pragma unroll
   for (int t2 = 0; t2 < TPW; ++t2) {
@@ -194,14 +228,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(const WgradTileMulti
         }
       }
   }
+bias_part:
   if (do_bias) {
     __syncthreads();
     float* red = (float*)smem;
-    red[bgrp * ycols + bcol] = bsum;
+    red[(grp * nbg + bgrp) * ycols + bcol] = bsum;
     __syncthreads();
-    if (tid < ycols && tid < g.N && (!g.fold_kw || (tid & 7) < g.fold_c)) {
+    if (grp == 0 && tid < ycols && tid < g.N && (!g.fold_kw || (tid & 7) < g.fold_c)) {
       float s = 0.f;
-      for (int k = 0; k < nbg; ++k) s += red[k * ycols + tid];
+      for (int k = 0; k < nbg * NG; ++k) s += red[k * ycols + tid];
       atomicAdd(g.dbias + (g.fold_kw ? (tid & 7) : tid), s);
     }
   }
@@ -257,18 +292,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   }
 }
 
-template <int TPW, int CIF, int COF, int KC>
-static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
-  const size_t lds = (size_t)a[0].in_bytes + a[0].dy_bytes;
+template <int TPW, int CIF, int COF, int KC, int NG>
+static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
+  constexpr int HFB = ((TPW * CIF * COF + 1) / 2) * 4 * 1024;     // bytes of the cross-group exchange (NG = 2)
+  size_t lds = NG * ((size_t)a[0].in_bytes + a[0].dy_bytes);
+  if (NG == 2 && lds < (size_t)HFB) lds = HFB;
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC>,
+    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC, NG>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
   // resident workgroups per CU: LDS, and 2 waves per SIMD (accumulator-heavy waves)
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 2) per_cu = 2;
+  if (per_cu > 2 / NG) per_cu = 2 / NG;
   if (per_cu < 1) per_cu = 1;
   static const int force_pc = getenv("SV_WT_PERCU") ? atoi(getenv("SV_WT_PERCU")) : 0;   // profiling knob
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
@@ -276,7 +313,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
   static const int dbg = getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0);
   int msplit = (256 * per_cu + groups - 1) / groups;
   if (msplit > a[0].ntiles) msplit = a[0].ntiles;
-  dim3 grid(msplit, groups, n), block(256);
+  dim3 grid(msplit, groups, n), block(256 * NG);
   constexpr int PER = 4 * TPW * CIF * COF * 256;
   const int64_t need = (int64_t)msplit * groups * PER * 4;
   static const bool no_slab = getenv("SV_WT_ATOMICS") != nullptr;
@@ -290,7 +327,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
     m.a[i].slab = slab ? a[i].ws : nullptr;
     r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW;
   }
-  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC>), grid, block, lds, st, m);
+  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
@@ -299,6 +336,21 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
     SV_LAUNCH_CHECK();
   }
   return SV_OK;
+}
+
+template <int TPW, int CIF, int COF, int KC>
+static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
+  static const bool ng1 = getenv("SV_WT_NG1") != nullptr;      // A/B knob: 4-wave workgroups, two per CU
+  constexpr size_t HFB = ((TPW * CIF * COF + 1) / 2) * 4 * 1024;
+  const size_t two = 2 * ((size_t)a[0].in_bytes + a[0].dy_bytes);
+  const bool slab = a[0].ws != nullptr;                         // halving the slabs is the point; atomics keep NG = 1
+  // measured per layer (B = 512): e2 -13 %, d2 -8 %, e1 -4 %, d3 0; d4 / d5 (the longest MFMA sections) lose
+  // 5-12 % to the lockstep of the two groups, so the wide-tile layers keep two independent workgroups per CU
+  static const char* ng2 = getenv("SV_WT_NG2") ? getenv("SV_WT_NG2") : "356";     // layer ids (see the table above)
+  const bool want = strchr(ng2, '0' + a[0].layer_id) != nullptr;
+  if (!ng1 && want && slab && two <= 160 * 1024 && HFB <= 160 * 1024 && a[0].ntiles >= 64)
+    return launch_wt_ng<TPW, CIF, COF, KC, 2>(a, n, groups, st, ev_mid);
+  return launch_wt_ng<TPW, CIF, COF, KC, 1>(a, n, groups, st, ev_mid);
 }
 
 // Returns SV_E_UNSUPPORTED when the layer shape has no tile instantiation (caller falls back to
@@ -349,7 +401,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   WgradTileArgs& a = av[0];
   memset(&a, 0, sizeof(a));
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.ups = w.ups;
-  a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
+  a.fold_kw = w.fold_kw; a.fold_c = w.fold_c; a.layer_id = id;
   static const bool contig = getenv("SV_WT_STRIDED") == nullptr;
   a.contig = contig ? 1 : 0;
   a.CW = CW; a.ncg = cin / CW;

@@ -157,6 +157,10 @@ def test_conv_fullsize_reproducible_and_linear(ops, name, Hl, Cin, Cout, k, s, y
     dw1, db1 = conv.wgrad(x, dy, workspace=True)
     dw2, _ = conv.wgrad(x, dy, workspace=True)
     assert torch.equal(dw1, dw2)
+    # the slab path (8-wave workgroups, two tile buffers merged through LDS) against the atomics path (4-wave workgroups)
+    dw0, db0 = conv.wgrad(x, dy, workspace=False)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-4, atol=1e-4 * float(dw0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-4 * float(db0.abs().max()))
     dwa, dba = half.wgrad(x[:B // 2].contiguous(), dy[:B // 2].contiguous(), workspace=True)
     dwb, dbb = half.wgrad(x[B // 2:].contiguous(), dy[B // 2:].contiguous(), workspace=True)
     torch.testing.assert_close(dwa + dwb, dw1, rtol=1e-4, atol=1e-4 * float(dw1.abs().max()))
