@@ -104,7 +104,7 @@ test_step.__test__ = False   # not a pytest test
 def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, test_dataset, config):
     """Loop of vae/trainer.py:72-421 for LGVae: train; every 10 000 steps (incl. step 0) evaluate
     on the test set and print the reference's report; stop after training_steps; save weights.
-    The PNG grids of vae/visualizer.py are outside the path."""
+    The image grids of vae/visualizer.py are written by _write_grids (visualizer.py)."""
     from . import gm
     if isinstance(model, gm.LGGMVae):               # vae/trainer.py:294-302: the step functions follow the model class
         return _train_lggmvae(model, optimizer, train_dataset, test_dataset, config)
@@ -144,6 +144,7 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
                                   te["x_recon_loss"], te["x_kl_loss"], te["x_recon_loss"] + te["x_kl_loss"],
                                   te["x_hat_recon_loss"], te["x_hat_kl_loss"], te["x_hat_recon_loss"] + te["x_hat_kl_loss"],
                                   tr["total_kl_loss"], te["total_kl_loss"]))
+            _write_grids(model, test_dataset, config, os.path.join("output", RUN_NAME), step)
             # vae/trainer.py:405-414 resets x_recon / x_kl / total_kl but never the x_hat_* means
             metrics.reset_states(["x_recon_loss", "x_kl_loss", "total_kl_loss"])
             start = time.time()
@@ -153,6 +154,24 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
     path = 'models/' + RUN_NAME
     model.save_weights(path)
     return path + ".npz"
+
+
+def _write_grids(model, test_dataset, config, run_dir, step):
+    """The image grids the reference writes at every evaluation (vae/trainer.py:385-396; vae/visualizer.py)."""
+    from . import visualizer
+    out = run_dir + "/"
+    tag = "_it_" + str(step)
+    visualizer.generate(model, filename="generate_it_" + str(step), filepath=out)
+    first = next(iter(test_dataset), None)
+    if first is not None:
+        visualizer.reconstruction_test_lg_vae(model, test_dataset, label=config.label, filename=tag, filepath=out)
+    visualizer.generate_varying_latent(model, vary="lower", filename="vary_lower_it_" + str(step), filepath=out)
+    visualizer.generate_varying_latent(model, vary="upper", filename="vary_upper_it_" + str(step), filepath=out)
+    svhn_file = os.path.join("data", "SVHN", "test_32x32.mat")
+    if config.dataset == "svhn" and os.path.exists(svhn_file):
+        visualizer.style_transfer_test(model, test_dataset, label=config.label, filename=tag, filepath=out)
+    elif first is not None and (first[0] if config.label else first).shape[0] >= 20:
+        visualizer.style_transfer_celeba(model, test_dataset, label=config.label, filename=tag, filepath=out)
 
 
 def _train_lggmvae(model, optimizer, train_dataset, test_dataset, config):
@@ -188,6 +207,7 @@ def _train_lggmvae(model, optimizer, train_dataset, test_dataset, config):
             for tag, v in (('', tr), ('Test ', te)):
                 print('            {}X Recon Loss: {:.4f}, {}X KLD loss: {:.4f}, {}X hat Recon Loss: {:.4f}, {}X hat KLD loss: {:.4f}, '
                       '{}Y KL loss: {:.4f}'.format(tag, v[0], tag, v[1], tag, v[2], tag, v[3], tag, v[4]))
+            _write_grids(model, test_dataset, config, os.path.join("output", RUN_NAME), step)
             acc, n_acc = None, 0
             start = time.time()
         if step >= config.training_steps:

@@ -141,3 +141,15 @@ def test_svhn_mat_reader_and_array_dataset(tmp_path):
     assert len(batches) == 2 and tuple(batches[0].shape) == (3, 32, 32, 3)
     it = iter(tr)                           # training iterator repeats
     assert all(tuple(next(it).shape) == (3, 32, 32, 3) for _ in range(5))
+
+
+def test_png_writer_round_trip(tmp_path):
+    from split_vae_amd import visualizer as viz
+    rng = np.random.default_rng(0)
+    canvas = rng.uniform(-0.2, 1.2, (13, 21, 3))                        # out-of-range values are clipped
+    p = viz.save_png(str(tmp_path / "sub" / "c.png"), canvas)
+    back = viz.load_png(p)
+    assert back.shape == (13, 21, 3) and back.dtype == np.uint8
+    assert np.array_equal(back, np.clip(np.rint(canvas * 255), 0, 255).astype(np.uint8))
+    grid = viz._tile(np.arange(4 * 2 * 3 * 3, dtype=np.float32).reshape(4, 2, 3, 3), 2, 2)
+    assert grid.shape == (4, 6, 3) and np.array_equal(grid[:2, 3:], np.arange(18, 36, dtype=np.float32).reshape(2, 3, 3))
