@@ -101,8 +101,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); none visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real N-GPU node; lets a gloo dry run share one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from split_vae_amd import data, trainer
     from split_vae_amd.augmentation import Augmentator

@@ -24,7 +24,7 @@ def init_from_env(backend=None):
         if backend is None:      # SV_DIST_BACKEND=gloo: several ranks sharing one GPU (tests); RCCL wants one device per rank
             backend = os.environ.get("SV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
