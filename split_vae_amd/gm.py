@@ -307,7 +307,9 @@ class LGGMVae(LGVae):
         return b["pm"].clone(), b["ps"].clone()
 
     def get_y(self, x):
-        out = self(torch.cat([x, x], dim=-1))
+        """vae/model.py:267-270: (y, y_logits) of encoder_x for x [n,H,W,3] (a 6-channel batch uses its x half)."""
+        x = x[..., :3]
+        out = self(torch.cat([x, x], dim=-1).contiguous())
         return out[10], out[11]
 
 

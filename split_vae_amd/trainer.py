@@ -172,6 +172,12 @@ def _write_grids(model, test_dataset, config, run_dir, step):
         visualizer.style_transfer_test(model, test_dataset, label=config.label, filename=tag, filepath=out)
     elif first is not None and (first[0] if config.label else first).shape[0] >= 20:
         visualizer.style_transfer_celeba(model, test_dataset, label=config.label, filename=tag, filepath=out)
+    from .gm import LGGMVae
+    if config.viz and isinstance(model, LGGMVae):                      # vae/trainer.py:398-403
+        visualizer.unseen_cluster_lg(model, test_dataset, label=config.label, filename=tag, filepath=out)
+        visualizer.generate_cluster(model, vary="zg", filename="generate_cluster_fix_zl_it_" + str(step), filepath=out)
+        visualizer.generate_cluster(model, vary="zg_zl", filename="generate_cluster_it_" + str(step), filepath=out)
+        visualizer.generate_cluster(model, vary="y_zg", filename="generate_multi_cluster_it_" + str(step), filepath=out)
 
 
 def _train_lggmvae(model, optimizer, train_dataset, test_dataset, config):

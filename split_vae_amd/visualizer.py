@@ -175,3 +175,61 @@ def style_transfer_test(model, test_dataset, label=True, filename=None, filepath
     canvas = np.concatenate([_tile(a[..., :3], 1, n), _tile(a[..., 3:], 1, n), _tile(x_recon, 1, n)], axis=0)
     save_png(_out(filepath, "style_transfer" + (filename or "")), canvas)
     return canvas
+
+
+# ---------------------------------------------------------------- LGGMVae only (behind -viz in the reference loop)
+def generate_cluster(model, vary, filename=None, filepath=None, seed=None):
+    """vae/visualizer.py:272-314.  vary='zg': 100 global draws from one cluster's prior, one local latent;
+    'zg_zl': 10 global draws (rows) x 10 local draws (columns); 'y_zg': 10 random clusters (rows) x 10 global draws."""
+    if not _is_gm(model):
+        raise TypeError("generate_cluster is for LGGMVae")
+    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    dev, Lg, Ll = model.device, model.global_latent_dims, model.local_latent_dims
+    rn = lambda *s: torch.randn(s, generator=gen).to(dev)
+    if vary == "y_zg":
+        ks = torch.randperm(model.y_size, generator=gen)[:10]
+        y = torch.zeros((10, model.y_size), dtype=torch.float32, device=dev)
+        y[torch.arange(10), ks.to(dev)] = 1.0
+        mean, sig = model.encode_y(y)                                        # [10, Lg] each
+        z_g = (rn(10, 10, Lg) * sig[:, None, :] + mean[:, None, :]).reshape(100, Lg)
+        z_l = rn(1, Ll).expand(100, -1)
+    else:
+        mean, sig = _prior(model, gen)
+        if vary == "zg_zl":
+            z_g = (rn(10, Lg) * sig + mean).repeat_interleave(10, dim=0)     # each global draw 10 times in a row
+            z_l = rn(10, Ll).repeat(10, 1)
+        elif vary == "zg":
+            z_g = rn(100, Lg) * sig + mean
+            z_l = rn(1, Ll).expand(100, -1)
+        else:
+            raise ValueError(vary)
+    x_gen, _ = model.decode(z_g.float().contiguous(), z_l.contiguous(), True)
+    canvas = _tile(x_gen, 10, 10)
+    save_png(_out(filepath, filename or ("generate_cluster_" + vary)), canvas)
+    return canvas
+
+
+def unseen_cluster_lg(model, test_dataset, label=True, filename=None, filepath=None, n=10):
+    """vae/visualizer.py:318-353: assign every test image to argmax softmax(y_logits); per non-empty cluster, one strip of
+    its (up to) 7 most confident images.  Returns {cluster: canvas}."""
+    if not _is_gm(model):
+        raise TypeError("unseen_cluster_lg is for LGGMVae")
+    best = {}
+    for d in test_dataset:
+        images = d[0] if label else d
+        _, y_logits = model.get_y(images[..., :3].contiguous())
+        p = torch.softmax(y_logits.float(), dim=1)
+        score, cluster = p.max(dim=1)
+        for c in cluster.unique().tolist():
+            sel = (cluster == c).nonzero().flatten()
+            prev = best.get(c, (torch.empty(0), torch.empty((0,) + tuple(images.shape[1:3]) + (3,))))
+            sc = torch.cat([prev[0], score[sel].cpu()])
+            im = torch.cat([prev[1], images[sel][..., :3].float().cpu()])
+            top = sc.argsort(descending=True)[:7]
+            best[c] = (sc[top], im[top])
+    out = {}
+    for c, (_, im) in sorted(best.items()):
+        canvas = _tile((im.numpy() + 1) * 0.5, 1, im.shape[0])
+        save_png(_out(filepath, "unseen_cluster_%s_%d" % (filename or "", c)), canvas)
+        out[c] = canvas
+    return out

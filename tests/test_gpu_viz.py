@@ -62,3 +62,20 @@ def test_decode_of_encode_is_the_forward_reconstruction(lib_built):
     torch.testing.assert_close(xh_mean, full[6], rtol=1e-4, atol=1e-4)
     r, _ = model.decode(z_x, z_h, rescale=True)
     torch.testing.assert_close(r, torch.clamp((full[0] + 1) * 0.5, 0, 1), rtol=1e-4, atol=1e-4)
+
+
+def test_cluster_grids(lib_built, tmp_path):
+    from split_vae_amd import visualizer as viz
+    from split_vae_amd.gm import LGGMVae
+    model = LGGMVae(128, 128, [-1, H, H, 3], 30, 0.4, dtype="bf16", device="cuda", seed=2)
+    out = str(tmp_path) + "/"
+    for vary in ("zg", "zg_zl", "y_zg"):
+        c = viz.generate_cluster(model, vary, filepath=out, seed=3)
+        assert c.shape == (10 * H, 10 * H, 3) and np.isfinite(c).all()
+    # 'zg_zl': rows share the global draw, columns share the local draw -> tiles differ along both axes
+    c = viz.generate_cluster(model, "zg_zl", filename="g", filepath=out, seed=4)
+    assert np.abs(c[:H, :H] - c[:H, H:2 * H]).max() > 0 and np.abs(c[:H, :H] - c[H:2 * H, :H]).max() > 0
+    strips = viz.unseen_cluster_lg(model, [_batch(40), _batch(24, seed=5)], label=False, filename="_t", filepath=out)
+    assert len(strips) >= 1 and all(v.shape[0] == H and v.shape[1] % H == 0 and v.shape[1] <= 7 * H for v in strips.values())
+    y, logits = model.get_y(_batch(6)[..., :3].contiguous())
+    assert y.shape == logits.shape == (6, 30) and torch.allclose(y.sum(1).cpu(), torch.ones(6), atol=1e-4)
