@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling: the default, 512 per GPU)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling instead: total batch split evenly over the GPUs (e.g. 512 -> 64 per GPU at N=8, SURVEY config C4)")
     ap.add_argument("--size", type=int, default=64, choices=[32, 64])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,6 +115,10 @@ def main():
 
     H = args.size
     B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not divisible by %d GPUs" % (args.global_batch, world))
+        B = args.global_batch // world
     beta, patch = (120.0, 8) if H == 64 else (40.0, 1)
     model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=args.dtype, device=dev, seed=3)
     model.beta = beta
@@ -175,7 +181,8 @@ def main():
     out = {
         "metric": "images/sec training step, SPLIT-VAE CelebA-64 bs512" if H == 64 else "images/sec training step, SPLIT-VAE SVHN-32",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong" if args.global_batch else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "SPLIT-VAE %s %dx%d beta=%g patch_size=%d latents=128+128 lr=1e-4, full train step "
                                "(scramble+fwd+ELBO+bwd+Adam%s), per-GPU batch %d" %
