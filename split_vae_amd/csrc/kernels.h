@@ -44,6 +44,7 @@ struct TileConvArgs {
   int TIW, TIH, y_lo, x_lo;   // LDS input tile extent (pixels) and the tap-offset origin
   int PS;                     // bytes per pixel in the LDS tile
   int plane_bytes;            // > 0: planar tile (tile_stage.hip.h), PS = 32
+  int nph, lnph;              // channel phases of the tile (1 << lnph); 1 = the whole pixel at once
   int xcd_chunk;              // > 0: XCD-aware tile order: workgroup id w runs tile (w & 7) * xcd_chunk + (w >> 3)
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
   int buf_bytes;              // persistent kernel: bytes of each of its two input-tile buffers

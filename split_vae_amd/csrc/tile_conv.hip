@@ -16,6 +16,7 @@
 #include "common.hip.h"
 #include "kernels.h"
 #include "tile_stage.hip.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -83,12 +84,18 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   // (kernarg fields used in the K loop are copied to locals: through the reference hipcc re-issued
   // their scalar loads, with an lgkmcnt(0) wait each, in every K step)
   const T* __restrict__ Wb = (const T*)g.Wt;
-  const int gP = g.P, gKtot = g.Ktot, gdbg = g.dbg;
+  // CHANNEL PHASES (g.nph > 1, planar tiles): the tile is staged nph times with 1/nph of the channels each, the
+  // K loop of a phase runs over (all taps) x (its channels), and the accumulators carry over.  The LDS tile shrinks
+  // nph-fold, so more workgroups fit a CU (the kernel is latency-bound: occupancy is what it lacks).
+  const int nph = g.nph, lcH = g.cl2 - g.lnph;        // log2(16-B chunks per pixel per phase)
+  const int gP = g.P >> g.lnph, gKtot = g.Ktot, gdbg = g.dbg;   // pieces of K per phase
   const int pp = tid % PPS, r0 = tid / PPS;
+  int ph = 0;                                         // current phase (read by load_b)
   uint4 rbA[BRN];
   auto load_b = [&](int ks, uint4 (&rb)[BRN]) {
-    const int p = ks * PPS + pp;
-    const bool pv = p < gP;
+    const int pl = ks * PPS + pp;                     // piece within the phase: (tap, local chunk)
+    const bool pv = pl < gP;
+    const int p = ((pl >> lcH) << g.cl2) + (ph << lcH) + (pl & ((1 << lcH) - 1));   // piece in the weight row
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + RPP * i;
@@ -106,23 +113,25 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   load_b(0, rbA);                                     // in flight while the input tile is staged
 
   // ---- piece-offset table
-  const int nkp = (g.P + PPS - 1) / PPS * PPS;
+  const int nkp = (gP + PPS - 1) / PPS * PPS;
   for (int p = tid; p < nkp; p += NT) {
     int off = 0;
-    if (p < g.P) {
-      const int tap = p >> g.cl2, c = p & (cpp - 1);
+    if (p < gP) {
+      const int tap = p >> lcH, c = p & ((1 << lcH) - 1);
       const int tp = ((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo);   // tap offset in tile pixels
       off = g.plane_bytes ? tp * 32 + (c >> 1) * g.plane_bytes + (c & 1) * 16 : tp * g.PS + c * 16;
     }
     sOff[p] = off;
   }
-  // ---- stage the input tile (zero-filled outside the image)
-  if (!(g.dbg & 1)) {
-    const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, g.plane_bytes};
+  auto stage = [&](int phase) {                       // input tile of one phase (zero-filled outside the image)
+    if (g.dbg & 1) return;
+    const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, lcH, g.TIW, g.TIH, g.PS, NB, g.plane_bytes};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
-    if (g.ups) stage_tile_upsampled<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
-    else stage_tile_plain<T, NT>((const T*)g.A, sg, b0, iy_base, ix_base, sIn, tid);
-  }
+    const T* Ap = (const T*)g.A + ((phase << lcH) * EPP);
+    if (g.ups) stage_tile_upsampled<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
+    else stage_tile_plain<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
+  };
+  stage(0);
   // ---- per-lane pixel bases of this wave's MF row fragments
   const int lr = lane & 15, lg = lane >> 4;
   int lbase[MF];
@@ -158,14 +167,21 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
         for (int j = 0; j < NF; ++j) MmaOpT<T>::run(bfr[j], af[i], acc[i][j]);   // D = W x pixels: a lane ends up with 4 CHANNELS of one pixel
     }
   };
-  write_b(0, rbA);
-  __syncthreads();                                    // input tile, offsets and weight tile 0 visible
-  for (int ks = 0; ks < nk; ++ks) {
-    const bool more = ks + 1 < nk && !(gdbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
-    if (more) load_b(ks + 1, rbA);
-    compute(ks, ks & 1);
-    if (more) write_b((ks & 1) ^ 1, rbA);
-    if (!(gdbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
+  for (ph = 0; ph < nph; ++ph) {
+    if (ph) {                                           // the last barrier of the previous K loop freed tile and weights
+      load_b(0, rbA);
+      stage(ph);
+    }
+    write_b(0, rbA);
+    __syncthreads();                                    // input tile, offsets and weight tile 0 visible
+    for (int ks = 0; ks < nk; ++ks) {
+      const bool more = ks + 1 < nk && !(gdbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
+      if (more) load_b(ks + 1, rbA);
+      compute(ks, ks & 1);
+      if (more) write_b((ks & 1) ^ 1, rbA);
+      if (!(gdbg & 16)) __syncthreads();                 // dbg 16: ablate the per-step barrier
+    }
+    if (nk == 0) __syncthreads();
   }
 
   // ---- epilogue.  The operands are swapped (D rows = output channels, cols = pixels), so a lane
@@ -304,8 +320,12 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // Stride-1 tiles of >= 64-B pixels are PLANAR (32-B planes: conflict-free with no padding; SV_TC_NO_PLANAR = the
   // padded linear layout for A/B)
   static const bool planar_on = getenv("SV_TC_NO_PLANAR") == nullptr;
-  const bool planar = planar_on && t.SX == 1 && t.S == 1 && pb >= 64;
-  const int PS = planar ? 32 : pb + (t.SX == 1 ? ((pb >= 128 || (pb == 64 && p64)) ? 32 : 0) : ((pb % 32 == 0 && s2pad) ? 16 : 0));
+  // layout of a pixel record of `bytes` channel bytes: planar (PS = 32) or linear with conflict-avoiding padding
+  auto layout = [&](int bytes, bool* planar_out) {
+    const bool pl = planar_on && t.SX == 1 && t.S == 1 && bytes >= 64;
+    *planar_out = pl;
+    return pl ? 32 : bytes + (t.SX == 1 ? ((bytes >= 128 || (bytes == 64 && p64)) ? 32 : 0) : ((bytes % 32 == 0 && s2pad) ? 16 : 0));
+  };
   const int lTW = OX >= 16 ? 4 : t.lOX;
   const int off_bytes = (((t.P + 31) / 32 * 32) * 4 + 15) / 16 * 16;   // padded to the largest K step
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
@@ -321,8 +341,22 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
     const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
     const int TIW = (TW - 1) * t.SX + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
-    const int plane_bytes = planar ? NB * TIH * TIW * 32 : 0;
-    const int64_t in_bytes = planar ? (int64_t)plane_bytes * (pb / 32) : (int64_t)NB * TIH * TIW * PS;
+    // channel phases (see the kernel): halve the channels per staging pass while the tile alone would keep a CU at
+    // <= 2 workgroups, the launch has several rounds of workgroups, and a phase keeps >= 32 B (two pieces) per pixel
+    static const int nph_max = getenv("SV_TC_NPH") ? atoi(getenv("SV_TC_NPH")) : 4;     // tuning knob (1 = off)
+    const int64_t wgs = (int64_t)(OX / TW) * (OY / TH) * ((B + NB - 1) / NB) * ((t.N + BN - 1) / BN);
+    int lnph = 0, PS = 0, plane_bytes = 0;
+    int64_t in_bytes = 0;
+    bool planar = false;
+    for (;; ++lnph) {
+      const int pbh = pb >> lnph;
+      PS = layout(pbh, &planar);
+      plane_bytes = planar ? NB * TIH * TIW * 32 : 0;
+      in_bytes = planar ? (int64_t)plane_bytes * (pbh / 32) : (int64_t)NB * TIH * TIW * PS;
+      static const bool s2_phases = getenv("SV_TC_NPH_NO_S2") == nullptr;               // A/B: phases for the padded stride-2 layouts too
+      if (!(wgs >= 1024 && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
+            in_bytes + 2 * BN * tile_pps(BN) * 16 > 40 * 1024)) break;
+    }
     const int64_t lds = 2 * BN * tile_pps(BN) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
@@ -335,6 +369,8 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->tilesX = OX / TW; a->tilesY = OY / TH;
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
+    a->nph = 1 << lnph; a->lnph = lnph;
+    if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
     {
       static const bool xcd = getenv("SV_TC_NO_XCD") == nullptr;
       a->xcd_chunk = (xcd && a->ntiles >= 64 && (a->ntiles & 7) == 0) ? a->ntiles / 8 : 0;

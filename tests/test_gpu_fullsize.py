@@ -149,7 +149,9 @@ def test_conv_fullsize_reproducible_and_linear(ops, name, Hl, Cin, Cout, k, s, y
     assert torch.equal(y1, y2)
     ya = half.fwd(x[:B // 2].contiguous(), bias).clone()
     yb = half.fwd(x[B // 2:].contiguous(), bias)
-    assert torch.equal(torch.cat([ya, yb]), y1)                   # images are independent: batch split changes nothing
+    # images are independent: a batch split changes nothing but (possibly) the order of the fp32 K accumulation
+    # (the channel-phase / tile heuristics look at the launch size), i.e. at most a last-place flip after rounding
+    torch.testing.assert_close(torch.cat([ya, yb]).float(), y1.float(), rtol=1.6e-2, atol=1e-3 * float(y1.float().abs().max()))
     OH = Hl // s
     dy = torch.randn(B, OH, OH, (Cout + 7) // 8 * 8, device="cuda", generator=g).bfloat16()
     if Cout % 8:
