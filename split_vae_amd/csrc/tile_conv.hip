@@ -353,9 +353,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
       PS = layout(pbh, &planar);
       plane_bytes = planar ? NB * TIH * TIW * 32 : 0;
       in_bytes = planar ? (int64_t)plane_bytes * (pbh / 32) : (int64_t)NB * TIH * TIW * PS;
+      static const int ph_kb = getenv("SV_TC_PH_KB") ? atoi(getenv("SV_TC_PH_KB")) : 53;   // LDS per workgroup the split aims below (3 workgroups per CU)
       static const bool s2_phases = getenv("SV_TC_NPH_NO_S2") == nullptr;               // A/B: phases for the padded stride-2 layouts too
-      if (!(wgs >= 1024 && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
-            in_bytes + 2 * BN * tile_pps(BN) * 16 > 40 * 1024)) break;
+      static const int ph_wgs = getenv("SV_TC_PH_WGS") ? atoi(getenv("SV_TC_PH_WGS")) : 256;   // launches smaller than this keep one pass
+      if (!(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
+            in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
     }
     const int64_t lds = 2 * BN * tile_pps(BN) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
