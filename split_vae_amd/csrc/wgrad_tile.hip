@@ -43,14 +43,14 @@ __device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_rea
 // run with the SAME tap split, and group 1's accumulators are added to group 0's through LDS before the flush --
 // the same waves per SIMD as two 4-wave workgroups per CU, but half the partial-sum slabs to write and reduce
 // (the slab traffic was 25-40 % of these kernels).
-template <int TPW, int CIF, int COF, int KC, int NG>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void wgrad_tile_kernel(const WgradTileMulti mg) {
+template <int TPW, int CIF, int COF, int KC, int NG, int OCC>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel(const WgradTileMulti mg) {
   const WgradTileArgs& g = mg.a[blockIdx.z];      // twin layers (x / x-hat networks) share one launch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int grp = NG == 1 ? 0 : (int)(threadIdx.x >> 8);
   char* sIn = smem + grp * (g.in_bytes + g.dy_bytes);   // [NB][TIH][TIW] pixels of PS bytes (+ slack)
   char* sDy = sIn + g.in_bytes;                         // [BM] pixels of YS bytes (+ slack)
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // thread / wave WITHIN the group
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // thread / wave WITHIN the group
   const int tg = blockIdx.y / g.ncg, cg = blockIdx.y - tg * g.ncg;   // tap group, channel slice
   const int tap0 = tg * (4 * TPW) + wave * TPW;                       // this wave's first tap
   const int ci0 = cg * g.CW;                                          // first input channel of the slice
@@ -58,18 +58,23 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void wgrad_tile_kernel(c
   const int cpp = 1 << g.cl2;                                         // 16-B chunks per pixel IN THE SLICE
   const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3, lr = lane & 15;
 
-  // per-lane LDS byte offsets for the transposed reads: read h of chunk kc -> tile pixel
-  // r = 32*kc + 16*h + 4*lg + lq, channel block 4*lp (see the K <-> pixel map above)
-  int inb[KC][2], dyb[KC][2];
-#pragma unroll
-  for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = kc * 32 + 16 * h + 4 * lg + lq;
-      const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
-      inb[kc][h] = ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS + 4 * lp * 2;
-      dyb[kc][h] = r * g.YS + 4 * lp * 2;
-    }
+  // LDS byte offsets for the transposed reads: read h of chunk kc -> tile pixel r = 32*kc + 16*h + (4*lg + lq),
+  // channel block 4*lp (see the K <-> pixel map above).  A tile holds >= 16 pixels per image row group, so the
+  // lane part (4*lg + lq < 16) and the chunk part (a multiple of 16) fill disjoint bit fields of (bl, ty, tx) and
+  // the offset splits into one per-lane register plus wave-uniform terms (SGPRs): 4*KC fewer VGPRs.
+  int in_lane, dy_lane;
+  {
+    const int r = 4 * lg + lq;
+    const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1);
+    in_lane = (ty * g.S * g.TIW + tx * g.SX) * g.PS + 4 * lp * 2;
+    dy_lane = r * g.YS + 4 * lp * 2;
+  }
+  auto in_chunk = [&](int kc, int h) -> int {       // uniform
+    const int r = kc * 32 + 16 * h;
+    const int ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+    return ((bl * g.TIH + ty * g.S) * g.TIW) * g.PS;
+  };
+  auto dy_chunk = [&](int kc, int h) -> int { return (kc * 32 + 16 * h) * g.YS; };
   int tapoff[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -132,25 +137,26 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void wgrad_tile_kernel(c
       short8_t bfr[COF];
 #pragma unroll
       for (int j = 0; j < COF; ++j) {
-        const short4_t lo = tr16(sDy + dyb[kc][0] + j * 32), hi = tr16(sDy + dyb[kc][1] + j * 32);
+        const short4_t lo = tr16(sDy + dy_lane + dy_chunk(kc, 0) + j * 32), hi = tr16(sDy + dy_lane + dy_chunk(kc, 1) + j * 32);
         bfr[j] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
       // A fragments of the (tap, ci-fragment) sequence u = t2*CIF + i, prefetched PF deep so the
       // LDS round trip (~100+ cycles) hides under the MFMAs of earlier fragments
       constexpr int U = TPW * CIF, PF = U < SV_WT_PF ? U : SV_WT_PF;
       short4_t alo[PF], ahi[PF];
+      const int ic0 = in_chunk(kc, 0), ic1 = in_chunk(kc, 1);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
-        alo[u] = tr16(sIn + inb[kc][0] + tapoff[u / CIF] + (u % CIF) * 32);
-        ahi[u] = tr16(sIn + inb[kc][1] + tapoff[u / CIF] + (u % CIF) * 32);
+        alo[u] = tr16(sIn + in_lane + ic0 + tapoff[u / CIF] + (u % CIF) * 32);
+        ahi[u] = tr16(sIn + in_lane + ic1 + tapoff[u / CIF] + (u % CIF) * 32);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const short4_t lo = alo[u % PF], hi = ahi[u % PF];
         const short8_t af = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (u + PF < U) {
-          alo[u % PF] = tr16(sIn + inb[kc][0] + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
-          ahi[u % PF] = tr16(sIn + inb[kc][1] + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
+          alo[u % PF] = tr16(sIn + in_lane + ic0 + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
+          ahi[u % PF] = tr16(sIn + in_lane + ic1 + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch PF fragments ahead of its MFMAs (hipcc sinks it otherwise)
 #pragma unroll
@@ -292,20 +298,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   }
 }
 
-template <int TPW, int CIF, int COF, int KC, int NG>
+template <int TPW, int CIF, int COF, int KC, int NG, int OCC = 2>
 static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
   constexpr int HFB = ((TPW * CIF * COF + 1) / 2) * 4 * 1024;     // bytes of the cross-group exchange (NG = 2)
   size_t lds = NG * ((size_t)a[0].in_bytes + a[0].dy_bytes);
   if (NG == 2 && lds < (size_t)HFB) lds = HFB;
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC, NG>,
+    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
   // resident workgroups per CU: LDS, and 2 waves per SIMD (accumulator-heavy waves)
   int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu > 2 / NG) per_cu = 2 / NG;
+  if (per_cu > OCC / NG) per_cu = OCC / NG;
   if (per_cu < 1) per_cu = 1;
   static const int force_pc = getenv("SV_WT_PERCU") ? atoi(getenv("SV_WT_PERCU")) : 0;   // profiling knob
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
@@ -327,7 +333,7 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
     m.a[i].slab = slab ? a[i].ws : nullptr;
     r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW;
   }
-  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG>), grid, block, lds, st, m);
+  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
@@ -376,8 +382,13 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   else if (nt == 42 && cin == 32 && cout == 16 && w.fold_kw) { id = 7; BM = 256; CW = 32; TT = 42; }   // d5, x-packed
   else return SV_E_UNSUPPORTED;
   if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
-  static const char* cw16 = getenv("SV_WT_CW16");             // A/B: 16-channel slices for these layer ids (half the slab traffic)
-  const bool narrow = cw16 && strchr(cw16, '0' + id) && (id == 1 || id == 2);
+  // 16-channel slices for d4 / d3 / packed d5: half the accumulators per wave, so three workgroups (3 waves per
+  // SIMD) fit per CU instead of two; e1 fits four.  Measured together: 185.5k -> 188.7k images/s (SV_WT_CW16= /
+  // SV_WT_HIOCC= with an empty list restore the wide variants).
+  static const char* cw16 = getenv("SV_WT_CW16") ? getenv("SV_WT_CW16") : "127";
+  const bool narrow = strchr(cw16, '0' + id) && (id == 1 || id == 2 || id == 7);
+  static const char* hiocc = getenv("SV_WT_HIOCC") ? getenv("SV_WT_HIOCC") : "6";
+  const bool hi = strchr(hiocc, '0' + id) != nullptr;
   if (narrow) CW = 16;
   if (!skip && id == 4) return SV_E_UNSUPPORTED;   // measured: e3 (8x8 output grid) is no faster here than on the im2col GEMM
   // every layer takes the two-stage flush when a workspace is given: even d5 (6 of 16 slab columns
@@ -442,9 +453,9 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   // <TPW, CIF, COF, KC>
   switch (id) {
     case 0: if (KC == 8) return launch_wt<9, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
-    case 1: if (KC == 8 && narrow) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
+    case 1: if (KC == 8 && narrow) return launch_wt_ng<9, 1, 2, 8, 1, 3>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8) return launch_wt<9, 2, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
-    case 2: if (KC == 8 && narrow) return launch_wt<4, 1, 4, 8>(av, n, groups, st, wv[0].ev_mid);
+    case 2: if (KC == 8 && narrow) return launch_wt_ng<4, 1, 4, 8, 1, 3>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8) return launch_wt<4, 2, 4, 8>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 2) return launch_wt<4, 2, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
     case 3: if (KC == 4) return launch_wt<4, 1, 8, 4>(av, n, groups, st, wv[0].ev_mid);
@@ -453,9 +464,11 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
             if (KC == 2) return launch_wt<4, 1, 8, 2>(av, n, groups, st, wv[0].ev_mid); break;
     case 5: if (KC == 4) return launch_wt<9, 1, 4, 4>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 2) return launch_wt<9, 1, 4, 2>(av, n, groups, st, wv[0].ev_mid); break;
-    case 6: if (KC == 8 && pairx) return launch_wt<5, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
+    case 6: if (KC == 8 && pairx && hi) return launch_wt_ng<5, 1, 2, 8, 1, 4>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 8 && pairx) return launch_wt<5, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
-    case 7: if (KC == 8) return launch_wt<11, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 7: if (KC == 8 && narrow) return launch_wt_ng<11, 1, 1, 8, 1, 3>(av, n, groups, st, wv[0].ev_mid);
+            if (KC == 8) return launch_wt<11, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
   }
   return SV_E_UNSUPPORTED;
 }
