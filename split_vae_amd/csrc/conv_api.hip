@@ -298,13 +298,16 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
       a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
       a->dx[kh * d->KW + kw] = (int8_t)(kw - pl);
     }
-  const int cfg = svg_pick_cfg(d->Cout);
-  static const int BRt[4] = {64, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
-  const int ms = d->dtype == SV_BF16 ? 64 : 32;
-  const int tiles = ((a->Nrows + BRt[cfg] - 1) / BRt[cfg]) * ((a->N + BNt[cfg] - 1) / BNt[cfg]);
-  // m-splits: every split adds one atomic pass over dW (~1.3 TB/s chip-wide), so use only as many
-  // as it takes to put ~2 workgroups on each of the 256 CUs (SV_WGRAD_WGS overrides for tuning)
   static const int target_wgs = getenv("SV_WGRAD_WGS") ? atoi(getenv("SV_WGRAD_WGS")) : 512;
+  svg_wgrad_set_msplit(a, svg_pick_cfg(d->Cout), d->dtype, target_wgs);
+}
+
+// m-splits of the im2col wgrad: every split adds one atomic pass over dW (~1.3 TB/s chip-wide), so use only as
+// many as it takes to put `target_wgs` workgroups (~2 per CU; SV_WGRAD_WGS overrides for tuning) on the chip
+void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs) {
+  static const int BRt[4] = {64, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
+  const int ms = dtype == SV_BF16 ? 64 : 32;
+  const int tiles = ((a->Nrows + BRt[cfg] - 1) / BRt[cfg]) * ((a->N + BNt[cfg] - 1) / BNt[cfg]);
   int z = target_wgs / (tiles > 0 ? tiles : 1);
   const int maxz = (a->M + ms - 1) / ms;
   if (z < 1) z = 1;

@@ -84,6 +84,7 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a);
 int svg_dgrad_classes(const sv_conv_desc* d);
 void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srctap[SV_MAX_TAPS]);
 void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a);
+void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs);
 void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j);
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls);

@@ -33,6 +33,14 @@ struct TapGemmArgs {
 };
 // cfg: 0 = 128x128 tile, 1 = 128x64, 2 = 256x32, 3 = 256x16
 int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st);
+// n <= SV_TAP_MAX_MULTI independent problems (any shapes, one tile configuration) in one launch
+#define SV_TAP_MAX_MULTI 4
+struct TapGemmMulti {
+  TapGemmArgs a[SV_TAP_MAX_MULTI];
+  int zbase[SV_TAP_MAX_MULTI];   // first blockIdx.z of each problem (its split-K slices follow)
+  int n;
+};
+int svk_tap_gemm_multi(const TapGemmArgs* a, int n, int dtype, int cfg, hipStream_t st);
 
 // ---- direct conv with the input tile resident in LDS (tile_conv.hip); planned from a TapGemmArgs
 struct TileConvArgs {
@@ -85,6 +93,15 @@ struct WgradArgs {
 };
 // cfg: 0 = 64 wrows x 128 cols, 1 = 128 x 64, 2 = 256 x 32, 3 = 256 x 16
 int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st);
+// n <= SV_WGRAD_IM2COL_MAX_MULTI independent problems (any shapes, one tile configuration) in one launch
+#define SV_WGRAD_IM2COL_MAX_MULTI 4
+struct WgradMulti {
+  WgradArgs a[SV_WGRAD_IM2COL_MAX_MULTI];
+  int zbase[SV_WGRAD_IM2COL_MAX_MULTI];   // first blockIdx.z of each problem (its m-splits follow)
+  int plain[SV_WGRAD_IM2COL_MAX_MULTI];   // the problem has one m-split: dW += acc without atomics (each element has one owner)
+  int n;
+};
+int svk_wgrad_multi(const WgradArgs* a, int n, int dtype, int cfg, hipStream_t st);
 
 // ---- weight gradient with LDS-resident input/dY tiles (wgrad_tile.hip, bf16); planned from WgradArgs
 struct WgradTileArgs {

@@ -371,6 +371,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   TapGemmArgs a[SV_MAX_MULTI];
   double fl = 0;
   int m = 0, tap_cfg = svg_pick_cfg(L[0]->d.Cin);
+  bool mixed = false;
   const int ncls = svg_dgrad_classes(&L[0]->d);
   for (int i = 0; i < n; ++i) {
     fl += conv_flops(L[i]->d);
@@ -383,11 +384,22 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       a[m].mask = mask[i];
       if (f32_atomic) {
         a[m].out_f32 = 1;
-        a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8, &tap_cfg);
+        int c2 = tap_cfg;
+        a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8, &c2);
+        if (m == 0) tap_cfg = c2;
+        else if (c2 != tap_cfg) mixed = true;
       }
     }
   }
   Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  if (mixed) {   // split-K problems whose widths pick different tiles: one launch each
+    for (int i = 0; i < m; ++i) {
+      int c2 = svg_pick_cfg(L[0]->d.Cin);
+      a[i].splitk = svg_choose_splitk(a[i].M, a[i].N, (a[i].P + 7) / 8, &c2);
+      SV_TRY(svk_conv_dispatch(a[i], L[0]->d.dtype, c2, st));
+    }
+    return SV_OK;
+  }
   // the classes of a stride-2 layer have different tap counts but plan to the same tile grid
   return svk_conv_dispatch_multi(a, m, L[0]->d.dtype, tap_cfg, st);
 }
@@ -453,22 +465,33 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       SV_TRY(run_fwd_layers(p, 2 - e0, Ls + e0, xs + e0, s->params, ys + e0, st));
     }
   }
+  if (do_enc) {
+    // heads: split-K GEMMs into the zeroed fp32 pre-activations (bias + softplus live in reparam_kl_fwd); the two
+    // networks' heads share one launch (each alone is 16 output tiles)
+    const int e0 = d.external_global_encoder ? 1 : 0;
+    TapGemmArgs a[2];
+    int cfg = 0, cfgs[2] = {0, 0};
+    double fl = 0;
+    for (int e = e0; e < 2; ++e) {
+      Layer& Lh = p->enc[e][3];
+      TapGemmArgs& t = a[e - e0];
+      svg_fwd_args(&Lh.d, &t);
+      t.A = p->bp(std::string("a3_") + en[e]);
+      t.Wt = (char*)p->bp("warena") + Lh.wf_off * p->esz();
+      t.bias = nullptr; t.out = p->bp(std::string("pre_") + en[e]); t.out_f32 = 1;
+      cfg = svg_pick_cfg(Lh.d.Cout);
+      t.splitk = svg_choose_splitk(t.M, t.N, (t.P + 7) / 8, &cfg);
+      cfgs[e - e0] = cfg;
+      fl += conv_flops(Lh.d);
+    }
+    Scope sc(p, st, "fwd.head", fl, 0);
+    if (e0 || cfgs[0] == cfgs[1]) SV_TRY(svk_tap_gemm_multi(a, 2 - e0, dt, cfgs[0], st));
+    else
+      for (int e = 0; e < 2; ++e) SV_TRY(svk_tap_gemm(a[e], dt, cfgs[e], st));   // latent sizes with different tiles
+  }
   for (int e = d.external_global_encoder ? 1 : 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
     const int L = e == 0 ? Lg : Ll;
-    // head: split-K GEMM into the zeroed fp32 pre-activation; bias + softplus live in reparam_kl_fwd
-    {
-      Layer& Lh = p->enc[e][3];
-      TapGemmArgs a;
-      svg_fwd_args(&Lh.d, &a);
-      a.A = p->bp("a3_" + sfx);
-      a.Wt = (char*)p->bp("warena") + Lh.wf_off * p->esz();
-      a.bias = nullptr; a.out = p->bp("pre_" + sfx); a.out_f32 = 1;
-      int cfg = svg_pick_cfg(Lh.d.Cout);
-      a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
-      Scope sc(p, st, "fwd.head", conv_flops(Lh.d), 0);
-      SV_TRY(svk_tap_gemm(a, dt, cfg, st));
-    }
     {
       Scope sc(p, st, "reparam_kl_fwd", 0, (double)B * L * 16);
       const Layer& Lh = p->enc[e][3];
@@ -483,8 +506,11 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
   }
   if (do_dec) {
     const void* zin[2] = {p->bp("zcat"), (const char*)p->bp("zcat") + (size_t)Lg * p->esz()};
-    for (int k = 0; k < 2; ++k)   // d1 differs between the twins (zcat vs local-only input)
-      SV_TRY(run_fwd_layer(p, p->dec[k][0], zin[k], s->params, p->bp(std::string("h1_") + en[k]), st));
+    {   // d1 differs between the twins (zcat vs local-only input): two shapes, one launch
+      Layer* Ls[2] = {&p->dec[0][0], &p->dec[1][0]};
+      void* ys[2] = {p->bp("h1_x"), p->bp("h1_xh")};
+      SV_TRY(run_fwd_layers(p, 2, Ls, zin, s->params, ys, st));
+    }
     {
       Layer* Ls[2] = {&p->dec[0][1], &p->dec[1][1]};
       const void* xs[2] = {p->bp("h1_x"), p->bp("h1_xh")};
@@ -584,18 +610,18 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     SV_TRY(run_wgrad_layers(p, 2, Ls, h1, g2, s->grads, st));
     SV_TRY(run_dgrad_layers(p, 2, Ls, g2, h1, (void* const*)g1, false, st));
   }
-  for (int k = 0; k < 2; ++k) {
-    const std::string sfx = en[k];
-    Layer* L = p->dec[k];
-    // d1 (dense): dz accumulated in fp32 over split K
-    const void* zin = (const char*)p->bp("zcat") + (k == 0 ? 0 : (size_t)Lg * p->esz());
-    SV_TRY(run_wgrad_layer(p, L[0], zin, p->bp("g1_" + sfx), s->grads, st));
-    {
-      // dz has its own row pitch (Lz), not the zcat pitch: patch ldo after building the args
-      Layer Ld = L[0];
-      Ld.d.ldx = Ld.d.Cin;
-      SV_TRY(run_dgrad_layer(p, Ld, p->bp("g1_" + sfx), nullptr, p->bp("gz_" + sfx), true, st));
-    }
+  {
+    // d1 (dense): dz accumulated in fp32 over split K; the twins (different input widths) share the launches
+    Layer Ld[2] = {p->dec[0][0], p->dec[1][0]};
+    Layer* Ls[2] = {&p->dec[0][0], &p->dec[1][0]};
+    Layer* Lds[2] = {&Ld[0], &Ld[1]};
+    const void* zin[2] = {p->bp("zcat"), (const char*)p->bp("zcat") + (size_t)Lg * p->esz()};
+    const void *g1[2], *none2[2] = {nullptr, nullptr};
+    void* gz[2] = {p->bp("gz_x"), p->bp("gz_xh")};
+    both("g1_", g1);
+    SV_TRY(run_wgrad_layers(p, 2, Ls, zin, g1, s->grads, st));
+    for (int k = 0; k < 2; ++k) Ld[k].d.ldx = Ld[k].d.Cin;   // dz has its own row pitch (Lz), not the zcat pitch
+    SV_TRY(run_dgrad_layers(p, 2, Lds, g1, none2, gz, true, st));
   }
   return SV_OK;
 }
@@ -617,23 +643,33 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
                              (const float*)p->bp("z_mean_xh"), (const float*)p->bp("z_sig_xh"),
                              (const float*)p->bp("eps_xh"), kl_scale, p->bp("ghead_xh"), dt, B, Ll, st));
   }
-  for (int e = e0; e < 2; ++e) {
-    const std::string sfx = en[e];
-    Layer* L = p->enc[e];
-    const int Lh = e == 0 ? Lg : Ll;
-    // head: two Keras kernels/biases -> two wgrad launches on column halves of ghead
-    for (int h = 0; h < 2 && do_heads; ++h) {
-      WgradArgs a;
-      svg_wgrad_args(&L[3].d, &a);
-      a.A = p->bp("a3_" + sfx);
-      a.dY = (const char*)p->bp("ghead_" + sfx) + (size_t)h * Lh * p->esz();
-      a.ycols = Lh; a.N = Lh;
-      a.dW = s->grads + p->params[L[3].kparam + 2 * h].off;
-      a.dbias = s->grads + p->params[L[3].kparam + 2 * h + 1].off;
-      Scope sc(p, st, "wgrad.head", conv_flops(L[3].d) / 2, 0);
-      SV_TRY(svk_wgrad(a, dt, svg_pick_cfg(Lh), st));
+  if (do_heads) {
+    // heads: two Keras kernels/biases per network -> wgrad problems on the column halves of ghead, all in one launch
+    WgradArgs a[4];
+    int n = 0;
+    double fl = 0;
+    for (int e = e0; e < 2; ++e) {
+      Layer* L = p->enc[e];
+      const int Lh = e == 0 ? Lg : Ll;
+      for (int h = 0; h < 2; ++h, ++n) {
+        svg_wgrad_args(&L[3].d, &a[n]);
+        a[n].A = p->bp(std::string("a3_") + en[e]);
+        a[n].dY = (const char*)p->bp(std::string("ghead_") + en[e]) + (size_t)h * Lh * p->esz();
+        a[n].ycols = Lh; a[n].N = Lh;
+        a[n].dW = s->grads + p->params[L[3].kparam + 2 * h].off;
+        a[n].dbias = s->grads + p->params[L[3].kparam + 2 * h + 1].off;
+        fl += conv_flops(L[3].d) / 2;
+      }
     }
-    if (do_heads) SV_TRY(run_dgrad_layer(p, L[3], p->bp("ghead_" + sfx), p->bp("a3_" + sfx), p->bp("ga3_" + sfx), false, st));
+    {
+      Scope sc(p, st, "wgrad.head", fl, 0);
+      const int cg = svg_pick_cfg(Lg), cl = svg_pick_cfg(Ll);      // the narrower tile serves both widths
+      SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), st));
+    }
+    Layer* Ls[2] = {&p->enc[0][3], &p->enc[1][3]};
+    const void *gh[2] = {p->bp("ghead_x"), p->bp("ghead_xh")}, *a3[2] = {p->bp("a3_x"), p->bp("a3_xh")};
+    void* ga3[2] = {p->bp("ga3_x"), p->bp("ga3_xh")};
+    SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gh + e0, a3 + e0, ga3 + e0, false, st));
   }
   if (do_convs) {
     auto both = [&](const char* n, const void** out) { out[0] = p->bp(std::string(n) + "x"); out[1] = p->bp(std::string(n) + "xh"); };

@@ -33,7 +33,15 @@ template <> struct MmaOp<float> {
 };
 
 template <typename T, int BN, int WM>
-__global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
+__global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
+  // up to SV_TAP_MAX_MULTI independent problems per launch (the twin networks' heads and dense layers: each alone
+  // fills a fraction of the chip).  blockIdx.z = (problem, split-K slice); problems may differ in every field,
+  // the grid is the largest of them and the surplus workgroups of the smaller ones leave at once.
+  int inst = 0;
+#pragma unroll
+  for (int i = 1; i < SV_TAP_MAX_MULTI; ++i) inst += (i < mg.n && (int)blockIdx.z >= mg.zbase[i]) ? 1 : 0;
+  const TapGemmArgs& g = mg.a[inst];
+  const int zi = (int)blockIdx.z - mg.zbase[inst];
   constexpr int BM = 4 * WM, MF = WM / 16, NF = BN / 16;
   constexpr int AR = BM / 32;                       // A pieces per thread per K-step
   constexpr int BRN = BN >= 32 ? BN / 32 : 1;       // B pieces per thread per K-step
@@ -45,6 +53,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= g.M || n0 >= ((g.N + BN - 1) / BN) * BN) return;
   if (tid < g.ntaps) {
     sTap[tid * 3 + 0] = g.dy[tid];
     sTap[tid * 3 + 1] = g.dx[tid];
@@ -70,8 +79,8 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
   const T* __restrict__ Ab = (const T*)g.A;
   const T* __restrict__ Wb = (const T*)g.Wt;
   const int nk_all = (g.P + 7) >> 3;
-  const int ks_begin = (int)(((int64_t)nk_all * blockIdx.z) / g.splitk);
-  const int ks_end = (int)(((int64_t)nk_all * (blockIdx.z + 1)) / g.splitk);
+  const int ks_begin = (int)(((int64_t)nk_all * zi) / g.splitk);
+  const int ks_end = (int)(((int64_t)nk_all * (zi + 1)) / g.splitk);
   __syncthreads();   // tap table visible
 
   uint4 ra[AR], rb[BRN];
@@ -258,42 +267,57 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmArgs g) {
 }
 
 template <typename T, int BN, int WM>
-static int launch_tap(const TapGemmArgs& a, hipStream_t st) {
+static int launch_tap(const TapGemmArgs* a, int n, hipStream_t st) {
   constexpr int BM = 4 * WM;
-  const int Npad = round_up(a.N, BN);
-  dim3 grid((a.M + BM - 1) / BM, Npad / BN, a.splitk), block(256);
+  TapGemmMulti m;
+  m.n = n;
+  int gx = 0, gy = 0, gz = 0;
   size_t lds = 2 * BM * 128 + 2 * BN * 128 + SV_MAX_TAPS * 3 * sizeof(int);
-  const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : sizeof(T)) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
-  if (lds < epi) lds = epi;
+  for (int i = 0; i < n; ++i) {
+    m.a[i] = a[i];
+    m.zbase[i] = gz;
+    gx = max(gx, (a[i].M + BM - 1) / BM);
+    gy = max(gy, round_up(a[i].N, BN) / BN);
+    gz += a[i].splitk;
+    const size_t epi = (size_t)BM * (((BN * (a[i].out_f32 ? 4 : sizeof(T)) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
+    if (lds < epi) lds = epi;
+  }
+  for (int i = n; i < SV_TAP_MAX_MULTI; ++i) m.zbase[i] = gz;
+  dim3 grid(gx, gy, gz), block(256);
   static size_t attr_set = 0;   // raise the dynamic-LDS cap when a launch needs more than any before it
   if (lds > attr_set) {
     (void)hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
 
-int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st) {
-  if (a.ntaps > SV_MAX_TAPS || a.splitk < 1) return SV_E_BADARG;
-  if (a.splitk > 1 && (!a.out_f32 || a.bias || a.act != SV_ACT_NONE || a.mask)) return SV_E_BADARG;
+int svk_tap_gemm_multi(const TapGemmArgs* a, int n, int dtype, int cfg, hipStream_t st) {
+  if (n < 1 || n > SV_TAP_MAX_MULTI) return SV_E_BADARG;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].ntaps > SV_MAX_TAPS || a[i].splitk < 1) return SV_E_BADARG;
+    if (a[i].splitk > 1 && (!a[i].out_f32 || a[i].bias || a[i].act != SV_ACT_NONE || a[i].mask)) return SV_E_BADARG;
+  }
   if (dtype == SV_BF16) {
     switch (cfg) {
-      case 0: return launch_tap<bf16_t, 128, 32>(a, st);
-      case 1: return launch_tap<bf16_t, 64, 32>(a, st);
-      case 2: return launch_tap<bf16_t, 32, 64>(a, st);
-      case 3: return launch_tap<bf16_t, 16, 64>(a, st);
-      case 4: return launch_tap<bf16_t, 32, 16>(a, st);   // 64 x 32: skinny split-K problems (heads, d1 dgrad)
+      case 0: return launch_tap<bf16_t, 128, 32>(a, n, st);
+      case 1: return launch_tap<bf16_t, 64, 32>(a, n, st);
+      case 2: return launch_tap<bf16_t, 32, 64>(a, n, st);
+      case 3: return launch_tap<bf16_t, 16, 64>(a, n, st);
+      case 4: return launch_tap<bf16_t, 32, 16>(a, n, st);   // 64 x 32: skinny split-K problems (heads, d1 dgrad)
     }
   } else if (dtype == SV_F32) {
     switch (cfg) {
-      case 0: return launch_tap<float, 128, 32>(a, st);
-      case 1: return launch_tap<float, 64, 32>(a, st);
-      case 2: return launch_tap<float, 32, 64>(a, st);
-      case 3: return launch_tap<float, 16, 64>(a, st);
-      case 4: return launch_tap<float, 32, 16>(a, st);
+      case 0: return launch_tap<float, 128, 32>(a, n, st);
+      case 1: return launch_tap<float, 64, 32>(a, n, st);
+      case 2: return launch_tap<float, 32, 64>(a, n, st);
+      case 3: return launch_tap<float, 16, 64>(a, n, st);
+      case 4: return launch_tap<float, 32, 16>(a, n, st);
     }
   }
   return SV_E_BADARG;
 }
+
+int svk_tap_gemm(const TapGemmArgs& a, int dtype, int cfg, hipStream_t st) { return svk_tap_gemm_multi(&a, 1, dtype, cfg, st); }

@@ -443,6 +443,20 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     if (all_tile && i > 0 && (cfg[i] != cfg[0] || a[i].ntiles != a[0].ntiles || a[i].N != a[0].N)) all_tile = false;
   }
   if (all_tile && !no_multi) return svk_tile_conv_multi(a, n, dtype, cfg[0], st);
+  // none of them plans to the tile kernel (dense layers, 1x1 grids): im2col GEMMs, SV_TAP_MAX_MULTI per launch
+  bool none_tile = !no_multi && n > 1;
+  for (int i = 0; i < n && none_tile; ++i) {
+    TileConvArgs b;
+    int c;
+    none_tile = !(t[i].ups || t[i].d2s) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &b, &c));
+  }
+  if (none_tile) {
+    for (int i = 0; i < n; i += SV_TAP_MAX_MULTI) {
+      const int rc = svk_tap_gemm_multi(t + i, n - i < SV_TAP_MAX_MULTI ? n - i : SV_TAP_MAX_MULTI, dtype, tap_cfg, st);
+      if (rc) return rc;
+    }
+    return SV_OK;
+  }
   for (int i = 0; i < n; ++i) {
     int rc;
     TileConvArgs b;

@@ -15,7 +15,14 @@ __device__ __forceinline__ short4_t lds_tr16_b64(const char* p) {
 }
 
 template <typename T, int WR, int WC, int CF>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mg) {
+  // several independent problems per launch (tap_gemm.hip has the same scheme): blockIdx.z = (problem, m-split)
+  int inst = 0;
+#pragma unroll
+  for (int i = 1; i < SV_WGRAD_IM2COL_MAX_MULTI; ++i) inst += (i < mg.n && (int)blockIdx.z >= mg.zbase[i]) ? 1 : 0;
+  const WgradArgs& g = mg.a[inst];
+  const int zi = (int)blockIdx.z - mg.zbase[inst];
+  const bool plain = mg.plain[inst] != 0;
   constexpr int EPP = ElemTraits<T>::EPP;
   constexpr int BR = 64 * WR;             // wrows (tap, ci) per block
   constexpr int BNW = 16 * CF * WC;       // output channels per block
@@ -35,12 +42,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int wrow0 = blockIdx.x * BR, n0 = blockIdx.y * BNW;
+  if (wrow0 >= g.Nrows || n0 >= g.N) return;
   if (tid < g.ntaps) {
     sTap[tid * 3 + 0] = g.dy[tid];
     sTap[tid * 3 + 1] = g.dx[tid];
     sTap[tid * 3 + 2] = ((int)g.dy[tid] * g.IW + (int)g.dx[tid]) * g.lda;
   }
-  const int mbeg = blockIdx.z * g.msplit;
+  const int mbeg = zi * g.msplit;
   const int mend = min(g.M, mbeg + g.msplit);
   const int nsteps = (mend - mbeg + MS - 1) / MS;
   const T* __restrict__ Ab = (const T*)g.A;
@@ -183,7 +191,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < CF; ++j) {
         const int n = n0 + (wc * CF + j) * 16 + lr;
-        if (n < g.N) atomicAdd(g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + n, acc[i][j][r]);
+        if (n < g.N) {
+          float* dst = g.dW + ((int64_t)(tap * g.Cin_real + ci)) * g.N + n;
+          if (plain) *dst += acc[i][j][r];
+          else atomicAdd(dst, acc[i][j][r]);
+        }
       }
     }
   }
@@ -200,40 +212,59 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs g) {
 }
 
 template <typename T, int WR, int WC, int CF>
-static int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+static int launch_wgrad(const WgradArgs* a, int n, hipStream_t st) {
   constexpr int BR = 64 * WR, BNW = 16 * CF * WC, MS = 128 / (int)sizeof(T);
   constexpr int SA = BR * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
   constexpr int SB = BNW * (int)sizeof(T) + (sizeof(T) == 2 && BNW >= 32 ? 32 : 16);
   const size_t lds = 2 * MS * SA + 2 * MS * SB + SV_MAX_TAPS * 3 * sizeof(int);
-  dim3 grid((a.Nrows + BR - 1) / BR, (a.N + BNW - 1) / BNW, (a.M + a.msplit - 1) / a.msplit), block(256);
+  static const bool no_plain = getenv("SV_WGRAD_NO_PLAIN") != nullptr;   // A/B knob: always atomics
+  WgradMulti m;
+  m.n = n;
+  int gx = 0, gy = 0, gz = 0;
+  for (int i = 0; i < n; ++i) {
+    m.a[i] = a[i];
+    m.zbase[i] = gz;
+    const int z = (a[i].M + a[i].msplit - 1) / a[i].msplit;
+    m.plain[i] = z == 1 && !no_plain;
+    gx = max(gx, (a[i].Nrows + BR - 1) / BR);
+    gy = max(gy, (a[i].N + BNW - 1) / BNW);
+    gz += z;
+  }
+  for (int i = n; i < SV_WGRAD_IM2COL_MAX_MULTI; ++i) { m.zbase[i] = gz; m.plain[i] = 0; }
+  dim3 grid(gx, gy, gz), block(256);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WR, WC, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<T, WR, WC, CF>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((wgrad_kernel<T, WR, WC, CF>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
 
-int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st) {
-  if (a.ntaps > SV_MAX_TAPS || a.msplit <= 0) return SV_E_BADARG;
+int svk_wgrad_multi(const WgradArgs* a, int n, int dtype, int cfg, hipStream_t st) {
+  if (n < 1 || n > SV_WGRAD_IM2COL_MAX_MULTI) return SV_E_BADARG;
   const int ms = dtype == SV_BF16 ? 64 : 32;
-  if (a.msplit % ms) return SV_E_BADARG;
+  for (int i = 0; i < n; ++i) {
+    if (a[i].ntaps > SV_MAX_TAPS || a[i].msplit <= 0 || a[i].msplit % ms) return SV_E_BADARG;
+    if (a[i].ups || a[i].fold_kw) return SV_E_UNSUPPORTED;   // needs the materialised hi-res tensor / cannot fold
+  }
   if (dtype == SV_BF16) {
     switch (cfg) {
-      case 0: return launch_wgrad<bf16_t, 1, 4, 2>(a, st);
-      case 1: return launch_wgrad<bf16_t, 2, 2, 2>(a, st);
-      case 2: return launch_wgrad<bf16_t, 4, 1, 2>(a, st);
-      case 3: return launch_wgrad<bf16_t, 4, 1, 1>(a, st);
+      case 0: return launch_wgrad<bf16_t, 1, 4, 2>(a, n, st);
+      case 1: return launch_wgrad<bf16_t, 2, 2, 2>(a, n, st);
+      case 2: return launch_wgrad<bf16_t, 4, 1, 2>(a, n, st);
+      case 3: return launch_wgrad<bf16_t, 4, 1, 1>(a, n, st);
     }
   } else if (dtype == SV_F32) {
     switch (cfg) {
-      case 0: return launch_wgrad<float, 1, 4, 2>(a, st);
-      case 1: return launch_wgrad<float, 2, 2, 2>(a, st);
-      case 2: return launch_wgrad<float, 4, 1, 2>(a, st);
-      case 3: return launch_wgrad<float, 4, 1, 1>(a, st);
+      case 0: return launch_wgrad<float, 1, 4, 2>(a, n, st);
+      case 1: return launch_wgrad<float, 2, 2, 2>(a, n, st);
+      case 2: return launch_wgrad<float, 4, 1, 2>(a, n, st);
+      case 3: return launch_wgrad<float, 4, 1, 1>(a, n, st);
     }
   }
   return SV_E_BADARG;
 }
+
+int svk_wgrad(const WgradArgs& a, int dtype, int cfg, hipStream_t st) { return svk_wgrad_multi(&a, 1, dtype, cfg, st); }

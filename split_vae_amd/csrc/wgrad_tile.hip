@@ -19,6 +19,7 @@
 #include "common.hip.h"
 #include "kernels.h"
 #include "tile_stage.hip.h"
+#include "conv_geom.h"
 
 #ifndef SV_WT_PF
 #define SV_WT_PF 4      // LDS prefetch depth (fragments) of the transposed A-operand reads
@@ -477,16 +478,29 @@ int svk_wgrad_tile(const WgradArgs& w, hipStream_t st) { return svk_wgrad_tile_m
 
 int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st) {
   static const bool no_multi = getenv("SV_NO_MULTI") != nullptr;
-  if (dtype == SV_BF16 && !no_multi) {
+  if (dtype == SV_BF16 && !no_multi && n <= SV_WGRAD_MAX_MULTI) {
     const int rc = svk_wgrad_tile_multi(w, n, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
-  for (int i = 0; i < n; ++i) {
-    WgradArgs wi = w[i];
-    wi.ev_mid[0] = wi.ev_mid[1] = nullptr;
-    const int rc = svk_wgrad_dispatch(wi, dtype, cfg, st);
-    if (rc) return rc;
+  // im2col kernel (no tile instantiation for this shape, or fp32): all of them in one launch
+  const bool any_tile = no_multi || n > SV_WGRAD_IM2COL_MAX_MULTI;
+  int rc = SV_OK;
+  if (!any_tile) {
+    WgradArgs wi[SV_WGRAD_IM2COL_MAX_MULTI];
+    for (int i = 0; i < n; ++i) {
+      wi[i] = w[i];
+      wi[i].ev_mid[0] = wi[i].ev_mid[1] = nullptr;
+      if (n > 1) svg_wgrad_set_msplit(&wi[i], cfg, dtype, 512 / n);   // the problems share the chip
+    }
+    rc = svk_wgrad_multi(wi, n, dtype, cfg, st);
+  } else {
+    for (int i = 0; i < n && !rc; ++i) {
+      WgradArgs wi = w[i];
+      wi.ev_mid[0] = wi.ev_mid[1] = nullptr;
+      rc = svk_wgrad_dispatch(wi, dtype, cfg, st);
+    }
   }
+  if (rc) return rc;
   if (w[0].ev_mid[0]) { (void)hipEventRecord(w[0].ev_mid[0], st); (void)hipEventRecord(w[0].ev_mid[1], st); }   // no second stage on this path
   return SV_OK;
 }
