@@ -49,7 +49,7 @@ static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr)
   int cfg = svg_pick_cfg(N);
   int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
   if (tiles >= 128) return 1;
-  static const bool small = getenv("SV_SPLITK_SMALL") != nullptr;      // A/B knob: 64 x 32 tiles (tap-GEMM cfg 4)
+  static const bool small = getenv("SV_SPLITK_NO_SMALL") == nullptr;   // 64 x 32 tiles (tap-GEMM cfg 4): +0.8 % on the step; knob restores 128 x 64
   if (small && cfg_io && (N % 32) == 0) {
     static const int tgt_small = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 512;
     const int t2 = ((M + 63) / 64) * (N / 32);
