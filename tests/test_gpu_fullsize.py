@@ -169,18 +169,21 @@ def test_conv_fullsize_reproducible_and_linear(ops, name, Hl, Cin, Cout, k, s, y
     torch.testing.assert_close(dba + dbb, db1, rtol=1e-4, atol=1e-4 * float(db1.abs().max()))
 
 
-def test_bf16_step_tracks_fp32_step_at_full_size(ops):
-    """B = 512: the bf16-MFMA step against the exact-fp32-MFMA step of the same library on the same batch, weights and
+@pytest.mark.parametrize("batch", [B, 466, 77])
+def test_bf16_step_tracks_fp32_step_at_full_size(ops, batch):
+    """Ragged sizes too: 466 is the last batch of an epoch of the 162 770 CelebA training images at 512 per batch
+    (`Dataset.batch` keeps the remainder, vae/main.py:57-61), 77 is not a multiple of any tile's images-per-tile.
+    B = 512: the bf16-MFMA step against the exact-fp32-MFMA step of the same library on the same batch, weights and
     draws (the fp32 path is the one pinned to the oracle at small sizes).  ELBO terms within 1e-3 relative; every
     gradient tensor within 8 % relative Frobenius and cosine > 0.995 (the deepest tensors, the first encoder convs,
     carry the bf16 rounding of the whole backward chain: ~4 %; the decoder tensors ~1 %)."""
     from split_vae_amd.model import LGVae
     model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="f32", device=torch.device("cuda"), seed=3)
     P = model.flat
-    _, img = _images(ops)
+    _, img = _images(ops, batch=batch)
     res = {}
     for dt in (torch.float32, torch.bfloat16):
-        plan = ops.LGVaePlan(B, H, H, beta=BETA, dtype=dt)
+        plan = ops.LGVaePlan(batch, H, H, beta=BETA, dtype=dt)
         per, G, L = _run(ops, plan, P, img, 0)
         res[dt] = (per, G.clone(), L.clone(), plan.param_table)
         del plan
