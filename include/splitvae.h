@@ -231,6 +231,19 @@ typedef struct {
 
 int sv_lgvae_step(sv_lgvae_plan* plan, const sv_lgvae_step_args* a, void* stream);
 
+/* hipGraph replay of sv_lgvae_step (no reference counterpart: the reference's tf.function traces its step once,
+ * vae/trainer.py:117 / :146; this is the HIP equivalent for the launch-bound small-batch configurations).  With it on,
+ * the first step of each distinct (phase mask, buffer set, Adam constants) runs eagerly, the second is captured on
+ * `stream`, later ones are ONE hipGraphLaunch; seed / step / sample_offset / lr / t stay per-step values (they reach
+ * the kernels through a small device record).  Steps issued on the legacy default stream (stream == NULL) are never
+ * captured; at most 16 distinct graphs are kept (callers that rotate buffers beyond that stay eager).  Disabling destroys
+ * the captured graphs.  Profiling turns replay off.  Measured (scripts/bench_graph.py, SVHN-32 B=64 .. CelebA-64
+ * B=512): replay == eager to 1 %: the kernels already run back to back, the small configurations are bound by the
+ * ~10 us dependent-kernel latency of an in-order stream, which a graph of the same chain keeps. */
+int sv_lgvae_graph_enable(sv_lgvae_plan* plan, int32_t enable);
+/* number of captured (instantiated) step graphs, or a negative SV_E_* */
+int sv_lgvae_graph_count(const sv_lgvae_plan* plan);
+
 /* per-kernel hipEvent timing (bench roofline): enable, run steps, read average ms per launch */
 int sv_lgvae_profile_enable(sv_lgvae_plan* plan, int32_t enable);
 /* restrict the event brackets to launches whose label equals `name` (NULL or "" = all launches) */

@@ -84,6 +84,8 @@ SYMBOLS = {
     "sv_lgvae_plan_bind": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sv_lgvae_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "sv_lgvae_step": (C.c_int, [_vp, C.POINTER(StepArgs), _vp]),
+    "sv_lgvae_graph_enable": (C.c_int, [_vp, _i32]),
+    "sv_lgvae_graph_count": (C.c_int, [_vp]),
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),
     "sv_lgvae_profile_read": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),

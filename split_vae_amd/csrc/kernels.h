@@ -154,10 +154,22 @@ int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob*
 int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st);
 int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,
                         int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st);
+// Step-varying scalars of a captured step (hipGraph replay, lgvae_plan.hip): the kernels that consume them read this
+// device record instead of their launch arguments when `dyn` is non-null; svk_set_dyn writes it before each replay.
+struct SvDynArgs {
+  uint64_t seed, step;
+  int64_t sample_offset;
+  float adam_alpha;       // lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+  float pad;
+};
+int svk_set_dyn(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha, hipStream_t st);
+double svk_adam_alpha(float lr, float beta1, float beta2, int64_t t);
+int svk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t t, float grad_scale, const SvDynArgs* dyn, hipStream_t st);
 int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* bias_sd, const float* eps,
                         float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
                         int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
-                        int64_t sample_offset, hipStream_t st);
+                        int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn = nullptr);
 int svk_dlogistic_nll_multi(const float* images6, int ch_off, const float* out6, int64_t zs_out, float* nll,
                             int64_t zs_nll, void* grad, int64_t zs_grad, int grad_dtype, float grad_scale, int B,
                             int H, int W, float* partial_ws, int64_t zs_part, int nets, hipStream_t st);

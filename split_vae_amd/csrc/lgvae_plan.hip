@@ -11,6 +11,7 @@
 #include <map>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "common.hip.h"
 #include "kernels.h"
 #include "conv_geom.h"
@@ -100,6 +101,11 @@ struct sv_lgvae_plan {
   int prep_blocks;
   int64_t arena_elems;
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
+  // captured steps (sv_lgvae_graph_enable): one executable graph per distinct (phase mask, buffers, baked scalars)
+  bool graph_on = false;
+  const SvDynArgs* dyn = nullptr;   // non-null while a step is being captured
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+  std::map<std::vector<uint64_t>, GraphEntry> graphs;
   // profiling
   bool prof_on;
   std::string prof_filter;
@@ -286,6 +292,7 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
   p->add_buf("warena", p->arena_elems * es);
   p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI);
+  p->add_buf("dyn", sizeof(SvDynArgs));
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
   p->add_buf("zcat", B * Lc * es);
@@ -501,7 +508,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
                                  s->params + p->params[Lh.kparam + 3].off, eps, (float*)p->bp("eps_" + sfx),
                                  (float*)p->bp("z_mean_" + sfx), (float*)p->bp("z_sig_" + sfx),
                                  (float*)p->bp("z_" + sfx), p->bp("zcat"), dt, Lc, e == 0 ? 0 : Lg,
-                                 (float*)p->bp("kl_" + sfx), B, L, s->seed, s->step, e, s->sample_offset, st));
+                                 (float*)p->bp("kl_" + sfx), B, L, s->seed, s->step, e, s->sample_offset, st, p->dyn));
     }
   }
   if (do_dec) {
@@ -736,6 +743,9 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   if (!p) return;
   for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto e : p->event_pool) (void)hipEventDestroy(e);
+  if (!p->graphs.empty()) (void)hipDeviceSynchronize();   // a replay may still be in flight
+  for (auto& kv : p->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   delete p;
 }
 
@@ -766,15 +776,8 @@ extern "C" int sv_lgvae_buffer(const sv_lgvae_plan* p, const char* name, int64_t
   return SV_OK;
 }
 
-extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void* stream) {
-  if (!p || !s) return SV_E_BADARG;
-  if (!p->bound) return SV_E_STATE;
-  hipStream_t st = (hipStream_t)stream;
+static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
   const int ph = s->phases;
-  const bool train = ph & SV_PHASE_BACKWARD;
-  if ((ph & (SV_PHASE_PREP | SV_PHASE_FORWARD | SV_PHASE_ADAM | SV_PHASE_BACKWARD)) && !s->params) return SV_E_BADARG;
-  if ((ph & (SV_PHASE_FWD_ENCODERS | SV_PHASE_LOSS)) && !s->images6) return SV_E_BADARG;
-  if (train && !s->grads) return SV_E_BADARG;
   if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
   if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, ph & SV_PHASE_FWD_ENCODERS, ph & SV_PHASE_FWD_DECODERS, st));
   if (ph & SV_PHASE_LOSS) {
@@ -788,12 +791,84 @@ extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void
   if (ph & (SV_PHASE_BWD_ENC_HEADS | SV_PHASE_BWD_ENC_CONVS))
     SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st));
   if (ph & SV_PHASE_ADAM) {
-    if (!s->grads || !s->adam_m || !s->adam_v) return SV_E_BADARG;
     Scope sc(p, st, "adam_step", 0, (double)p->nparams * 28);
-    SV_TRY(sv_adam_step(s->params, s->grads, s->adam_m, s->adam_v, p->nparams, s->lr, s->beta1, s->beta2,
-                        s->adam_eps, s->t, s->grad_scale, st));
+    SV_TRY(svk_adam_step(s->params, s->grads, s->adam_m, s->adam_v, p->nparams, s->lr, s->beta1, s->beta2,
+                         s->adam_eps, s->t, s->grad_scale, p->dyn, st));
   }
   return SV_OK;
+}
+
+// everything of a step that is baked into a captured graph: the phase mask, every buffer, every scalar that reaches a
+// kernel as a launch argument.  seed / step / sample_offset / (lr, t) do not belong here: they travel through SvDynArgs.
+static std::vector<uint64_t> graph_key(const sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+  auto f = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint64_t)u; };
+  const bool adam = s->phases & SV_PHASE_ADAM;
+  return {(uint64_t)(uint32_t)s->phases, (uint64_t)s->params, (uint64_t)s->grads, (uint64_t)s->adam_m, (uint64_t)s->adam_v,
+          (uint64_t)s->images6, (uint64_t)s->eps_x, (uint64_t)s->eps_x_hat, (uint64_t)st,
+          adam ? f(s->beta1) : 0, adam ? f(s->beta2) : 0, adam ? f(s->adam_eps) : 0, adam ? f(s->grad_scale) : 0,
+          (uint64_t)s->accumulate_metrics, (uint64_t)p->gz_clean, (uint64_t)p->ws};
+}
+
+extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void* stream) {
+  if (!p || !s) return SV_E_BADARG;
+  if (!p->bound) return SV_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  const int ph = s->phases;
+  const bool train = ph & SV_PHASE_BACKWARD;
+  if ((ph & (SV_PHASE_PREP | SV_PHASE_FORWARD | SV_PHASE_ADAM | SV_PHASE_BACKWARD)) && !s->params) return SV_E_BADARG;
+  if ((ph & (SV_PHASE_FWD_ENCODERS | SV_PHASE_LOSS)) && !s->images6) return SV_E_BADARG;
+  if (train && !s->grads) return SV_E_BADARG;
+  if ((ph & SV_PHASE_ADAM) && (!s->grads || !s->adam_m || !s->adam_v || s->t <= 0)) return SV_E_BADARG;
+  // no capture on the legacy default stream (HIP forbids it): callers that want replay run on a created stream
+  if (!p->graph_on || p->prof_on || !st) return run_phases(p, s, st);
+
+  // hipGraph replay: the first step with a given key runs eagerly (it also raises the kernels' dynamic-LDS caps, which
+  // must not happen inside a capture), the second is captured, every later one is one graph launch.
+  const std::vector<uint64_t> key = graph_key(p, s, st);
+  if (p->graphs.size() >= 16 && !p->graphs.count(key)) return run_phases(p, s, st);   // callers that rotate buffers: stay eager
+  sv_lgvae_plan::GraphEntry& e = p->graphs[key];
+  if (!e.exec && e.seen++ == 0) return run_phases(p, s, st);
+  const float alpha = (ph & SV_PHASE_ADAM) ? (float)svk_adam_alpha(s->lr, s->beta1, s->beta2, s->t) : 0.f;
+  SV_TRY(svk_set_dyn((SvDynArgs*)p->bp("dyn"), s->seed, s->step, s->sample_offset, alpha, st));
+  if (!e.exec) {
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return (int)hipGetLastError();
+    p->dyn = (const SvDynArgs*)p->bp("dyn");
+    const int rc = run_phases(p, s, st);
+    p->dyn = nullptr;
+    const hipError_t he = hipStreamEndCapture(st, &g);
+    if (rc || he != hipSuccess || !g) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc ? rc : (int)he;
+    }
+    const hipError_t hi = hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (hi != hipSuccess) { e.exec = nullptr; return (int)hi; }
+  } else {
+    // the host-side state the phases would have left behind
+    if (ph & SV_PHASE_FWD_ENCODERS) p->gz_clean = true;
+    if (ph & SV_PHASE_BWD_DECODERS) p->gz_clean = false;
+  }
+  if (hipGraphLaunch(e.exec, st) != hipSuccess) return (int)hipGetLastError();
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_graph_enable(sv_lgvae_plan* p, int32_t enable) {
+  if (!p) return SV_E_BADARG;
+  p->graph_on = enable != 0;
+  if (!enable) {
+    for (auto& kv : p->graphs)
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    p->graphs.clear();
+  }
+  return SV_OK;
+}
+
+extern "C" int sv_lgvae_graph_count(const sv_lgvae_plan* p) {
+  if (!p) return SV_E_BADARG;
+  int n = 0;
+  for (auto& kv : p->graphs) n += kv.second.exec != nullptr;
+  return n;
 }
 
 extern "C" int sv_lgvae_profile_enable(sv_lgvae_plan* p, int32_t enable) {

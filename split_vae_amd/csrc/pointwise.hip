@@ -254,10 +254,11 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
     const float* __restrict__ pre, const float* __restrict__ bias_mean, const float* __restrict__ bias_sd,
     const float* __restrict__ eps, float* __restrict__ eps_out, float* __restrict__ z_mean, float* __restrict__ z_sig,
     float* __restrict__ z, TZ* __restrict__ z_lp, int ldz, int z_col, float* __restrict__ kl, int B,
-    int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset) {
+    int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset, const SvDynArgs* __restrict__ dyn) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= B) return;
+  if (dyn) { seed = dyn->seed; step = dyn->step; sample_offset = dyn->sample_offset; }   // captured step (graph replay)
   Philox ph(seed ^ 0xe9515eedULL);
   const uint64_t gs = (uint64_t)(sample_offset + b);
   float acc = 0.f;
@@ -290,15 +291,15 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
 int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* bias_sd, const float* eps,
                         float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
                         int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
-                        int64_t sample_offset, hipStream_t st) {
+                        int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn) {
   if (!pre || !bias_mean || !bias_sd || !z_mean || !z_sig || !z || !z_lp || !kl || B <= 0 || L <= 0) return SV_E_BADARG;
   dim3 grid((B + 3) / 4), block(256);
   if (z_dtype == SV_BF16)
     hipLaunchKernelGGL((reparam_kl_fwd_kernel<bf16_t>), grid, block, 0, st, pre, bias_mean, bias_sd, eps, eps_out,
-                       z_mean, z_sig, z, (bf16_t*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset);
+                       z_mean, z_sig, z, (bf16_t*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset, dyn);
   else if (z_dtype == SV_F32)
     hipLaunchKernelGGL((reparam_kl_fwd_kernel<float>), grid, block, 0, st, pre, bias_mean, bias_sd, eps, eps_out,
-                       z_mean, z_sig, z, (float*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset);
+                       z_mean, z_sig, z, (float*)z_lp, ldz, z_col, kl, B, L, seed, step, stream_id, sample_offset, dyn);
   else
     return SV_E_BADARG;
   SV_LAUNCH_CHECK();
@@ -359,7 +360,9 @@ extern "C" int sv_reparam_kl_bwd(const float* dz, int32_t ld_dz, const float* dz
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n4, int64_t n, float alpha, float omb1,
-                                                   float omb2, float eps, float gscale) {
+                                                   float omb2, float eps, float gscale,
+                                                   const SvDynArgs* __restrict__ dyn) {
+  if (dyn) alpha = dyn->adam_alpha;   // captured step (graph replay): the bias-corrected rate of THIS iteration
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = ((float4*)p)[i], gg = ((const float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
@@ -386,18 +389,36 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                            float beta1, float beta2, float eps, int64_t t, float grad_scale,
-                            void* stream) {
+double svk_adam_alpha(float lr, float beta1, float beta2, int64_t t) {
+  return (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+}
+
+int svk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t t, float grad_scale, const SvDynArgs* dyn, hipStream_t st) {
   if (!p || !g || !m || !v || n <= 0 || t <= 0) return SV_E_BADARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return SV_E_BADARG;
-  const double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  const double alpha = svk_adam_alpha(lr, beta1, beta2, t);
   const int64_t n4 = n / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     n4, n, (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v,
+                     n4, n, (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale, dyn);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                            float beta1, float beta2, float eps, int64_t t, float grad_scale,
+                            void* stream) {
+  return svk_adam_step(p, g, m, v, n, lr, beta1, beta2, eps, t, grad_scale, nullptr, (hipStream_t)stream);
+}
+
+__global__ void set_dyn_kernel(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha) {
+  dyn->seed = seed; dyn->step = step; dyn->sample_offset = sample_offset; dyn->adam_alpha = adam_alpha; dyn->pad = 0.f;
+}
+int svk_set_dyn(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha, hipStream_t st) {
+  hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, st, dyn, seed, step, sample_offset, adam_alpha);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

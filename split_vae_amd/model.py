@@ -8,6 +8,8 @@ zero-copy views and `save_weights` emits the 40 arrays a TF user would expect.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -111,6 +113,9 @@ class LGVae:
         if key not in self._plans:
             self._plans[key] = ops.LGVaePlan(B, self.H, self.W, self.global_latent_dims, self.local_latent_dims,
                                              beta=beta, dtype=self.dtype, device=self.device)
+            if os.environ.get("SV_GRAPH", "0") == "1":      # opt-in hipGraph replay of repeated steps (non-default streams only;
+                                                            # measured: no gain, the step is GPU-bound at every batch size)
+                self._plans[key].graph_enable(True)
         return self._plans[key]
 
     def _outputs(self, plan, B, copy):

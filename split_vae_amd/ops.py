@@ -229,6 +229,13 @@ class LGVaePlan:
         a.grad_scale, a.phases, a.accumulate_metrics = grad_scale, phases, 1 if accumulate_metrics else 0
         check(self.lib.sv_lgvae_step(self.handle, C.byref(a), _stream()), "sv_lgvae_step")
 
+    def graph_enable(self, on=True):
+        """hipGraph replay of `step` (include/splitvae.h: sv_lgvae_graph_enable); effective on a non-default stream."""
+        check(self.lib.sv_lgvae_graph_enable(self.handle, 1 if on else 0), "sv_lgvae_graph_enable")
+
+    def graph_count(self):
+        return int(self.lib.sv_lgvae_graph_count(self.handle))
+
     def profile_enable(self, on=True):
         check(self.lib.sv_lgvae_profile_enable(self.handle, 1 if on else 0), "sv_lgvae_profile_enable")
 

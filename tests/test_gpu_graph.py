@@ -1,0 +1,116 @@
+"""hipGraph replay of the step (include/splitvae.h: sv_lgvae_graph_enable) against the eager launches: same batch,
+same weights, same Philox streams -> the same losses, draws and weights, step after step (the per-step scalars --
+seed, step, sample offset, Adam's bias-corrected rate -- reach the captured kernels through the device record)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, PATCH, BETA = 32, 4, 40.0
+
+
+@pytest.fixture(scope="module")
+def ops(lib_built):
+    assert torch.cuda.is_available()
+    from split_vae_amd import ops as o
+    return o
+
+
+def _setup(B, dtype):
+    from split_vae_amd import data
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+    model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=dtype, device=torch.device("cuda"), seed=11)
+    model.beta = BETA
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    images = Augmentator("scramble", size=PATCH, seed=1).augment(x)
+    return model, Adam(learning_rate=1e-3), images
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_replayed_steps_equal_eager_steps(ops, dtype, monkeypatch):
+    from split_vae_amd import trainer
+    monkeypatch.setenv("SV_GRAPH", "1")                              # LGVae.plan() enables replay on its plans
+    B, steps = 16, 6
+    eager, opt_e, images = _setup(B, dtype)
+    graph, opt_g, _ = _setup(B, dtype)
+    assert torch.equal(eager.flat, graph.flat)
+    side = torch.cuda.Stream()
+    hist = []
+    for t in range(steps):
+        pe = trainer.train_step(eager, images, opt_e)                 # legacy default stream: never captured
+        le = pe.buffer("losses", torch.float32, (8,)).clone()
+        eps_e = pe.buffer("eps_x", torch.float32, (B, 128)).clone()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pg = trainer.train_step(graph, images, opt_g)
+            lg = pg.buffer("losses", torch.float32, (8,)).clone()
+            eps_g = pg.buffer("eps_x", torch.float32, (B, 128)).clone()
+        side.synchronize()
+        assert torch.equal(eps_e, eps_g), t                           # the replay drew THIS step's noise
+        hist.append(eps_g)
+        torch.testing.assert_close(lg[:6], le[:6], rtol=2e-4, atol=1e-4)
+        # split-K atomics reorder fp32 sums run to run; Adam normalises, so an element whose gradient is rounding noise
+        # can move by +-lr in either run: bound the count of such elements and their distance (tests/test_gpu_step.py)
+        d = (graph.flat - eager.flat).abs()
+        assert float(d.max()) <= 2.1e-3 * (t + 1), (t, float(d.max()))
+        assert float((d > 1e-5).float().mean()) < 2e-3, (t, float((d > 1e-5).float().mean()))
+    assert pe.graph_count() == 0 and pg.graph_count() == 1            # eager / eager, capture, then replays
+    assert not torch.equal(hist[2], hist[3])                          # consecutive replays draw different noise
+    assert np.isfinite(float(lg[5]))
+
+
+def test_split_phase_replay_matches_one_call(ops):
+    """The data-parallel trainer issues the step as four phase groups (all-reduces in between): each group is its own
+    graph; the sequence equals the single PHASE_ALL call."""
+    from split_vae_amd._lib import (PHASE_ALL, PHASE_PREP, PHASE_FORWARD, PHASE_LOSS, PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS,
+                                    PHASE_BWD_ENC_CONVS, PHASE_ADAM)
+    B = 8
+    ref, _, images = _setup(B, "f32")
+    P0 = ref.flat.clone()
+    side = torch.cuda.Stream()
+    groups = [PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM]
+
+    def run(split, use_graph, steps=5):
+        plan = ops.LGVaePlan(B, H, H, beta=BETA, dtype=torch.float32)
+        plan.graph_enable(use_graph)
+        P, G, M, V = P0.clone(), torch.zeros_like(P0), torch.zeros_like(P0), torch.zeros_like(P0)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t in range(1, steps + 1):
+                kw = dict(params=P, grads=G, adam_m=M, adam_v=V, images6=images, seed=3, step=t, lr=1e-3, t=t)
+                for ph in (groups if split else [PHASE_ALL]):
+                    plan.step(ph, **kw)
+        side.synchronize()
+        return P, plan.graph_count()
+
+    Pa, na = run(False, False)
+    Pb, nb = run(True, True)
+    Pc, nc = run(False, True)
+    assert (na, nb, nc) == (0, 4, 1)
+    for Px in (Pb, Pc):
+        d = (Px - Pa).abs()
+        assert float(d.max()) <= 1.1e-2 and float((d > 1e-5).float().mean()) < 2e-3, (float(d.max()), float((d > 1e-5).float().mean()))
+
+
+def test_replay_sees_a_changed_learning_rate(ops):
+    """lr and t are per-step values of a captured step (ExponentialDecay in vae/main.py:66-69 changes lr between steps)."""
+    from split_vae_amd._lib import PHASE_ALL
+    B = 4
+    ref, _, images = _setup(B, "f32")
+    side = torch.cuda.Stream()
+    out = {}
+    for use_graph in (False, True):
+        plan = ops.LGVaePlan(B, H, H, beta=BETA, dtype=torch.float32)
+        plan.graph_enable(use_graph)
+        P, G, M, V = ref.flat.clone(), torch.zeros_like(ref.flat), torch.zeros_like(ref.flat), torch.zeros_like(ref.flat)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for t, lr in enumerate([1e-3, 1e-3, 1e-3, 4e-4, 1.6e-4], start=1):
+                plan.step(PHASE_ALL, params=P, grads=G, adam_m=M, adam_v=V, images6=images, seed=3, step=t, lr=lr, t=t)
+        side.synchronize()
+        out[use_graph] = P
+    d = (out[True] - out[False]).abs()
+    assert float(d.max()) <= 1.1e-2 and float((d > 1e-5).float().mean()) < 2e-3, (float(d.max()), float((d > 1e-5).float().mean()))
