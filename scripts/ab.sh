@@ -1,20 +1,7 @@
 run() { echo -n "$1: "; env $1 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"; }
+run SV_NO_SIDE=1
 run A=1
-run SV_TC_PH_KB=40
-run SV_TC_PH_KB=64
-run SV_TC_PH_KB=80
-run SV_TC_NPH=2
-run SV_SPLITK_WGS=64
-run SV_SPLITK_WGS=256
-run SV_SPLITK_SMALL=1
-run SV_WT_NG2=35
-run SV_WT_NG2=3
-run SV_WT_NG2=56
-run SV_WT_NG2=3567
-run SV_WT_NG2=0
-run SV_WGRAD_WGS=256
-run SV_WGRAD_WGS=1024
-run SV_WGRAD_IM2COL_IDS=9
-run SV_TC_PH_WGS=128
-run SV_TC_PH_WGS=512
-run A=2
+run SV_SIDE_PRIO_NORMAL=1
+run SV_NO_SIDE=1
+run A=1
+run SV_SIDE_PRIO_NORMAL=1

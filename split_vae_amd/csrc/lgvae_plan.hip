@@ -101,6 +101,34 @@ struct sv_lgvae_plan {
   int prep_blocks;
   int64_t arena_elems;
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
+  // weight gradients on a second stream (they feed only Adam / the all-reduce; the input-gradient chain is the critical
+  // path): fork = the side stream waits for the event recorded on the main stream when dY is ready, join before Adam and
+  // at the end of every sv_lgvae_step call
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_pending = false;
+  hipStream_t wgrad_stream(hipStream_t st) {
+    static const bool off = getenv("SV_NO_SIDE") != nullptr;
+    if (off || (prof_on && prof_filter.empty())) return st;     // the full per-kernel table wants serial launches
+    if (graph_on) return st;   // a captured fork/join replayed wrongly on ROCm 7.2 (corrupt gradients, then a crash): keep captures single-stream
+    if (!side) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
+      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side = nullptr; return st; }
+      (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+    }
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return st;
+    side_pending = true;
+    return side;
+  }
+  int join_side(hipStream_t st) {
+    if (!side_pending) return SV_OK;
+    side_pending = false;
+    if (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return (int)hipGetLastError();
+    return SV_OK;
+  }
   // captured steps (sv_lgvae_graph_enable): one executable graph per distinct (phase mask, buffers, baked scalars)
   bool graph_on = false;
   const SvDynArgs* dyn = nullptr;   // non-null while a step is being captured
@@ -430,6 +458,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     fl += conv_flops(L[i]->d);
   }
   const std::string nm = "wgrad." + L[0]->name.substr(L[0]->name.find('.') + 1);
+  st = p->wgrad_stream(st);
   Scope sc(p, st, nm, fl, 0);
   sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
@@ -669,9 +698,10 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       }
     }
     {
-      Scope sc(p, st, "wgrad.head", fl, 0);
+      hipStream_t ws = p->wgrad_stream(st);
+      Scope sc(p, ws, "wgrad.head", fl, 0);
       const int cg = svg_pick_cfg(Lg), cl = svg_pick_cfg(Ll);      // the narrower tile serves both widths
-      SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), st));
+      SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), ws));
     }
     Layer* Ls[2] = {&p->enc[0][3], &p->enc[1][3]};
     const void *gh[2] = {p->bp("ghead_x"), p->bp("ghead_xh")}, *a3[2] = {p->bp("a3_x"), p->bp("a3_xh")};
@@ -743,6 +773,12 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   if (!p) return;
   for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto e : p->event_pool) (void)hipEventDestroy(e);
+  if (p->side) {
+    (void)hipStreamSynchronize(p->side);
+    (void)hipStreamDestroy(p->side);
+    (void)hipEventDestroy(p->ev_fork);
+    (void)hipEventDestroy(p->ev_join);
+  }
   if (!p->graphs.empty()) (void)hipDeviceSynchronize();   // a replay may still be in flight
   for (auto& kv : p->graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -790,6 +826,7 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
   if (ph & SV_PHASE_BWD_DECODERS) SV_TRY(phase_bwd_decoders(p, s, st));
   if (ph & (SV_PHASE_BWD_ENC_HEADS | SV_PHASE_BWD_ENC_CONVS))
     SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st));
+  SV_TRY(p->join_side(st));
   if (ph & SV_PHASE_ADAM) {
     Scope sc(p, st, "adam_step", 0, (double)p->nparams * 28);
     SV_TRY(svk_adam_step(s->params, s->grads, s->adam_m, s->adam_v, p->nparams, s->lr, s->beta1, s->beta2,
