@@ -34,7 +34,7 @@ SCOPE_KERNEL = {"fwd.d5": "_Z16tile_conv_kernelIDF16bLi16ELi4ELi4EEv13TileConvMu
                 "wgrad.d5": "void wgrad_tile_kernel<11, 2, 1, 8>(WgradTileMulti)",
                 "wgrad.d4": "void wgrad_tile_kernel<9, 2, 2, 8>(WgradTileMulti)",
                 "dgrad.d4": "_Z16tile_conv_kernelIDF16bLi64ELi4ELi4EEv13TileConvMulti"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_i_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_j_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
 
 
 def measured_traffic(scope):
@@ -197,7 +197,7 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         out["roofline"] = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(prof[0]["name"]),
-                           "traffic_source": "profiles/r01_i_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)",
+                           "traffic_source": "profiles/r01_j_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)",
                            "hip_kernel": SCOPE_KERNEL.get(prof[0]["name"]),
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"]}
