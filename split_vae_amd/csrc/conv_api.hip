@@ -19,7 +19,8 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
     const int idx = block_in_job * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = idx % j.inner, t2 = idx / j.inner, t = t2 % j.ntaps, row = t2 / j.ntaps;
-    const int px = row >> 3, co = row & 7, ky = t / (j.packx_kw + 1), tx = t - ky * (j.packx_kw + 1);
+    const int KH = j.ntaps / (j.packx_kw + 1);        // taps are tx-major: t = tx * KH + ky (see svg_fwd_args)
+    const int px = row >> 3, co = row & 7, tx = t / KH, ky = t - tx * KH;
     const int kx = tx - px;
     float v = 0.f;
     if (co < j.Cout && c < j.Cin && (unsigned)kx < (unsigned)j.packx_kw)
@@ -204,15 +205,16 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
     a->SX = 2; a->N = 16; a->d2s = d->Cout;
     for (int ky = 0; ky < d->KH; ++ky)
       for (int tx = 0; tx <= d->KW; ++tx) {
-        a->dy[ky * (d->KW + 1) + tx] = (int8_t)(ky - pt);
-        a->dx[ky * (d->KW + 1) + tx] = (int8_t)(tx - pl);
+        a->dy[tx * d->KH + ky] = (int8_t)(ky - pt);
+        a->dx[tx * d->KH + ky] = (int8_t)(tx - pl);
       }
     return;
   }
   for (int kh = 0; kh < d->KH; ++kh)
     for (int kw = 0; kw < d->KW; ++kw) {
-      a->dy[kh * d->KW + kw] = (int8_t)(kh - pt);
-      a->dx[kh * d->KW + kw] = (int8_t)(kw - pl);
+      const int t = svg_fwd_tap(d, kh, kw);
+      a->dy[t] = (int8_t)(kh - pt);
+      a->dx[t] = (int8_t)(kw - pl);
     }
 }
 
@@ -238,8 +240,8 @@ void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srct
   int nt = 0;
   if (s == 1) {
     // dx[ih] = sum_kh dy[ih - kh + pt] w[kh]; kh = KH-1-kh' -> offset kh' - (KH-1-pt)
-    for (int khp = 0; khp < d->KH; ++khp)
-      for (int kwp = 0; kwp < d->KW; ++kwp) {
+    for (int kwp = 0; kwp < d->KW; ++kwp)        // x-major, y-minor (as the forward taps: svg_fwd_tap)
+      for (int khp = 0; khp < d->KH; ++khp) {
         a->dy[nt] = (int8_t)(khp - (d->KH - 1 - pt));
         a->dx[nt] = (int8_t)(kwp - (d->KW - 1 - pl));
         srctap[nt] = (uint8_t)((d->KH - 1 - khp) * d->KW + (d->KW - 1 - kwp));
@@ -330,6 +332,9 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
     j->packx_kw = d->KW;
   }
   for (int t = 0; t < j->ntaps; ++t) j->srctap[t] = (uint8_t)t;
+  if (!j->packx_kw)
+    for (int kh = 0; kh < d->KH; ++kh)
+      for (int kw = 0; kw < d->KW; ++kw) j->srctap[svg_fwd_tap(d, kh, kw)] = (uint8_t)(kh * d->KW + kw);
   j->nblocks = svg_prep_nblocks(j);
 }
 

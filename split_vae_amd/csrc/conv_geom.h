@@ -40,6 +40,12 @@ static inline int svg_pick_cfg(int N) {
   if (N % 32 == 0) return 2;
   return 3;
 }
+// Position of filter tap (kh, kw) in the K order of the forward weight image / tap tables.  Stride-1 layers run
+// x-major, y-minor (t = kw*KH + kh): the KH taps of one filter column are consecutive, which is what the row-window
+// reuse of the tile kernel (tile_conv.hip, YR) walks.  Stride 2 keeps the HWIO order.
+static inline int svg_fwd_tap(const sv_conv_desc* d, int kh, int kw) {
+  return d->stride == 1 ? kw * d->KH + kh : kh * d->KW + kw;
+}
 // split K across workgroups when the M x N tile grid cannot fill 256 CUs.  *cfg (optional) is the
 // tap-GEMM tile: a split-K problem on 128-column tiles drops to 64 columns (twice the workgroups for
 // the same number of atomic passes; prepared weight rows are padded to 128, so either tile fits).

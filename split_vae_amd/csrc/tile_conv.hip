@@ -26,7 +26,11 @@
 #ifndef SV_TC_PPS32
 #define SV_TC_PPS32 8     // K-step pieces of the 32-column kernel (build-time A/B knob)
 #endif
-static __host__ __device__ constexpr int tile_pps(int BN) { return BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8; }
+// with row-window reuse (YR = KH) the 16-column kernel steps one whole filter column (KH taps x 4 pieces), the wider
+// ones two taps (their weight tiles are BN x PPS x 16 B x 2 buffers of LDS)
+static __host__ __device__ constexpr int tile_pps(int BN, int YR = 0) {
+  return YR ? (BN == 16 ? YR * 4 : 8) : BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8;
+}
 
 template <typename T> struct MmaOpT;
 template <> struct MmaOpT<bf16_t> {
@@ -46,8 +50,17 @@ template <> struct MmaOpT<float> {
 
 // NW waves per workgroup: 4, or 8 (same tile, half the row fragments per wave) where the LDS tile
 // limits a CU to two workgroups -- the kernel is latency-bound and wants waves
-template <typename T, int BN, int MF, int NW>
-__global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti mg) {
+// YR > 0 (= filter height KH; stride-1 layers, taps x-major / y-minor, 32 bf16 channels per tap and phase, 16-pixel tile
+// rows): ROW-WINDOW REUSE.  The A fragment of tap (ky, kx) for output row y is the A fragment of tap (ky+1, kx) for row
+// y-1, and a wave's MF fragments are MF consecutive tile rows: per filter column a wave reads the MF+KH-1 input-row
+// fragments it touches ONCE into registers and issues all MF*KH MFMAs from them -- 9 LDS reads instead of 24 for
+// KH = 6 (the narrow-N layers are LDS-read-bound: every A fragment used to feed NF MFMAs only), back to back, so their
+// latency overlaps the MFMAs of the rows that arrived first.
+// waves per SIMD the row-window kernels are compiled for (left alone, hipcc spreads the window over AGPR copies and
+// drops a wave: 92 + 120 registers for <64,4,4,YR=4>)
+static constexpr int tile_min_waves(int BN, int NW, int YR) { return YR && NW == 4 ? (BN == 64 ? 3 : 4) : 1; }
+template <typename T, int BN, int MF, int NW, int YR>
+__global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv_kernel(const TileConvMulti mg) {
   // blockIdx.z picks one of up to 8 problems of identical geometry (the x / x_hat twin networks and
   // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
   // workgroups instead of paying the ~10 us fixed latency of a launch each
@@ -55,9 +68,9 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   constexpr int NT = 64 * NW, WM = 16 * MF, BM = NW * WM, NF = BN / 16;
   // 16-B pieces of K per step.  128 B per weight row normally; the 16-column kernel takes 512-B steps:
   // its steps are otherwise 8 MFMAs per wave between two barriers (21 -> 6 steps for the packed d5)
-  constexpr int PPS = tile_pps(BN), RB = PPS * 16;   // RB = bytes per weight row per step
+  constexpr int PPS = tile_pps(BN, YR), RB = PPS * 16;   // RB = bytes per weight row per step
   constexpr int RPP = NT / PPS;                      // weight rows loaded per pass (PPS threads per row)
-  constexpr int BRN = BN >= RPP ? BN / RPP : 1;      // weight pieces per thread per step
+  constexpr int BRN = (BN + RPP - 1) / RPP;          // weight pieces per thread per step
   constexpr int EPP = ElemTraits<T>::EPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sB = smem;                                   // [2][BN][128 B], XOR-swizzled
@@ -99,14 +112,14 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + RPP * i;
-      rb[i] = (pv && n < BN) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * gKtot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
+      rb[i] = (pv && n < BN && r0 < RPP) ? *(const uint4*)(Wb + (int64_t)(n0 + n) * gKtot + (int64_t)p * EPP) : make_uint4(0, 0, 0, 0);
     }
   };
   auto write_b = [&](int slot, const uint4 (&rb)[BRN]) {
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + RPP * i;
-      if (n < BN) *(uint4*)(sB + slot * (BN * RB) + n * RB + ((pp ^ (n & 7)) << 4)) = rb[i];   // XOR swizzle within each 8-piece group
+      if (n < BN && r0 < RPP) *(uint4*)(sB + slot * (BN * RB) + n * RB + ((pp ^ (n & 7)) << 4)) = rb[i];   // XOR swizzle within each 8-piece group
     }
   };
   const int nk = (gdbg & 2) ? 0 : (gP + PPS - 1) / PPS;
@@ -167,6 +180,9 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
         for (int j = 0; j < NF; ++j) MmaOpT<T>::run(bfr[j], af[i], acc[i][j]);   // D = W x pixels: a lane ends up with 4 CHANNELS of one pixel
     }
   };
+  // row-window variant: one filter column (YR taps = YR*4 pieces) per group, SPG K steps per group
+  constexpr int SPG = YR ? YR * 4 / PPS : 1, TPS = PPS / 4;       // steps per group, taps per step
+  const int rowpitch = g.TIW * g.PS;
   for (ph = 0; ph < nph; ++ph) {
     if (ph) {                                           // the last barrier of the previous K loop freed tile and weights
       load_b(0, rbA);
@@ -174,6 +190,36 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
     }
     write_b(0, rbA);
     __syncthreads();                                    // input tile, offsets and weight tile 0 visible
+    if constexpr (YR > 0) {
+      for (int gq = 0; gq * SPG < nk; ++gq) {
+        uint4 aw[MF + YR - 1];                          // input-row fragments ty .. ty+MF+YR-2 of this filter column
+        const char* wp = sIn + lbase[0] + sOff[gq * (YR * 4) + lg];
+#pragma unroll
+        for (int iy = 0; iy < MF + YR - 1; ++iy) aw[iy] = *(const uint4*)(wp + iy * rowpitch);
+#pragma unroll
+        for (int sg = 0; sg < SPG; ++sg) {
+          const int ks = gq * SPG + sg;
+          const bool more = ks + 1 < nk;
+          if (more) load_b(ks + 1, rbA);
+          const char* cB = sB + (ks & 1) * (BN * RB);
+#pragma unroll
+          for (int kk = 0; kk < TPS; ++kk) {
+            uint4 bfr[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+              const int n = j * 16 + lr;
+              bfr[j] = *(const uint4*)(cB + n * RB + (((kk * 4 + lg) ^ (n & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+              for (int j = 0; j < NF; ++j) MmaOpT<T>::run(bfr[j], aw[i + sg * TPS + kk], acc[i][j]);
+          }
+          if (more) write_b((ks & 1) ^ 1, rbA);
+          __syncthreads();
+        }
+      }
+    } else
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + 1 < nk && !(gdbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
       if (more) load_b(ks + 1, rbA);
@@ -259,13 +305,13 @@ __global__ __launch_bounds__(64 * NW) void tile_conv_kernel(const TileConvMulti 
   }
 }
 
-static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_t esz) {
-  size_t lds = 2 * BN * tile_pps(BN) * 16 + a.off_bytes + a.in_bytes;
+static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_t esz, int YR = 0) {
+  size_t lds = 2 * BN * tile_pps(BN, YR) * 16 + a.off_bytes + a.in_bytes;
   const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
   return lds < epi ? epi : lds;
 }
 
-template <typename T, int BN, int MF, int NW = 4>
+template <typename T, int BN, int MF, int NW = 4, int YR = 0>
 static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   const int Npad = round_up(a[0].N, BN);
   dim3 grid(a[0].ntiles, Npad / BN, n), block(64 * NW);
@@ -273,15 +319,15 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   TileConvMulti m;
   for (int i = 0; i < n; ++i) {
     m.a[i] = a[i];
-    const size_t l = tile_lds_bytes(BN, NW * 16 * MF, a[i], sizeof(T));
+    const size_t l = tile_lds_bytes(BN, NW * 16 * MF, a[i], sizeof(T), YR);
     if (l > lds) lds = l;
   }
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW, YR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW>), grid, block, lds, st, m);
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -343,12 +389,26 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     const int TIW = (TW - 1) * t.SX + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
     // channel phases (see the kernel): halve the channels per staging pass while the tile alone would keep a CU at
     // <= 2 workgroups, the launch has several rounds of workgroups, and a phase keeps >= 32 B (two pieces) per pixel
+    // row-window reuse (kernel comment, YR): stride-1 rows, 16-pixel tile rows, x-major taps in columns of KH = 4 / 6
+    // consecutive dy, >= 32 channels (a phase = exactly 32: one tap per MFMA)
+    int yr = 0;
+    static const char* yr_off = getenv("SV_TC_NO_YR");     // A/B knob: "1" = off everywhere, or BN letters (a=16, b=32, c=64)
+    if (dtype == SV_BF16 && MF == 4 && t.S == 1 && lTW == 4 && TH >= MF && cin >= 32 && BN <= 64 &&
+        !(yr_off && (yr_off[0] == '1' || strchr(yr_off, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')))) {
+      int kh = 1;
+      while (kh < t.ntaps && t.dx[kh] == t.dx[0]) ++kh;
+      bool ok = (kh == 4 || kh == 6) && t.ntaps % kh == 0;
+      for (int i = 0; i < t.ntaps && ok; ++i)
+        ok = t.dx[i] == t.dx[i / kh * kh] && t.dy[i] == t.dy[0] + i % kh && t.dy[0] == y_lo;
+      if (ok) yr = kh;
+    }
     static const int nph_max = getenv("SV_TC_NPH") ? atoi(getenv("SV_TC_NPH")) : 4;     // tuning knob (1 = off)
     const int64_t wgs = (int64_t)(OX / TW) * (OY / TH) * ((B + NB - 1) / NB) * ((t.N + BN - 1) / BN);
     int lnph = 0, PS = 0, plane_bytes = 0;
     int64_t in_bytes = 0;
     bool planar = false;
     for (;; ++lnph) {
+      if (yr) lnph = t.cl2 - 2;                        // 4 pieces (32 channels) per tap and phase
       const int pbh = pb >> lnph;
       PS = layout(pbh, &planar);
       plane_bytes = planar ? NB * TIH * TIW * 32 : 0;
@@ -356,10 +416,10 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
       static const int ph_kb = getenv("SV_TC_PH_KB") ? atoi(getenv("SV_TC_PH_KB")) : 53;   // LDS per workgroup the split aims below (3 workgroups per CU)
       static const bool s2_phases = getenv("SV_TC_NPH_NO_S2") == nullptr;               // A/B: phases for the padded stride-2 layouts too
       static const int ph_wgs = getenv("SV_TC_PH_WGS") ? atoi(getenv("SV_TC_PH_WGS")) : 256;   // launches smaller than this keep one pass
-      if (!(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
-            in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
+      if (yr || !(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
+                  in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
     }
-    const int64_t lds = 2 * BN * tile_pps(BN) * 16 + off_bytes + in_bytes;
+    const int64_t lds = 2 * BN * tile_pps(BN, yr) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
     memset(a, 0, sizeof(*a));
@@ -372,7 +432,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
     a->nph = 1 << lnph; a->lnph = lnph;
-    if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
+    if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: yr=%d N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", yr, t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
     {
       static const bool xcd = getenv("SV_TC_NO_XCD") == nullptr;
       a->xcd_chunk = (xcd && a->ntiles >= 64 && (a->ntiles & 7) == 0) ? a->ntiles / 8 : 0;
@@ -382,7 +442,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;
     memcpy(a->dy, t.dy, sizeof(a->dy));
     memcpy(a->dx, t.dx, sizeof(a->dx));
-    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1);
+    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : 0);
     // 256-row tiles that leave room for at most two workgroups per CU: 8 waves share the tile
     static const char* nw8 = getenv("SV_TC_NW8");       // tuning knob: BN classes (a=16, b=32, c=64) run with 8-wave workgroups
     if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) *cfg_out = 16 + cfgN;
@@ -407,6 +467,12 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
       case 5: return launch_tile<bf16_t, 32, 2>(a, n, st);
       case 7: return launch_tile<bf16_t, 16, 2>(a, n, st);
       case 6: return launch_tile<bf16_t, 16, 4>(a, n, st);
+      case 32 + 2: return launch_tile<bf16_t, 64, 4, 4, 4>(a, n, st);     // row-window reuse, KH = 4
+      case 32 + 4: return launch_tile<bf16_t, 32, 4, 4, 4>(a, n, st);
+      case 32 + 6: return launch_tile<bf16_t, 16, 4, 4, 4>(a, n, st);
+      case 64 + 2: return launch_tile<bf16_t, 64, 4, 4, 6>(a, n, st);     // KH = 6
+      case 64 + 4: return launch_tile<bf16_t, 32, 4, 4, 6>(a, n, st);
+      case 64 + 6: return launch_tile<bf16_t, 16, 4, 4, 6>(a, n, st);
       case 17: return launch_tile<bf16_t, 64, 2, 8>(a, n, st);
       case 18: return launch_tile<bf16_t, 32, 2, 8>(a, n, st);
       case 19: return launch_tile<bf16_t, 16, 2, 8>(a, n, st);

@@ -53,7 +53,8 @@ def test_replayed_steps_equal_eager_steps(ops, dtype, monkeypatch):
         side.synchronize()
         assert torch.equal(eps_e, eps_g), t                           # the replay drew THIS step's noise
         hist.append(eps_g)
-        torch.testing.assert_close(lg[:6], le[:6], rtol=2e-4, atol=1e-4)
+        rt = 2e-4 if dtype == "f32" else 3e-3           # bf16: the two trajectories drift apart step by step (see below)
+        torch.testing.assert_close(lg[:6], le[:6], rtol=rt, atol=rt)
         # Run-to-run noise floor: the split-K atomics of the heads reorder fp32 sums, a last-bit change of z can flip a
         # bf16 rounding or a ReLU mask downstream, and Adam normalises every element (an element whose gradient is
         # noise moves by +-lr either way).  Two eager runs differ the same way (scripts/dbg_graph.py); a wrong
