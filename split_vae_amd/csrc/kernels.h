@@ -56,6 +56,7 @@ struct TileConvArgs {
   int xcd_chunk;              // > 0: XCD-aware tile order: workgroup id w runs tile (w & 7) * xcd_chunk + (w >> 3)
   int off_bytes, in_bytes;    // LDS carve: piece-offset table, input tile
   int buf_bytes;              // persistent kernel: bytes of each of its two input-tile buffers
+  int wslots;                 // weight-tile slots in LDS: 2 (ring, streamed per K step) or the number of K steps (whole K resident)
   int N, OHF, OWF, OS, ooy, oox, ldo, act, out_f32, ntaps;
   int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
   int ups;                    // input tile staged through the fused 2x bilinear upsample

@@ -58,9 +58,9 @@ template <> struct MmaOpT<float> {
 // latency overlaps the MFMAs of the rows that arrived first.
 // waves per SIMD the row-window kernels are compiled for (left alone, hipcc spreads the window over AGPR copies and
 // drops a wave: 92 + 120 registers for <64,4,4,YR=4>)
-static constexpr int tile_min_waves(int BN, int NW, int YR) { return YR && NW == 4 ? (BN == 64 ? 3 : 4) : 1; }
-template <typename T, int BN, int MF, int NW, int YR>
-__global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv_kernel(const TileConvMulti mg) {
+static constexpr int tile_min_waves(int BN, int NW, int YR, bool WR = false) { return (YR || WR) && NW == 4 ? (BN == 64 ? 3 : 4) : 1; }
+template <typename T, int BN, int MF, int NW, int YR, bool WR>
+__global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_conv_kernel(const TileConvMulti mg) {
   // blockIdx.z picks one of up to 8 problems of identical geometry (the x / x_hat twin networks and
   // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
   // workgroups instead of paying the ~10 us fixed latency of a launch each
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv
   constexpr int EPP = ElemTraits<T>::EPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sB = smem;                                   // [2][BN][128 B], XOR-swizzled
-  int* sOff = (int*)(smem + 2 * BN * RB);            // piece offsets, padded to a multiple of PPS
-  char* sIn = smem + 2 * BN * RB + g.off_bytes;      // input tile [NB][TIH][TIW] pixels of PS bytes
+  int* sOff = (int*)(smem + g.wslots * BN * RB);     // piece offsets, padded to a multiple of PPS
+  char* sIn = smem + g.wslots * BN * RB + g.off_bytes;   // input tile [NB][TIH][TIW] pixels of PS bytes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- which tile
@@ -123,7 +123,17 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv
     }
   };
   const int nk = (gdbg & 2) ? 0 : (gP + PPS - 1) / PPS;
+  // WHOLE K RESIDENT (g.wslots > 2; small-K layers: the 8-channel d5 input gradient and e1): all K steps' weight tiles
+  // (<= 24 KB) go to LDS once, next to the input tile, and the K loop runs without global loads or barriers.  Streamed,
+  // each of its 5 steps is 16 MFMAs per wave behind a dependent L2 round trip and a barrier.
+  constexpr int WRMAX = 6;
+  constexpr bool wres = WR && YR == 0;
+  uint4 rbw[wres ? WRMAX - 1 : 1][BRN];
   load_b(0, rbA);                                     // in flight while the input tile is staged
+  if constexpr (wres) {
+#pragma unroll
+    for (int ks = 1; ks < WRMAX; ++ks) load_b(ks, rbw[ks - 1]);   // zero-filled past the last step
+  }
 
   // ---- piece-offset table
   const int nkp = (gP + PPS - 1) / PPS * PPS;
@@ -189,7 +199,12 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv
       stage(ph);
     }
     write_b(0, rbA);
-    __syncthreads();                                    // input tile, offsets and weight tile 0 visible
+    if constexpr (wres) {
+#pragma unroll
+      for (int ks = 1; ks < WRMAX; ++ks)
+        if (ks < nk) write_b(ks, rbw[ks - 1]);
+    }
+    __syncthreads();                                    // input tile, offsets and weight tile 0 (or all of them) visible
     if constexpr (YR > 0) {
       for (int gq = 0; gq * SPG < nk; ++gq) {
         uint4 aw[MF + YR - 1];                          // input-row fragments ty .. ty+MF+YR-2 of this filter column
@@ -219,6 +234,9 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv
           __syncthreads();
         }
       }
+    } else if constexpr (wres) {
+      for (int ks = 0; ks < nk; ++ks) compute(ks, ks);
+      __syncthreads();                                  // the epilogue reuses the LDS
     } else
     for (int ks = 0; ks < nk; ++ks) {
       const bool more = ks + 1 < nk && !(gdbg & 8);      // dbg 8: ablate the weight streaming (stale LDS weights)
@@ -306,12 +324,12 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR)) void tile_conv
 }
 
 static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_t esz, int YR = 0) {
-  size_t lds = 2 * BN * tile_pps(BN, YR) * 16 + a.off_bytes + a.in_bytes;
+  size_t lds = (size_t)a.wslots * BN * tile_pps(BN, YR) * 16 + a.off_bytes + a.in_bytes;
   const size_t epi = (size_t)BM * (((BN * (a.out_f32 ? 4 : esz) + 15) & ~(size_t)15) + 16);   // epilogue transpose tile
   return lds < epi ? epi : lds;
 }
 
-template <typename T, int BN, int MF, int NW = 4, int YR = 0>
+template <typename T, int BN, int MF, int NW = 4, int YR = 0, bool WR = false>
 static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   const int Npad = round_up(a[0].N, BN);
   dim3 grid(a[0].ntiles, Npad / BN, n), block(64 * NW);
@@ -324,10 +342,10 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   }
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW, YR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW, YR, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR>), grid, block, lds, st, m);
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR, WR>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -419,7 +437,12 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
       if (yr || !(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
                   in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
     }
-    const int64_t lds = 2 * BN * tile_pps(BN, yr) * 16 + off_bytes + in_bytes;
+    // whole K resident in LDS (kernel comment): one phase, <= 6 K steps, <= 24 KB of weights
+    static const bool wres_on = getenv("SV_TC_NO_WRES") == nullptr;
+    const int nks = (int)(((t.P >> lnph) + tile_pps(BN) - 1) / tile_pps(BN));
+    // (measured: d5's input gradient -5 %; e1's stride-2 forward +10 %, so stride 1 only)
+    const int wslots = (wres_on && !yr && dtype == SV_BF16 && BN == 32 && MF == 4 && t.S == 1 && lnph == 0 && nks > 2 && nks <= 6 && nks * BN * tile_pps(BN) * 16 <= 24 * 1024) ? nks : 2;
+    const int64_t lds = (int64_t)wslots * BN * tile_pps(BN, yr) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
     memset(a, 0, sizeof(*a));
@@ -431,8 +454,8 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->tilesX = OX / TW; a->tilesY = OY / TH;
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
-    a->nph = 1 << lnph; a->lnph = lnph;
-    if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: yr=%d N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", yr, t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
+    a->nph = 1 << lnph; a->lnph = lnph; a->wslots = wslots;
+    if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: yr=%d wslots=%d N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", yr, wslots, t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
     {
       static const bool xcd = getenv("SV_TC_NO_XCD") == nullptr;
       a->xcd_chunk = (xcd && a->ntiles >= 64 && (a->ntiles & 7) == 0) ? a->ntiles / 8 : 0;
@@ -442,7 +465,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;
     memcpy(a->dy, t.dy, sizeof(a->dy));
     memcpy(a->dx, t.dx, sizeof(a->dx));
-    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : 0);
+    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : 0) + (wslots > 2 ? 128 : 0);
     // 256-row tiles that leave room for at most two workgroups per CU: 8 waves share the tile
     static const char* nw8 = getenv("SV_TC_NW8");       // tuning knob: BN classes (a=16, b=32, c=64) run with 8-wave workgroups
     if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) *cfg_out = 16 + cfgN;
@@ -467,6 +490,7 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
       case 5: return launch_tile<bf16_t, 32, 2>(a, n, st);
       case 7: return launch_tile<bf16_t, 16, 2>(a, n, st);
       case 6: return launch_tile<bf16_t, 16, 4>(a, n, st);
+      case 128 + 4: return launch_tile<bf16_t, 32, 4, 4, 0, true>(a, n, st);   // whole K resident in LDS
       case 32 + 2: return launch_tile<bf16_t, 64, 4, 4, 4>(a, n, st);     // row-window reuse, KH = 4
       case 32 + 4: return launch_tile<bf16_t, 32, 4, 4, 4>(a, n, st);
       case 32 + 6: return launch_tile<bf16_t, 16, 4, 4, 4>(a, n, st);
