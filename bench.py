@@ -29,22 +29,30 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
-# plan scope -> HIP kernel symbol (as rocprofv3 prints it) for the launches that can be the dominant one
-SCOPE_KERNEL = {"fwd.d5": "_Z16tile_conv_kernelIDF16bLi16ELi4ELi4EEv13TileConvMulti",
-                "wgrad.d5": "void wgrad_tile_kernel<11, 2, 1, 8>(WgradTileMulti)",
-                "wgrad.d4": "void wgrad_tile_kernel<9, 2, 2, 8>(WgradTileMulti)",
-                "dgrad.d4": "_Z16tile_conv_kernelIDF16bLi64ELi4ELi4EEv13TileConvMulti"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_j_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
+# plan scope -> the stem of its HIP kernel symbol (as rocprofv3 prints it; the trailing template arguments select
+# variants of the same kernel) for the launches that can be the dominant one
+SCOPE_KERNEL = {"fwd.d5": "_Z16tile_conv_kernelIDF16bLi16ELi4ELi4E",
+                "wgrad.d5": "void wgrad_tile_kernel<11, ",
+                "wgrad.d4": "void wgrad_tile_kernel<9, 1, 2, 8, ",
+                "dgrad.d4": "_Z16tile_conv_kernelIDF16bLi64ELi4ELi4ELi6E",
+                "fwd.d4": "_Z16tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_k_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
 
 
 def measured_traffic(scope):
-    """HBM bytes per launch of the scope's kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs, gfx950 x2 read correction); None when that kernel was not measured."""
+    """(HBM bytes per launch, kernel symbol) of the scope's kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 x2 read correction); (None, stem) when not measured."""
+    stem = SCOPE_KERNEL.get(scope)
     try:
-        k = json.load(open(TRAFFIC_FILE))["kernels"].get(SCOPE_KERNEL.get(scope, ""), None)
-        return None if k is None else k["hbm_bytes_per_launch"]
+        kernels = json.load(open(TRAFFIC_FILE))["kernels"]
+        hits = [(n, k) for n, k in kernels.items() if stem and n.startswith(stem)]
+        if len(hits) == 1:
+            return hits[0][1]["hbm_bytes_per_launch"], hits[0][0]
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return None, stem
+
+
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}   # BASELINE.md section 2
 
 
@@ -195,10 +203,11 @@ def main():
         avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
         ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        traffic, symbol = measured_traffic(prof[0]["name"])
         out["roofline"] = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": measured_traffic(prof[0]["name"]),
-                           "traffic_source": "profiles/r01_j_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)",
-                           "hip_kernel": SCOPE_KERNEL.get(prof[0]["name"]),
+                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                           "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)" % os.path.basename(TRAFFIC_FILE),
+                           "hip_kernel": symbol,
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"]}
     if world == 1 and not args.no_cpu_baseline:

@@ -410,7 +410,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     // row-window reuse (kernel comment, YR): stride-1 rows, 16-pixel tile rows, x-major taps in columns of KH = 4 / 6
     // consecutive dy, >= 32 channels (a phase = exactly 32: one tap per MFMA)
     int yr = 0;
-    static const char* yr_off = getenv("SV_TC_NO_YR");     // A/B knob: "1" = off everywhere, or BN letters (a=16, b=32, c=64)
+    // off for the 16-column kernel (BN letter a): the packed d5's un-phased 62 KB tile leaves two workgroups per CU
+    // instead of three, which costs what the window saves (0.200 vs 0.191 ms in the step)
+    static const char* yr_off = getenv("SV_TC_NO_YR") ? getenv("SV_TC_NO_YR") : "a";   // "1" = off everywhere, or BN letters (a=16, b=32, c=64)
     if (dtype == SV_BF16 && MF == 4 && t.S == 1 && lTW == 4 && TH >= MF && cin >= 32 && BN <= 64 &&
         !(yr_off && (yr_off[0] == '1' || strchr(yr_off, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')))) {
       int kh = 1;
