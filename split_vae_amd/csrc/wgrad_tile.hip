@@ -424,7 +424,10 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   a.TIW = (TW - 1) * w.SX + (x_hi - x_lo) + 1; a.TIH = (TH - 1) * w.S + (y_hi - y_lo) + 1;
   a.y_lo = y_lo; a.x_lo = x_lo;
   // 16 / 32 / 96 B: PS/32 odd (or a single 16-B chunk); at x stride 2 the K pixels are 2*PS apart: 80 B
-  a.PS = CW * 2 + (CW == 32 ? (w.SX == 2 ? 16 : 32) : 0);
+  // SV_WT_PAD16: 16-channel slices at x stride 2 (packed d5) on a 96-B K-pixel pitch.  Measured: LDS bank conflicts
+  // 46 % -> 1.3 %, LDS-active cycles -45 %, kernel time unchanged (110 us): the loop is not LDS-throughput-bound.
+  static const bool pad16 = getenv("SV_WT_PAD16") != nullptr;
+  a.PS = CW * 2 + (CW == 32 ? (w.SX == 2 ? 16 : 32) : (CW == 16 && w.SX == 2 && pad16) ? 16 : 0);
   a.ldy = cout; a.YS = cout * 2 + (cout >= 32 ? 32 : 0);
   a.lycp = ilog2_exact(cout / 8);
   a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;   // slack: 16-column transposed reads of narrow pixels
