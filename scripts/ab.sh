@@ -1,7 +1,2 @@
-run() { echo -n "$1: "; env $1 python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"; }
-run SV_WT_NO_PAD16=1
-run A=1
-run SV_WT_NO_PAD16=1
-run A=1
-run SV_WT_NO_PAD16=1
-run A=1
+export SV_BENCH_OPS=fwd,dgrad
+for d in 0 1 2 4 8 16 24 25 31; do echo "--- SV_TC_DBG=$d"; SV_TC_DBG=$d python scripts/bench_layers.py 512 d5 d4 2>&1 | grep -v amdgpu; done
