@@ -1,2 +1,6 @@
-export SV_BENCH_OPS=fwd,dgrad
-for d in 0 1 2 4 8 16 24 25 31; do echo "--- SV_TC_DBG=$d"; SV_TC_DBG=$d python scripts/bench_layers.py 512 d5 d4 2>&1 | grep -v amdgpu; done
+export SV_BENCH_OPS=fwd
+for rep in 1 2; do
+echo "--- base"; python scripts/bench_layers.py 512 d5 e1 e2 e3 2>&1 | grep -v amdgpu
+echo "--- NO_S2PAD"; SV_TC_NO_S2PAD=1 python scripts/bench_layers.py 512 d5 e1 e2 e3 2>&1 | grep -v amdgpu
+done
+SV_TC_NO_S2PAD=1 SV_TC_VERBOSE=1 python scripts/bench_layers.py 512 d5 2>&1 | grep "plan" | sort | uniq -c
