@@ -80,7 +80,14 @@ class GMEncoder:
             g_c2=z(B, H // 4, H // 4, 128), g_c1=z(B, H // 2, H // 2, 128))
 
     def views(self, flat):
-        return [flat[off:off + int(np.prod(shp))].view(*shp) for (_, off, shp) in self.table]
+        # cached per buffer: this runs ~25 times per step (it was over half of the step's host time)
+        key = (flat.data_ptr(), flat.numel())
+        cache = self.__dict__.setdefault("_view_cache", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = [flat[off:off + int(np.prod(shp))].view(*shp) for (_, off, shp) in self.table]
+        return cache[key]
 
     def _kb(self, flat, name):
         i = self.LAYERS.index(name)
@@ -332,6 +339,11 @@ def train_step_lg_gm_vae(model, images, optimizer, eps=None, noise=None, sample_
     + alpha * KL(softmax(y_logits) || uniform); gradients of the 54 variables; Adam; returns the [6] metric tensor."""
     if not isinstance(model, LGGMVae):
         raise NotImplementedError("train_step_lg_gm_vae needs an LGGMVae")
+    with ops.hold_stream():
+        return _train_step_lg_gm_vae(model, images, optimizer, eps, noise, sample_offset)
+
+
+def _train_step_lg_gm_vae(model, images, optimizer, eps, noise, sample_offset):
     B = images.shape[0]
     m, v = optimizer.slots(model.flat)
     gm_m, gm_v = optimizer.slots(model.gm_flat)
@@ -357,7 +369,8 @@ def train_step_lg_gm_vae(model, images, optimizer, eps=None, noise=None, sample_
 def test_step_lg_gm_vae(model, images, eps=None, noise=None):
     """Evaluation counterpart: same loss terms with training=False (no dropout), no update."""
     B = images.shape[0]
-    plan, enc, _ = model._forward(images, False, eps, noise, True, {})
-    model._calls += 1
-    enc.y_kl_only()
-    return _metrics(model, plan, enc, B)
+    with ops.hold_stream():
+        plan, enc, _ = model._forward(images, False, eps, noise, True, {})
+        model._calls += 1
+        enc.y_kl_only()
+        return _metrics(model, plan, enc, B)

@@ -23,8 +23,24 @@ def sv_dtype(dt):
     return _SV_DT[dt]
 
 
+_STREAM_HOLD = []      # hold_stream(): the stream handle of the enclosing step (torch's lookup is ~9 us, ~75 of them per GM step)
+
+
 def _stream():
+    if _STREAM_HOLD:
+        return _STREAM_HOLD[-1]
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class hold_stream:
+    """`with ops.hold_stream():` -- every op inside launches on the stream that was current at entry."""
+
+    def __enter__(self):
+        _STREAM_HOLD.append(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def __exit__(self, *exc):
+        _STREAM_HOLD.pop()
+        return False
 
 
 def _p(t):
