@@ -171,6 +171,49 @@ int sv_gm_head_bwd(const float* dz, int32_t ld_dz, const float* z_mean, const fl
                    const float* prior_sig, const float* eps, float kl_scale, void* g_a_mean, void* g_a_sig,
                    void* g_a_prior_mean, void* g_a_prior_sig, int32_t g_dtype, int32_t B, int32_t L, void* stream);
 
+/* ---------------------------------------------------------------- A9: the SPLIT-GMVAE global encoder as one object
+ * Replaces Encoder(type='gmvae').call_gmvae (vae/model.py:48-79, :116-135) and its adjoint in train_step_lg_gm_vae
+ * (vae/trainer.py:146-173) with native launch sequences over one caller-owned workspace.  It plugs into an LGVae plan
+ * created with external_global_encoder = 1: FWD_ENCODERS phase -> sv_gm_encoder_forward (writes z_x into zcat[:, :L])
+ * -> FWD_DECODERS/LOSS/BWD_DECODERS phases -> sv_gm_encoder_backward (reads dL/dz_x from the plan's gz_x) -> ... */
+typedef struct {
+  int32_t B, H, W;          /* H == W, power of two >= 8 */
+  int32_t latent;           /* global latent size L (power of two) */
+  int32_t y_size;           /* categorical size K (2..128) */
+  float tau;                /* Gumbel-softmax temperature */
+  int32_t dtype;            /* sv_dtype of the contractions */
+} sv_gm_desc;
+typedef struct {
+  const float* params;      /* flat fp32 [sv_gm_param_count]: the 24 arrays in the reference's variable order */
+  float* grads;             /* backward: same layout, ACCUMULATED into (zero it first) */
+  const void* in8_x;        /* [B,H,W,8] network input in `dtype` (the plan's buffer "in8_x") */
+  void* zcat; int32_t ldz;  /* forward: decoder input rows (the plan's "zcat"), row pitch in elements */
+  const float* gz; int32_t ld_gz;   /* backward: dL/dz_x rows (the plan's "gz_x"), columns [0, L) */
+  const float* eps;         /* [B,L]     or NULL -> Philox        (pins for parity tests) */
+  const float* u;           /* [B,K]     Gumbel uniforms or NULL */
+  const float* keep1;       /* [B,1024]  y_block dropout mask (0/1) or NULL */
+  const float* keep5;       /* [B,F]     do5 dropout mask or NULL */
+  int32_t training;         /* dropout on (vae/trainer.py:149) */
+  float beta, alpha;        /* backward: weights of the two-Gaussian KL and of the categorical KL */
+  uint64_t seed, step;
+  int64_t sample_offset;
+} sv_gm_args;
+typedef struct sv_gm_encoder sv_gm_encoder;
+int64_t sv_gm_param_count(const sv_gm_desc* d);
+int sv_gm_param_info(const sv_gm_desc* d, int32_t index, int64_t* offset, int32_t* ndim, int64_t shape[4], char name[96]);
+int sv_gm_encoder_create(const sv_gm_desc* d, sv_gm_encoder** enc);
+void sv_gm_encoder_destroy(sv_gm_encoder* enc);
+int64_t sv_gm_encoder_workspace_bytes(const sv_gm_encoder* enc);
+int sv_gm_encoder_bind(sv_gm_encoder* enc, void* workspace, int64_t bytes, void* stream);
+/* named activation / gradient buffers inside the workspace (z, zm, zs, pm, ps, y, logits, kl2, ykl, keep1, ...) */
+int sv_gm_encoder_buffer(const sv_gm_encoder* enc, const char* name, int64_t* offset, int64_t* bytes);
+/* fp32 masters -> MFMA-ready weight images of the twelve layers (after every parameter update) */
+int sv_gm_encoder_prep(sv_gm_encoder* enc, const float* params, void* stream);
+int sv_gm_encoder_forward(sv_gm_encoder* enc, const sv_gm_args* a, void* stream);
+int sv_gm_encoder_backward(sv_gm_encoder* enc, const sv_gm_args* a, void* stream);
+/* evaluation: the per-image categorical KL term "ykl" of the last forward, no gradients */
+int sv_gm_encoder_y_kl(sv_gm_encoder* enc, void* stream);
+
 /* ---------------------------------------------------------------- A2/A3/A5/A8: the whole LGVae step
  * Replaces LGVae.call (vae/model.py:189-200) and train_step_lg_vae (vae/trainer.py:120-144)
  * with one native launch sequence on `stream` (captured into a hipGraph by the caller if wanted). */

@@ -44,6 +44,18 @@ class StepArgs(C.Structure):
                 ("accumulate_metrics", C.c_int32)]
 
 
+class GmDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("latent", C.c_int32), ("y_size", C.c_int32),
+                ("tau", C.c_float), ("dtype", C.c_int32)]
+
+
+class GmArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("in8_x", C.c_void_p), ("zcat", C.c_void_p), ("ldz", C.c_int32),
+                ("gz", C.c_void_p), ("ld_gz", C.c_int32), ("eps", C.c_void_p), ("u", C.c_void_p), ("keep1", C.c_void_p),
+                ("keep5", C.c_void_p), ("training", C.c_int32), ("beta", C.c_float), ("alpha", C.c_float),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("sample_offset", C.c_int64)]
+
+
 # every symbol include/splitvae.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 SYMBOLS = {
@@ -75,6 +87,17 @@ SYMBOLS = {
     "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sv_conv2d_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sv_conv2d_nhwc_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sv_gm_param_count": (_i64, [C.POINTER(GmDesc)]),
+    "sv_gm_param_info": (C.c_int, [C.POINTER(GmDesc), _i32, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64 * 4), C.c_char_p]),
+    "sv_gm_encoder_create": (C.c_int, [C.POINTER(GmDesc), C.POINTER(_vp)]),
+    "sv_gm_encoder_destroy": (None, [_vp]),
+    "sv_gm_encoder_workspace_bytes": (_i64, [_vp]),
+    "sv_gm_encoder_bind": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sv_gm_encoder_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sv_gm_encoder_prep": (C.c_int, [_vp, _vp, _vp]),
+    "sv_gm_encoder_forward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
+    "sv_gm_encoder_backward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
+    "sv_gm_encoder_y_kl": (C.c_int, [_vp, _vp]),
     "sv_lgvae_param_count": (_i64, [C.POINTER(LGVaeDesc)]),
     "sv_lgvae_param_info": (C.c_int, [C.POINTER(LGVaeDesc), _i32, C.POINTER(_i64), C.POINTER(_i32),
                                       C.POINTER(_i64 * 4), C.c_char_p]),

@@ -12,7 +12,9 @@ Trainable variables, in the reference's layer-tracking order: the 24 arrays of t
 arrays LGVae has after encoder_x.  The Dropout layers do1-4, do6, do7 exist in the reference but are never
 called (vae/model.py:59-75 vs :116-135); only y_block's Dropout and do5 act, in training.
 """
+import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -187,6 +189,69 @@ class GMEncoder:
         ops.gumbel_softmax_bwd(None, b["y"], b["logits"], self.K, self.tau, 0.0, None, b["ykl"])
 
 
+class NativeGMEncoder:
+    """The same encoder sequenced natively (csrc/gm_encoder.hip, include/splitvae.h `sv_gm_encoder_*`): one C call each
+    for weight preparation, forward and backward instead of ~110 ctypes calls per step.  `buf[name]` are views of
+    its workspace (same names as GMEncoder.buf)."""
+
+    def __init__(self, B, H, W, latent, y_size, tau, dtype, device):
+        self.B, self.H, self.W, self.L, self.K, self.tau, self.dtype, self.device = B, H, W, latent, y_size, tau, dtype, device
+        self.F = (H // 8) * (W // 8) * 128
+        lib = _lib.load()
+        self.lib = lib
+        self.desc = _lib.GmDesc(B, H, W, latent, y_size, float(tau), ops.sv_dtype(dtype))
+        h = C.c_void_p()
+        ops.check(lib.sv_gm_encoder_create(C.byref(self.desc), C.byref(h)), "sv_gm_encoder_create")
+        self.handle = h
+        nbytes = lib.sv_gm_encoder_workspace_bytes(h)
+        self.workspace = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+        ops.check(lib.sv_gm_encoder_bind(h, ops._p(self.workspace), nbytes, ops._stream()), "sv_gm_encoder_bind")
+        T, f32, F_, K, L, Kp = dtype, torch.float32, self.F, y_size, latent, _r8(y_size)
+        shapes = dict(
+            h1=(T, (B, H // 2, H // 2, 128)), h2=(T, (B, H // 4, H // 4, 128)), h3=(T, (B, F_)), a1=(f32, (B, 1024)),
+            yh1a=(T, (B, 1024)), yh1=(T, (B, 1024)), keep1=(f32, (B, 1024)), a2=(f32, (B, 128)), yh2=(T, (B, 128)),
+            logits=(f32, (B, K)), y=(f32, (B, K)), y_lp=(T, (B, Kp)), u=(f32, (B, K)), a_pm=(f32, (B, L)), a_ps=(f32, (B, L)),
+            a_t=(f32, (B, 512)), h_top=(T, (B, 512)), h5=(T, (B, F_)), keep5=(f32, (B, F_)), a_e=(f32, (B, 512)),
+            he=(T, (B, 512)), hh=(T, (B, 512)), a_m=(f32, (B, L)), a_s=(f32, (B, L)), zm=(f32, (B, L)), zs=(f32, (B, L)),
+            z=(f32, (B, L)), pm=(f32, (B, L)), ps=(f32, (B, L)), eps=(f32, (B, L)), kl2=(f32, (B,)), ykl=(f32, (B,)))
+        self.buf = {}
+        off, nb = C.c_int64(), C.c_int64()
+        for name, (dt, shp) in shapes.items():
+            ops.check(lib.sv_gm_encoder_buffer(h, name.encode(), C.byref(off), C.byref(nb)), "sv_gm_encoder_buffer " + name)
+            self.buf[name] = self.workspace[off.value: off.value + nb.value].view(dt).view(*shp)
+        self._args = _lib.GmArgs()
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.sv_gm_encoder_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def prep(self, flat):
+        ops.check(self.lib.sv_gm_encoder_prep(self.handle, ops._p(flat), ops._stream()), "sv_gm_encoder_prep")
+
+    def _fill(self, **kw):
+        a = self._args
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        return a
+
+    def forward(self, flat, in8_x, zcat, training, eps=None, u=None, keep1=None, keep5=None, seed=0, step=0, sample_offset=0):
+        a = self._fill(params=flat, grads=None, in8_x=in8_x, zcat=zcat, ldz=zcat.shape[1], gz=None, ld_gz=0, eps=eps, u=u,
+                       keep1=keep1, keep5=keep5, training=1 if training else 0, beta=0.0, alpha=0.0, seed=seed, step=step,
+                       sample_offset=sample_offset)
+        ops.check(self.lib.sv_gm_encoder_forward(self.handle, C.byref(a), ops._stream()), "sv_gm_encoder_forward")
+
+    def backward(self, flat, grad_flat, in8_x, gz, beta, alpha):
+        a = self._fill(params=flat, grads=grad_flat, in8_x=in8_x, gz=gz, ld_gz=gz.shape[1], beta=float(beta), alpha=float(alpha))
+        ops.check(self.lib.sv_gm_encoder_backward(self.handle, C.byref(a), ops._stream()), "sv_gm_encoder_backward")
+
+    def y_kl_only(self):
+        ops.check(self.lib.sv_gm_encoder_y_kl(self.handle, ops._stream()), "sv_gm_encoder_y_kl")
+
+
 class LGGMVae(LGVae):
     """vae/model.py:221-246: LGGMVae(global_latent_dims, local_latent_dims, image_shape, y_size, tau)."""
 
@@ -195,7 +260,7 @@ class LGGMVae(LGVae):
         super().__init__(global_latent_dims, local_latent_dims, image_shape, variational, type, dtype, device, seed)
         self.y_size, self.tau = y_size, tau
         self.alpha = 40.0                                  # vae/main.py:29 (--alpha)
-        self._enc = {}
+        self._enc, self._enc_py = {}, {}
         self.gm_table = GMEncoder(1, self.H, self.W, global_latent_dims, y_size, tau, self.dtype, self.device).table
         self.gm_n_params = self.gm_table[-1][1] + (int(np.prod(self.gm_table[-1][2])) + 3) // 4 * 4
         self.gm_flat = torch.zeros(self.gm_n_params, dtype=torch.float32, device=self.device)
@@ -261,9 +326,17 @@ class LGGMVae(LGVae):
         return self._plans[key]
 
     def encoder(self, B):
+        """The natively sequenced encoder (SV_GM_PYTHON=1: the per-layer Python sequence, kept as the readable restatement
+        of the launch order and for A/B)."""
         if B not in self._enc:
-            self._enc[B] = GMEncoder(B, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
+            cls = GMEncoder if os.environ.get("SV_GM_PYTHON") == "1" else NativeGMEncoder
+            self._enc[B] = cls(B, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
         return self._enc[B]
+
+    def _py_encoder(self, n):
+        if n not in self._enc_py:
+            self._enc_py[n] = GMEncoder(n, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
+        return self._enc_py[n]
 
     def _forward(self, inputs, training, eps, noise, want_loss, plan_kw):
         """noise = (u, keep1, keep5) pins the Gumbel uniforms / dropout masks (parity tests)."""
@@ -301,7 +374,7 @@ class LGGMVae(LGVae):
     def encode_y(self, y, rescale=True):
         """vae/model.py:263-265 / :137-140: prior mean and sig of a given y [n, y_size] (fp32)."""
         n = y.shape[0]
-        enc = self.encoder(n)
+        enc = self._py_encoder(n)                          # two Dense layers and a head: the per-layer objects
         enc.prep(self.gm_flat)
         b = enc.buf
         b["y_lp"].zero_(); b["y_lp"][:, :self.y_size] = y.to(self.dtype)

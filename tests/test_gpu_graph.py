@@ -62,7 +62,10 @@ def test_replayed_steps_equal_eager_steps(ops, dtype, monkeypatch):
         d, d0 = (graph.flat - eager.flat).abs(), (twin.flat - eager.flat).abs()
         assert float(d.max()) <= 2.1e-3 * (t + 1), (t, float(d.max()))
         frac, frac0 = float((d > 1e-5).float().mean()), float((d0 > 1e-5).float().mean())
-        assert frac <= 3 * frac0 + 2e-2, (t, frac, frac0)
+        # (two eager runs share one launch schedule and are often bit-identical; the replay runs the weight gradients on
+        # the main stream, another valid order of the same atomics, and bf16 amplifies it: 2 % was seen, a stale
+        # scalar gives ~100 %)
+        assert frac <= 3 * frac0 + (2e-2 if dtype == "f32" else 1e-1), (t, frac, frac0)
     assert pe.graph_count() == 0 and pg.graph_count() == 1            # eager / eager, capture, then replays
     assert not torch.equal(hist[2], hist[3])                          # consecutive replays draw different noise
     assert np.isfinite(float(lg[5]))
