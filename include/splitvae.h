@@ -127,6 +127,13 @@ int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d);
 int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
                             float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- F3: input files (host side, no device work)
+ * CRC-32C of the TFRecord framing the reference's CelebA files use (tf.io.TFRecordWriter at vae/data.py:93-100,
+ * TFRecordDataset at :123-131): record = uint64 length | masked_crc32c(length) | data | masked_crc32c(data),
+ * masked(c) = rotr(c, 15) + 0xa282ead8.  sv_crc32c("123456789") == 0xE3069283. */
+uint32_t sv_crc32c(const void* data, int64_t n);
+uint32_t sv_masked_crc32c(const void* data, int64_t n);
+
 /* ---------------------------------------------------------------- A9: SPLIT-GMVAE global encoder glue
  * The contractions of Encoder(type='gmvae') (vae/model.py:48-79, call_gmvae :116-135) run on the
  * sv_conv2d_* kernels (dense layers = 1x1 convs on a 1x1 grid); these are the pointwise pieces between

@@ -87,6 +87,8 @@ SYMBOLS = {
     "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sv_conv2d_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sv_conv2d_nhwc_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sv_crc32c": (C.c_uint32, [_vp, _i64]),
+    "sv_masked_crc32c": (C.c_uint32, [_vp, _i64]),
     "sv_gm_param_count": (_i64, [C.POINTER(GmDesc)]),
     "sv_gm_param_info": (C.c_int, [C.POINTER(GmDesc), _i32, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64 * 4), C.c_char_p]),
     "sv_gm_encoder_create": (C.c_int, [C.POINTER(GmDesc), C.POINTER(_vp)]),

@@ -36,8 +36,31 @@ def _table():
     return _TABLE
 
 
+_NATIVE = None
+
+
+def _native():
+    """sv_crc32c of the C ABI (slicing-by-8, ~1.5 GB/s) when the library is built; the table loop below otherwise."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            from . import _lib
+            _NATIVE = _lib.load().sv_crc32c
+        except Exception:
+            _NATIVE = False
+    return _NATIVE
+
+
 def crc32c(data):
     """CRC-32C (Castagnoli, reflected 0x1EDC6F41) of a bytes-like object."""
+    f = _native()
+    if f:
+        b = bytes(data)
+        return int(f(b, len(b)))
+    return crc32c_py(data)
+
+
+def crc32c_py(data):
     t = _table()
     c = 0xFFFFFFFF
     for b in bytes(data):
@@ -158,6 +181,31 @@ def serialize_tensor(a):
     shape = b"".join(b"\x12" + _enc_varint(len(d)) + d for d in (b"\x08" + _enc_varint(int(s)) for s in a.shape))
     content = a.tobytes()
     return b"\x08" + _enc_varint(DT_FLOAT) + b"\x12" + _enc_varint(len(shape)) + shape + b"\x22" + _enc_varint(len(content)) + content
+
+
+def read_celeba_tfrec_array(path, size):
+    """The whole file as one [N, size, size, 3] float32 array without a per-record Python loop: the records of these
+    files all have the same length (one serialize_tensor of a fixed-shape float image), so after parsing the first
+    record the tensor contents are a strided view of the file.  Falls back to the record loop if the lengths differ.
+    Every length header is still CRC-checked (vectorised over the distinct header values)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size == 0:
+        return np.zeros((0, size, size, 3), np.float32)
+    (n0,) = struct.unpack("<Q", raw[:8].tobytes())
+    rec = 12 + n0 + 4
+    first = raw[12:12 + n0].tobytes()
+    img0 = parse_tensor(first)
+    content = img0.astype("<f4").tobytes()
+    at = first.rfind(content)                              # offset of tensor_content inside the payload
+    if raw.size % rec or at < 0 or img0.size != size * size * 3:
+        return np.stack(list(read_celeba_tfrec(path, size)))
+    recs = raw.reshape(-1, rec)
+    if not (recs[:, :12] == recs[0, :12]).all() or masked_crc32c(raw[:8].tobytes()) != struct.unpack("<I", raw[8:12].tobytes())[0]:
+        return np.stack(list(read_celeba_tfrec(path, size)))
+    if not (recs[:, 12:12 + at] == recs[0, 12:12 + at]).all():      # same proto prefix (dtype, shape, content length)
+        return np.stack(list(read_celeba_tfrec(path, size)))
+    body = np.ascontiguousarray(recs[:, 12 + at:12 + at + len(content)])
+    return body.view("<f4").reshape(-1, size, size, 3)
 
 
 def read_celeba_tfrec(path, size, verify_data_crc=False):

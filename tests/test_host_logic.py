@@ -97,6 +97,9 @@ def test_tfrecord_codec_and_shuffle_buffer(tmp_path):
     from split_vae_amd import tfrecord as tfr
     assert tfr.crc32c(b"123456789") == 0xE3069283                       # CRC-32C check value
     assert tfr.crc32c(b"") == 0
+    blob = bytes(range(256)) * 5 + b"tail"                              # native (sv_crc32c, slicing-by-8) == table loop,
+    for lo, hi in [(0, len(blob)), (1, 777), (3, 12), (5, 5), (7, 8)]:  # at every alignment / length class
+        assert tfr.crc32c(blob[lo:hi]) == tfr.crc32c_py(blob[lo:hi])
     # hand-assembled TensorProto: dtype DT_FLOAT, shape [2,3], tensor_content of 6 floats
     vals = np.arange(6, dtype="<f4") * 0.5 - 1
     proto = b"\x08\x01" + b"\x12\x08" + b"\x12\x02\x08\x02" + b"\x12\x02\x08\x03" + b"\x22\x18" + vals.tobytes()
@@ -110,6 +113,7 @@ def test_tfrecord_codec_and_shuffle_buffer(tmp_path):
     tfr.write_celeba_tfrec(str(path), imgs)
     back = np.stack(list(tfr.read_celeba_tfrec(str(path), 64, verify_data_crc=True)))
     assert np.array_equal(back, imgs)
+    assert np.array_equal(tfr.read_celeba_tfrec_array(str(path), 64), imgs)   # vectorised whole-file reader
     raw = bytearray(path.read_bytes()); raw[40] ^= 1                    # flip a payload bit: the data CRC must catch it
     bad = tmp_path / "bad.tfrec"; bad.write_bytes(bytes(raw))
     with pytest.raises(IOError):
