@@ -200,7 +200,9 @@ typedef struct {
   const float* u;           /* [B,K]     Gumbel uniforms or NULL */
   const float* keep1;       /* [B,1024]  y_block dropout mask (0/1) or NULL */
   const float* keep5;       /* [B,F]     do5 dropout mask or NULL */
-  int32_t training;         /* dropout on (vae/trainer.py:149) */
+  int32_t training;         /* 1: y_block's Dropout and do5 act (vae/model.py:56,:72,:129).  train_step_lg_gm_vae passes
+                             training=True (vae/trainer.py:149) but LGGMVae.call drops it before encoder_x (:241): under the
+                             pinned tensorflow 2.0.0 the dropouts never fire (pass 0), under >= 2.1 they do (pass 1) */
   float beta, alpha;        /* backward: weights of the two-Gaussian KL and of the categorical KL */
   uint64_t seed, step;
   int64_t sample_offset;

@@ -77,8 +77,21 @@ def gumbel_softmax(logits, u, tau):
     return torch.softmax((logits - torch.log(-torch.log(u))) / tau, dim=1)
 
 
-def encoder_gmvae(x, p, eps, u, keep1, keep5, tau):
-    """Encoder.call_gmvae -- vae/model.py:116-135.  keep1 [B,1024], keep5 [B,F]: 0/1 dropout keep masks."""
+def encoder_gmvae(x, p, eps, u, keep1, keep5, tau, dropout=True):
+    """Encoder.call_gmvae -- vae/model.py:116-135.  keep1 [B,1024], keep5 [B,F]: 0/1 dropout keep masks.
+
+    `dropout`: whether y_block's Dropout(0.2) (:56) and do5 (:72, called at :129) act in this call.  The reference
+    trains with model(images, training=True) (vae/trainer.py:149) but LGGMVae.call invokes self.encoder_x(x) WITHOUT
+    forwarding `training` (:241) and call_gmvae's own default is False (:116).  Whether the flag reaches the two
+    Dropout layers is a property of the Keras version [TF-2.0 semantics, not executable here]:
+      * tensorflow 2.0.0 (the pinned version, requirements.txt:7): no call-context propagation of `training`; a layer
+        called without it falls back to K.learning_phase() = 0 outside the Keras graph -> dropout=False even in training;
+      * tensorflow >= 2.1: `training=True` of the outer Model call propagates to every nested layer that was called
+        without the argument -> dropout=True in training.
+    Both are restated; dropout=False ignores the masks."""
+    if not dropout:
+        keep1 = torch.ones_like(keep1) * (1.0 - GM_RATE)
+        keep5 = torch.ones_like(keep5) * (1.0 - GM_RATE)
     h = conv_elu(x, p[0], p[1], 2)
     h = conv_elu(h, p[2], p[3], 2)
     h = conv_elu(h, p[4], p[5], 2)
@@ -99,11 +112,11 @@ def encoder_gmvae(x, p, eps, u, keep1, keep5, tau):
     return z, z_mean, z_sig, y, y_logits, z_prior_mean, z_prior_sig
 
 
-def lggmvae_forward(images, params, eps_x, eps_x_hat, u, keep1, keep5, tau=0.4):
+def lggmvae_forward(images, params, eps_x, eps_x_hat, u, keep1, keep5, tau=0.4, dropout=True):
     """LGGMVae.call -- vae/model.py:236-246; same 14-tuple order."""
     H, W = images.shape[1:3]
     x, x_hat = images[..., :3], images[..., 3:]
-    z_x, z_mean_x, z_sig_x, y, y_logits, zpm, zps = encoder_gmvae(x, params[0:24], eps_x, u, keep1, keep5, tau)
+    z_x, z_mean_x, z_sig_x, y, y_logits, zpm, zps = encoder_gmvae(x, params[0:24], eps_x, u, keep1, keep5, tau, dropout)
     z_x_hat, z_mean_x_hat, z_sig_x_hat = torch_ref.encoder_conv(x_hat, params[24:34], eps_x_hat)
     x_mean, x_log_scale = torch_ref.decoder(torch.cat([z_x, z_x_hat], 1), params[34:44], H, W)
     x_hat_mean, x_hat_log_scale = torch_ref.decoder(z_x_hat, params[44:54], H, W)
@@ -143,7 +156,8 @@ def lggmvae_losses(images, fwd, beta, alpha, y_size):
 class GMRefTrainer:
     """Stateful restatement of train_step_lg_gm_vae (vae/trainer.py:146-173) + Keras Adam."""
 
-    def __init__(self, params, beta, alpha, y_size=30, tau=0.4, lr=1e-4, dtype=torch.float32):
+    def __init__(self, params, beta, alpha, y_size=30, tau=0.4, lr=1e-4, dtype=torch.float32, dropout=True):
+        self.dropout = dropout
         self.params = [torch.as_tensor(p).to(dtype).clone().requires_grad_(True) for p in params]
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
@@ -153,7 +167,7 @@ class GMRefTrainer:
     def forward_losses(self, images, eps_x, eps_x_hat, u, keep1, keep5):
         c = lambda a: torch.as_tensor(a).to(self.dtype)
         images = c(images)
-        fwd = lggmvae_forward(images, self.params, c(eps_x), c(eps_x_hat), c(u), c(keep1), c(keep5), self.tau)
+        fwd = lggmvae_forward(images, self.params, c(eps_x), c(eps_x_hat), c(u), c(keep1), c(keep5), self.tau, self.dropout)
         return fwd, lggmvae_losses(images, fwd, self.beta, self.alpha, self.y_size)
 
     def grads(self, *a):

@@ -10,7 +10,12 @@ torch only owns the buffers.
 Trainable variables, in the reference's layer-tracking order: the 24 arrays of the gmvae encoder
 (h_block x3, y_block x2, y_dense, h_top_dense, z_prior_mean, z_prior_sig, e1, z_mean, z_sig), then the 30
 arrays LGVae has after encoder_x.  The Dropout layers do1-4, do6, do7 exist in the reference but are never
-called (vae/model.py:59-75 vs :116-135); only y_block's Dropout and do5 act, in training.
+called (vae/model.py:59-75 vs :116-135); only y_block's Dropout and do5 can act.
+
+Whether they DO act in train_step_lg_gm_vae depends on the Keras version (LGGMVae.call drops `training` on the way to
+encoder_x, vae/model.py:241; oracle/gm_ref.py::encoder_gmvae has the analysis): under the pinned tensorflow 2.0.0 they
+do not, under tensorflow >= 2.1 they do.  `LGGMVae(dropout_in_training=...)` selects; the default False is the pinned
+version's behaviour.
 """
 import ctypes as C
 import math
@@ -256,9 +261,11 @@ class LGGMVae(LGVae):
     """vae/model.py:221-246: LGGMVae(global_latent_dims, local_latent_dims, image_shape, y_size, tau)."""
 
     def __init__(self, global_latent_dims, local_latent_dims, image_shape, y_size, tau, variational=True, type='conv',
-                 dtype='bf16', device=None, seed=0):
+                 dtype='bf16', device=None, seed=0, dropout_in_training=False):
         super().__init__(global_latent_dims, local_latent_dims, image_shape, variational, type, dtype, device, seed)
         self.y_size, self.tau = y_size, tau
+        # False: tensorflow 2.0.0 (pinned) -- `training` never reaches encoder_x's Dropout layers; True: tensorflow >= 2.1
+        self.dropout_in_training = bool(dropout_in_training)
         self.alpha = 40.0                                  # vae/main.py:29 (--alpha)
         self._enc, self._enc_py = {}, {}
         self.gm_table = GMEncoder(1, self.H, self.W, global_latent_dims, y_size, tau, self.dtype, self.device).table
@@ -299,7 +306,23 @@ class LGGMVae(LGVae):
         return self._gm_views(self.gm_grad_flat) + self._views(self.grad_flat)[10:]
 
     def keras_names(self):
-        return [n for n, _, _ in self.gm_table] + [n for n, _, _ in self.param_table][10:]
+        # same convention as LGVae.keras_names: <sublayer>/<attr>/<kernel|bias>:0
+        return [n + ":0" for n, _, _ in self.gm_table] + [n + ":0" for n, _, _ in self.param_table][10:]
+
+    KERAS_MODEL_NAME = "lggm_vae"
+
+    def _keras_kind(self, name):
+        parts = name.split("/")
+        if parts[0] != "encoder_x":
+            return super()._keras_kind(name)
+        attr = parts[1]
+        if attr == "h_block":                              # Sequential of three Conv2D (vae/model.py:49-52)
+            return "conv2d", None, "h_block"
+        if attr == "y_block":                              # Sequential(Dense, Dropout, Dense) (:54-58)
+            return "dense", None, "y_block"
+        if attr in ("y_dense", "z_prior_mean", "z_prior_sig"):      # layers given explicit names (:60,:66,:68)
+            return "dense", attr, None
+        return "dense", None, None                         # h_top_dense, e1, z_mean, z_sig: auto-named Dense
 
     def summary(self):
         total = 0
@@ -350,7 +373,8 @@ class LGGMVae(LGVae):
         enc.prep(self.gm_flat)
         Lc = self.global_latent_dims + self.local_latent_dims
         enc.forward(self.gm_flat, plan.buffer("in8_x", self.dtype, (B, self.H, self.W, 8)),
-                    plan.buffer("zcat", self.dtype, (B, Lc)), training, eps=ex, u=u, keep1=k1, keep5=k5, seed=self.seed,
+                    plan.buffer("zcat", self.dtype, (B, Lc)), bool(training) and self.dropout_in_training, eps=ex, u=u,
+                    keep1=k1, keep5=k5, seed=self.seed,
                     step=self._calls, sample_offset=kw.get("sample_offset", 0))
         plan.step(PHASE_FWD_DECODERS | (PHASE_LOSS if want_loss else 0), **kw)
         return plan, enc, kw

@@ -2,7 +2,7 @@
 
     python -m split_vae_amd.main --beta 120 --patch_size 8 --dataset celeba64 -no_label --synthetic
 
-Extra flags (not in the reference): --synthetic, --dtype, --seed, --log_every.
+Extra flags (not in the reference): --synthetic, --dtype, --seed, --log_every, --data_dir, --gm_dropout.
 """
 import argparse
 
@@ -31,6 +31,10 @@ def build_parser():
     ap.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log_every", type=int, default=10000)
+    ap.add_argument("--gm_dropout", type=str, default="tf2.0", choices=["tf2.0", "tf2.1"],
+                    help="lggmvae: whether encoder_x's Dropout layers fire in training (tf2.0 = pinned tensorflow 2.0.0: no; "
+                         "tf2.1 = call-context propagation of `training`: yes); see split_vae_amd/gm.py")
+    ap.add_argument("--data_dir", type=str, default="data", help="holds SVHN/*.mat and celeba/*.tfrec (vae/data.py:24,:103)")
     return ap
 
 
@@ -45,11 +49,22 @@ def main(argv=None):
     from .optimizer import Adam
 
     augmentor = Augmentator(type=config.augmentation, size=config.patch_size, seed=config.seed)
-    train_ds, test_ds, input_shape = data.get_dataset(config.dataset, config.batch_size, synthetic=config.synthetic)
-    if config.label and config.synthetic:
-        config.label = False      # synthetic batches carry no labels
-    train_ds = (augmentor.augment(x) for x in train_ds)                 # vae/main.py:57-61
-    test_batches = [augmentor.augment(x) for x in test_ds]
+    train_ds, test_ds, input_shape = data.get_dataset(config.dataset, config.batch_size, synthetic=config.synthetic,
+                                                      data_dir=config.data_dir, get_label=config.label)
+    if config.label and not train_ds.labelled:
+        # only the SVHN files carry labels (vae/data.py:54-62); the reference's labelled pipeline (vae/main.py:56-58)
+        # cannot run on CelebA either, its README passes -no_label there
+        print('Note: dataset %r serves no labels; continuing as with -no_label' % config.dataset)
+        config.label = False
+    if config.label:
+        # vae/trainer.py:81-97 trains / loads the SVHN probe classifier here; its weights blob is missing upstream
+        # (.MISSING_LARGE_BLOBS:1), so the labels ride along unused and the classifier metrics are not reported
+        print('Note: classifier-based test metrics are not available (svhn_classifier_weights.h5 is not in the reference repo)')
+        train_ds = ((augmentor.augment(x), y) for x, y in train_ds)     # vae/main.py:57-58
+        test_batches = [(augmentor.augment(x), y) for x, y in test_ds]
+    else:
+        train_ds = (augmentor.augment(x) for x in train_ds)             # vae/main.py:60-61
+        test_batches = [augmentor.augment(x) for x in test_ds]
     if args.model == 'lgvae':
         model = LGVae(global_latent_dims=config.global_latent_dims, local_latent_dims=config.local_latent_dims,
                       image_shape=input_shape, dtype=config.dtype, seed=config.seed)
@@ -60,7 +75,8 @@ def main(argv=None):
         lr_schedule = ExponentialDecay(config.learning_rate, decay_steps=1000000, decay_rate=0.4, staircase=True)
         optimizer = Adam(learning_rate=lr_schedule)
         model = LGGMVae(global_latent_dims=config.global_latent_dims, local_latent_dims=config.local_latent_dims,
-                        image_shape=input_shape, y_size=config.y_size, tau=config.tau, dtype=config.dtype, seed=config.seed)
+                        image_shape=input_shape, y_size=config.y_size, tau=config.tau, dtype=config.dtype, seed=config.seed,
+                        dropout_in_training=config.gm_dropout == "tf2.1")
     else:
         raise NotImplementedError("--model %s: GMVae has no local branch and is outside the SPLIT path (SURVEY 8f)" % args.model)
     model.summary()

@@ -90,14 +90,77 @@ class LGVae:
         # vae/model.py layer attribute names under the model: <sublayer>/<attr>/<kernel|bias>:0
         return [n + ":0" for (n, _, _) in self.param_table]
 
+    # ---------------------------------------------------------------- checkpoints (vae/trainer.py:421)
+    KERAS_MODEL_NAME = "lg_vae"             # keras to_snake_case(class name): the outer name scope of every variable
+
+    def _keras_kind(self, name):
+        """Keras class of the layer that owns variable `name` (<sublayer>/<attr>/<kernel|bias>) -> (class uid stem,
+        explicit layer name or None, enclosing Sequential attr or None)."""
+        attr = name.split("/")[1]
+        return ("dense" if attr in ("e4_mean", "e4_sd", "d1") else "conv2d"), None, None
+
+    def keras_h5_layers(self):
+        """[(layer name, [weight name, ...]), ...] as Keras names them for model.save_weights(*.h5) [TF-2.0 semantics:
+        global per-class uid counters in creation order (conv2d, conv2d_1, ..., dense, dense_1, ...), variables scoped
+        <model>/<layer>/<inner layer>/<kernel|bias>:0; sub-models are named encoder, encoder_1, decoder, decoder_1].
+        Aligned with trainable_variables order.  Only cosmetic for a round trip: loading goes by order."""
+        uid, seq_uid, layers, sub_names, sub_uid, inner = {}, {}, [], {}, {}, {}
+        names = [n[:-2] if n.endswith(":0") else n for n in self.keras_names()]
+        for n in names:
+            sub, attr, kind = n.split("/")[0], n.split("/")[1:-1], n.split("/")[-1]
+            if sub not in sub_names:
+                stem = "encoder" if sub.startswith("encoder") else "decoder"
+                k = sub_uid.get(stem, 0)
+                sub_uid[stem] = k + 1
+                sub_names[sub] = stem if k == 0 else "%s_%d" % (stem, k)
+                layers.append((sub_names[sub], []))
+            key = (sub, tuple(attr))
+            if key not in inner:
+                cls, explicit, seq = self._keras_kind(n)
+                if explicit:
+                    lname = explicit
+                else:
+                    k = uid.get(cls, 0)
+                    uid[cls] = k + 1
+                    lname = cls if k == 0 else "%s_%d" % (cls, k)
+                if seq:
+                    if (sub, seq) not in seq_uid:
+                        k = len(seq_uid)
+                        seq_uid[(sub, seq)] = "sequential" if k == 0 else "sequential_%d" % k
+                    lname = seq_uid[(sub, seq)] + "/" + lname
+                inner[key] = lname
+            layers[-1][1].append("%s/%s/%s/%s:0" % (self.KERAS_MODEL_NAME, sub_names[sub], inner[key], kind))
+        return layers
+
     def save_weights(self, path):
-        """vae/trainer.py:421 (Keras HDF5 there; h5py is unavailable, so an .npz with the same 40
-        arrays under Keras-style names in Keras layouts)."""
-        arrs = {n: w for n, w in zip(self.keras_names(), self.get_weights())}
-        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **arrs)
+        """vae/trainer.py:421 model.save_weights('models/<run>.h5'): a Keras HDF5 weights file (h5io.py: the layer_names /
+        weight_names attribute layout of keras/saving/hdf5_format.py) when the path ends in .h5 / .hdf5 / .keras;
+        otherwise an .npz with the same arrays under <sublayer>/<attr>/<kernel|bias>:0 names.  Keras layouts either way
+        (conv HWIO, dense [in,out], flatten order h,w,c).  Returns the path written."""
+        path = str(path)
+        ws = self.get_weights()
+        if path.endswith((".h5", ".hdf5", ".keras")):
+            from . import h5io
+            it = iter(ws)
+            return h5io.save_keras_weights(path, [(ln, [(wn, next(it)) for wn in wns]) for ln, wns in self.keras_h5_layers()])
+        path = path if path.endswith(".npz") else path + ".npz"
+        np.savez(path, **{n: w for n, w in zip(self.keras_names(), ws)})
+        return path
 
     def load_weights(self, path):
-        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        """Inverse of save_weights; HDF5 files are read BY ORDER like Keras' load_weights_from_hdf5_group (so a file the
+        reference wrote loads whatever uids its layer names carry), shapes checked."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5", ".keras")):
+            from . import h5io
+            arrs = [a for _, ws in h5io.load_keras_weights(path) for _, a in ws]
+            want = [tuple(v.shape) for v in self.trainable_variables]
+            if [tuple(a.shape) for a in arrs] != want:
+                raise ValueError("weight file %s holds %d arrays with shapes %s; this model expects %d with shapes %s" %
+                                 (path, len(arrs), [tuple(a.shape) for a in arrs][:4], len(want), want[:4]))
+            self.set_weights(arrs)
+            return
+        z = np.load(path if path.endswith(".npz") else path + ".npz")
         self.set_weights([z[n] for n in self.keras_names()])
 
     def summary(self):

@@ -49,6 +49,16 @@ def last_losses(plan):
     return {k: float(l[i]) for i, k in enumerate(METRIC_NAMES + ["total_loss"])}
 
 
+def _check_images(model, images):
+    """The kernels read B*H*W*6 floats from the pointer: refuse anything that is not a [B,H,W,6] fp32 device batch
+    (e.g. one image of a batch taken by a stray `train_data[0]`)."""
+    if not torch.is_tensor(images) or images.dim() != 4 or tuple(images.shape[1:]) != (model.H, model.W, 6):
+        raise ValueError("images must be a [B, %d, %d, 6] tensor (x | x_hat on the channel axis), got %s" %
+                         (model.H, model.W, tuple(images.shape) if torch.is_tensor(images) else type(images)))
+    if images.dtype != torch.float32 or not images.is_cuda or not images.is_contiguous():
+        raise ValueError("images must be contiguous fp32 on the HIP device")
+
+
 def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0, accumulate_metrics=True):
     """train_step_lg_vae (vae/trainer.py:120-144): forward, total = recon_x + recon_x_hat +
     beta*KL, gradients of the 40 variables, Adam update, metric update.  `images` [B,H,W,6] fp32
@@ -58,6 +68,7 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
         raise TypeError("LGGMVae trains with gm.train_step_lg_gm_vae (vae/trainer.py:297-299 picks the step by model class)")
     if not isinstance(model, LGVae):
         raise NotImplementedError("GMVae (no local branch) is outside the SPLIT path (SURVEY 8f)")
+    _check_images(model, images)
     B = images.shape[0]
     plan = model.plan(B)
     m, v = optimizer.slots(model.flat)
@@ -89,6 +100,7 @@ def test_step(model, images, labels=None, eps=None):
     probe classifier's weights are not in the reference repo, .MISSING_LARGE_BLOBS:1)."""
     if labels is not None:
         raise NotImplementedError("classifier-based metrics need svhn_classifier_weights.h5 (missing upstream)")
+    _check_images(model, images)
     B = images.shape[0]
     plan = model.plan(B)
     ex, eh = (None, None) if eps is None else eps
@@ -151,9 +163,13 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
         if step >= config.training_steps:
             print('Training done!')
             break
-    path = 'models/' + RUN_NAME
-    model.save_weights(path)
-    return path + ".npz"
+    return _save(model, RUN_NAME)
+
+
+def _save(model, run_name):
+    """vae/trainer.py:421: model.save_weights('models/'+RUN_NAME+'.h5') -- Keras HDF5 when libhdf5 is present, else .npz."""
+    from . import h5io
+    return model.save_weights('models/' + run_name + ('.h5' if h5io.available() else '.npz'))
 
 
 def _write_grids(model, test_dataset, config, run_dir, step):
@@ -219,6 +235,4 @@ def _train_lggmvae(model, optimizer, train_dataset, test_dataset, config):
         if step >= config.training_steps:
             print('Training done!')
             break
-    path = 'models/' + RUN_NAME
-    model.save_weights(path)
-    return path + ".npz"
+    return _save(model, RUN_NAME)

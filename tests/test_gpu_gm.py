@@ -49,24 +49,28 @@ def test_gm_variable_table_matches_reference_order(ops):
     from split_vae_amd.gm import LGGMVae
     m = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda", seed=1)
     want = gm_ref.gm_param_shapes(H, H, y_size=K)
-    assert m.keras_names() == [n for n, _ in want]
+    assert m.keras_names() == [n + ":0" for n, _ in want]
     assert [tuple(v.shape) for v in m.trainable_variables] == [tuple(s) for _, s in want]
     assert sum(v.numel() for v in m.trainable_variables) == 6775370          # 6.78 M parameters
     b = dict(zip(m.keras_names(), m.get_weights()))
-    assert np.all(b["encoder_x/z_sig/bias"] == 1) and np.all(b["encoder_x/z_prior_sig/bias"] == 1)   # vae/model.py:68,:78
-    assert np.all(b["encoder_x/z_mean/bias"] == 0)
+    assert np.all(b["encoder_x/z_sig/bias:0"] == 1) and np.all(b["encoder_x/z_prior_sig/bias:0"] == 1)   # vae/model.py:68,:78
+    assert np.all(b["encoder_x/z_mean/bias:0"] == 0)
 
 
-def test_gm_step_fp32_matches_oracle(ops):
+@pytest.mark.parametrize("dropout", [False, True], ids=["tf2.0-no-dropout", "tf2.1-dropout"])
+def test_gm_step_fp32_matches_oracle(ops, dropout):
     """fp32 MFMA path: the 14-tuple, the 5 metrics + total, all 54 gradients, weights after Adam.
-    Tolerances as for the LGVae step (tests/test_gpu_step.py): fp32 with different summation orders."""
+    Tolerances as for the LGVae step (tests/test_gpu_step.py): fp32 with different summation orders.
+    Both readings of `training` (oracle/gm_ref.py::encoder_gmvae): dropout off in training (tensorflow 2.0.0, the
+    default) and on (tensorflow >= 2.1)."""
     from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae, LOSS_KEYS
     from split_vae_amd.optimizer import Adam
     B = 4
     images, nz = _inputs(B)
     params = _params()
-    ref = gm_ref.GMRefTrainer(params, BETA, ALPHA, y_size=K, tau=TAU, dtype=torch.float64)
-    model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda", seed=1)
+    ref = gm_ref.GMRefTrainer(params, BETA, ALPHA, y_size=K, tau=TAU, dtype=torch.float64, dropout=dropout)
+    model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda", seed=1, dropout_in_training=dropout)
+    assert LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda").dropout_in_training is False   # pinned-TF default
     model.beta, model.alpha = BETA, ALPHA
     model.set_weights(params)
     opt = Adam(learning_rate=1e-4)
@@ -138,12 +142,14 @@ def test_gm_training_descends_with_device_rng(ops):
     from split_vae_amd.optimizer import Adam
     B = 16
     images, _ = _inputs(B, seed=7)
-    model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="bf16", device="cuda", seed=4)
-    model.beta, model.alpha = BETA, ALPHA
-    opt = Adam(learning_rate=1e-3)
-    img = torch.from_numpy(images).cuda()
-    tot = [float(train_step_lg_gm_vae(model, img, opt)[5]) for _ in range(15)]
-    assert all(np.isfinite(tot)) and min(tot[-3:]) < tot[0], tot
-    keep1 = model.encoder(B).buf["keep1"]
-    frac = float(keep1.mean())
-    assert 0.75 < frac < 0.85, frac                                     # Dropout(rate=0.2) keeps ~80 %
+    for dropout in (True, False):
+        model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="bf16", device="cuda", seed=4, dropout_in_training=dropout)
+        model.beta, model.alpha = BETA, ALPHA
+        opt = Adam(learning_rate=1e-3)
+        img = torch.from_numpy(images).cuda()
+        tot = [float(train_step_lg_gm_vae(model, img, opt)[5]) for _ in range(15)]
+        assert all(np.isfinite(tot)) and min(tot[-3:]) < tot[0], tot
+        if dropout:
+            keep1 = model.encoder(B).buf["keep1"]
+            frac = float(keep1.mean())
+            assert 0.75 < frac < 0.85, frac                             # Dropout(rate=0.2) keeps ~80 %

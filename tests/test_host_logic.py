@@ -1,5 +1,7 @@
 """CPU: host-side mirror of the reference's Python surface (flags, dotdict, optimizer schedule,
 augmentor selection, data-parallel bookkeeping) -- everything that needs no device."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,26 +127,132 @@ def test_tfrecord_codec_and_shuffle_buffer(tmp_path):
     assert all(v <= i + 10 for i, v in enumerate(out))                  # item v cannot be emitted before position v - buffer
 
 
-def test_svhn_mat_reader_and_array_dataset(tmp_path):
-    """vae/data.py:44-53: loadmat(...)['X'] is [32,32,3,N] uint8 -> [N,32,32,3] in [-1,1]; labels 10 -> 0."""
+def _write_svhn(root, n_train=7, n_extra=5, n_test=7, seed=0):
+    """Tiny data/SVHN/{train,extra,test}_32x32.mat files in the layout scipy.io.loadmat gives the reference."""
     import scipy.io
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "SVHN"), exist_ok=True)
+    out = {}
+    for name, n in (("train", n_train), ("extra", n_extra), ("test", n_test)):
+        X = rng.integers(0, 256, (32, 32, 3, n), dtype=np.uint8)
+        X[:16, :16, 0, 0] = np.arange(256, dtype=np.uint8).reshape(16, 16)     # image 0 holds every pixel level
+        y = rng.integers(1, 11, (n, 1)).astype(np.uint8)                        # SVHN labels are 1..10 (10 = digit 0)
+        scipy.io.savemat(os.path.join(root, "SVHN", name + "_32x32.mat"), {"X": X, "y": y})
+        out[name] = (X, y)
+    return out
+
+
+def test_svhn_normalisation_is_float64_then_cast():
+    """vae/data.py:52: (x / 255.0 * 2 - 1).astype(np.float32) computes in float64; every one of the 256 levels must equal
+    that, bit for bit -- the same arithmetic in fp32 is 1 ulp off on 128 of them."""
     from split_vae_amd import data
-    rng = np.random.default_rng(0)
-    X = rng.integers(0, 256, (32, 32, 3, 7), dtype=np.uint8)
-    y = np.array([[1], [10], [3], [10], [9], [2], [5]], dtype=np.uint8)
-    for name in ("train_32x32.mat", "test_32x32.mat"):
-        scipy.io.savemat(str(tmp_path / name), {"X": X, "y": y})
-    x, lab = data.load_svhn_mat(str(tmp_path / "train_32x32.mat"))
+    levels = np.arange(256, dtype=np.uint8)
+    want = np.array([np.float32(float(k) / 255.0 * 2 - 1) for k in range(256)], dtype=np.float32)   # Python floats are float64
+    got = data.normalise_u8(levels)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    fp32_way = levels.astype(np.float32) / np.float32(255.0) * np.float32(2) - np.float32(1)
+    assert int((fp32_way.view(np.uint32) != want.view(np.uint32)).sum()) == 128      # what the round-1 loader got wrong
+    # the synthetic generator draws from the same domain, the same way
+    syn = data.synthetic_images(2, 8, 8, seed=0, device="cpu").numpy()
+    assert np.isin(syn.view(np.uint32), want.view(np.uint32)).all()
+
+
+def test_svhn_reader_paths_labels_extra_and_remainder(tmp_path):
+    """vae/data.py:23-75: data/SVHN/*.mat, `svhn` = train + extra, `svhn_no_extra` = train only, labels one_hot(y - 1)
+    (digit 0 at the LAST index); vae/main.py:56-61: training batches never partial, the test set keeps its remainder."""
+    from split_vae_amd import data
+    files = _write_svhn(str(tmp_path))
+    X, y = files["train"]
+    x, lab = data.load_svhn_mat(str(tmp_path / "SVHN" / "train_32x32.mat"))
     assert x.shape == (7, 32, 32, 3) and x.dtype == np.float32
-    assert np.array_equal(x[2], (X[..., 2].astype(np.float32) / 255.0 * 2 - 1))
-    assert lab.tolist() == [1, 0, 3, 0, 9, 2, 5]
-    assert float(x.min()) >= -1.0 and float(x.max()) <= 1.0
-    tr, te, shape = data.get_dataset("svhn", batch_size=3, synthetic=False, data_dir=str(tmp_path), device="cpu")
-    assert shape == [-1, 32, 32, 3]
-    batches = list(te)                      # finite test iterator: 7 images -> two full batches of 3
-    assert len(batches) == 2 and tuple(batches[0].shape) == (3, 32, 32, 3)
-    it = iter(tr)                           # training iterator repeats
-    assert all(tuple(next(it).shape) == (3, 32, 32, 3) for _ in range(5))
+    assert np.array_equal(x, (np.transpose(X, (3, 0, 1, 2)) / 255.0 * 2 - 1).astype(np.float32))
+    assert lab.tolist() == y.reshape(-1).tolist()                   # raw labels, 1..10
+    oh = data.one_hot_svhn(np.array([[1], [10], [3]]))
+    assert oh.shape == (3, 10) and oh[0].argmax() == 0 and oh[1].argmax() == 9 and oh[2].argmax() == 2 and oh.sum() == 3
+    # no labels: bare image batches
+    tr, te, shape = data.get_dataset("svhn", batch_size=3, data_dir=str(tmp_path), device="cpu")
+    assert shape == [-1, 32, 32, 3] and not tr.labelled and not te.labelled
+    assert tr.x.shape[0] == 12 and np.array_equal(tr.x[7:], data.normalise_u8(np.transpose(files["extra"][0], (3, 0, 1, 2))))
+    tb = list(te)                                                   # 7 test images -> 3 + 3 + 1 (Dataset.batch keeps the remainder)
+    assert [tuple(b.shape) for b in tb] == [(3, 32, 32, 3), (3, 32, 32, 3), (1, 32, 32, 3)]
+    seen = np.concatenate([b.numpy() for b in tb])                  # a permutation of the test set
+    want = data.normalise_u8(np.transpose(files["test"][0], (3, 0, 1, 2)))
+    assert sorted(map(bytes, seen)) == sorted(map(bytes, want))
+    it = iter(tr)                                                   # .repeat().batch(3) over 12 images: always full batches
+    got = [next(it) for _ in range(9)]
+    assert all(tuple(b.shape) == (3, 32, 32, 3) for b in got)
+    first_epoch = np.concatenate([b.numpy() for b in got[:4]])
+    assert sorted(map(bytes, first_epoch)) == sorted(map(bytes, tr.x))          # every image once per epoch
+    tr2, _, _ = data.get_dataset("svhn_no_extra", batch_size=3, data_dir=str(tmp_path), device="cpu")
+    assert tr2.x.shape[0] == 7
+    # 7 images, batch 3, repeat: the third batch spans the epoch boundary
+    b3 = [next(iter_) for iter_ in [iter(tr2)] for _ in range(3)]
+    assert all(tuple(b.shape) == (3, 32, 32, 3) for b in b3)
+    # labels: (images, one-hot) tuples in both sets, rows aligned
+    trl, tel, _ = data.get_dataset("svhn", batch_size=4, data_dir=str(tmp_path), device="cpu", get_label=True)
+    assert trl.labelled and tel.labelled
+    xb, yb = next(iter(trl))
+    assert tuple(xb.shape) == (4, 32, 32, 3) and tuple(yb.shape) == (4, 10)
+    allx = np.concatenate([trl.x]); ally = trl.y
+    for r in range(4):
+        k = [i for i in range(allx.shape[0]) if np.array_equal(allx[i], xb[r].numpy())]
+        assert any(np.array_equal(ally[i], yb[r].numpy()) for i in k)
+    os.remove(str(tmp_path / "SVHN" / "extra_32x32.mat"))
+    with pytest.raises(FileNotFoundError):
+        data.get_dataset("svhn", batch_size=3, data_dir=str(tmp_path), device="cpu")
+    data.get_dataset("svhn_no_extra", batch_size=3, data_dir=str(tmp_path), device="cpu")
+    with pytest.raises(NotImplementedError):
+        data.get_dataset("mnist", batch_size=3, data_dir=str(tmp_path), device="cpu")          # vae/data.py:21
+
+
+def test_celeba_stream_keeps_remainder_and_spans_epochs(tmp_path):
+    from split_vae_amd import data, tfrecord as tfr
+    rng = np.random.default_rng(1)
+    imgs = (rng.integers(0, 256, (7, 64, 64, 3)) / 255.0 * 2 - 1).astype(np.float32)
+    os.makedirs(str(tmp_path / "celeba"))
+    for name in ("train", "test"):
+        tfr.write_celeba_tfrec(str(tmp_path / "celeba" / (name + "_64x64.tfrec")), imgs)
+    tr, te, shape = data.get_dataset("celeba64", batch_size=3, data_dir=str(tmp_path), device="cpu", get_label=True)
+    assert shape == [-1, 64, 64, 3] and not tr.labelled           # get_celeba_tfrec ignores get_label (vae/data.py:18-19)
+    assert [b.shape[0] for b in te] == [3, 3, 1]
+    it = iter(tr)
+    assert all(next(it).shape[0] == 3 for _ in range(6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["-no_label"]], ids=["labels", "no_label"])
+def test_main_runs_on_svhn_files(tmp_path, monkeypatch, capsys, flags, lib_built):
+    """The reference's first README command (main.py --beta 40 --patch_size 1, SVHN with labels) and its -no_label form,
+    driven through main() on tiny .mat files: labelled batches are (images, labels) tuples and the step sees [B,32,32,6]."""
+    from split_vae_amd import main as svmain
+    _write_svhn(str(tmp_path / "data"), n_train=9, n_extra=4, n_test=5)
+    monkeypatch.chdir(tmp_path)
+    path = svmain.main(["--beta", "40", "--patch_size", "1", "--batch_size", "4", "--training_steps", "3", "--log_every", "2",
+                        "--dtype", "f32"] + flags)
+    out = capsys.readouterr().out
+    assert "Training step 0" in out and "Training step 2" in out and "Training done!" in out
+    assert os.path.exists(path)
+    assert ("classifier-based test metrics are not available" in out) == (not flags)
+
+
+@pytest.mark.gpu
+def test_main_runs_on_celeba_tfrec(tmp_path, monkeypatch, capsys, lib_built):
+    """README CelebA command (--dataset celeba64 --beta 120 --patch_size 8 -no_label) on a tiny TFRecord pair, and the
+    same without -no_label: the CelebA files serve no labels, the run continues unlabelled."""
+    from split_vae_amd import main as svmain, tfrecord as tfr
+    rng = np.random.default_rng(2)
+    imgs = (rng.integers(0, 256, (25, 64, 64, 3)) / 255.0 * 2 - 1).astype(np.float32)
+    os.makedirs(str(tmp_path / "data" / "celeba"))
+    for name in ("train", "test"):
+        tfr.write_celeba_tfrec(str(tmp_path / "data" / "celeba" / (name + "_64x64.tfrec")), imgs)
+    monkeypatch.chdir(tmp_path)
+    for flags in (["-no_label"], []):
+        svmain.main(["--dataset", "celeba64", "--beta", "120", "--patch_size", "8", "--batch_size", "20", "--training_steps", "2",
+                     "--log_every", "2"] + flags)
+        out = capsys.readouterr().out
+        assert "Training done!" in out
+        assert ("serves no labels" in out) == (not flags)
+    assert any(f.startswith("style_transfer_celeba") for d, _, fs in os.walk(str(tmp_path / "output")) for f in fs)
 
 
 def test_png_writer_round_trip(tmp_path):
