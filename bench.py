@@ -9,181 +9,332 @@ beta=120, patch_size=8, latents 128+128, lr 1e-4, bf16 MFMA contractions with fp
 master weights / ELBO / Adam.  Per-GPU batch is fixed at 512 (weak scaling): `value` is the
 whole-job aggregate N*512*K / t.
 
-    python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py                                  # N=1, 200 timed steps
+    python bench.py --gpus N --steps K --warmup W    # N>1: spawns N ranks itself (one per GPU, RCCL), or runs as one
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # rank of a launcher that set WORLD_SIZE
 
-Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, hipEvent-timed inside
-the timed region on the launch stream) and `cpu_baseline` (the oracle restatement timed on the
-host cores; N=1 only; reported baseline, not the target).
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      dominant kernel (hipEvent-timed inside the timed region on its launch stream), the decoder conv stack
+                aggregate (north_star's >= 70 % target) and the HBM-bound ELBO kernel
+  cpu_baseline  the oracle restatement timed on the host cores (N=1 only; reported baseline, not the target)
+  rows          the other configurations of BASELINE.md section 4 measured in the same process, outside the timed region:
+                fp32 parity path, SVHN-32 B=64, the 64- and 128-image shards of config 4 (strong scaling)
+  rccl_ranks / allreduce_ms / strong   (N>1) the collective actually used, its per-bucket time, the 512-global-batch row
+The per-launch table goes to stderr.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
-# plan scope -> the stem of its HIP kernel symbol (as rocprofv3 prints it; the trailing template arguments select
-# variants of the same kernel) for the launches that can be the dominant one
-SCOPE_KERNEL = {"fwd.d5": "_Z16tile_conv_kernelIDF16bLi16ELi4ELi4E",
-                "wgrad.d5": "void wgrad_tile_kernel<11, ",
-                "wgrad.d4": "void wgrad_tile_kernel<9, 1, 2, 8, ",
-                "dgrad.d4": "_Z16tile_conv_kernelIDF16bLi64ELi4ELi4ELi6E",
-                "fwd.d4": "_Z16tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_k_traffic.json")   # scripts/traffic.sh: FETCH_SIZE / WRITE_SIZE passes
-
-
-def measured_traffic(scope):
-    """(HBM bytes per launch, kernel symbol) of the scope's kernel from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 x2 read correction); (None, stem) when not measured."""
-    stem = SCOPE_KERNEL.get(scope)
-    try:
-        kernels = json.load(open(TRAFFIC_FILE))["kernels"]
-        hits = [(n, k) for n, k in kernels.items() if stem and n.startswith(stem)]
-        if len(hits) == 1:
-            return hits[0][1]["hbm_bytes_per_launch"], hits[0][0]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None, stem
-
-
+PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}   # BASELINE.md section 2
+PROFILE_TAG = "r02"                             # profiles/<tag>_traffic.json: the committed PMC passes `traffic` cites
 
 
-def cpu_baseline(H, patch, beta, seconds_budget=20.0):
-    """The oracle (torch-CPU fp32 restatement, kind "port") on this box's host cores: same step
-    definition on a bounded sample of the workload (a 128-image batch instead of 512)."""
+def _traffic_file():
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_*traffic.json")))
+    return c[-1] if c else os.path.join(ROOT, "profiles", "r01_k_traffic.json")
+
+
+def measured_traffic(kernel_stems):
+    """(HBM bytes per launch, kernel symbol, file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate runs, gfx950 x2 read correction) for the first stem that matches exactly one kernel; the
+    value is CACHED evidence of that profile run, not measured by this process: None when no symbol matches."""
+    path = _traffic_file()
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None, path
+    for stem in kernel_stems:
+        hits = [(n, k) for n, k in kernels.items() if stem and stem in n]
+        if len(hits) == 1:
+            return hits[0][1]["hbm_bytes_per_launch"], hits[0][0], path
+    return None, None, path
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (torch-CPU fp32 restatement, kind "port") on this box's host cores, SURVEY 8d: config C1 (SVHN-32
+    B=64) for >= 20 steps and the headline workload (CelebA-64 B=512) for >= 3 steps, same step definition
+    (scramble + forward + ELBO + backward + Keras-Adam).  `value` is the CelebA-64 B=512 rate, the unit of `metric`."""
     import numpy as np
+    import torch
     from oracle import np_ref, torch_ref
     # measured on the GPU box (256 hardware threads): the oneDNN/ATen step peaks at 16 threads
     # (8: 320, 16: 499, 32: 460, 64: 208, 128: 96, 256: 1.5 images/s), so 16 is what is used and reported
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    Bc = 128
-    rng = np.random.Generator(np.random.PCG64(0))
-    x = (rng.integers(0, 256, size=(Bc, H, H, 3)) / 255.0 * 2 - 1).astype(np.float32)
-    G2 = (H // patch) ** 2
-    tr = torch_ref.RefTrainer(np_ref.glorot_init(H, H, seed=3), beta, dtype=torch.float32)
-    eps = torch.randn(2, Bc, 128)
 
-    def one():
-        perm = np.stack([rng.permutation(G2) for _ in range(Bc)])
-        img = torch_ref.scramble_batch(torch.from_numpy(x), perm, patch)
-        tr.train_step(img, eps[0], eps[1])
+    def run(H, Bc, patch, beta, min_steps, budget):
+        rng = np.random.Generator(np.random.PCG64(0))
+        x = (rng.integers(0, 256, size=(Bc, H, H, 3)) / 255.0 * 2 - 1).astype(np.float32)
+        G2 = (H // patch) ** 2
+        tr = torch_ref.RefTrainer(np_ref.glorot_init(H, H, seed=3), beta, dtype=torch.float32)
+        eps = torch.randn(2, Bc, 128)
 
-    one()
-    t0 = time.time()
-    n = 0
-    while True:
+        def one():
+            perm = np.stack([rng.permutation(G2) for _ in range(Bc)])
+            img = torch_ref.scramble_batch(torch.from_numpy(x), perm, patch)
+            tr.train_step(img, eps[0], eps[1])
+
         one()
-        n += 1
-        dt = time.time() - t0
-        if dt > seconds_budget or n >= 40:
-            break
-    return {"value": round(Bc * n / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of a %d-image CelebA-64 batch (scramble+fwd+ELBO+bwd+Adam), torch-CPU fp32 "
-                      "restatement of the TF2 reference (TF2 not installable)" % (n, Bc)}
+        t0, n = time.time(), 0
+        while True:
+            one()
+            n += 1
+            dt = time.time() - t0
+            if n >= min_steps and (dt > budget or n >= 4 * min_steps):
+                break
+        return Bc * n / dt, n
+
+    svhn, n1 = run(32, 64, 1, 40.0, 20, 0.3 * seconds_budget)
+    celeba, n2 = run(64, 512, 8, 120.0, 3, 0.7 * seconds_budget)
+    return {"value": round(celeba, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "svhn32_b64": round(svhn, 2),
+            "sample": "%d steps of a 512-image CelebA-64 batch (value) and %d steps of a 64-image SVHN-32 batch (svhn32_b64); "
+                      "scramble+fwd+ELBO+bwd+Adam, torch-CPU fp32 restatement of the TF2 reference (TF2 not installable), "
+                      "%d of the box's %d hardware threads (the restatement's measured optimum)" % (n2, n1, cores, os.cpu_count() or 1)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
+    touches the GPU, wait for them, exit non-zero if any failed.  Rank 0 prints the JSON line."""
+    import torch
+    have = torch.cuda.device_count()             # counting devices does not initialise HIP on this image
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but this box has %d GPU(s): refusing to report a %d-GPU number from fewer "
+                         "devices (one rank per GPU over RCCL is the contract)\n" % (n, have, n))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, c))
+            rc = rc or (c if c > 0 else 1)
+    return rc
+
+
+class Workload:
+    """One configuration of the step, resident on this rank's GPU."""
+
+    def __init__(self, H, B, dtype, dev, rank, world, reducer_cls=None):
+        from split_vae_amd import data
+        from split_vae_amd.augmentation import Augmentator
+        from split_vae_amd.model import LGVae
+        from split_vae_amd.optimizer import Adam
+        self.H, self.B, self.dtype = H, B, dtype
+        self.beta, self.patch = (120.0, 8) if H == 64 else (40.0, 1)
+        self.model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=dtype, device=dev, seed=3)
+        self.model.beta = self.beta
+        self.opt = Adam(learning_rate=1e-4)
+        self.aug = Augmentator("scramble", size=self.patch, seed=1)
+        self.off = rank * B
+        self.x = data.synthetic_images(B, H, H, seed=0, device=dev, sample_offset=self.off)   # resident in HBM
+        self.reducer = reducer_cls(self.model.param_table, self.model.n_params) if (reducer_cls and world > 1) else None
+
+    def step(self):
+        from split_vae_amd import trainer
+        images = self.aug.augment(self.x, sample_offset=self.off)
+        return trainer.train_step(self.model, images, self.opt, reducer=self.reducer, sample_offset=self.off)
+
+    def timed(self, steps, warmup, world, dev):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks -> seconds."""
+        import torch
+        import torch.distributed as tdist
+        for _ in range(max(warmup, 1)):
+            self.step()
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            tdist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+
+TABLE_PASSES = 3
+
+
+def kernel_table(w, passes=TABLE_PASSES):
+    """Per-launch hipEvent table of the whole step (serial launches: the weight-gradient side stream is off in this
+    mode), outside the timed region."""
+    import torch
+    plan = w.step()
+    torch.cuda.synchronize()
+    plan.profile_filter(None)
+    plan.profile_enable(True)
+    for _ in range(passes):
+        w.step()
+    torch.cuda.synchronize()
+    table = plan.profile_read()
+    plan.profile_enable(False)
+    table.sort(key=lambda r: -r["total_ms"])
+    return plan, table
+
+
+DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "upsample_bwd", "upsample_fwd")   # d2..d5 convs + everything that exists only for them
+
+
+def decoder_stack(table, dtype, passes):
+    """FLOPs and time of both decoders' conv stacks (d2..d5: forward, input and weight gradients incl. their slab reduces,
+    the bilinear-resize adjoints) from the serial per-launch table -- the sub-target north_star quotes against the MFMA peak."""
+    fl = ms = 0.0
+    for r in table:
+        n = r["name"]
+        if not n.startswith(DECODER_STACK) or n.split(".")[1].startswith("d1"):
+            continue
+        ms += r["total_ms"] / passes
+        fl += r["flops"] * r["launches"] / passes
+    ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+    return {"flops_per_step": fl, "ms_per_step": round(ms, 4), "achieved": round(ach, 1), "unit": "TFLOP/s",
+            "peak": PEAK_TFLOPS[dtype], "frac": round(ach / PEAK_TFLOPS[dtype], 4),
+            "scope": "d2-d5 of both decoders: fwd + dgrad + wgrad (+ slab reduce) + resize adjoint, serial launches"}
+
+
+# plan scope -> substrings of its HIP kernel symbol as rocprofv3 prints it (profiles/*_traffic.json keys)
+SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi16ELi4ELi4E"], "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
+                "dgrad.d4": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi6E"], "wgrad.d5": ["wgrad_tile_kernel<11, "],
+                "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling: the default, 512 per GPU)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling instead: total batch split evenly over the GPUs (e.g. 512 -> 64 per GPU at N=8, SURVEY config C4)")
     ap.add_argument("--size", type=int, default=64, choices=[32, 64])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-all", action="store_true", help="print the per-kernel hipEvent table to stderr")
+    ap.add_argument("--no-rows", action="store_true", help="skip the extra configurations (fp32, SVHN-32, small shards)")
+    ap.add_argument("--profile-all", action="store_true", help="(kept for compatibility: the per-launch table always goes to stderr)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # nothing above touched the GPU
+
+    import torch
     from split_vae_amd import dist as svdist
     rank, local_rank, world = svdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report one as the other" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); none visible")
+    backend = torch.distributed.get_backend() if world > 1 else None
     dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real N-GPU node; lets a gloo dry run share one GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    from split_vae_amd import data, trainer
-    from split_vae_amd.augmentation import Augmentator
-    from split_vae_amd.model import LGVae
-    from split_vae_amd.optimizer import Adam
-    import torch.distributed as tdist
-
-    H = args.size
-    B = args.batch
+    H, B = args.size, args.batch
     if args.global_batch:
         if args.global_batch % world:
             raise SystemExit("--global-batch %d is not divisible by %d GPUs" % (args.global_batch, world))
         B = args.global_batch // world
-    beta, patch = (120.0, 8) if H == 64 else (40.0, 1)
-    model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=args.dtype, device=dev, seed=3)
-    model.beta = beta
-    opt = Adam(learning_rate=1e-4)
-    aug = Augmentator("scramble", size=patch, seed=1)
-    off = rank * B
-    x = data.synthetic_images(B, H, H, seed=0, device=dev, sample_offset=off)   # resident in HBM
-    reducer = svdist.GradReducer(model.param_table, model.n_params) if world > 1 else None
-
-    def step():
-        images = aug.augment(x, sample_offset=off)
-        return trainer.train_step(model, images, opt, reducer=reducer, sample_offset=off)
-
-    plan = None
+    w = Workload(H, B, args.dtype, dev, rank, world, svdist.make_reducer)
     for _ in range(max(args.warmup, 1)):
-        plan = step()
+        w.step()
     torch.cuda.synchronize()
 
-    # find the dominant kernel family with a short fully-instrumented pass (outside the timed region)
-    plan.profile_filter(None)
-    plan.profile_enable(True)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    table = plan.profile_read()
-    plan.profile_enable(False)
-    table.sort(key=lambda r: -r["total_ms"])
-    if args.profile_all and rank == 0:
+    # per-launch table + the dominant kernel family (outside the timed region)
+    plan, table = kernel_table(w)
+    if rank == 0:
         tot = sum(r["total_ms"] for r in table)
+        sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (args.dtype, H, H, B))
         for r in table:
             avg = r["total_ms"] / max(r["launches"], 1)
             tf = r["flops"] / (avg * 1e-3) / 1e12 if r["flops"] else 0.0
             gb = r["bytes"] / (avg * 1e-3) / 1e9 if r["bytes"] else 0.0
-            print("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s" %
-                  (r["name"], r["launches"], avg, 100 * r["total_ms"] / tot, tf, gb), file=sys.stderr)
+            frac = tf / PEAK_TFLOPS[args.dtype] if tf else gb / PEAK_HBM_GBS
+            sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of peak\n" %
+                             (r["name"], r["launches"], avg, 100 * r["total_ms"] / tot, tf, gb, 100 * frac))
     dom = next(r for r in table if r["flops"] > 0)
 
     plan.profile_filter(dom["name"])
     plan.profile_enable(True)
-    if world > 1:
-        tdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        tdist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = w.timed(args.steps, 0, world, dev)               # the warm-up already ran
     prof = [r for r in plan.profile_read() if r["name"] == dom["name"]]
     plan.profile_enable(False)
 
+    extra = {}
+    if world > 1:
+        # per-bucket all-reduce time, alone on the chip (what the backward has to hide)
+        ar = {}
+        for name in w.reducer.buckets:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for it in range(6):
+                if it == 1:
+                    torch.cuda.synchronize(); e0.record()
+                w.reducer.launch(w.model.grad_flat, name)
+                w.reducer.wait()
+            e1.record(); torch.cuda.synchronize()
+            ar[name] = round(e0.elapsed_time(e1) / 5, 4)
+        native = os.environ.get("SV_DIST_BACKEND") == "sv_comm"
+        extra["rccl_ranks"] = world if (backend == "nccl" or native) else 0
+        extra["dist_backend"] = "sv_comm (RCCL through the C ABI)" if native else backend
+        extra["allreduce_ms"] = ar
+        extra["allreduce_bytes"] = {k: int(sum(e - b for b, e in v) * 4) for k, v in w.reducer.buckets.items()}
+        if not args.global_batch and 512 % world == 0 and H == 64:
+            # the strong-scaling row of config 4: global batch 512 split over the ranks (64 per GPU at N = 8)
+            ws = Workload(64, 512 // world, args.dtype, dev, rank, world, svdist.make_reducer)
+            ks = max(args.steps, 100)
+            dts = ws.timed(ks, 10, world, dev)
+            extra["strong"] = {"global_batch": 512, "per_gpu_batch": 512 // world, "value": round(512 * ks / dts, 1),
+                               "ms_per_step": round(1e3 * dts / ks, 4), "steps": ks, "scaling": "strong"}
+            del ws
+    rows = {}
+    if world == 1 and not args.no_rows and H == 64 and args.dtype == "bf16" and B == 512:
+        def row(Hr, Br, dt_, steps, warm=10):
+            wr = Workload(Hr, Br, dt_, dev, 0, 1)
+            t = wr.timed(steps, warm, 1, dev)
+            r = {"value": round(Br * steps / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t / steps, 4), "steps": steps,
+                 "step_tflops": round(Br * steps / t * TRAIN_FLOP_PER_IMAGE[Hr] / 1e12, 2)}
+            r["frac_of_peak"] = round(r["step_tflops"] / PEAK_TFLOPS[dt_], 4)
+            return r
+        rows["fp32"] = row(64, 512, "f32", 40, 5)              # the fp32-parity path (the reference's own precision)
+        rows["fp32"]["frac_of_157TF"] = rows["fp32"].pop("frac_of_peak")
+        rows["svhn32_b64"] = row(32, 64, "bf16", 200)          # config C1's shape on the GPU
+        rows["celeba64_b64"] = row(64, 64, "bf16", 200)        # config 4's per-GPU shard (512 / 8)
+        rows["celeba64_b128"] = row(64, 128, "bf16", 200)
+        rows["long_run"] = {"steps": 400, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
+
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     value = world * B * args.steps / dt
     out = {
@@ -194,25 +345,41 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "SPLIT-VAE %s %dx%d beta=%g patch_size=%d latents=128+128 lr=1e-4, full train step "
                                "(scramble+fwd+ELBO+bwd+Adam%s), per-GPU batch %d" %
-                               ("CelebA-64" if H == 64 else "SVHN-32", H, H, beta, patch,
+                               ("CelebA-64" if H == 64 else "SVHN-32", H, H, w.beta, w.patch,
                                 "+RCCL grad all-reduce" if world > 1 else "", B),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world},
         "step_tflops": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12, 2),
+        "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[args.dtype] / world, 4),
     }
+    out.update(extra)
     if prof and prof[0]["launches"]:
         avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
         ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        traffic, symbol = measured_traffic(prof[0]["name"])
+        traffic, symbol, tfile = measured_traffic(SCOPE_KERNEL.get(prof[0]["name"], []))
         out["roofline"] = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                           "traffic_source": "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, bytes per launch)" % os.path.basename(TRAFFIC_FILE),
+                           "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                             "bench, bytes per launch; null when the kernel symbol of this build is not in it)" % os.path.basename(tfile),
                            "hip_kernel": symbol,
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
-                           "flops_per_launch": prof[0]["flops"]}
+                           "flops_per_launch": prof[0]["flops"],
+                           "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
+        elbo = next((r for r in table if r["name"].startswith("dlogistic")), None)
+        if elbo and elbo["launches"]:
+            ems = elbo["total_ms"] / elbo["launches"]
+            etr, esym, _ = measured_traffic(["dlogistic_kernel"])
+            out["roofline"]["hbm"] = {"bound": "hbm", "kernel": elbo["name"], "algorithmic_bytes": elbo["bytes"],
+                                      "avg_launch_ms": round(ems, 4), "achieved": round(elbo["bytes"] / (ems * 1e-3) / 1e9, 1),
+                                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(elbo["bytes"] / (ems * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                      "traffic": etr, "traffic_gbs": round(etr / (ems * 1e-3) / 1e9, 1) if etr else None}
+    if rows:
+        out["rows"] = rows
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(H, patch, beta)
+        out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

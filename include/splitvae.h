@@ -304,6 +304,22 @@ int sv_lgvae_profile_read(sv_lgvae_plan* plan, int32_t max_entries, char names[]
                           double* total_ms, int32_t* launches, double* flops_per_launch,
                           double* bytes_per_launch);
 
+/* ---- K16 data-parallel gradient exchange: absent in the reference (single device) -----------
+ * One process per GPU; gradients of the batch-mean loss (vae/trainer.py:13,:127-128,:137) are averaged over equal
+ * shards by an in-place all-reduce(sum) of the flat fp32 gradient buffer; 1/world is sv_adam_step's grad_scale.
+ * RCCL is loaded at run time (the process's own copy if it has one, e.g. PyTorch's): SV_E_UNSUPPORTED without it.
+ *   sv_comm_unique_id   rank 0 draws the 128-byte rendezvous id and ships it to the others out of band
+ *   sv_comm_init        collective over all ranks; binds the calling thread's current HIP device
+ *   sv_comm_allreduce   enqueue on `stream` (asynchronous): buf[0..count) <- sum over ranks
+ *   sv_comm_allreduce_ranges   n disjoint element ranges [begin[i], end[i]) of one buffer as one RCCL group
+ *                       (a bucket = the contiguous runs of the parameters whose gradients one backward phase completes) */
+typedef struct sv_comm sv_comm;
+int sv_comm_unique_id(void* id128);
+int sv_comm_init(const void* id128, int32_t rank, int32_t world, sv_comm** out);
+int sv_comm_allreduce(sv_comm* comm, float* buf, int64_t count, void* stream);
+int sv_comm_allreduce_ranges(sv_comm* comm, float* base, const int64_t* begin, const int64_t* end, int32_t n, void* stream);
+int sv_comm_destroy(sv_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,11 @@ SYMBOLS = {
     "sv_gm_encoder_forward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
     "sv_gm_encoder_backward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
     "sv_gm_encoder_y_kl": (C.c_int, [_vp, _vp]),
+    "sv_comm_unique_id": (C.c_int, [_vp]),
+    "sv_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "sv_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sv_comm_allreduce_ranges": (C.c_int, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _i32, _vp]),
+    "sv_comm_destroy": (C.c_int, [_vp]),
     "sv_lgvae_param_count": (_i64, [C.POINTER(LGVaeDesc)]),
     "sv_lgvae_param_info": (C.c_int, [C.POINTER(LGVaeDesc), _i32, C.POINTER(_i64), C.POINTER(_i32),
                                       C.POINTER(_i64 * 4), C.c_char_p]),

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("SV_LIB_NAME", "libsplitvae_hip.so"))
 OBJ_TAG = os.environ.get("SV_OBJ_TAG", "")          # build variants side by side (kernel A/B experiments)
 EXTRA = os.environ.get("SV_EXTRA_FLAGS", "").split()
-SOURCES = ["pointwise.hip", "gm_pointwise.hip", "tap_gemm.hip", "tile_conv.hip", "wgrad.hip", "wgrad_tile.hip", "conv_api.hip", "lgvae_plan.hip", "gm_encoder.hip", "hostio.hip"]
+SOURCES = ["pointwise.hip", "gm_pointwise.hip", "tap_gemm.hip", "tile_conv.hip", "wgrad.hip", "wgrad_tile.hip", "conv_api.hip", "lgvae_plan.hip", "gm_encoder.hip", "hostio.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=off"]
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(len(jobs), 6) or 1) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -23,8 +23,11 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:      # SV_DIST_BACKEND=gloo: several ranks sharing one GPU (tests); RCCL wants one device per rank
             backend = os.environ.get("SV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        if backend in ("nccl", "sv_comm"):
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        if backend == "sv_comm":  # gradients over the library's own RCCL communicator (sv_comm_*); gloo only as control plane
+            backend = "gloo"
+            os.environ["SV_DIST_BACKEND"] = "sv_comm"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -61,6 +64,71 @@ def param_buckets(param_table, n_params):
     covered = sum(e - b for rs in (dec, heads, convs) for b, e in rs)
     assert covered == n_params, (covered, n_params)
     return {"decoders": dec, "enc_heads": heads, "enc_convs": convs}
+
+
+def make_reducer(param_table, n_params):
+    """GradReducer over torch.distributed (default: backend nccl = RCCL) or, with SV_DIST_BACKEND=sv_comm, NativeGradReducer
+    over the C ABI's own RCCL communicator."""
+    if os.environ.get("SV_DIST_BACKEND") == "sv_comm" and dist.is_initialized() and dist.get_world_size() > 1:
+        return NativeGradReducer(param_table, n_params)
+    return GradReducer(param_table, n_params)
+
+
+class NativeGradReducer:
+    """The same bucketed asynchronous all-reduce through sv_comm_* (include/splitvae.h): one RCCL communicator owned by
+    libsplitvae_hip.so, one dedicated HIP stream; a bucket = one RCCL group over its contiguous parameter runs, forked off
+    the compute stream by an event when the phase that filled it has been enqueued, joined before Adam.  torch.distributed
+    (any backend) only carries the 128-byte rendezvous id."""
+
+    def __init__(self, param_table, n_params, group=None):
+        import ctypes as C
+        from . import _lib
+        self.C, self.lib = C, _lib.load()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.buckets = param_buckets(param_table, n_params)
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            raw = C.create_string_buffer(128)
+            _lib.check(self.lib.sv_comm_unique_id(raw), "sv_comm_unique_id")
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        if dist.get_backend(group) == "nccl":
+            idbuf = idbuf.cuda()
+        dist.broadcast(idbuf, src=0, group=group)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.sv_comm_init(C.c_char_p(bytes(idbuf.cpu().numpy().tobytes())), self.rank, self.world,
+                                         C.byref(self.handle)), "sv_comm_init")
+        self.stream = torch.cuda.Stream()
+        self._ranges = {}
+        for k, spans in self.buckets.items():
+            n = len(spans)
+            self._ranges[k] = ((C.c_int64 * n)(*[b for b, _ in spans]), (C.c_int64 * n)(*[e for _, e in spans]), n)
+        self._dirty = False
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def launch(self, flat, bucket):
+        from . import _lib
+        self.stream.wait_stream(torch.cuda.current_stream())           # the phase that filled the bucket
+        b, e, n = self._ranges[bucket]
+        _lib.check(self.lib.sv_comm_allreduce_ranges(self.handle, self.C.c_void_p(flat.data_ptr()), b, e, n,
+                                                     self.C.c_void_p(self.stream.cuda_stream)), "sv_comm_allreduce_ranges")
+        self._dirty = True
+
+    def wait(self):
+        if self._dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)        # no host sync
+            self._dirty = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                torch.cuda.synchronize()
+                self.lib.sv_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class GradReducer:

@@ -1,0 +1,193 @@
+"""PyTorch-ROCm custom ops over the C ABI ("a thin torch.library shim that pulls pointers and the current
+HIP stream from tensors and turns non-zero codes into RuntimeError; torch.autograd.Function wrappers pair fwd/bwd").
+
+    import split_vae_amd.torch_ops            # registers the `split_vae::*` operators
+    y = split_vae_amd.torch_ops.conv2d(x, w_hwio, bias, stride=1, act="relu")          # differentiable, NHWC
+    nll = split_vae_amd.torch_ops.dlogistic_nll(images6, 0, out6)                      # differentiable in out6
+    torch.ops.split_vae.adam_step(p, g, m, v, t, lr, b1, b2, eps, scale)               # raw entry points
+
+Every operator has a HIP ("CUDA" dispatch key on ROCm) implementation only: a CPU tensor raises NotImplementedError
+from the dispatcher -- there is no CPU kernel and nothing here imports the oracle.  Each implementation is one or two
+calls into libsplitvae_hip.so (ops.py); torch owns the memory and the stream.  The whole-step plan (sv_lgvae_step) does
+not go through these ops: it sequences the same kernels natively; these exist so that the kernels compose with autograd
+in a user's own graph.
+"""
+import torch
+
+from . import ops
+
+_lib_def = torch.library.Library("split_vae", "DEF")
+_lib_impl = torch.library.Library("split_vae", "IMPL", "CUDA")        # HIP devices dispatch under the CUDA key on ROCm
+
+_lib_def.define("scramble_gather(Tensor x, Tensor perm, int patch) -> Tensor")
+_lib_def.define("conv2d_nhwc_fwd(Tensor x, Tensor w_hwio, Tensor? bias, int stride, int act, bool ups_in, bool y_f32) -> Tensor")
+_lib_def.define("conv2d_nhwc_dgrad(Tensor dy, Tensor w_hwio, Tensor? relu_mask, int H, int W, int ldx, int stride, bool ups_in) -> Tensor")
+_lib_def.define("conv2d_nhwc_wgrad(Tensor x, Tensor dy, int KH, int KW, int Cin, int Cout, int stride, bool ups_in) -> (Tensor, Tensor)")
+_lib_def.define("dlogistic_nll(Tensor images6, int ch_off, Tensor out6, float grad_scale, bool bf16_grad) -> (Tensor, Tensor)")
+_lib_def.define("reparam_kl_fwd(Tensor pre, Tensor bias, Tensor? eps, int seed, int step, int stream_id, int sample_offset) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_lib_def.define("reparam_kl_bwd(Tensor dz, Tensor z_mean, Tensor z_sig, Tensor eps, float kl_scale) -> Tensor")
+_lib_def.define("upsample2x_bwd(Tensor g_hi, Tensor? relu_mask) -> Tensor")
+_lib_def.define("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps, float grad_scale) -> ()")
+
+ACT = {None: 0, "none": 0, "relu": 1}
+
+
+def _conv(x, Cin, Cout, KH, stride, act, ups_in, y_f32, H=None, W=None):
+    B = x.shape[0]
+    H = x.shape[1] * (2 if ups_in else 1) if H is None else H
+    W = x.shape[2] * (2 if ups_in else 1) if W is None else W
+    return ops.Conv2D(B, H, W, Cin, Cout, KH, stride, act="relu" if act == 1 else None, dtype=x.dtype, y_f32=y_f32, ups_in=ups_in)
+
+
+def _impl(name):
+    def deco(fn):
+        _lib_impl.impl(name, fn)
+        return fn
+    return deco
+
+
+@_impl("scramble_gather")
+def _scramble_gather(x, perm, patch):
+    return ops.scramble_gather(x.contiguous(), perm.to(torch.int32).contiguous(), patch)
+
+
+@_impl("conv2d_nhwc_fwd")
+def _conv_fwd(x, w_hwio, bias, stride, act, ups_in, y_f32):
+    """x [B,h,w,ldx] NHWC (ldx = Cin rounded up to 8; with ups_in the conv sees the 2x bilinear upsample of x),
+    w_hwio [KH,KW,Cin,Cout] fp32 Keras layout -> y [B,OH,OW,ldy] (ldy = Cout rounded up to 8, or Cout fp32 when y_f32)."""
+    KH, KW, Cin, Cout = w_hwio.shape
+    c = _conv(x, Cin, Cout, KH, stride, act, ups_in, y_f32)
+    c.prep(w_hwio.contiguous())
+    if bias is None:
+        bias = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
+    return c.fwd(x.contiguous(), bias.contiguous())
+
+
+@_impl("conv2d_nhwc_dgrad")
+def _conv_dgrad(dy, w_hwio, relu_mask, H, W, ldx, stride, ups_in):
+    """dL/dx of the conv for x [B,H,W,ldx] (H, W: the conv's logical input size, i.e. hi-res when ups_in)."""
+    KH, KW, Cin, Cout = w_hwio.shape
+    c = _conv(dy, Cin, Cout, KH, stride, 0, ups_in, False, H=H, W=W)
+    c.prep(w_hwio.contiguous())
+    return c.dgrad(dy.contiguous(), relu_mask)
+
+
+@_impl("conv2d_nhwc_wgrad")
+def _conv_wgrad(x, dy, KH, KW, Cin, Cout, stride, ups_in):
+    c = _conv(x, Cin, Cout, KH, stride, 0, ups_in, False)
+    assert KH == KW
+    return c.wgrad(x.contiguous(), dy.contiguous(), workspace=True)
+
+
+@_impl("dlogistic_nll")
+def _dlogistic(images6, ch_off, out6, grad_scale, bf16_grad):
+    """-> (nll [B] per-image sums, grad [B,H,W,8] = grad_scale * d nll / d out6 in channels 0..5)."""
+    return ops.dlogistic_nll(images6.contiguous(), ch_off, out6.contiguous(), torch.bfloat16 if bf16_grad else torch.float32,
+                             grad_scale)
+
+
+@_impl("reparam_kl_fwd")
+def _reparam_fwd(pre, bias, eps, seed, step, stream_id, sample_offset):
+    z_mean, z_sig, z, _, kl, eps_out = ops.reparam_kl_fwd(pre.contiguous(), bias.contiguous(), eps, torch.float32, seed, step,
+                                                          stream_id, sample_offset)
+    return z, z_mean, z_sig, kl, eps_out
+
+
+@_impl("reparam_kl_bwd")
+def _reparam_bwd(dz, z_mean, z_sig, eps, kl_scale):
+    return ops.reparam_kl_bwd(dz.contiguous(), z_mean, z_sig, eps, kl_scale, torch.float32)
+
+
+@_impl("upsample2x_bwd")
+def _ups_bwd(g_hi, relu_mask):
+    return ops.upsample2x_bwd(g_hi.contiguous(), relu_mask)
+
+
+@_impl("adam_step")
+def _adam(p, g, m, v, t, lr, beta1, beta2, eps, grad_scale):
+    ops.adam_step(p, g, m, v, t, lr, beta1, beta2, eps, grad_scale)
+
+
+# ---------------------------------------------------------------------------------------------- autograd pairing
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_hwio, bias, stride, act, ups_in, y_f32):
+        a = ACT[act]
+        y = torch.ops.split_vae.conv2d_nhwc_fwd(x, w_hwio, bias, stride, a, ups_in, y_f32)
+        ctx.save_for_backward(x, w_hwio, y if a else None)
+        ctx.cfg = (stride, a, ups_in, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, a, ups_in, has_bias = ctx.cfg
+        KH, KW, Cin, Cout = w.shape
+        gy = gy.to(x.dtype)
+        if gy.shape[-1] != (Cout + 7) // 8 * 8:                       # fp32 head (y_f32): pad the gradient to the 8-channel pitch
+            gy = torch.nn.functional.pad(gy, (0, (Cout + 7) // 8 * 8 - gy.shape[-1]))
+        if a:                                                         # this layer's ReLU: dY * (y > 0)
+            gy = gy * (y > 0).to(gy.dtype)
+        gy = gy.contiguous()
+        H, W = x.shape[1] * (2 if ups_in else 1), x.shape[2] * (2 if ups_in else 1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.split_vae.conv2d_nhwc_dgrad(gy, w, None, H, W, x.shape[-1], stride, ups_in)
+            if ups_in:                                                # adjoint of the fused bilinear resize
+                gx = torch.ops.split_vae.upsample2x_bwd(gx, None)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw, gb = torch.ops.split_vae.conv2d_nhwc_wgrad(x, gy, KH, KW, Cin, Cout, stride, ups_in)
+        return gx, gw, (gb if has_bias else None), None, None, None, None
+
+
+def conv2d(x, w_hwio, bias=None, stride=1, act=None, ups_in=False, y_f32=False):
+    """Conv2D(padding='same') of vae/model.py:36-38,:153-156 on the MFMA kernels, differentiable in x, w, bias.
+    x is NHWC with its channel pitch padded to a multiple of 8 (pad channels must be zero)."""
+    return _Conv2dFn.apply(x, w_hwio, bias, stride, act, ups_in, y_f32)
+
+
+class _DlogisticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images6, ch_off, out6):
+        nll, grad = torch.ops.split_vae.dlogistic_nll(images6, ch_off, out6, 1.0, False)
+        ctx.save_for_backward(grad)
+        return nll
+
+    @staticmethod
+    def backward(ctx, g_nll):
+        (grad,) = ctx.saved_tensors                                   # d nll_b / d out6 (fused into the forward kernel)
+        return None, None, grad[..., :6] * g_nll.view(-1, 1, 1, 1)
+
+
+def dlogistic_nll(images6, ch_off, out6):
+    """Per-image discretised-logistic NLL sums (vae/trainer.py:21-38 + reduce_sum[1,2,3], :127): images6 [B,H,W,6] fp32
+    (x at channels ch_off..ch_off+2), out6 [B,H,W,6] fp32 (mean | log_scale) -> [B]; differentiable in out6."""
+    return _DlogisticFn.apply(images6, ch_off, out6)
+
+
+class _ReparamKlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, bias, eps):
+        z, z_mean, z_sig, kl, eps_out = torch.ops.split_vae.reparam_kl_fwd(pre, bias, eps, 0, 0, 0, 0)
+        ctx.save_for_backward(z_mean, z_sig, eps_out)
+        ctx.mark_non_differentiable(z_mean, z_sig)
+        return z, kl, z_mean, z_sig
+
+    @staticmethod
+    def backward(ctx, gz, gkl, _gm, _gs):
+        z_mean, z_sig, eps = ctx.saved_tensors
+        # the kernel applies ONE scalar KL weight: d(sum_b w_b kl_b) needs a uniform w_b (batch mean * beta: what the step uses)
+        w = gkl.reshape(-1)
+        if not bool((w == w[0]).all()):
+            raise NotImplementedError("reparam_kl backward takes a uniform KL cotangent (e.g. beta * kl.mean())")
+        g = torch.ops.split_vae.reparam_kl_bwd(gz.contiguous(), z_mean, z_sig, eps, float(w[0]))
+        L = z_mean.shape[1]
+        gb = g.sum(dim=0)
+        return g, torch.cat([gb[:L], gb[L:]]), None
+
+
+def reparam_kl(pre, bias, eps):
+    """Sampling + KL (vae/model.py:9-13,:111-113; vae/trainer.py:11-15) on the head pre-activations pre [B,2L] (mean |
+    sd, before bias and softplus), bias [2L], eps [B,L] -> (z, kl [B] per-image terms, z_mean, z_sig); differentiable in
+    pre and bias through z and a uniformly weighted kl."""
+    return _ReparamKlFn.apply(pre, bias, eps)

@@ -16,8 +16,8 @@ from split_vae_amd.optimizer import Adam                    # noqa: E402
 
 def main():
     out, GB, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    rank, _, world = svdist.init_from_env()
-    torch.cuda.set_device(0)
+    rank, local_rank, world = svdist.init_from_env()
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())      # nccl: one device per rank; gloo: the ranks share device 0
     H, patch = 32, 4
     lo, hi = svdist.shard_bounds(GB, rank, world)
     model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="f32", device="cuda", seed=3)
@@ -25,7 +25,7 @@ def main():
     opt = Adam(learning_rate=1e-3)
     aug = Augmentator("scramble", size=patch, seed=1)
     x = data.synthetic_images(hi - lo, H, H, seed=0, device="cuda", sample_offset=lo)
-    reducer = svdist.GradReducer(model.param_table, model.n_params) if world > 1 else None
+    reducer = svdist.make_reducer(model.param_table, model.n_params) if world > 1 else None
     losses = []
     for _ in range(steps):
         img = aug.augment(x, sample_offset=lo)

@@ -23,12 +23,12 @@ def _free_port():
     return p
 
 
-def _run(world, out, gb=32, steps=3):
+def _run(world, out, gb=32, steps=3, backend="gloo"):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r) if backend == "nccl" else "0", WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SV_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps)],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -47,6 +47,61 @@ def test_two_ranks_equal_one(lib_built, tmp_path):
     # Adam turns rounding-level differences of near-zero gradients into full-lr moves: compare to the 3-step movement
     assert np.linalg.norm(p1 - p2) <= 5e-2 * np.linalg.norm(p1 - _init_params())
     assert np.all(np.isfinite(two["losses"]))
+
+
+@pytest.mark.parametrize("backend", ["nccl", "sv_comm"])
+def test_two_ranks_over_rccl_equal_one(lib_built, tmp_path, backend):
+    """The same equivalence with the production backends: one rank per GPU, `nccl` (= RCCL over xGMI through
+    torch.distributed) and `sv_comm` (RCCL through the C ABI's own communicator).  Needs two devices."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL wants one device per rank; this box has %d" % torch.cuda.device_count())
+    one = _run(1, str(tmp_path / "one.npz"))
+    two = _run(2, str(tmp_path / "two.npz"), backend=backend)
+    g1, g2 = one["grads"], two["grads"] / 2.0
+    assert np.linalg.norm(g1 - g2) <= 2e-3 * np.linalg.norm(g1)
+    assert np.linalg.norm(one["params"] - two["params"]) <= 5e-2 * np.linalg.norm(one["params"] - _init_params())
+
+
+def test_sv_comm_single_rank_on_the_device(lib_built):
+    """sv_comm_* end to end on the one GPU of this box: RCCL is found at run time, a world-1 communicator is created on the
+    current device, all-reduce(sum) over one rank leaves the buffer as it was, asynchronously on the caller's stream."""
+    import ctypes as C
+    import torch
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    raw = C.create_string_buffer(128)
+    assert lib.sv_comm_unique_id(raw) == 0 and any(raw.raw)
+    h = C.c_void_p()
+    assert lib.sv_comm_init(raw, 0, 1, C.byref(h)) == 0 and h.value
+    assert lib.sv_comm_init(raw, 1, 1, C.byref(C.c_void_p())) == _lib.STATUS_BADARG        # rank outside [0, world)
+    buf = torch.randn(1 << 20, device="cuda")
+    want = buf.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    assert lib.sv_comm_allreduce(h, C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(st.cuda_stream)) == 0
+    b, e = (C.c_int64 * 2)(0, 4096), (C.c_int64 * 2)(1024, 8192)
+    assert lib.sv_comm_allreduce_ranges(h, C.c_void_p(buf.data_ptr()), b, e, 2, C.c_void_p(st.cuda_stream)) == 0
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    assert lib.sv_comm_allreduce(h, None, 4, None) == _lib.STATUS_BADARG
+    assert lib.sv_comm_destroy(h) == 0
+
+
+def test_bench_refuses_more_ranks_than_gpus(lib_built):
+    """`python bench.py --gpus N` spawns N ranks itself; with fewer devices than N it must fail loudly, never report
+    a 1-GPU number as an N-GPU one."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+    # a rank count that disagrees with the launcher's WORLD_SIZE is refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
 def _init_params():
