@@ -107,6 +107,33 @@ __device__ __forceinline__ float u32_to_unit_open(uint32_t u) {   // (0,1]
   return ((float)(u >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
+// Raise a kernel's dynamic-LDS cap (hipFuncAttributeMaxDynamicSharedMemorySize) when a launch needs more than any launch
+// of that kernel ON THAT DEVICE asked for before.  The only process-wide state of the library: a mutex-protected
+// (device, kernel) -> bytes table, so concurrent host threads and several devices in one process are safe.
+#include <map>
+#include <mutex>
+#include <utility>
+inline void sv_ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> have;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& cur = have[std::make_pair(dev, kernel)];
+  if (bytes > cur) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    cur = bytes;
+  }
+}
+
+// Timing-ablation bits (skip staging / the MFMA loop / stores: WRONG results, for profiling only) exist only in builds
+// with -DSV_DEBUG_KNOBS (SV_EXTRA_FLAGS=-DSV_DEBUG_KNOBS python split_vae_amd/build.py); the shipped library has none.
+#ifdef SV_DEBUG_KNOBS
+#define SV_DBG(x) (x)
+#else
+#define SV_DBG(x) 0
+#endif
+
 static inline int ilog2_exact(int v) {   // -1 if not a power of two
   if (v <= 0 || (v & (v - 1))) return -1;
   int l = 0;

@@ -70,6 +70,8 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
 int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStream_t st);
 int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg, hipStream_t st);
 int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st);
+// weight-stationary row-ring kernel (row_conv.hip): SV_E_UNSUPPORTED when the shape has no instantiation
+int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st);
 // picks the direct kernel when the problem fits it, the im2col tap GEMM otherwise
 int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st);
 

@@ -1,0 +1,529 @@
+// Weight-stationary stride-1 NHWC convolution for the decoder stack (d3/d4 forward and input gradients), gfx950.
+//
+// tile_conv.hip re-streams the weight tile of every K step through LDS for every 256-pixel tile and runs its phases
+// (stage -> K loop -> store) one after the other inside a workgroup.  Here the roles are turned around:
+//
+//   * WEIGHTS LIVE IN REGISTERS.  A wave owns a 16-channel output block and (all of, or half of) K: its share of the
+//     prepared weight image [Cout][tap][Cin] is loaded ONCE per workgroup into <= 144 VGPRs as MFMA A-operands
+//     (v_mfma_f32_16x16x32_bf16, D = W x pixels) and stays there for every image the workgroup processes.
+//   * THE IMAGE ROLLS THROUGH AN LDS ROW RING.  A workgroup (8 waves, one per CU) walks an image top to bottom in steps
+//     of STEP output rows; the ring holds the STEP + KH - 1 input rows of the current step and the STEP rows of the
+//     next one, so every input row is staged exactly once (no vertical halo re-staging; with the fused 2x bilinear
+//     upsample, vae/model.py:163-167, the hi-res rows are blended on the fly from the LOW-RES tensor, bitwise as
+//     tile_stage.hip.h does it).  Rows are planar (32-B planes, as tile_stage.hip.h: conflict-free ds_read_b128).
+//   * ROW-WINDOW REUSE from registers: for one 16-pixel strip, filter column kx and 32-channel chunk, a wave reads the
+//     MF + KH - 1 input-row fragments once and issues MF * KH MFMAs from them (9 LDS reads per 24 MFMAs at KH = 6).
+//   * NO K-LOOP BARRIERS, NO WEIGHT TRAFFIC: the only workgroup barrier is one per step (a raw s_barrier behind
+//     lgkmcnt(0): __syncthreads() would also drain the step's global stores).  d3 (its weights need 8 waves' registers):
+//     one 8-wave workgroup per CU whose two 4-wave halves run STAGGERED (half 0 stages its share of the next step's rows,
+//     then computes; half 1 computes, then stages).  d4: 4-wave workgroups, two per CU, independent of each other.
+//   * Layers whose K does not fit 144 registers (K = 2304: d4 forward; 2048: d3 forward) split K over wave PAIRS by
+//     channel chunk; the odd wave hands its partial sums to the even one through a double-buffered LDS slot guarded by
+//     two workgroup-scope counters (no barrier: the pair stays decoupled from the other waves).
+//   * STAGING one step ahead.  Upsampled layers: the blend (global loads of the low-res pieces, packed-fp32 lerps, LDS
+//     stores).  Plain layers: LDS-DMA (global_load_lds_dwordx4) of whole in-image row planes, no registers, no VALU; the
+//     halo columns are zeroed once per launch.
+//
+// Measured (MI355X, one network pair = 1024 images per launch; profiles/r02_*): d3 forward 85 -> 82 us, d3 input
+// gradient 116 -> 70, d4 forward 174 -> 158, d4 input gradient 163 -> 129; at 128 images d3 33 -> 18 / 23 -> 18 us.
+// In-kernel stamps (SV_DEBUG_KNOBS builds, SV_RC_STAMP=1): the MFMA loop runs at 18-21 cycles per MFMA (16 = pipe
+// rate); what keeps the launch at ~55 % matrix-pipe utilisation is the per-wave serial tail around it -- stores
+// (21-26 k cycles per wave and launch), staging (20-28 k; the blend of the upsampled layers 60-120 k: its global-load
+// latency and ~300 VALU instructions per 2x2x8-channel item), weight load / unit prologue (25 k) -- which two waves per
+// SIMD that synchronise every step overlap only partly.
+//
+// Planned from the same TapGemmArgs as the other conv kernels (svk_row_conv_try), reading the same prepared weight
+// images (conv_api.hip), so it is a drop-in below svk_conv_dispatch_multi.
+#include "common.hip.h"
+#include "kernels.h"
+#include "tile_stage.hip.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+struct RowConvArgs {
+  const void* A; const void* Wt; const float* bias; void* out;
+  int B, H, W;          // logical (hi-res when `ups`) input extent == output extent (stride 1, SAME)
+  int lda, ldo, Ktot, act;
+  int y_lo, x_lo;       // tap (ky, kx) reads input pixel (y + ky + y_lo, x + kx + x_lo)
+  int bands, band_rows; // an image is cut into `bands` row bands of band_rows rows (a unit of work = one band)
+};
+struct RowConvMulti { RowConvArgs a[2]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
+
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8>
+struct RowCfg {
+  static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
+  static constexpr bool UPS = UPS_;
+  static constexpr int WAVES = WAVES_, NT = 64 * WAVES_;      // 8 waves: one workgroup per CU, its two halves staggered;
+                                                              // 4 waves: two independent workgroups per CU (<= 80 KB of LDS each)
+  static constexpr int NCH = CIN / 32, CPW = NCH / KS, NBG = N / 16 / NBW;
+  static_assert(NBG * KS * XG * RG == WAVES, "one role per wave");
+  static_assert(CIN % 32 == 0 && NCH % KS == 0 && N % (16 * NBW) == 0 && WIDTH % (16 * XG) == 0, "shape");
+  static constexpr int TIW = WIDTH + KW - 1, STEP = RG * MF, WIN = MF + KH - 1;
+  // ring rows.  8 waves: two windows (the current one + the next step's STEP new rows, or the whole first window of the
+  // workgroup's NEXT unit, staged during the last step).  4 waves: one window + one step (the next unit's first window
+  // is staged between units; the other workgroup of the CU computes meanwhile)
+  static constexpr bool PRE = WAVES == 8;
+  static constexpr int R = PRE ? 2 * (STEP + KH - 1) : 2 * STEP + KH - 1;
+  static constexpr int NPL = CIN / 16, PLB = R * TIW * 32;    // planes (two 16-B pieces each), bytes per plane
+  static constexpr int RING = NPL * PLB;
+  static constexpr int EXS = 2;                               // exchange slots per wave pair
+  static constexpr int EXF = NBW * MF * 1024;                 // bytes per slot: NBW*MF accumulator fragments of 1 KB
+  static constexpr int EXB = KS == 2 ? (WAVES / 2) * EXS * EXF : 0;
+  static constexpr int LDS = RING + EXB + 64;
+  static constexpr int SPW = WIDTH / 16 / XG;                 // strips per wave and row group
+  static constexpr int CPP = CIN / 8;                         // 16-B pieces per pixel
+};
+
+// rows [Ya, Ya + nrows) x columns [x_lo, x_lo + TIW) of the conv's logical input into ring slots qa.. (mod R); zero
+// outside the image (SAME padding lives in hi-res space).  The nt threads t take share `part` of `nparts` of the tasks.
+template <typename C>
+__device__ __forceinline__ void stage_rows(const RowConvArgs& g, int b, int Ya, int nrows, int qa, char* sRing, int t, int nt,
+                                           int part, int nparts) {
+  const bf16_t* Ab = (const bf16_t*)g.A;
+  if constexpr (C::UPS) {
+    const int LH = g.H >> 1, LW = g.W >> 1;
+    const int i_lo = (Ya - 1) >> 1, nbi = ((Ya + nrows - 2) >> 1) - i_lo + 1;
+    const int j_lo = (g.x_lo - 1) >> 1, nbj = ((g.x_lo + C::TIW - 2) >> 1) - j_lo + 1;
+    const int total = nbi * nbj * C::CPP;
+    const int t0 = (int)((int64_t)total * part / nparts), t1 = (int)((int64_t)total * (part + 1) / nparts);
+    const float inv_nbj = 1.0f / (float)nbj;
+    const bf16_t* img = Ab + (int64_t)b * LH * LW * g.lda;
+    // two tasks per thread per round: all eight global loads are issued before the first blend, so a thread pays the
+    // L2 / HBM latency once per round (a staging share is 1-2 tasks per thread)
+    for (int q = t0 + t; q < t1; q += 2 * nt) {
+      uint4 ld[2][4];
+      int ti[2], tj[2], tc[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int qq = q + k * nt;
+        const bool on = qq < t1;
+        const int c = qq & (C::CPP - 1), r2 = qq / C::CPP;
+        const int bi = (int)(((float)r2 + 0.5f) * inv_nbj), bj = r2 - bi * nbj;
+        const int i = i_lo + bi, j = j_lo + bj;
+        ti[k] = on ? i : -0x40000000; tj[k] = j; tc[k] = c;
+        const int y0 = min(max(i, 0), LH - 1), y1 = min(max(i + 1, 0), LH - 1);
+        const int x0 = min(max(j, 0), LW - 1), x1 = min(max(j + 1, 0), LW - 1);
+        const bf16_t* p = img + c * 8;
+        ld[k][0] = ld[k][1] = ld[k][2] = ld[k][3] = make_uint4(0, 0, 0, 0);
+        if (on) {
+          ld[k][0] = *(const uint4*)(p + ((int64_t)y0 * LW + x0) * g.lda);
+          ld[k][1] = *(const uint4*)(p + ((int64_t)y0 * LW + x1) * g.lda);
+          ld[k][2] = *(const uint4*)(p + ((int64_t)y1 * LW + x0) * g.lda);
+          ld[k][3] = *(const uint4*)(p + ((int64_t)y1 * LW + x1) * g.lda);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = ti[k], j = tj[k], c = tc[k];
+        uint4 blk[2][2];
+        blend2x2<bf16_t>(ld[k][0], ld[k][1], ld[k][2], ld[k][3], blk);
+#pragma unroll
+        for (int dyb = 0; dyb < 2; ++dyb) {
+          const int Y = 2 * i + 1 + dyb, d = Y - Ya;
+          if ((unsigned)d >= (unsigned)nrows) continue;
+          int slot = qa + d;
+          if (slot >= C::R) slot -= C::R;
+#pragma unroll
+          for (int dxb = 0; dxb < 2; ++dxb) {
+            const int X = 2 * j + 1 + dxb, xi = X - g.x_lo;
+            if ((unsigned)xi >= (unsigned)C::TIW) continue;
+            const bool in = (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W;
+            *(uint4*)(sRing + (c >> 1) * C::PLB + (slot * C::TIW + xi) * 32 + (c & 1) * 16) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+    }
+  } else {
+    const int total = nrows * C::TIW * C::CPP;
+    const int t0 = (int)((int64_t)total * part / nparts), t1 = (int)((int64_t)total * (part + 1) / nparts);
+    const bf16_t* img = Ab + (int64_t)b * g.H * g.W * g.lda;
+    constexpr float inv_row = 1.0f / (float)(C::TIW * C::CPP);
+    for (int q = t0 + t; q < t1; q += 4 * nt) {             // four 16-B loads in flight per thread
+      uint4 v[4];
+      int off[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int qq = q + k * nt;
+        const int d = (int)(((float)qq + 0.5f) * inv_row), r2 = qq - d * (C::TIW * C::CPP);
+        const int c = r2 & (C::CPP - 1), xi = r2 / C::CPP;
+        const int Y = Ya + d, X = g.x_lo + xi;
+        int slot = qa + d;
+        if (slot >= C::R) slot -= C::R;
+        off[k] = qq < t1 ? (c >> 1) * C::PLB + (slot * C::TIW + xi) * 32 + (c & 1) * 16 : -1;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (qq < t1 && (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W) v[k] = *(const uint4*)(img + ((int64_t)Y * g.W + X) * g.lda + c * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (off[k] >= 0) *(uint4*)(sRing + off[k]) = v[k];
+    }
+  }
+}
+
+// Non-upsampled layers: the rows go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no VALU, the wave does
+// not wait), issued a whole step ahead.  One wave-instruction moves one (row, plane): WIDTH pixels x 32 B = the in-image
+// part of the row in that plane, lane-linear (lane l = pixel l>>1, piece l&1) exactly as the plane stores it.  The halo
+// columns are zeroed once per launch and never written again; rows outside the image are zero-filled by plain stores.
+template <typename C>
+__device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int Ya, int nrows, int qa, char* sRing, int w, int nw, int lane) {
+  static_assert(C::WIDTH * 2 <= 64, "one DMA instruction per (row, plane)");
+  const bf16_t* img = (const bf16_t*)g.A + (int64_t)b * g.H * g.W * g.lda;
+  const int PL = -g.x_lo;
+  const bool on = lane < C::WIDTH * 2;
+  for (int idx = w; idx < nrows * C::NPL; idx += nw) {
+    const int d = idx / C::NPL, p = idx - d * C::NPL;
+    const int Y = Ya + d;
+    int slot = qa + d;
+    if (slot >= C::R) slot -= C::R;
+    char* dst = sRing + p * C::PLB + (slot * C::TIW + PL) * 32;
+    if ((unsigned)Y < (unsigned)g.H) {
+      const bf16_t* src = img + ((int64_t)Y * g.W + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
+      if (on) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    } else if (on) {
+      *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+#ifdef SV_DEBUG_KNOBS
+#define SV_STAMP(acc_) do { if (mg.stamps) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); acc_ += t__ - tlast; tlast = t__; } } while (0)
+#else
+#define SV_STAMP(acc_) do {} while (0)
+#endif
+
+template <typename C>
+__global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti mg) {
+  constexpr int KH = C::KH, KW = C::KW, MF = C::MF, NBW = C::NBW, CPW = C::CPW, WIN = C::WIN, R = C::R, TIW = C::TIW, STEP = C::STEP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sRing = smem;
+  char* sEx = smem + C::RING;
+  int* sFlag = (int*)(smem + C::RING + C::EXB);              // [4 pairs][2]: strips produced (odd wave), consumed (even wave)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int idx = wave;
+  const int ks = idx % C::KS; idx /= C::KS;                  // K half (fastest: partners are waves 2p, 2p+1 -- different SIMDs)
+  const int nbg = idx % C::NBG; idx /= C::NBG;
+  const int xg = idx % C::XG; idx /= C::XG;
+  const int rg = idx;                                        // row group
+  const int pair = wave >> 1, half = wave >> 2;
+  constexpr bool STAG = C::WAVES == 8 && C::UPS;            // staggered halves (only the VALU blend staging needs them)
+  constexpr int NT = C::NT;
+  const int dbg0 = SV_DBG(mg.dbg);
+  const int m = lane & 15, kq = lane >> 4;
+  const int lane_off = m * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
+  if (tid < 16) sFlag[tid] = 0;
+  const int dbg = SV_DBG(mg.dbg);                           // 1 skip staging, 2 skip the MFMA loop, 4 skip the stores, 8 skip the K-half exchange
+
+  unsigned long long tlast = 0, t_stage = 0, t_mfma = 0, t_exch = 0, t_epi = 0, t_bar = 0, t_other = 0;
+#ifdef SV_DEBUG_KNOBS
+  if (mg.stamps) tlast = __builtin_amdgcn_s_memtime();
+#endif
+  bf16x8 Wr[NBW][CPW][KW][KH];
+  float bv[NBW][4];
+  int cur_prob = -1;
+  int strips = 0;                                            // strips this wave has finished (the pair counts in lockstep)
+
+  // Every staging job is issued one step ahead: the next step's STEP new rows or -- in a unit's last step -- the whole
+  // first window of the workgroup's NEXT unit, which lands right behind the current window (R = two windows).
+  constexpr int NST = C::SPW * NBW * MF;                      // global stores a storing wave issues per step (behind its DMAs)
+  if (!(dbg & 1)) {
+    const int prob = blockIdx.x / mg.units_per_prob, r0 = blockIdx.x - prob * mg.units_per_prob;
+    const RowConvArgs& g = mg.a[prob];
+    if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
+    else {
+      const int PL = -g.x_lo;                                // halo columns of every ring row: zero, once
+      constexpr int HC = C::TIW - C::WIDTH;
+      for (int q = tid; q < C::NPL * R * HC * 2; q += NT) {
+        const int pc = q & 1, r2 = q >> 1;
+        const int hx = r2 % HC, r3 = r2 / HC;
+        const int slot = r3 % R, p = r3 / R;
+        const int xi = hx < PL ? hx : hx + C::WIDTH;
+        *(uint4*)(sRing + p * C::PLB + (slot * TIW + xi) * 32 + pc * 16) = make_uint4(0, 0, 0, 0);
+      }
+      stage_rows_dma<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  int q0 = 0;                                                // ring slot of input row y0 + y_lo of the current step
+  for (int u = blockIdx.x; u < mg.units; u += gridDim.x) {
+    const int prob = u / mg.units_per_prob;
+    const RowConvArgs& g = mg.a[prob];
+    const int r0 = u - prob * mg.units_per_prob;
+    const int band = r0 % g.bands, b = r0 / g.bands;
+    const int yb = band * g.band_rows;
+    const int un = u + gridDim.x;                            // the next unit of this workgroup
+    const bool has_next = un < mg.units;
+    const int nprob = has_next ? un / mg.units_per_prob : prob;
+    const RowConvArgs& gn = mg.a[nprob];
+    const int rn = un - nprob * mg.units_per_prob;
+    if (prob != cur_prob) {
+      cur_prob = prob;
+      const bf16_t* Wt = (const bf16_t*)g.Wt;
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const int n = (nbg * NBW + nb) * 16 + m;
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky)
+              Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[nb][e] = g.bias ? g.bias[(nbg * NBW + nb) * 16 + kq * 4 + e] : 0.f;
+      }
+    }
+    if (u == (int)blockIdx.x) __syncthreads();               // the first window (and the flag words) are in place
+    SV_STAMP(t_other);
+    const int nsteps = g.band_rows / STEP;
+    for (int s = 0; s < nsteps; ++s) {
+      const int y0 = yb + s * STEP;
+      const bool more = s + 1 < nsteps;
+      int qn = q0 + STEP + KH - 1;                           // ring slot right behind the current window
+      if (qn >= R) qn -= R;
+      // the staging job of this step
+      const bool job = (more || (has_next && C::PRE)) && !(dbg & 1);
+      const RowConvArgs& gj = more ? g : gn;
+      const int jb = more ? b : rn / gn.bands;
+      const int jY = more ? y0 + g.y_lo + STEP + KH - 1 : (rn % gn.bands) * gn.band_rows + gn.y_lo;
+      const int jrows = more ? STEP : STEP + KH - 1;
+      if constexpr (STAG) {
+        if (job && half == 0) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid, 256, 0, 2);
+      } else if constexpr (C::UPS) {
+        if (job) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid, NT, 0, 1);
+      } else {
+        if (job) stage_rows_dma<C>(gj, jb, jY, jrows, qn, sRing, wave, C::WAVES, lane);      // lands while this step computes
+      }
+      SV_STAMP(t_stage);
+      // ---------------- compute: this wave's MF rows x SPW strips x NBW channel blocks
+      const int yw = y0 + rg * MF;
+      int qw = q0 + rg * MF;
+      if (qw >= R) qw -= R;
+      for (int si = 0; si < C::SPW; ++si) {
+        const int x0 = (xg + si * C::XG) * 16;
+        int abase[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) {
+          int slot = qw + j;
+          if (slot >= R) slot -= R;
+          abase[j] = lane_off + (slot * TIW + x0) * 32;
+        }
+        f32x4 acc[NBW][MF];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+          for (int j = 0; j < MF; ++j) acc[nb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 2)) {
+          // NIT = CPW * KW window iterations (one 32-channel chunk x one filter column each).  The window ROLLS: row w of
+          // the next iteration is fetched as soon as the last MFMA that reads row w of this one has been issued, so the
+          // LDS latency of every fragment sits behind >= MF * (KH - 1) MFMAs and a wave that is alone on its SIMD (its
+          // partner staging) still keeps the matrix pipe fed
+          constexpr int NIT = CPW * KW;
+          bf16x8 win[WIN];
+#pragma unroll
+          for (int j = 0; j < WIN; ++j) win[j] = *(const bf16x8*)(sRing + abase[j]);
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int cc = it / KW, kx = it % KW;
+            const int ncc = (it + 1) / KW, nkx = (it + 1) % KW;
+#pragma unroll
+            for (int w = 0; w < WIN; ++w) {
+#pragma unroll
+              for (int ky = 0; ky < KH; ++ky) {
+                const int j = w - ky;
+                if (j < 0 || j >= MF) continue;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+                  acc[nb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[nb][cc][kx][ky], win[w], acc[nb][j], 0, 0, 0);
+              }
+              if (it + 1 < NIT) win[w] = *(const bf16x8*)(sRing + abase[w] + ncc * 2 * C::PLB + nkx * 32);
+              // pin the order: left alone, hipcc sinks every fetch to just in front of its first use (one register
+              // for all of them) and the wave stalls on the LDS latency of each fragment
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        SV_STAMP(t_mfma);
+        if (C::KS == 2 && !(dbg & 8)) {
+          // K halves meet: the odd wave of the pair publishes its partial sums, the even one adds them
+          char* slot = sEx + (pair * C::EXS + (strips & (C::EXS - 1))) * C::EXF + lane * 16;
+          if (ks == 1) {
+            while (strips - __hip_atomic_load(&sFlag[pair * 2 + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= C::EXS)
+              __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+              for (int j = 0; j < MF; ++j) *(f32x4*)(slot + (nb * MF + j) * 1024) = acc[nb][j];
+            __hip_atomic_store(&sFlag[pair * 2], strips + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            while (__hip_atomic_load(&sFlag[pair * 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= strips)
+              __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+              for (int j = 0; j < MF; ++j) acc[nb][j] += *(const f32x4*)(slot + (nb * MF + j) * 1024);
+            __hip_atomic_store(&sFlag[pair * 2 + 1], strips + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        ++strips;
+        SV_STAMP(t_exch);
+        if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
+          // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m
+          bf16_t* ob = (bf16_t*)g.out + (((int64_t)b * g.H + yw) * g.W + x0 + m) * g.ldo + kq * 4;
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[e] = acc[nb][j][e] + bv[nb][e];
+                if (g.act == SV_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+              }
+              bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              *(uint2*)(ob + (int64_t)j * g.W * g.ldo + (nbg * NBW + nb) * 16) = *(const uint2*)pk;
+            }
+        }
+        SV_STAMP(t_epi);
+      }
+      SV_STAMP(t_other);
+      if constexpr (STAG) {
+        if (job && half == 1) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid - 256, 256, 1, 2);
+      } else if constexpr (!C::UPS) {
+        // the DMAs of this step are older than its stores: wait for everything but the stores
+        if ((C::KS == 1 || ks == 0) && !(dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      SV_STAMP(t_stage);
+      // the staged rows are in place (LDS writes drained), this step's reads are done.  A raw barrier: __syncthreads()
+      // would also wait for this step's global STORES (vmcnt(0)) and expose their HBM latency once per step
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      SV_STAMP(t_bar);
+      q0 = more ? q0 + STEP : (C::PRE ? qn : 0);             // a new unit starts at its own first window
+      if (q0 >= R) q0 -= R;
+    }
+    if (!C::PRE && has_next && !(dbg & 1)) {                 // no room to prefetch: stage the next unit's first window now
+      if constexpr (C::UPS) stage_rows<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
+      else {
+        stage_rows_dma<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#ifdef SV_DEBUG_KNOBS
+  if (mg.stamps && lane == 0) {
+    unsigned long long* o = mg.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = t_stage; o[1] = t_mfma; o[2] = t_exch; o[3] = t_epi; o[4] = t_bar; o[5] = t_other;
+  }
+#endif
+}
+
+template <typename C>
+static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
+  RowConvMulti m;
+  for (int i = 0; i < n; ++i) m.a[i] = a[i];
+  if (n == 1) m.a[1] = a[0];
+  m.units_per_prob = a[0].B * a[0].bands;
+  m.units = n * m.units_per_prob;
+  m.dbg = 0;
+  m.stamps = nullptr;
+#ifdef SV_DEBUG_KNOBS
+  static const int dbg = getenv("SV_RC_DBG") ? atoi(getenv("SV_RC_DBG")) : 0;
+  m.dbg = dbg;
+  static unsigned long long* stamp_buf = nullptr;
+  static const bool stamp = getenv("SV_RC_STAMP") != nullptr;
+  if (stamp && !stamp_buf) (void)hipMalloc(&stamp_buf, 512 * 8 * 8 * 8);
+  if (stamp) { m.stamps = stamp_buf; (void)hipMemsetAsync(stamp_buf, 0, 512 * 8 * 8 * 8, st); }
+#endif
+  static const int wgs_env = getenv("SV_RC_WGS") ? atoi(getenv("SV_RC_WGS")) : 0;
+  const int wgs_max = wgs_env ? wgs_env : 256 * (8 / C::WAVES);                          // one 8-wave or two 4-wave workgroups per CU
+  const int grid = m.units < wgs_max ? m.units : wgs_max;
+  sv_ensure_dynamic_lds((const void*)row_conv_kernel<C>, C::LDS);
+  hipLaunchKernelGGL((row_conv_kernel<C>), dim3(grid), dim3(C::NT), C::LDS, st, m);
+  SV_LAUNCH_CHECK();
+#ifdef SV_DEBUG_KNOBS
+  if (m.stamps) {                                            // diagnostic build only: per-phase cycle shares of the launch
+    static int shown = 0;
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h(512 * 8 * 8);
+    (void)hipMemcpy(h.data(), m.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    if (shown++ % 16 == 15) {
+      const char* nm[6] = {"stage", "mfma", "exch", "epi", "barrier", "other"};
+      for (int hf = 0; hf < 2; ++hf) {
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < grid; ++w)
+          for (int wv = hf * (C::WAVES / 2); wv < (hf + 1) * (C::WAVES / 2); ++wv)
+            for (int k = 0; k < 6; ++k) s[k] += (double)h[((size_t)w * 8 + wv) * 8 + k];
+        fprintf(stderr, "row_conv stamps half %d (cycles per wave):", hf);
+        for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.0f", nm[k], s[k] / (grid * (C::WAVES / 2)));
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
+  return SV_OK;
+}
+
+//                 KH KW CIN   N  W  MF NBW KS XG RG UPS
+using RC_d4f = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4>;  // d4 forward   (K 2304: pairs split the two 32-channel chunks)
+using RC_d4g = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>; // d4 input gradient (K 1152)
+using RC_d3f = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;    // d3 forward   (K 2048)
+using RC_d3g = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;   // d3 input gradient (K 1024)
+
+}  // namespace
+
+// n (1 or 2: the x / x-hat twins) tap-GEMM problems of identical geometry on the row-ring kernel; SV_E_UNSUPPORTED when
+// the shape has no instantiation (the caller falls back to the tile kernel)
+int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
+  static const bool off = getenv("SV_NO_ROWCONV") != nullptr;          // A/B: the tile kernel for every layer
+  if (off || dtype != SV_BF16 || n < 1 || n > 2) return SV_E_UNSUPPORTED;
+  RowConvArgs a[2];
+  int cfg = -1;
+  for (int i = 0; i < n; ++i) {
+    const TapGemmArgs& p = t[i];
+    if (p.S != 1 || p.SX != 1 || p.OS != 1 || p.splitk != 1 || p.d2s || p.mask || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
+    const int OY = 1 << p.lOY, OX = 1 << p.lOX;
+    if (OY != p.IH || OX != p.IW || p.OHF != OY || p.OWF != OX) return SV_E_UNSUPPORTED;
+    const int cin = (1 << p.cl2) * 8;
+    if (p.lda != cin || p.Ktot != p.ntaps * cin) return SV_E_UNSUPPORTED;
+    int kh = 1;
+    while (kh < p.ntaps && p.dx[kh] == p.dx[0]) ++kh;
+    if (p.ntaps % kh) return SV_E_UNSUPPORTED;
+    const int kw = p.ntaps / kh;
+    for (int q = 0; q < p.ntaps; ++q)                                  // x-major, y-minor full grid
+      if (p.dy[q] != p.dy[0] + q % kh || p.dx[q] != p.dx[0] + q / kh) return SV_E_UNSUPPORTED;
+    int c = -1;
+    if (kh == 6 && kw == 6 && cin == 64 && p.N == 32 && OX == 32 && p.ups) c = 0;
+    else if (kh == 6 && kw == 6 && cin == 32 && p.N == 64 && OX == 32 && !p.ups) c = 1;
+    else if (kh == 4 && kw == 4 && cin == 128 && p.N == 64 && OX == 16 && p.ups) c = 2;
+    else if (kh == 4 && kw == 4 && cin == 64 && p.N == 128 && OX == 16 && !p.ups) c = 3;
+    if (c < 0 || (i && c != cfg)) return SV_E_UNSUPPORTED;
+    cfg = c;
+    const int step = 4;
+    if (OY % step || p.ldo < p.N) return SV_E_UNSUPPORTED;
+    RowConvArgs& r = a[i];
+    r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out;
+    r.B = p.M >> (p.lOY + p.lOX); r.H = OY; r.W = OX;
+    r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
+    r.y_lo = p.dy[0]; r.x_lo = p.dx[0];
+    // small batches: cut the images into row bands until there is a unit of work for every CU
+    int bands = 1;
+    while (n * r.B * bands < (c < 2 ? 512 : 256) && OY / (bands * 2) >= step && (OY / (bands * 2)) % step == 0) bands *= 2;
+    r.bands = bands; r.band_rows = OY / bands;
+    if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
+  }
+  switch (cfg) {
+    case 0: return launch_row<RC_d4f>(a, n, st);
+    case 1: return launch_row<RC_d4g>(a, n, st);
+    case 2: return launch_row<RC_d3f>(a, n, st);
+    case 3: return launch_row<RC_d3g>(a, n, st);
+  }
+  return SV_E_UNSUPPORTED;
+}

@@ -284,11 +284,7 @@ static int launch_tap(const TapGemmArgs* a, int n, hipStream_t st) {
   }
   for (int i = n; i < SV_TAP_MAX_MULTI; ++i) m.zbase[i] = gz;
   dim3 grid(gx, gy, gz), block(256);
-  static size_t attr_set = 0;   // raise the dynamic-LDS cap when a launch needs more than any before it
-  if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)tap_gemm_kernel<T, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = lds;
-  }
+  sv_ensure_dynamic_lds((const void*)tap_gemm_kernel<T, BN, WM>, lds);
   hipLaunchKernelGGL((tap_gemm_kernel<T, BN, WM>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;

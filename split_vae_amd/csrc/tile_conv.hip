@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
   // K loop of a phase runs over (all taps) x (its channels), and the accumulators carry over.  The LDS tile shrinks
   // nph-fold, so more workgroups fit a CU (the kernel is latency-bound: occupancy is what it lacks).
   const int nph = g.nph, lcH = g.cl2 - g.lnph;        // log2(16-B chunks per pixel per phase)
-  const int gP = g.P >> g.lnph, gKtot = g.Ktot, gdbg = g.dbg;   // pieces of K per phase
+  const int gP = g.P >> g.lnph, gKtot = g.Ktot, gdbg = SV_DBG(g.dbg);   // pieces of K per phase
   const int pp = tid % PPS, r0 = tid / PPS;
   int ph = 0;                                         // current phase (read by load_b)
   uint4 rbA[BRN];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     sOff[p] = off;
   }
   auto stage = [&](int phase) {                       // input tile of one phase (zero-filled outside the image)
-    if (g.dbg & 1) return;
+    if (SV_DBG(g.dbg) & 1) return;
     const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, lcH, g.TIW, g.TIH, g.PS, NB, g.plane_bytes};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
     const T* Ap = (const T*)g.A + ((phase << lcH) * EPP);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     }
   }
   __syncthreads();
-  if (g.dbg & 4) return;
+  if (SV_DBG(g.dbg) & 4) return;
   const int psz = (rowb & 15) ? 8 : 16;                 // piece size; rowb is a multiple of 8
   const int ppr_o = rowb / psz;
   for (int q = tid; q < BM * ppr_o; q += NT) {
@@ -340,11 +340,7 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
     const size_t l = tile_lds_bytes(BN, NW * 16 * MF, a[i], sizeof(T), YR);
     if (l > lds) lds = l;
   }
-  static size_t attr_set = 0;
-  if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)tile_conv_kernel<T, BN, MF, NW, YR, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = lds;
-  }
+  sv_ensure_dynamic_lds((const void*)tile_conv_kernel<T, BN, MF, NW, YR, WR>, lds);
   hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR, WR>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
@@ -524,8 +520,12 @@ int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st) { r
 int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg, hipStream_t st) {
   static const bool force_tap = getenv("SV_FORCE_IM2COL") != nullptr;   // A/B switch for tests and profiling
   static const bool no_multi = getenv("SV_NO_MULTI") != nullptr;        // A/B: one launch per problem
-  static const int dbg = getenv("SV_TC_DBG") ? atoi(getenv("SV_TC_DBG")) : 0;
+  static const int dbg = SV_DBG(getenv("SV_TC_DBG") ? atoi(getenv("SV_TC_DBG")) : 0);
   if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
+  if (!force_tap && n <= 2) {                          // the decoder's wide stride-1 layers: weights in registers, rows rolling through LDS
+    const int rc = svk_row_conv_try(t, n, dtype, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
   TileConvArgs a[SV_MAX_MULTI];
   int cfg[SV_MAX_MULTI];
   bool all_tile = !force_tap;

@@ -232,11 +232,7 @@ static int launch_wgrad(const WgradArgs* a, int n, hipStream_t st) {
   }
   for (int i = n; i < SV_WGRAD_IM2COL_MAX_MULTI; ++i) { m.zbase[i] = gz; m.plain[i] = 0; }
   dim3 grid(gx, gy, gz), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<T, WR, WC, CF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  sv_ensure_dynamic_lds((const void*)wgrad_kernel<T, WR, WC, CF>, lds);
   hipLaunchKernelGGL((wgrad_kernel<T, WR, WC, CF>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;

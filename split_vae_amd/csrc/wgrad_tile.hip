@@ -117,12 +117,12 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
-      if ((g.dbg & 2) || !has) {}
+      if ((SV_DBG(g.dbg) & 2) || !has) {}
       else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
       else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
     }
     // ---- stage dY patch
-    for (int q = tid; q < dy_total && !(g.dbg & 4) && has; q += 256) {
+    for (int q = tid; q < dy_total && !(SV_DBG(g.dbg) & 4) && has; q += 256) {
       const int r = q >> lycp, c = q & ((1 << lycp) - 1);
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
     }
     __syncthreads();
     // ---- MFMA: K = pixels
-    if (!(g.dbg & 8) && has)
+    if (!(SV_DBG(g.dbg) & 8) && has)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       short8_t bfr[COF];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
   // a fixed order.  (fp32 atomics straight into dW run at ~1.3 TB/s chip-wide and were 40-60 % of
   // this kernel's time: SV_WT_NOFLUSH ablation.)
   if (g.slab) {
-    if ((g.dbg & 1) || !flusher) goto bias_part;
+    if ((SV_DBG(g.dbg) & 1) || !flusher) goto bias_part;
     {
     float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * CIF * COF)) * 256 + lane;
 #pragma unroll
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
           const int co = j * 16 + lr;
           const int otap = g.pairx ? 2 * tap + (cl >> 3) : tap;
           const int64_t di = co < g.N ? dw_index(otap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
-          if (di >= 0 && !(g.dbg & 1)) atomicAdd(g.dW + di, acc[t2][i][j][r4]);
+          if (di >= 0 && !(SV_DBG(g.dbg) & 1)) atomicAdd(g.dW + di, acc[t2][i][j][r4]);
         }
       }
   }
@@ -304,12 +304,7 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   constexpr int HFB = ((TPW * CIF * COF + 1) / 2) * 4 * 1024;     // bytes of the cross-group exchange (NG = 2)
   size_t lds = NG * ((size_t)a[0].in_bytes + a[0].dy_bytes);
   if (NG == 2 && lds < (size_t)HFB) lds = HFB;
-  static size_t attr_set = 0;
-  if (lds > attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = lds;
-  }
+  sv_ensure_dynamic_lds((const void*)wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>, lds);
   // resident workgroups per CU: LDS, and 2 waves per SIMD (accumulator-heavy waves)
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > OCC / NG) per_cu = OCC / NG;
@@ -317,7 +312,7 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   static const int force_pc = getenv("SV_WT_PERCU") ? atoi(getenv("SV_WT_PERCU")) : 0;   // profiling knob
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
   // ablation bits: 1 skip the flush (+reduce), 2 skip input staging, 4 skip dY staging, 8 skip the MFMA loop
-  static const int dbg = getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0);
+  static const int dbg = SV_DBG(getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0));
   int msplit = (256 * per_cu + groups - 1) / groups;
   if (msplit > a[0].ntiles) msplit = a[0].ntiles;
   dim3 grid(msplit, groups, n), block(256 * NG);

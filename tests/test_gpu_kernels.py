@@ -360,3 +360,71 @@ def test_dense_as_conv(ops, K, N, dtype):
     torch.testing.assert_close(dw[0, 0].double().cpu(), wr.grad, rtol=rtol, atol=atol * float(wr.grad.abs().max()))
     dx = conv.dgrad(dy.cuda(), f32_atomic=True)
     torch.testing.assert_close(dx[:, 0, 0].double().cpu(), xr.grad, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
+
+
+# ------------------------------------------------------------------ row-ring kernel (row_conv.hip): the CelebA-64 decoder geometries
+ROW_LAYERS = [  # name, H (conv input = output size), Cin, Cout, k
+    ("d3_64", 16, 128, 64, 4),
+    ("d4_64", 32, 64, 32, 6),
+]
+
+
+@pytest.mark.parametrize("B", [3, 70])      # 3: every image cut into row bands; 70: several images per workgroup + the twin-net launch shape
+@pytest.mark.parametrize("layer", ROW_LAYERS, ids=[l[0] for l in ROW_LAYERS])
+def test_row_ring_conv_forward_and_dgrad(ops, layer, B, monkeypatch):
+    """Weights in registers, image rows rolling through the LDS ring (fused 2x bilinear upsample on the forward): forward
+    against fp64 conv(resize(x)) from the same bf16 operands, input gradient against fp64 autograd; and against the LDS-tile
+    kernel (SV_NO_ROWCONV) to accumulation order."""
+    name, H, Cin, Cout, k = layer
+    rng = np.random.default_rng(sum(map(ord, name)) + B)
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act="relu", dtype=torch.bfloat16, ups_in=True)
+    conv.prep(w.cuda())
+    y = conv.fwd(x_lo.cuda(), b.cuda())
+    # the kernel blends in fp32 and rounds the hi-res pixels to bf16 (as upsample2x_fwd does): reference from those operands
+    x_hi = ops.upsample2x_fwd(x_lo.cuda()).float().cpu().double()
+    torch.testing.assert_close(x_hi, torch_ref.resize_bilinear_2x(x_lo.double()), rtol=1e-2, atol=1e-2)
+    xr = x_hi.clone().requires_grad_(True)
+    wr = w.bfloat16().double()
+    pre = torch_ref.conv2d_same(xr, wr, b.double(), 1, None)
+    yr = torch.relu(pre).detach()
+    torch.testing.assert_close(y.double().cpu(), yr, rtol=BF16_RTOL, atol=1e-2 * float(yr.abs().max()))
+    assert float((y.double().cpu() - yr).norm() / yr.norm()) < 4e-3          # bf16 output rounding only
+    # input gradient (at the virtual hi-res input), no mask
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, Cout)).astype(np.float32)).bfloat16()
+    pre.backward(dy.double())
+    dx = conv.dgrad(dy.cuda())
+    torch.testing.assert_close(dx.double().cpu(), xr.grad, rtol=BF16_RTOL, atol=1e-2 * float(xr.grad.abs().max()))
+    assert float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm()) < 4e-3
+
+
+def test_row_ring_matches_tile_kernel_in_a_subprocess(lib_built, tmp_path):
+    """A/B inside the product: the same forward + dgrad with SV_NO_ROWCONV=1 (LDS-tile kernel) and without, in separate
+    processes (the knob is latched at first use); fp32 accumulation order is the only difference."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "outs = []\n"
+        "for (H, Cin, Cout, k) in ((16, 128, 64, 4), (32, 64, 32, 6)):\n"
+        "    B = 9\n"
+        "    x = torch.randn(B, H // 2, H // 2, Cin, generator=g).bfloat16().cuda()\n"
+        "    w = (torch.randn(k, k, Cin, Cout, generator=g) * 0.03).cuda()\n"
+        "    dy = torch.randn(B, H, H, Cout, generator=g).bfloat16().cuda()\n"
+        "    c = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act='relu', dtype=torch.bfloat16, ups_in=True); c.prep(w)\n"
+        "    outs += [c.fwd(x, torch.zeros(Cout, device='cuda')).float().cpu().numpy(), c.dgrad(dy).float().cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env in (("row", {}), ("tile", {"SV_NO_ROWCONV": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    for key in res[0].files:
+        a, b = res[0][key].astype(np.float64), res[1][key].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 4e-3 * np.linalg.norm(b), key      # both rounded to bf16 from differently ordered fp32 sums
+        assert not np.array_equal(a, np.zeros_like(a))
