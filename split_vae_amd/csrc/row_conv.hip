@@ -519,6 +519,11 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     r.bands = bands; r.band_rows = OY / bands;
     if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
   }
+  // The upsampled forward layers: in the training step at B = 512 the LDS-tile kernel is as fast (fwd.d4 0.140 vs 0.141 ms,
+  // fwd.d3 0.077 vs 0.081: their blend staging costs this kernel what the weight streaming costs that one); at small
+  // batches this kernel wins clearly (128 images: d3 18 vs 33 us).  SV_RC_FWD=1 / 0 forces it on / off.
+  static const int fwd_mode = getenv("SV_RC_FWD") ? atoi(getenv("SV_RC_FWD")) : -1;
+  if ((cfg == 0 || cfg == 2) && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512))) return SV_E_UNSUPPORTED;
   switch (cfg) {
     case 0: return launch_row<RC_d4f>(a, n, st);
     case 1: return launch_row<RC_d4g>(a, n, st);

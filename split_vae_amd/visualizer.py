@@ -129,6 +129,7 @@ def reconstruction_test_lg_vae(model, test_dataset, label=True, filename=None, f
     """vae/visualizer.py:13-55: first n test images; row 0 = reconstruction (decode(encode(x))), row 1 = the input, for x
     and for x_hat."""
     images = _first_batch(test_dataset, label)
+    n = min(n, int(images.shape[0]))                # the reference slices [:10] out of a 64-image batch; a smaller first batch gives a narrower grid
     x_test = images[:n].contiguous()
     z_x, z_x_hat = model.encode(x_test)
     x_recon, x_hat_recon = model.decode(z_x, z_x_hat, True)

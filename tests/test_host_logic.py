@@ -225,9 +225,9 @@ def test_main_runs_on_svhn_files(tmp_path, monkeypatch, capsys, flags, lib_built
     """The reference's first README command (main.py --beta 40 --patch_size 1, SVHN with labels) and its -no_label form,
     driven through main() on tiny .mat files: labelled batches are (images, labels) tuples and the step sees [B,32,32,6]."""
     from split_vae_amd import main as svmain
-    _write_svhn(str(tmp_path / "data"), n_train=9, n_extra=4, n_test=5)
+    _write_svhn(str(tmp_path / "data"), n_train=30, n_extra=9, n_test=27)
     monkeypatch.chdir(tmp_path)
-    path = svmain.main(["--beta", "40", "--patch_size", "1", "--batch_size", "4", "--training_steps", "3", "--log_every", "2",
+    path = svmain.main(["--beta", "40", "--patch_size", "1", "--batch_size", "12", "--training_steps", "3", "--log_every", "2",
                         "--dtype", "f32"] + flags)
     out = capsys.readouterr().out
     assert "Training step 0" in out and "Training step 2" in out and "Training done!" in out
