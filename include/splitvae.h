@@ -116,6 +116,13 @@ int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, 
  * dx_f32_atomic!=0: K is split over workgroups and dx (fp32, pre-zeroed) is accumulated atomically. */
 int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
                          const void* relu_mask, void* dx, int32_t dx_f32_atomic, void* stream);
+/* The same for a layer with ups_in (its input is the 2x bilinear upsample of a low-res tensor, vae/model.py:163-167),
+ * delivered AT THE LOW-RES TENSOR: dx_lo[B,H/2,W/2,ldx] = (relu_mask_lo > 0) * resize_adjoint(conv-transpose(dy, w)) in
+ * one launch -- ResizeBilinearGrad + ReluGrad of tape.gradient (vae/trainer.py:137) fused into the Conv2DBackpropInput
+ * kernel; the hi-res gradient never reaches HBM.  SV_E_UNSUPPORTED when the geometry has no fused kernel: call
+ * sv_conv2d_nhwc_dgrad followed by sv_upsample2x_bwd instead (bitwise the same result). */
+int sv_conv2d_nhwc_dgrad_lowres(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
+                                const void* relu_mask_lo, void* dx_lo, void* stream);
 /* dw[KH,KW,Cin,Cout] += x^T*dy, dbias[Cout] += colsum(dy) (fp32 HWIO, atomically accumulated:
  * zero them first). */
 int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,

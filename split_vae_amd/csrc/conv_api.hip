@@ -429,6 +429,21 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
   return SV_OK;
 }
 
+// Input gradient of a layer whose input is the 2x bilinear upsample of a low-res tensor (ups_in), delivered at the
+// LOW-RES tensor: dx_lo = mask(resize_adjoint(conv_transpose(dy, w))) in one launch (row_conv.hip).
+extern "C" int sv_conv2d_nhwc_dgrad_lowres(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
+                                           const void* relu_mask_lo, void* dx_lo, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!dy || !w_dgrad || !dx_lo) return SV_E_BADARG;
+  if (!d->ups_in || d->stride != 1) return SV_E_BADARG;
+  TapGemmArgs a;
+  uint8_t srctap[SV_MAX_TAPS];
+  svg_dgrad_args(d, 0, &a, srctap);
+  a.A = dy; a.Wt = w_dgrad; a.out = dx_lo; a.mask = relu_mask_lo; a.adj = 1;
+  return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
+}
+
 extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
                                     float* dbias, void* stream) {
   int rc = svg_check(d);

@@ -28,6 +28,9 @@ struct TapGemmArgs {
   int ups;              // A is the LOW-RES tensor [B, IH/2, IW/2, lda]; the conv sees its 2x bilinear upsample
   int d2s;              // > 0: x-pixel-packed conv: column n = px*8 + co holds channel co < d2s of output pixel
                         // (oy, 2*ox + px); out is the unpacked [B, OHF, OWF, ldo] tensor
+  int adj;              // input gradient of a layer whose input is a 2x bilinear upsample, FUSED with the resize adjoint: `out`
+                        // is the LOW-RES gradient [B, OHF/2, OWF/2, ldo], `mask` the low-res activation (ReLU gate, may be
+                        // null).  Only the row-ring kernel implements it (SV_E_UNSUPPORTED elsewhere)
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -72,6 +75,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
 int svk_tile_conv(const TileConvArgs& a, int dtype, int cfg, hipStream_t st);
 // weight-stationary row-ring kernel (row_conv.hip): SV_E_UNSUPPORTED when the shape has no instantiation
 int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st);
+bool svk_row_conv_supported(const TapGemmArgs* t, int n, int dtype);   // would svk_row_conv_try launch? (nothing is launched)
 // picks the direct kernel when the problem fits it, the im2col tap GEMM otherwise
 int svk_conv_dispatch(const TapGemmArgs& t, int dtype, int tap_cfg, hipStream_t st);
 

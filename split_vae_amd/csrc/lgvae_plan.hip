@@ -402,7 +402,7 @@ static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float*
 
 // all parity classes of all n twin layers in one launch (stride 2: 4 classes x 2 networks = 8 problems)
 static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* dy, const void* const* mask,
-                            void* const* dx, bool f32_atomic, hipStream_t st) {
+                            void* const* dx, bool f32_atomic, hipStream_t st, bool adj = false) {
   TapGemmArgs a[SV_MAX_MULTI];
   double fl = 0;
   int m = 0, tap_cfg = svg_pick_cfg(L[0]->d.Cin);
@@ -417,6 +417,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       a[m].Wt = (char*)p->bp("warena") + L[i]->wd_off[c] * p->esz();
       a[m].out = dx[i];
       a[m].mask = mask[i];
+      a[m].adj = adj ? 1 : 0;           // dx = the LOW-RES gradient, mask = the low-res activation (row_conv.hip)
       if (f32_atomic) {
         a[m].out_f32 = 1;
         int c2 = tap_cfg;
@@ -425,6 +426,10 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
         else if (c2 != tap_cfg) mixed = true;
       }
     }
+  }
+  if (adj) {                            // no fused kernel for this geometry: nothing was launched, the caller falls back
+    TapGemmArgs probe = a[0];
+    if (!svk_row_conv_supported(&probe, m, L[0]->d.dtype)) return SV_E_UNSUPPORTED;
   }
   Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
   if (mixed) {   // split-K problems whose widths pick different tiles: one launch each
@@ -624,10 +629,17 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     const void* xin[2];
     for (int k = 0; k < 2; ++k) xin[k] = p->bp(std::string(Ls[k]->d.ups_in ? lo_name[l] : hi_name[l]) + en[k]);
     SV_TRY(run_wgrad_layers(p, 2, Ls, xin, gy, s->grads, st));
+    const void *lo[2], *gl[2];
+    both(lo_name[l], lo); both(gl_name[l], gl);
+    // the input gradient lands at the LOW-RES activation in one launch where the fused kernel exists (ResizeBilinearGrad +
+    // ReluGrad in the epilogue of Conv2DBackpropInput: the hi-res gradient gu never reaches HBM) ...
+    static const bool no_adj = getenv("SV_NO_FUSED_ADJOINT") != nullptr;
+    int frc = SV_E_UNSUPPORTED;
+    if (Ls[0]->d.ups_in && Ls[1]->d.ups_in && !no_adj) frc = run_dgrad_layers(p, 2, Ls, gy, lo, (void* const*)gl, false, st, true);
+    if (frc != SV_E_UNSUPPORTED) { SV_TRY(frc); continue; }
+    // ... else the hi-res gradient goes through HBM and a stand-alone adjoint pass
     SV_TRY(run_dgrad_layers(p, 2, Ls, gy, none, (void* const*)gu, false, st));
     {
-      const void *lo[2], *gl[2];
-      both(lo_name[l], lo); both(gl_name[l], gl);
       const int h = (H / 2) >> l, w = (W / 2) >> l, c = 32 << l;
       const int64_t lo_bytes = (int64_t)B * h * w * c * p->esz();
       const bool contig = (const char*)gu[1] == (const char*)gu[0] + 4 * lo_bytes &&

@@ -50,30 +50,50 @@ struct RowConvArgs {
   int lda, ldo, Ktot, act;
   int y_lo, x_lo;       // tap (ky, kx) reads input pixel (y + ky + y_lo, x + kx + x_lo)
   int bands, band_rows; // an image is cut into `bands` row bands of band_rows rows (a unit of work = one band)
+  const void* mask;     // ADJ configs: the low-res activation whose ReLU mask (> 0) gates the low-res gradient (or null);
+                        // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo]
 };
 struct RowConvMulti { RowConvArgs a[2]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
   static constexpr int WAVES = WAVES_, NT = 64 * WAVES_;      // 8 waves: one workgroup per CU, its two halves staggered;
                                                               // 4 waves: two independent workgroups per CU (<= 80 KB of LDS each)
-  static constexpr int NCH = CIN / 32, CPW = NCH / KS, NBG = N / 16 / NBW;
+  // ADJ: the layer's logical input is a 2x bilinear upsample and this is its INPUT GRADIENT: the hi-res gradient rows
+  // stay in an LDS ring and leave as the LOW-RES gradient through the adjoint of the resize (+ ReLU mask) -- the hi-res
+  // tensor and the stand-alone upsample2x_bwd pass never exist (vae/model.py:163-167 backwards).
+  static constexpr bool ADJ = ADJ_;
+  // TP: 8-channel pixels (the 6-channel head's gradient): one 16-B piece per pixel, so an MFMA K step (32) packs FOUR
+  // taps -- the four lane quarters read four consecutive input ROWS (ky = 4g + kq; KH = 6 -> two groups, 2 of 8 dummies)
+  static constexpr bool TP = CIN == 8;
+  static_assert(!TP || (KH == 6 && !UPS_ && KS == 1), "tap-packed form");
+  static_assert(!ADJ_ || (!UPS_ && KS_ == 1), "the adjoint epilogue belongs to plain input-gradient layers");
+  static constexpr int NCH = TP ? 1 : CIN / 32, CPW = NCH / KS, NBG = N / 16 / NBW;
+  static constexpr int KHG = TP ? 2 : KH;                     // weight fragments per (chunk, filter column)
   static_assert(NBG * KS * XG * RG == WAVES, "one role per wave");
-  static_assert(CIN % 32 == 0 && NCH % KS == 0 && N % (16 * NBW) == 0 && WIDTH % (16 * XG) == 0, "shape");
-  static constexpr int TIW = WIDTH + KW - 1, STEP = RG * MF, WIN = MF + KH - 1;
+  static_assert((TP || CIN % 32 == 0) && NCH % KS == 0 && N % (16 * NBW) == 0 && WIDTH % (16 * XG) == 0, "shape");
+  static constexpr int TIW = WIDTH + KW - 1, STEP = RG * MF, WIN = TP ? MF + 4 : MF + KH - 1;
   // ring rows.  8 waves: two windows (the current one + the next step's STEP new rows, or the whole first window of the
   // workgroup's NEXT unit, staged during the last step).  4 waves: one window + one step (the next unit's first window
   // is staged between units; the other workgroup of the CU computes meanwhile)
   static constexpr bool PRE = WAVES == 8;
   static constexpr int R = PRE ? 2 * (STEP + KH - 1) : 2 * STEP + KH - 1;
-  static constexpr int NPL = CIN / 16, PLB = R * TIW * 32;    // planes (two 16-B pieces each), bytes per plane
+  static constexpr int PIXB = TP ? 16 : 32;                   // bytes per pixel in a plane
+  // TP: a fragment's four lane quarters read four consecutive rows: the row pitch is a multiple of 256 B (then the 16-lane
+  // groups of ds_read_b128 cover each bank row exactly once) and the ring's first three rows are kept twice, behind its
+  // end, so that rows slot .. slot+3 are always linear
+  static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : TIW * 32;
+  static constexpr int RDUP = TP ? 3 : 0;
+  static constexpr int NPL = TP ? 1 : CIN / 16, PLB = (R + RDUP) * ROWB;    // planes (two 16-B pieces each; TP: one piece), bytes per plane
   static constexpr int RING = NPL * PLB;
   static constexpr int EXS = 2;                               // exchange slots per wave pair
   static constexpr int EXF = NBW * MF * 1024;                 // bytes per slot: NBW*MF accumulator fragments of 1 KB
   static constexpr int EXB = KS == 2 ? (WAVES / 2) * EXS * EXF : 0;
-  static constexpr int LDS = RING + EXB + 64;
+  // ADJ: ring of hi-res gradient rows [slot][pixel][N] bf16: STEP rows being written + STEP + 3 being read by the adjoint
+  static constexpr int ORR = ADJ ? 2 * STEP + 3 : 0, OROWB = WIDTH * N * 2, OUTB = ORR * OROWB;
+  static constexpr int LDS = RING + EXB + OUTB + 64;
   static constexpr int SPW = WIDTH / 16 / XG;                 // strips per wave and row group
   static constexpr int CPP = CIN / 8;                         // 16-B pieces per pixel
 };
@@ -132,7 +152,7 @@ __device__ __forceinline__ void stage_rows(const RowConvArgs& g, int b, int Ya, 
             const int X = 2 * j + 1 + dxb, xi = X - g.x_lo;
             if ((unsigned)xi >= (unsigned)C::TIW) continue;
             const bool in = (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W;
-            *(uint4*)(sRing + (c >> 1) * C::PLB + (slot * C::TIW + xi) * 32 + (c & 1) * 16) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
+            *(uint4*)(sRing + (c >> 1) * C::PLB + slot * C::ROWB + xi * 32 + (c & 1) * 16) = in ? blk[dyb][dxb] : make_uint4(0, 0, 0, 0);
           }
         }
       }
@@ -153,7 +173,7 @@ __device__ __forceinline__ void stage_rows(const RowConvArgs& g, int b, int Ya, 
         const int Y = Ya + d, X = g.x_lo + xi;
         int slot = qa + d;
         if (slot >= C::R) slot -= C::R;
-        off[k] = qq < t1 ? (c >> 1) * C::PLB + (slot * C::TIW + xi) * 32 + (c & 1) * 16 : -1;
+        off[k] = qq < t1 ? (c >> 1) * C::PLB + slot * C::ROWB + xi * 32 + (c & 1) * 16 : -1;
         v[k] = make_uint4(0, 0, 0, 0);
         if (qq < t1 && (unsigned)Y < (unsigned)g.H && (unsigned)X < (unsigned)g.W) v[k] = *(const uint4*)(img + ((int64_t)Y * g.W + X) * g.lda + c * 8);
       }
@@ -170,22 +190,70 @@ __device__ __forceinline__ void stage_rows(const RowConvArgs& g, int b, int Ya, 
 // columns are zeroed once per launch and never written again; rows outside the image are zero-filled by plain stores.
 template <typename C>
 __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int Ya, int nrows, int qa, char* sRing, int w, int nw, int lane) {
-  static_assert(C::WIDTH * 2 <= 64, "one DMA instruction per (row, plane)");
+  constexpr int LPR = C::TP ? C::WIDTH : C::WIDTH * 2;      // lanes per (row, plane): one 16-B piece each
+  static_assert(LPR <= 64, "one DMA instruction per (row, plane)");
   const bf16_t* img = (const bf16_t*)g.A + (int64_t)b * g.H * g.W * g.lda;
   const int PL = -g.x_lo;
-  const bool on = lane < C::WIDTH * 2;
+  const bool on = lane < LPR;
   for (int idx = w; idx < nrows * C::NPL; idx += nw) {
     const int d = idx / C::NPL, p = idx - d * C::NPL;
     const int Y = Ya + d;
     int slot = qa + d;
     if (slot >= C::R) slot -= C::R;
-    char* dst = sRing + p * C::PLB + (slot * C::TIW + PL) * 32;
-    if ((unsigned)Y < (unsigned)g.H) {
-      const bf16_t* src = img + ((int64_t)Y * g.W + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
-      if (on) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    } else if (on) {
-      *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+    const bf16_t* src = C::TP ? img + ((int64_t)Y * g.W + lane) * g.lda
+                              : img + ((int64_t)Y * g.W + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
+    const bool inside = (unsigned)Y < (unsigned)g.H;
+#pragma unroll
+    for (int dup = 0; dup < (C::RDUP ? 2 : 1); ++dup) {
+      if (dup && slot >= C::RDUP) break;                     // TP: the ring's first rows live a second time behind its end
+      char* dst = sRing + p * C::PLB + (slot + dup * C::R) * C::ROWB + PL * C::PIXB;
+      if (inside) {
+        if (on) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      } else if (on) {
+        *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+      }
     }
+  }
+}
+
+// ADJ: low-res gradient rows [e_lo, e_hi] of image b from the hi-res gradient rows in the out ring:
+//   g_lo[i, j] = sum_{a, d in -1..2} wy[a] wx[d] g_hi[clamp(2i + a), clamp(2j + d)],  w = (.25, .75, .75, .25)
+// then the ReLU mask of the low-res activation -- the arithmetic (and summation order) of upsample2x_bwd_kernel
+// (pointwise.hip), on the same bf16-rounded hi-res values: bitwise the unfused result.
+template <typename C>
+__device__ __forceinline__ void adjoint_rows(const RowConvArgs& g, int b, int e_lo, int e_hi, int obase, const char* sOut, int t, int nt) {
+  constexpr int NP8 = C::N / 8, LW = C::WIDTH / 2, IPR = LW * NP8;
+  const int LH = g.H >> 1;
+  const int total = (e_hi - e_lo + 1) * IPR;
+  for (int it = t; it < total; it += nt) {
+    const int ii = it / IPR, r = it - ii * IPR;
+    const int i = e_lo + ii, j = r / NP8, c = r - j * NP8;
+    const int64_t o = (((int64_t)b * LH + i) * LW + j) * g.ldo + c * 8;
+    uint4 mv = make_uint4(0, 0, 0, 0);
+    if (g.mask) mv = *(const uint4*)((const bf16_t*)g.mask + o);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = -1; a <= 2; ++a) {
+      const int oy = min(max(2 * i + a, 0), g.H - 1);
+      const float wy = (a == -1 || a == 2) ? 0.25f : 0.75f;
+      const char* row = sOut + ((obase + oy) % C::ORR) * C::OROWB + c * 16;
+#pragma unroll
+      for (int d = -1; d <= 2; ++d) {
+        const int ox = min(max(2 * j + d, 0), C::WIDTH - 1);
+        const float wgt = wy * ((d == -1 || d == 2) ? 0.25f : 0.75f);
+        bf16_t v[8];
+        *(uint4*)v = *(const uint4*)(row + ox * (C::N * 2));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
+      }
+    }
+    bf16_t res[8], m8[8];
+    *(uint4*)m8 = mv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) res[e] = (bf16_t)((!g.mask || (float)m8[e] > 0.f) ? acc[e] : 0.f);
+    *(uint4*)((bf16_t*)g.out + o) = *(const uint4*)res;
   }
 }
 
@@ -201,7 +269,8 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sRing = smem;
   char* sEx = smem + C::RING;
-  int* sFlag = (int*)(smem + C::RING + C::EXB);              // [4 pairs][2]: strips produced (odd wave), consumed (even wave)
+  char* sOut = smem + C::RING + C::EXB;                      // ADJ: hi-res gradient rows
+  int* sFlag = (int*)(smem + C::RING + C::EXB + C::OUTB);    // [pairs][2]: strips produced (odd wave), consumed (even wave)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int idx = wave;
@@ -214,7 +283,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   constexpr int NT = C::NT;
   const int dbg0 = SV_DBG(mg.dbg);
   const int m = lane & 15, kq = lane >> 4;
-  const int lane_off = m * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
+  const int lane_off = C::TP ? m * 16 + kq * C::ROWB : m * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
   if (tid < 16) sFlag[tid] = 0;
   const int dbg = SV_DBG(mg.dbg);                           // 1 skip staging, 2 skip the MFMA loop, 4 skip the stores, 8 skip the K-half exchange
 
@@ -222,8 +291,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #ifdef SV_DEBUG_KNOBS
   if (mg.stamps) tlast = __builtin_amdgcn_s_memtime();
 #endif
-  bf16x8 Wr[NBW][CPW][KW][KH];
+  bf16x8 Wr[NBW][CPW][KW][C::KHG];
   float bv[NBW][4];
+  int obase = 0;                                             // ADJ: out-ring slot of hi-res row 0 of the current unit
   int cur_prob = -1;
   int strips = 0;                                            // strips this wave has finished (the pair counts in lockstep)
 
@@ -237,12 +307,13 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     else {
       const int PL = -g.x_lo;                                // halo columns of every ring row: zero, once
       constexpr int HC = C::TIW - C::WIDTH;
-      for (int q = tid; q < C::NPL * R * HC * 2; q += NT) {
-        const int pc = q & 1, r2 = q >> 1;
+      constexpr int PPP = C::PIXB / 16, RP = R + C::RDUP;    // pieces per pixel and plane, physical ring rows
+      for (int q = tid; q < C::NPL * RP * HC * PPP; q += NT) {
+        const int pc = q % PPP, r2 = q / PPP;
         const int hx = r2 % HC, r3 = r2 / HC;
-        const int slot = r3 % R, p = r3 / R;
+        const int slot = r3 % RP, p = r3 / RP;
         const int xi = hx < PL ? hx : hx + C::WIDTH;
-        *(uint4*)(sRing + p * C::PLB + (slot * TIW + xi) * 32 + pc * 16) = make_uint4(0, 0, 0, 0);
+        *(uint4*)(sRing + p * C::PLB + slot * C::ROWB + xi * C::PIXB + pc * 16) = make_uint4(0, 0, 0, 0);
       }
       stage_rows_dma<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,8 +342,14 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #pragma unroll
           for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
-            for (int ky = 0; ky < KH; ++ky)
-              Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
+            for (int ky = 0; ky < C::KHG; ++ky) {
+              if constexpr (C::TP) {                         // fragment (kx, group ky): lane quarter kq carries tap (4*ky + kq, kx), zero past KH
+                const int kyy = 4 * ky + kq;
+                bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                Wr[nb][cc][kx][ky] = kyy < KH ? *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + kyy) * 8) : z;
+              } else
+                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
+            }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[nb][e] = g.bias ? g.bias[(nbg * NBW + nb) * 16 + kq * 4 + e] : 0.f;
       }
@@ -280,6 +357,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     if (u == (int)blockIdx.x) __syncthreads();               // the first window (and the flag words) are in place
     SV_STAMP(t_other);
     const int nsteps = g.band_rows / STEP;
+    int emitted = 0;                                         // ADJ: next low-res row to emit
     for (int s = 0; s < nsteps; ++s) {
       const int y0 = yb + s * STEP;
       const bool more = s + 1 < nsteps;
@@ -291,6 +369,12 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
       const int jb = more ? b : rn / gn.bands;
       const int jY = more ? y0 + g.y_lo + STEP + KH - 1 : (rn % gn.bands) * gn.band_rows + gn.y_lo;
       const int jrows = more ? STEP : STEP + KH - 1;
+      if constexpr (C::ADJ) {
+        // hi-res rows < y0 are complete: low-res row i needs hi-res rows 2i-1 .. 2i+2
+        const int e_hi = (y0 - 3) >> 1;
+        if (e_hi >= emitted && !(dbg & 4)) adjoint_rows<C>(g, b, emitted, e_hi, obase, sOut, tid, NT);
+        if (e_hi >= emitted) emitted = e_hi + 1;
+      }
       if constexpr (STAG) {
         if (job && half == 0) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid, 256, 0, 2);
       } else if constexpr (C::UPS) {
@@ -310,7 +394,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
         for (int j = 0; j < WIN; ++j) {
           int slot = qw + j;
           if (slot >= R) slot -= R;
-          abase[j] = lane_off + (slot * TIW + x0) * 32;
+          abase[j] = lane_off + slot * C::ROWB + x0 * C::PIXB;
         }
         f32x4 acc[NBW][MF];
 #pragma unroll
@@ -326,6 +410,25 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
           bf16x8 win[WIN];
 #pragma unroll
           for (int j = 0; j < WIN; ++j) win[j] = *(const bf16x8*)(sRing + abase[j]);
+          if constexpr (C::TP) {
+            // fragment w = input rows qw+w .. qw+w+3 (one per lane quarter) at filter column kx: it is tap group g of output row w - 4g
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+#pragma unroll
+              for (int w = 0; w < WIN; ++w) {
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+                  const int j = w - 4 * gq;
+                  if (j < 0 || j >= MF) continue;
+#pragma unroll
+                  for (int nb = 0; nb < NBW; ++nb)
+                    acc[nb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[nb][0][kx][gq], win[w], acc[nb][j], 0, 0, 0);
+                }
+                if (kx + 1 < KW) win[w] = *(const bf16x8*)(sRing + abase[w] + (kx + 1) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          } else
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const int cc = it / KW, kx = it % KW;
@@ -371,6 +474,16 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
         }
         ++strips;
         SV_STAMP(t_exch);
+        if constexpr (C::ADJ) {
+          // the hi-res gradient row goes to the out ring (bf16, as it would go to HBM); adjoint_rows picks it up
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+              bf16_t pk[4] = {(bf16_t)acc[nb][j][0], (bf16_t)acc[nb][j][1], (bf16_t)acc[nb][j][2], (bf16_t)acc[nb][j][3]};
+              *(uint2*)(sOut + ((obase + yw + j) % C::ORR) * C::OROWB + (x0 + m) * (C::N * 2) + ((nbg * NBW + nb) * 16 + kq * 4) * 2) = *(const uint2*)pk;
+            }
+        } else
         if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
           // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m
           bf16_t* ob = (bf16_t*)g.out + (((int64_t)b * g.H + yw) * g.W + x0 + m) * g.ldo + kq * 4;
@@ -394,8 +507,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
       if constexpr (STAG) {
         if (job && half == 1) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid - 256, 256, 1, 2);
       } else if constexpr (!C::UPS) {
-        // the DMAs of this step are older than its stores: wait for everything but the stores
-        if ((C::KS == 1 || ks == 0) && !(dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        // the DMAs of this step are older than its stores: wait for everything but the stores (ADJ: this step's only
+        // global stores are the adjoint's, issued before the DMAs)
+        if (!C::ADJ && (C::KS == 1 || ks == 0) && !(dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       SV_STAMP(t_stage);
@@ -406,6 +520,10 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
       SV_STAMP(t_bar);
       q0 = more ? q0 + STEP : (C::PRE ? qn : 0);             // a new unit starts at its own first window
       if (q0 >= R) q0 -= R;
+    }
+    if constexpr (C::ADJ) {                                  // the image's last low-res rows (the step loop ended behind a barrier)
+      if (!(dbg & 4)) adjoint_rows<C>(g, b, emitted, (g.H >> 1) - 1, obase, sOut, tid, NT);
+      obase = (obase + g.H) % C::ORR;
     }
     if (!C::PRE && has_next && !(dbg & 1)) {                 // no room to prefetch: stage the next unit's first window now
       if constexpr (C::UPS) stage_rows<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
@@ -471,24 +589,28 @@ static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
   return SV_OK;
 }
 
-//                 KH KW CIN   N  W  MF NBW KS XG RG UPS
-using RC_d4f = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4>;  // d4 forward   (K 2304: pairs split the two 32-channel chunks)
-using RC_d4g = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>; // d4 input gradient (K 1152)
-using RC_d3f = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;    // d3 forward   (K 2048)
-using RC_d3g = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;   // d3 input gradient (K 1024)
+//                  KH KW CIN   N   W MF NBW KS XG RG UPS  WAVES ADJ
+using RC_d4f  = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4>;          // d4 forward   (K 2304: pairs split the two 32-channel chunks)
+using RC_d4g  = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>;         // d4 input gradient (K 1152)
+using RC_d4ga = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true>;   //   ... fused with the resize adjoint
+using RC_d3f  = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;            // d3 forward   (K 2048)
+using RC_d3g  = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;           // d3 input gradient (K 1024)
+using RC_d3ga = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true>;
+using RC_d5g  = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4>;          // d5 input gradient (8-channel pixels: four taps per K step)
+using RC_d5ga = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4, true>;
 
 }  // namespace
 
 // n (1 or 2: the x / x-hat twins) tap-GEMM problems of identical geometry on the row-ring kernel; SV_E_UNSUPPORTED when
 // the shape has no instantiation (the caller falls back to the tile kernel)
-int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
+static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {      // -> instantiation id, or SV_E_UNSUPPORTED
   static const bool off = getenv("SV_NO_ROWCONV") != nullptr;          // A/B: the tile kernel for every layer
   if (off || dtype != SV_BF16 || n < 1 || n > 2) return SV_E_UNSUPPORTED;
-  RowConvArgs a[2];
   int cfg = -1;
   for (int i = 0; i < n; ++i) {
     const TapGemmArgs& p = t[i];
-    if (p.S != 1 || p.SX != 1 || p.OS != 1 || p.splitk != 1 || p.d2s || p.mask || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
+    if (p.S != 1 || p.SX != 1 || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
+    if (p.mask && !p.adj) return SV_E_UNSUPPORTED;                     // a ReLU mask on the output itself: tile kernel
     const int OY = 1 << p.lOY, OX = 1 << p.lOX;
     if (OY != p.IH || OX != p.IW || p.OHF != OY || p.OWF != OX) return SV_E_UNSUPPORTED;
     const int cin = (1 << p.cl2) * 8;
@@ -500,22 +622,25 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     for (int q = 0; q < p.ntaps; ++q)                                  // x-major, y-minor full grid
       if (p.dy[q] != p.dy[0] + q % kh || p.dx[q] != p.dx[0] + q / kh) return SV_E_UNSUPPORTED;
     int c = -1;
-    if (kh == 6 && kw == 6 && cin == 64 && p.N == 32 && OX == 32 && p.ups) c = 0;
-    else if (kh == 6 && kw == 6 && cin == 32 && p.N == 64 && OX == 32 && !p.ups) c = 1;
-    else if (kh == 4 && kw == 4 && cin == 128 && p.N == 64 && OX == 16 && p.ups) c = 2;
-    else if (kh == 4 && kw == 4 && cin == 64 && p.N == 128 && OX == 16 && !p.ups) c = 3;
+    if (kh == 6 && kw == 6 && cin == 64 && p.N == 32 && OX == 32 && p.ups && !p.adj) c = 0;
+    else if (kh == 6 && kw == 6 && cin == 32 && p.N == 64 && OX == 32 && !p.ups) c = p.adj ? 4 : 1;
+    else if (kh == 4 && kw == 4 && cin == 128 && p.N == 64 && OX == 16 && p.ups && !p.adj) c = 2;
+    else if (kh == 4 && kw == 4 && cin == 64 && p.N == 128 && OX == 16 && !p.ups) c = p.adj ? 5 : 3;
+    else if (kh == 6 && kw == 6 && cin == 8 && p.N == 32 && OX == 64 && !p.ups) c = p.adj ? 7 : 6;
     if (c < 0 || (i && c != cfg)) return SV_E_UNSUPPORTED;
     cfg = c;
     const int step = 4;
     if (OY % step || p.ldo < p.N) return SV_E_UNSUPPORTED;
     RowConvArgs& r = a[i];
-    r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out;
+    r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out; r.mask = p.adj ? p.mask : nullptr;
     r.B = p.M >> (p.lOY + p.lOX); r.H = OY; r.W = OX;
     r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
     r.y_lo = p.dy[0]; r.x_lo = p.dx[0];
-    // small batches: cut the images into row bands until there is a unit of work for every CU
+    // small batches: cut the images into row bands until there is a unit of work for every workgroup slot (not with the
+    // fused adjoint: its low-res rows straddle band edges)
+    const bool four = c == 0 || c == 1 || c == 4 || c == 6 || c == 7;
     int bands = 1;
-    while (n * r.B * bands < (c < 2 ? 512 : 256) && OY / (bands * 2) >= step && (OY / (bands * 2)) % step == 0) bands *= 2;
+    while (!p.adj && n * r.B * bands < (four ? 512 : 256) && OY / (bands * 2) >= step && (OY / (bands * 2)) % step == 0) bands *= 2;
     r.bands = bands; r.band_rows = OY / bands;
     if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
   }
@@ -524,11 +649,26 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
   // batches this kernel wins clearly (128 images: d3 18 vs 33 us).  SV_RC_FWD=1 / 0 forces it on / off.
   static const int fwd_mode = getenv("SV_RC_FWD") ? atoi(getenv("SV_RC_FWD")) : -1;
   if ((cfg == 0 || cfg == 2) && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512))) return SV_E_UNSUPPORTED;
+  return cfg;
+}
+
+bool svk_row_conv_supported(const TapGemmArgs* t, int n, int dtype) {
+  RowConvArgs a[2];
+  return row_plan(t, n, dtype, a) >= 0;
+}
+
+int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
+  RowConvArgs a[2];
+  const int cfg = row_plan(t, n, dtype, a);
   switch (cfg) {
     case 0: return launch_row<RC_d4f>(a, n, st);
     case 1: return launch_row<RC_d4g>(a, n, st);
     case 2: return launch_row<RC_d3f>(a, n, st);
     case 3: return launch_row<RC_d3g>(a, n, st);
+    case 4: return launch_row<RC_d4ga>(a, n, st);
+    case 5: return launch_row<RC_d3ga>(a, n, st);
+    case 6: return launch_row<RC_d5g>(a, n, st);
+    case 7: return launch_row<RC_d5ga>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }

@@ -526,6 +526,9 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     const int rc = svk_row_conv_try(t, n, dtype, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
+  for (int i = 0; i < n; ++i)
+    if (t[i].adj) return SV_E_UNSUPPORTED;            // the fused resize adjoint exists on the row-ring kernel only: the caller
+                                                      // runs the plain input gradient and sv_upsample2x_bwd instead
   TileConvArgs a[SV_MAX_MULTI];
   int cfg[SV_MAX_MULTI];
   bool all_tile = !force_tap;

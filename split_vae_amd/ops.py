@@ -180,6 +180,17 @@ class Conv2D:
                                                1 if f32_atomic else 0, _stream()), "sv_conv2d_nhwc_dgrad")
         return dx
 
+    def dgrad_lowres(self, dy, relu_mask_lo=None):
+        """ups_in layers: the gradient at the LOW-RES input [B,H/2,W/2,ldx] in one launch (conv-transpose, resize adjoint, ReLU
+        mask); None when the geometry has no fused kernel (then: upsample2x_bwd(dgrad(dy), mask))."""
+        d = self.desc
+        dx = torch.empty((d.B, d.H // 2, d.W // 2, d.ldx), dtype=self.dtype, device=dy.device)
+        rc = _lib.load().sv_conv2d_nhwc_dgrad_lowres(C.byref(d), _p(dy), _p(self.w_dgrad), _p(relu_mask_lo), _p(dx), _stream())
+        if rc == _lib.STATUS_UNSUPPORTED:
+            return None
+        check(rc, "sv_conv2d_nhwc_dgrad_lowres")
+        return dx
+
     def wgrad(self, x, dy, workspace=False, dw=None, db=None):
         """dw / db: zeroed fp32 views to accumulate into (e.g. slices of a flat gradient buffer)."""
         d = self.desc

@@ -428,3 +428,63 @@ def test_row_ring_matches_tile_kernel_in_a_subprocess(lib_built, tmp_path):
         a, b = res[0][key].astype(np.float64), res[1][key].astype(np.float64)
         assert np.linalg.norm(a - b) <= 4e-3 * np.linalg.norm(b), key      # both rounded to bf16 from differently ordered fp32 sums
         assert not np.array_equal(a, np.zeros_like(a))
+
+
+ADJ_LAYERS = [  # name, H (hi-res conv input = output size), Cin, Cout, k, y_f32
+    ("d3_64", 16, 128, 64, 4, False),
+    ("d4_64", 32, 64, 32, 6, False),
+    ("d5_64", 64, 32, 6, 6, True),
+]
+
+
+@pytest.mark.parametrize("B", [2, 37])
+@pytest.mark.parametrize("layer", ADJ_LAYERS, ids=[l[0] for l in ADJ_LAYERS])
+def test_input_gradient_fused_with_resize_adjoint(ops, layer, B):
+    """sv_conv2d_nhwc_dgrad_lowres (Conv2DBackpropInput + ResizeBilinearGrad + ReluGrad in one launch, the hi-res gradient
+    kept in LDS) against (a) the two-launch form dgrad -> upsample2x_bwd: BITWISE (same bf16-rounded hi-res values, same
+    adjoint arithmetic), (b) fp64 autograd through relu -> tf.image.resize -> conv of the oracle restatement."""
+    name, H, Cin, Cout, k, yf32 = layer
+    rng = np.random.default_rng(sum(map(ord, name)) + 7 * B)
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.bfloat16, y_f32=yf32, ups_in=True)
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    conv.prep(w.cuda())
+    gdy = (Cout + 7) // 8 * 8
+    dy = torch.zeros(B, H, H, gdy)
+    dy[..., :Cout] = torch.from_numpy(rng.standard_normal((B, H, H, Cout)).astype(np.float32))
+    dy = dy.bfloat16()
+    pre_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16()   # pre-activation sign pattern
+    act_lo = torch.relu(pre_lo)                                    # the low-res activation the mask is read from
+    fused = conv.dgrad_lowres(dy.cuda(), act_lo.cuda())
+    assert fused is not None, "no fused kernel for %s" % name
+    two = ops.upsample2x_bwd(conv.dgrad(dy.cuda()), act_lo.cuda())
+    assert torch.equal(fused, two)
+    # fp64: d/d(pre_lo) of <conv(resize(relu(pre_lo))), dy>
+    xr = pre_lo.double().requires_grad_(True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.relu(xr)), w.bfloat16().double(), None, 1, None)
+    (y * dy[..., :Cout].double()).sum().backward()
+    want = xr.grad
+    got = fused[..., :Cin].double().cpu()
+    assert float((got - want).norm() / want.norm()) < 6e-3                       # bf16 rounding of the hi-res gradient and of the result
+    torch.testing.assert_close(got, want, rtol=BF16_RTOL, atol=1.5e-2 * float(want.abs().max()))
+    assert bool((got[act_lo.double() <= 0] == 0).all())                            # the mask, exactly
+    nomask = conv.dgrad_lowres(dy.cuda(), None)
+    assert torch.equal(nomask, ops.upsample2x_bwd(conv.dgrad(dy.cuda()), None))
+
+
+def test_d5_input_gradient_on_the_row_ring_kernel(ops):
+    """8-channel pixels (the head's gradient): four taps per MFMA K step.  Against fp64 and, in a second process, against the
+    LDS-tile kernel."""
+    rng = np.random.default_rng(11)
+    B, H, Cin, Cout, k = 5, 64, 32, 6, 6
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.bfloat16, y_f32=True, ups_in=True)
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    conv.prep(w.cuda())
+    dy = torch.zeros(B, H, H, 8)
+    dy[..., :Cout] = torch.from_numpy(rng.standard_normal((B, H, H, Cout)).astype(np.float32))
+    dy = dy.bfloat16()
+    dx = conv.dgrad(dy.cuda())
+    xr = torch.zeros(B, H, H, Cin, dtype=torch.float64, requires_grad=True)
+    y = torch_ref.conv2d_same(xr, w.bfloat16().double(), None, 1, None)
+    (y * dy[..., :Cout].double()).sum().backward()
+    assert float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm()) < 4e-3
+    torch.testing.assert_close(dx.double().cpu(), xr.grad, rtol=BF16_RTOL, atol=1e-2 * float(xr.grad.abs().max()))
