@@ -305,16 +305,12 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     const RowConvArgs& g = mg.a[prob];
     if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
     else {
-      const int PL = -g.x_lo;                                // halo columns of every ring row: zero, once
-      constexpr int HC = C::TIW - C::WIDTH;
-      constexpr int PPP = C::PIXB / 16, RP = R + C::RDUP;    // pieces per pixel and plane, physical ring rows
-      for (int q = tid; q < C::NPL * RP * HC * PPP; q += NT) {
-        const int pc = q % PPP, r2 = q / PPP;
-        const int hx = r2 % HC, r3 = r2 / HC;
-        const int slot = r3 % RP, p = r3 / RP;
-        const int xi = hx < PL ? hx : hx + C::WIDTH;
-        *(uint4*)(sRing + p * C::PLB + slot * C::ROWB + xi * C::PIXB + pc * 16) = make_uint4(0, 0, 0, 0);
-      }
+      // The whole ring starts as zeros, once per launch: the halo columns (the DMAs only ever write in-image pixels) and --
+      // TP -- the rows the two DUMMY taps of the second tap group read (rows behind the window: their weights are zero, but
+      // 0 x stale-LDS-garbage is NaN when the garbage is not finite; 0 x any old or half-landed gradient row is 0)
+      for (int q = tid; q < C::RING / 16; q += NT) *(uint4*)(sRing + q * 16) = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       stage_rows_dma<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -628,6 +624,10 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
     else if (kh == 4 && kw == 4 && cin == 64 && p.N == 128 && OX == 16 && !p.ups) c = p.adj ? 5 : 3;
     else if (kh == 6 && kw == 6 && cin == 8 && p.N == 32 && OX == 64 && !p.ups) c = p.adj ? 7 : 6;
     if (c < 0 || (i && c != cfg)) return SV_E_UNSUPPORTED;
+    // the fused adjoint works on whole images (its low-res rows straddle row bands): below ~one image per workgroup slot the
+    // banded plain input gradient + upsample2x_bwd is faster (64 images per network: d5 43 vs 55 us, d4 40 vs 49; 128: 69 vs 56)
+    static const int adj_min = getenv("SV_RC_ADJ_MIN") ? atoi(getenv("SV_RC_ADJ_MIN")) : 256;
+    if (p.adj && n * (p.M >> (p.lOY + p.lOX)) < adj_min) return SV_E_UNSUPPORTED;
     cfg = c;
     const int step = 4;
     if (OY % step || p.ldo < p.N) return SV_E_UNSUPPORTED;

@@ -45,6 +45,7 @@ def test_bf16_elbo_trajectory_tracks_fp32_over_300_steps(lib_built):
     i16, w16, l16 = _run("bf16")
     assert torch.equal(i32, i16)
     worst = 0.0
+    print("step: fp32 / bf16 total loss:", [(s, round(a, 2), round(b, 2)) for (s, a), (_, b) in zip(l32, l16)][::5])
     for (s32, a), (s16, b) in zip(l32, l16):
         assert s32 == s16 and np.isfinite(a) and np.isfinite(b)
         rel = abs(a - b) / abs(a)

@@ -488,3 +488,24 @@ def test_d5_input_gradient_on_the_row_ring_kernel(ops):
     (y * dy[..., :Cout].double()).sum().backward()
     assert float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm()) < 4e-3
     torch.testing.assert_close(dx.double().cpu(), xr.grad, rtol=BF16_RTOL, atol=1e-2 * float(xr.grad.abs().max()))
+
+
+def test_d5_input_gradient_ignores_stale_lds(ops):
+    """The tap-packed form reads two DUMMY taps (zero weights) from rows behind its window: they must never meet non-finite
+    LDS leftovers (0 x NaN).  Interleave kernels that leave fp32 bit patterns in LDS; the result stays finite and bitwise stable."""
+    g = torch.Generator().manual_seed(3)
+    B, H = 64, 64
+    conv = ops.Conv2D(B, H, H, 32, 6, 6, 1, act=None, dtype=torch.bfloat16, y_f32=True, ups_in=True)
+    conv.prep((torch.randn(6, 6, 32, 6, generator=g) * 0.05).cuda())
+    dy = torch.zeros(B, H, H, 8)
+    dy[..., :6] = torch.randn(B, H, H, 6, generator=g)
+    dy = dy.bfloat16().cuda()
+    first = conv.dgrad(dy).clone()
+    assert torch.isfinite(first.float()).all()
+    f32conv = ops.Conv2D(8, 32, 32, 32, 64, 6, 2, act="relu", dtype=torch.float32)
+    f32conv.prep(torch.full((6, 6, 32, 64), float("nan"), device="cuda"))
+    xin = torch.full((8, 32, 32, 32), float("inf"), device="cuda")
+    for _ in range(6):
+        f32conv.fwd(xin, torch.zeros(64, device="cuda"))           # NaN / Inf operands through LDS on every CU
+        again = conv.dgrad(dy)
+        assert torch.equal(again, first)
