@@ -624,10 +624,6 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
     else if (kh == 4 && kw == 4 && cin == 64 && p.N == 128 && OX == 16 && !p.ups) c = p.adj ? 5 : 3;
     else if (kh == 6 && kw == 6 && cin == 8 && p.N == 32 && OX == 64 && !p.ups) c = p.adj ? 7 : 6;
     if (c < 0 || (i && c != cfg)) return SV_E_UNSUPPORTED;
-    // the fused adjoint works on whole images (its low-res rows straddle row bands): below ~one image per workgroup slot the
-    // banded plain input gradient + upsample2x_bwd is faster (64 images per network: d5 43 vs 55 us, d4 40 vs 49; 128: 69 vs 56)
-    static const int adj_min = getenv("SV_RC_ADJ_MIN") ? atoi(getenv("SV_RC_ADJ_MIN")) : 256;
-    if (p.adj && n * (p.M >> (p.lOY + p.lOX)) < adj_min) return SV_E_UNSUPPORTED;
     cfg = c;
     const int step = 4;
     if (OY % step || p.ldo < p.N) return SV_E_UNSUPPORTED;
