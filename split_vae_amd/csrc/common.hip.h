@@ -64,6 +64,19 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
+// GEMM row m -> (image, oy, ox) of an OY x OX iteration grid: shifts for power-of-two grids (every SPLIT-VAE layer),
+// two integer divisions otherwise (wave-uniform choice)
+__device__ __forceinline__ void sv_decode_row(int m, int lOY, int lOX, int OY, int OX, int& b, int& oy, int& ox) {
+  if (lOY >= 0 && lOX >= 0) {
+    b = m >> (lOY + lOX); oy = (m >> lOX) & (OY - 1); ox = m & (OX - 1);
+  } else {
+    const int pp = OY * OX;
+    b = m / pp;
+    const int r = m - b * pp;
+    oy = r / OX; ox = r - oy * OX;
+  }
+}
+
 // 64-lane butterfly sum (wavefront shuffles; every lane ends with the total)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -164,12 +164,16 @@ int svg_check(const sv_conv_desc* d) {
   if (!d) return SV_E_BADARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0) return SV_E_BADARG;
   if (d->dtype != SV_BF16 && d->dtype != SV_F32) return SV_E_BADARG;
-  if (d->stride != 1 && d->stride != 2) return SV_E_UNSUPPORTED;
+  if (d->stride < 1 || d->stride > 3) return SV_E_UNSUPPORTED;
   if (d->KH * d->KW > SV_MAX_TAPS) return SV_E_UNSUPPORTED;
-  if (ilog2_exact(d->H) < 0 || ilog2_exact(d->W) < 0) return SV_E_UNSUPPORTED;
-  if (d->stride == 2 && ((d->H & 1) || (d->W & 1) || (d->KH & 1) || (d->KW & 1))) return SV_E_UNSUPPORTED;
+  // Power-of-two extents run on the LDS-tile / row-ring kernels; any other extent (SPLIT-SPAIR's 48 / 24 / 12 backbone and
+  // its stride-3 layer, spair/spair.py:382-384) on the im2col kernels, whose row decode divides.  Strided layers need the
+  // stride to divide the extent (the input gradient iterates H/s x W/s parity classes).
+  if (d->stride > 1 && ((d->H % d->stride) || (d->W % d->stride))) return SV_E_UNSUPPORTED;
+  if (d->stride == 2 && ((d->KH & 1) || (d->KW & 1))) return SV_E_UNSUPPORTED;
   if (d->ldx < d->Cin || d->ldx % 8) return SV_E_BADARG;
-  if (ilog2_exact(svg_cin_pad(d)) < 0 || ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
+  if (ilog2_exact(svg_cin_pad(d)) < 0) return SV_E_UNSUPPORTED;      // K pieces per tap: a power of two (the input gradient
+                                                                   // contracts over Cout instead: checked there)
   if (d->ldy < d->Cout) return SV_E_BADARG;
   if (!d->y_f32 && d->ldy % 8) return SV_E_BADARG;
   if (d->ups_in && (d->stride != 1 || (d->H & 1) || (d->W & 1))) return SV_E_UNSUPPORTED;
@@ -185,7 +189,7 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   int pt, pl;
   svg_pads(d, &pt, &pl);
   a->M = d->B * OH * OW;
-  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW);
+  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW); a->OY = OH; a->OX = OW;
   a->IH = d->H; a->IW = d->W; a->lda = d->ldx;
   a->cl2 = ilog2_exact(cpad / epp);
   a->ntaps = d->KH * d->KW;
@@ -198,7 +202,7 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   if (svg_packx(d)) {
     // rows = output pixel pairs (y, 2X .. 2X+1); tap (ky, tx) reads input pixel (y + ky - pt, 2X + tx - pl)
     a->M = d->B * OH * (OW / 2);
-    a->lOX = ilog2_exact(OW / 2);
+    a->lOX = ilog2_exact(OW / 2); a->OX = OW / 2;
     a->ntaps = d->KH * (d->KW + 1);
     a->Ktot = a->ntaps * cpad;
     a->P = a->Ktot / epp;
@@ -230,7 +234,7 @@ void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srct
   const int ph = cls / s, pw = cls % s;
   const int gy = d->H / s, gx = d->W / s;     // iteration grid of this class
   a->M = d->B * gy * gx;
-  a->lOY = ilog2_exact(gy); a->lOX = ilog2_exact(gx);
+  a->lOY = ilog2_exact(gy); a->lOX = ilog2_exact(gx); a->OY = gy; a->OX = gx;
   a->IH = OH; a->IW = OW; a->lda = gdy;
   a->cl2 = ilog2_exact(gdy / epp);
   a->S = 1; a->SX = 1;
@@ -248,13 +252,14 @@ void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srct
         ++nt;
       }
   } else {
-    // kh = kh0 + 2a with kh0 = (ph+pt)&1 ; oh = i2 + (ph+pt-kh0)/2 - a
-    const int kh0 = (ph + pt) & 1, kw0 = (pw + pl) & 1;
-    for (int ay = 0; ay < d->KH / 2; ++ay)
-      for (int ax = 0; ax < d->KW / 2; ++ax) {
-        a->dy[nt] = (int8_t)((ph + pt - kh0) / 2 - ay);
-        a->dx[nt] = (int8_t)((pw + pl - kw0) / 2 - ax);
-        srctap[nt] = (uint8_t)((kh0 + 2 * ay) * d->KW + (kw0 + 2 * ax));
+    // input row ih = s*i2 + ph receives dy[oh] w[kh] with s*oh = ih + pt - kh: kh = kh0 + s*a, kh0 = (ph + pt) mod s,
+    // oh = i2 + (ph + pt - kh0)/s - a.  (s = 2, even kernels: KH/2 taps in every class; s = 3, k = 4: 2 or 1.)
+    const int kh0 = (ph + pt) % s, kw0 = (pw + pl) % s;
+    for (int ay = 0; kh0 + s * ay < d->KH; ++ay)
+      for (int ax = 0; kw0 + s * ax < d->KW; ++ax) {
+        a->dy[nt] = (int8_t)((ph + pt - kh0) / s - ay);
+        a->dx[nt] = (int8_t)((pw + pl - kw0) / s - ax);
+        srctap[nt] = (uint8_t)((kh0 + s * ay) * d->KW + (kw0 + s * ax));
         ++nt;
       }
   }
@@ -270,7 +275,7 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   int pt, pl;
   svg_pads(d, &pt, &pl);
   a->M = d->B * OH * OW;
-  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW);
+  a->lOY = ilog2_exact(OH); a->lOX = ilog2_exact(OW); a->OY = OH; a->OX = OW;
   a->IH = d->H; a->IW = d->W; a->lda = d->ldx; a->S = d->stride; a->SX = d->stride;
   a->ldy = svg_gdy(d);
   a->ycols = svg_gdy(d);
@@ -282,7 +287,7 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
     // the x-packed conv's weight gradient: rows = pixel pairs, dY = the [B,H,W,8] gradient viewed as
     // [B,H,W/2,16]; the tile kernel folds dW' back into the HWIO gradient (the im2col kernel cannot)
     a->M = d->B * OH * (OW / 2);
-    a->lOX = ilog2_exact(OW / 2);
+    a->lOX = ilog2_exact(OW / 2); a->OX = OW / 2;
     a->SX = 2; a->ldy = 16; a->ycols = 16; a->N = 16;
     a->fold_kw = d->KW; a->fold_c = d->Cout;
     a->ntaps = d->KH * (d->KW + 1);
@@ -410,6 +415,7 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
   if (rc != SV_OK) return rc;
   if (!dy || !w_dgrad || !dx) return SV_E_BADARG;
   if (dx_f32_atomic && relu_mask) return SV_E_BADARG;
+  if (ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
   const size_t esz = d->dtype == SV_BF16 ? 2 : 4;
   int64_t off = 0;
   for (int c = 0; c < svg_dgrad_classes(d); ++c) {
@@ -437,6 +443,7 @@ extern "C" int sv_conv2d_nhwc_dgrad_lowres(const sv_conv_desc* d, const void* dy
   if (rc != SV_OK) return rc;
   if (!dy || !w_dgrad || !dx_lo) return SV_E_BADARG;
   if (!d->ups_in || d->stride != 1) return SV_E_BADARG;
+  if (ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
   TapGemmArgs a;
   uint8_t srctap[SV_MAX_TAPS];
   svg_dgrad_args(d, 0, &a, srctap);

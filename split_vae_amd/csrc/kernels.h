@@ -16,7 +16,9 @@ struct TapGemmArgs {
   void* out;            // T, or float when out_f32
   const void* mask;     // optional ReLU mask (T), indexed like out
   int M;                // B*OY*OX
-  int lOY, lOX;         // log2 of the per-image iteration grid
+  int lOY, lOX;         // log2 of the per-image iteration grid, or -1 when OY / OX is not a power of two (SPLIT-SPAIR's
+                        // 48 -> 24 -> 12 -> 4 backbone, spair/spair.py:382-384: im2col kernels only, divide-based row decode)
+  int OY, OX;           // the per-image iteration grid itself
   int IH, IW, lda;
   int cl2;              // log2(16-byte pieces per tap) ; Cin = (1<<cl2)*EPP
   int P;                // total 16-byte pieces along K
@@ -85,7 +87,7 @@ struct WgradArgs {
   const void* dY;     // [M, ldy]
   float* dW;          // [ntaps*Cin_real][N] fp32, atomically accumulated
   float* dbias;       // [N] or null
-  int M, lOY, lOX, IH, IW, lda, S, SX;   // SX: x stride (= S except for the x-packed conv)
+  int M, lOY, lOX, OY, OX, IH, IW, lda, S, SX;   // SX: x stride (= S except for the x-packed conv); lOY / lOX = -1: not a power of two
   int fold_kw, fold_c;   // x-packed conv (svg_packx): dW'[(ky,tx)][ci][px*8+co] folds into dW[ky][tx-px][ci][co], co < fold_c
   int ldy, ycols;     // dY row stride and number of valid columns from the dY pointer (multiple of 8)
   int cl2;            // log2(pieces per tap)

@@ -605,6 +605,7 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
   int cfg = -1;
   for (int i = 0; i < n; ++i) {
     const TapGemmArgs& p = t[i];
+    if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
     if (p.S != 1 || p.SX != 1 || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
     if (p.mask && !p.adj) return SV_E_UNSUPPORTED;                     // a ReLU mask on the output itself: tile kernel
     const int OY = 1 << p.lOY, OX = 1 << p.lOX;

@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
   const int pp = tid & 7, r0 = tid >> 3;
   int iy0[AR], ix0[AR], roff[AR];
   {
-    const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int m = m0 + r0 + 32 * i;
       if (m < g.M) {
-        const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+        int b, oy, ox;
+        sv_decode_row(m, g.lOY, g.lOX, g.OY, g.OX, b, oy, ox);
         iy0[i] = oy * g.S;
         ix0[i] = ox * g.S;
         roff[i] = ((b * g.IH + iy0[i]) * g.IW + ix0[i]) * g.lda;
@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
 
   // ---- epilogue.  Operands swapped: D rows = channels, cols = GEMM rows, so a lane holds channels
   // n0 + j*16 + (lane>>4)*4 + {0..3} of row lane&15 of each fragment (see tile_conv.hip).
-  const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
-  const int ncols = min(BN, g.N - n0);
+  // columns stored: the real channels, and -- for a low-precision output whose channel count is not a multiple of 8 (SPAIR's
+  // 100-channel z3) -- the zero pad channels up to the tensor's 8-channel pitch (weight rows >= N are zero, the bias is skipped)
+  const int Nst = (!g.out_f32 && g.splitk == 1 && (g.N & 7)) ? min(g.ldo, (g.N + 7) & ~7) : g.N;
+  const int ncols = min(BN, Nst - n0);
   {
     // transposed through LDS into row-contiguous 16-B (8-B for narrow fp32 rows) stores; split-K
     // partial sums take the same route so that their fp32 atomics are issued row-contiguously
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int nl = j * 16 + lg * 4 + e;
-          bv[j][e] = (g.bias && nl < ncols) ? g.bias[n0 + nl] : 0.f;
+          bv[j][e] = (g.bias && n0 + nl < g.N) ? g.bias[n0 + nl] : 0.f;
         }
       const bool relu = g.act == SV_ACT_RELU;
 #pragma unroll
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
           const int rl = (int)(((float)q + 0.5f) * rinv), n = q - rl * ncols;
           const int m = m0 + rl;
           if (m >= g.M) continue;
-          const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+          int b, oy, ox;
+        sv_decode_row(m, g.lOY, g.lOX, g.OY, g.OX, b, oy, ox);
           const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
           atomicAdd((float*)g.out + pix * g.ldo + n0 + n, *(const float*)(sC + rl * srow + n * 4));
         }
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
         const int rl = q / ppr_o, c = q - rl * ppr_o;
         const int m = m0 + rl;
         if (m >= g.M) continue;
-        const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+        int b, oy, ox;
+        sv_decode_row(m, g.lOY, g.lOX, g.OY, g.OX, b, oy, ox);
         const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
         const int64_t ob = (pix * g.ldo + n0) * oesz + c * psz;
         if (psz == 16) {
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
   for (int i = 0; i < MF; ++i) {
     const int m = m0 + wave * WM + i * 16 + lr;
     if (m >= g.M) continue;
-    const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+    int b, oy, ox;
+        sv_decode_row(m, g.lOY, g.lOX, g.OY, g.OX, b, oy, ox);
     const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * g.OS + g.oox;
 #pragma unroll
     for (int j = 0; j < NF; ++j)

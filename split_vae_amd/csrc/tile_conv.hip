@@ -351,6 +351,7 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
 // the im2col kernel instead.
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out) {
   if (t.splitk != 1) return false;
+  if (t.lOY < 0 || t.lOX < 0 || t.S > 2) return false;    // power-of-two grids, stride <= 2 (the tile maps shift and mask)
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
   if (t.ups && t.S != 1) return false;
   if (t.d2s && (t.N != 16 || !t.out_f32)) return false;
@@ -533,7 +534,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   int cfg[SV_MAX_MULTI];
   bool all_tile = !force_tap;
   for (int i = 0; i < n && all_tile; ++i) {
-    all_tile = svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &a[i], &cfg[i]);
+    all_tile = svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &a[i], &cfg[i]);
     a[i].dbg = dbg;
     if (all_tile && i > 0 && (cfg[i] != cfg[0] || a[i].ntiles != a[0].ntiles || a[i].N != a[0].N)) all_tile = false;
   }
@@ -543,7 +544,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   for (int i = 0; i < n && none_tile; ++i) {
     TileConvArgs b;
     int c;
-    none_tile = !(t[i].ups || t[i].d2s) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &b, &c));
+    none_tile = !(t[i].ups || t[i].d2s) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
   }
   if (none_tile) {
     for (int i = 0; i < n; i += SV_TAP_MAX_MULTI) {
@@ -556,7 +557,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     int rc;
     TileConvArgs b;
     int c;
-    if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M >> (t[i].lOY + t[i].lOX), &b, &c)) {
+    if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c)) {
       b.dbg = dbg;
       rc = svk_tile_conv(b, dtype, c, st);
     } else if (t[i].ups || t[i].d2s) {

@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mg) {
   const int nsteps = (mend - mbeg + MS - 1) / MS;
   const T* __restrict__ Ab = (const T*)g.A;
   const T* __restrict__ Yb = (const T*)g.dY;
-  const int OYm = (1 << g.lOY) - 1, OXm = (1 << g.lOX) - 1;
   const int Ptot = g.Nrows / EPP;
   __syncthreads();
 
@@ -81,7 +80,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradMulti mg) {
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int m = mb + a_row[i];
-      const int b = m >> (g.lOY + g.lOX), oy = (m >> g.lOX) & OYm, ox = m & OXm;
+      int b, oy, ox;
+        sv_decode_row(m, g.lOY, g.lOX, g.OY, g.OX, b, oy, ox);
       const int iy = oy * g.S + a_dy[i], ix = ox * g.S + a_dx[i];
       const bool ok = m < mend && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
       const int64_t o = (int64_t)((b * g.IH + oy * g.S) * g.IW + ox * g.S) * g.lda + a_off[i];

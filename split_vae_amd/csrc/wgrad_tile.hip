@@ -362,7 +362,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const WgradArgs& w = wv[0];                       // the n problems share one geometry, pointers differ
   static const bool force_old = getenv("SV_FORCE_IM2COL") != nullptr;
   static const char* skip = getenv("SV_WGRAD_IM2COL_IDS");    // e.g. "23": these layer ids use the im2col kernel (A/B)
-  if (force_old) return SV_E_UNSUPPORTED;
+  if (force_old || w.lOY < 0 || w.lOX < 0 || w.S > 2) return SV_E_UNSUPPORTED;   // power-of-two grids, stride <= 2
   const int OY = 1 << w.lOY, OX = 1 << w.lOX;
   if (OY * OX < 16 || w.ycols != w.ldy || (w.ups && w.S != 1)) return SV_E_UNSUPPORTED;
   const int cin = w.Cin_pad, cout = w.ldy, nt = w.ntaps;

@@ -84,7 +84,11 @@ def test_kernel_entry_points_validate_arguments(lib_built):
     assert lib.sv_scramble_gather(None, None, None, 1, 32, 32, 4, None) == _lib.STATUS_BADARG
     assert lib.sv_random_perm(None, 1, 16, 0, 0, 0, None) == _lib.STATUS_BADARG
     assert lib.sv_adam_step(None, None, None, None, 16, 1e-4, .9, .999, 1e-7, 1, 1.0, None) == _lib.STATUS_BADARG
-    d = _lib.ConvDesc(4, 24, 24, 32, 32, 4, 4, 1, 0, 1, 32, 32, 0)       # 24 is not a power of two
+    d = _lib.ConvDesc(4, 24, 24, 32, 32, 4, 4, 1, 0, 1, 32, 32, 0)       # 24: not a power of two -> im2col kernels (SPLIT-SPAIR backbone)
+    assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) == 32 * 16 * 32
+    d = _lib.ConvDesc(4, 50, 50, 32, 32, 4, 4, 3, 0, 1, 32, 32, 0)       # a stride that does not divide the extent
+    assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) < 0
+    d = _lib.ConvDesc(4, 48, 48, 32, 32, 4, 4, 4, 0, 1, 32, 32, 0)       # strides 1..3
     assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) < 0
     d = _lib.ConvDesc(4, 32, 32, 32, 6, 6, 6, 1, 0, 1, 32, 6, 1)
     # bf16 head (Cout 6): the x-pixel-packed image, 16 columns (2 pixels x 8) x 6x7 taps x Cin

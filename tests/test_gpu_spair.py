@@ -1,0 +1,88 @@
+"""SPLIT-SPAIR, first blocker: the conv backbone of spair.Encoder (spair/spair.py:382-388) -- 48 -> 24 ->
+12 -> 4x4 cells with strides 2, 2, 3 and three 1x1 convs, the only non-power-of-two extents and the only stride 3 of the repo --
+on the MFMA im2col kernels (divide-based row decode), at the reference's shape [32, 48, 48, 3] (batch 32 is hard-coded,
+spair/trainer.py:346), against the fp64 oracle restatement: forward chain, and per layer the input and weight gradients."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spair_ref, torch_ref
+
+pytestmark = pytest.mark.gpu
+B = 32
+
+
+@pytest.fixture(scope="module")
+def ops(lib_built):
+    assert torch.cuda.is_available()
+    from split_vae_amd import ops as o
+    return o
+
+
+def _pad8(t):
+    c = t.shape[-1]
+    return torch.nn.functional.pad(t, (0, (c + 7) // 8 * 8 - c))
+
+
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_backbone_forward_chain(ops, dtype, rtol):
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy((rng.integers(0, 256, (B, 48, 48, 3)) / 255.0).astype(np.float32))       # spair/data.py: canvases in [0,1]
+    params = spair_ref.backbone_init(3)
+    for i in range(1, len(params), 2):
+        params[i] = (rng.standard_normal(params[i].shape) * 0.05).astype(np.float32)             # exercise the bias path
+    # fp64 reference from the operands as the device sees them (bf16 path: weights and every activation rounded to bf16)
+    rnd = (lambda t: t.to(dtype).double())
+    h_ref, refs = rnd(x), []
+    h = _pad8(x).to(dtype).cuda()
+    H = 48
+    for i, (name, k, s, ci, co) in enumerate(spair_ref.BACKBONE):
+        w, b = torch.from_numpy(params[2 * i]), torch.from_numpy(params[2 * i + 1])
+        conv = ops.Conv2D(B, H, H, ci, co, k, s, act="relu", dtype=dtype)
+        conv.prep(w.cuda())
+        h = conv.fwd(h.contiguous(), b.cuda())
+        h_ref = rnd(torch_ref.conv2d_same(h_ref, rnd(w), b.double(), s, "relu"))
+        H = (H + s - 1) // s
+        assert tuple(h.shape) == (B, H, H, (co + 7) // 8 * 8)
+        got = h[..., :co].double().cpu()
+        torch.testing.assert_close(got, h_ref, rtol=rtol, atol=rtol * float(h_ref.abs().max()), msg=lambda m: name + ": " + m)
+        if co % 8:
+            assert float(h[..., co:].abs().max()) == 0.0                                          # pad channels stay zero
+        h_ref = got if dtype == torch.bfloat16 else h_ref                                         # bf16: continue from the device's rounding
+    assert H == 4
+
+
+@pytest.mark.parametrize("layer", [l for l in spair_ref.BACKBONE if l[0] != "z3"], ids=lambda l: l[0])
+def test_backbone_layer_gradients(ops, layer):
+    """Input gradient (stride 3: nine parity classes with 1, 2 or 4 taps) and weight gradient, bf16 operands, fp64 reference."""
+    name, k, s, ci, co = layer
+    H = {"conv1": 48, "conv2": 24, "conv3": 12}.get(name, 4)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    x = torch.from_numpy(rng.standard_normal((B, H, H, ci)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, ci, co)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (ci + co)))
+    OH = (H + s - 1) // s
+    dy = torch.from_numpy(rng.standard_normal((B, OH, OH, co)).astype(np.float32)).bfloat16()
+    conv = ops.Conv2D(B, H, H, ci, co, k, s, act="relu", dtype=torch.bfloat16)
+    conv.prep(w.cuda())
+    xr = x.double().requires_grad_(True)
+    wr = w.bfloat16().double().requires_grad_(True)
+    br = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    torch_ref.conv2d_same(xr, wr, br, s, None).backward(dy.double())
+    dw, db = conv.wgrad(_pad8(x).cuda(), dy.cuda())
+    torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(db.double().cpu(), br.grad, rtol=3e-2, atol=3e-2 * float(br.grad.abs().max()))
+    if name == "conv1":
+        return                                                 # the canvas needs no gradient
+    dx = conv.dgrad(dy.cuda())
+    assert float((dx[..., :ci].double().cpu() - xr.grad).norm() / xr.grad.norm()) < 5e-3
+    torch.testing.assert_close(dx[..., :ci].double().cpu(), xr.grad, rtol=3e-2, atol=1.5e-2 * float(xr.grad.abs().max()))
+
+
+def test_unsupported_geometries_are_refused(ops):
+    from split_vae_amd import _lib
+    with pytest.raises(_lib.SplitVaeError):
+        ops.Conv2D(4, 50, 50, 8, 8, 4, 3)                       # stride must divide the extent
+    with pytest.raises(_lib.SplitVaeError):
+        ops.Conv2D(4, 48, 48, 8, 8, 4, 4)                       # strides 1..3
