@@ -25,5 +25,8 @@ for k in sorted(set(rd) | set(wr)):
     out[k[:120]] = {"launches_sampled": len(r), "read_bytes_per_launch": round(2 * 1024 * sum(r) / len(r)),
                     "write_bytes_per_launch": round(1024 * sum(w) / len(w)),
                     "hbm_bytes_per_launch": round(2 * 1024 * sum(r) / len(r) + 1024 * sum(w) / len(w))}
-print(json.dumps({"unit": "bytes per launch", "correction": "FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE KiB x1",
+# bytes per training step: every launch of every kernel, divided by the number of steps run (= launches of the Adam kernel)
+steps = max([len(v) for k, v in wr.items() if "adam_kernel" in k] + [1])
+total = sum(2 * 1024 * sum(v) for v in rd.values()) + sum(1024 * sum(v) for v in wr.values())
+print(json.dumps({"unit": "bytes per launch", "steps_profiled": steps, "total_bytes_per_step": round(total / steps), "correction": "FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE KiB x1",
                   "kernels": out}, indent=1))

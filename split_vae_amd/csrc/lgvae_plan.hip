@@ -428,8 +428,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     }
   }
   if (adj) {                            // no fused kernel for this geometry: nothing was launched, the caller falls back
-    TapGemmArgs probe = a[0];
-    if (!svk_row_conv_supported(&probe, m, L[0]->d.dtype)) return SV_E_UNSUPPORTED;
+    if (!svk_row_conv_supported(a, m, L[0]->d.dtype)) return SV_E_UNSUPPORTED;
   }
   Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
   if (mixed) {   // split-K problems whose widths pick different tiles: one launch each

@@ -145,55 +145,79 @@ __device__ __forceinline__ void dll_elem(float x, float m, float ls, float& nll,
   }
 }
 
-template <typename TG, bool GRAD>
+// TWIN: one thread handles the x AND the x-hat reconstruction of its pixel (images6 holds x | x-hat in one 24-B record:
+// a launch per network -- or a network per blockIdx.z -- fetches every record twice, 1.23x the algorithmic bytes of the
+// whole kernel by the PMC counters); the second network's buffers lie one stride (zs_*) further.
+template <typename TG, bool GRAD, bool TWIN>
 __global__ __launch_bounds__(256) void dlogistic_kernel(const float* __restrict__ images6, int ch_off,
                                                         const float* __restrict__ out6,
                                                         TG* __restrict__ grad, float gscale,
                                                         float* __restrict__ partial, int HW,
                                                         int pix_per_block, int64_t zs_out, int64_t zs_grad,
                                                         int64_t zs_part) {
-  // blockIdx.z = network (x / x-hat twin launch): channel triple 3z of images6, buffers one net stride apart
-  ch_off += 3 * blockIdx.z;
-  out6 += blockIdx.z * zs_out;
-  if (GRAD) grad += blockIdx.z * zs_grad;
-  partial += blockIdx.z * zs_part;
+  constexpr int NN = TWIN ? 2 : 1;
+  if (!TWIN) {
+    // blockIdx.z = network (stand-alone use): channel triple 3z of images6, buffers one net stride apart
+    ch_off += 3 * blockIdx.z;
+    out6 += blockIdx.z * zs_out;
+    if (GRAD) grad += blockIdx.z * zs_grad;
+    partial += blockIdx.z * zs_part;
+  }
   const int part = blockIdx.x, b = blockIdx.y, P = gridDim.x;
   const int64_t base = (int64_t)b * HW;
   const int p0 = part * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
-  float acc = 0.f;
+  float acc[NN];
+#pragma unroll
+  for (int z = 0; z < NN; ++z) acc[z] = 0.f;
   for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const float* xi = images6 + (base + p) * 6 + ch_off;
-    const float* oi = out6 + (base + p) * 6;
-    const float2 o01 = *(const float2*)(oi), o23 = *(const float2*)(oi + 2), o45 = *(const float2*)(oi + 4);
-    const float x0 = xi[0], x1 = xi[1], x2 = xi[2];
-    float n0, n1, n2, dm0, dm1, dm2, dl0, dl1, dl2;
-    dll_elem(x0, o01.x, o23.y, n0, dm0, dl0);
-    dll_elem(x1, o01.y, o45.x, n1, dm1, dl1);
-    dll_elem(x2, o23.x, o45.y, n2, dm2, dl2);
-    acc += (n0 + n1) + n2;
-    if (GRAD) {
-      TG* gp = grad + (base + p) * 8;
-      if constexpr (sizeof(TG) == 2) {
-        bf16x8 v;
-        v[0] = (bf16_t)(dm0 * gscale); v[1] = (bf16_t)(dm1 * gscale); v[2] = (bf16_t)(dm2 * gscale);
-        v[3] = (bf16_t)(dl0 * gscale); v[4] = (bf16_t)(dl1 * gscale); v[5] = (bf16_t)(dl2 * gscale);
-        v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
-        *(bf16x8*)gp = v;
-      } else {
-        float4 a = make_float4(dm0 * gscale, dm1 * gscale, dm2 * gscale, dl0 * gscale);
-        float4 c = make_float4(dl1 * gscale, dl2 * gscale, 0.f, 0.f);
-        *(float4*)gp = a;
-        *(float4*)(gp + 4) = c;
+    const float* xi = images6 + (base + p) * 6;
+    float xv[6];
+    if (TWIN) {
+      const float2 a = *(const float2*)(xi), c = *(const float2*)(xi + 2), e = *(const float2*)(xi + 4);
+      xv[0] = a.x; xv[1] = a.y; xv[2] = c.x; xv[3] = c.y; xv[4] = e.x; xv[5] = e.y;
+    } else {
+      xv[0] = xi[ch_off]; xv[1] = xi[ch_off + 1]; xv[2] = xi[ch_off + 2];
+    }
+#pragma unroll
+    for (int z = 0; z < NN; ++z) {
+      const float* oi = out6 + z * zs_out + (base + p) * 6;
+      const float2 o01 = *(const float2*)(oi), o23 = *(const float2*)(oi + 2), o45 = *(const float2*)(oi + 4);
+      const float x0 = xv[3 * z], x1 = xv[3 * z + 1], x2 = xv[3 * z + 2];
+      float n0, n1, n2, dm0, dm1, dm2, dl0, dl1, dl2;
+      dll_elem(x0, o01.x, o23.y, n0, dm0, dl0);
+      dll_elem(x1, o01.y, o45.x, n1, dm1, dl1);
+      dll_elem(x2, o23.x, o45.y, n2, dm2, dl2);
+      acc[z] += (n0 + n1) + n2;
+      if (GRAD) {
+        TG* gp = grad + z * zs_grad + (base + p) * 8;
+        if constexpr (sizeof(TG) == 2) {
+          bf16x8 v;
+          v[0] = (bf16_t)(dm0 * gscale); v[1] = (bf16_t)(dm1 * gscale); v[2] = (bf16_t)(dm2 * gscale);
+          v[3] = (bf16_t)(dl0 * gscale); v[4] = (bf16_t)(dl1 * gscale); v[5] = (bf16_t)(dl2 * gscale);
+          v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
+          *(bf16x8*)gp = v;
+        } else {
+          float4 a = make_float4(dm0 * gscale, dm1 * gscale, dm2 * gscale, dl0 * gscale);
+          float4 c = make_float4(dl1 * gscale, dl2 * gscale, 0.f, 0.f);
+          *(float4*)gp = a;
+          *(float4*)(gp + 4) = c;
+        }
       }
     }
   }
   // per-image reduction: 64-lane shuffle, then 4 waves through LDS (deterministic order)
-  __shared__ float red[4];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __shared__ float red[NN][4];
+#pragma unroll
+  for (int z = 0; z < NN; ++z) {
+    const float a = wave_sum(acc[z]);
+    if ((threadIdx.x & 63) == 0) red[z][threadIdx.x >> 6] = a;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partial[(int64_t)b * P + part] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x < NN) {
+    const int z = threadIdx.x;
+    partial[z * zs_part + (int64_t)b * P + part] = (red[z][0] + red[z][1]) + (red[z][2] + red[z][3]);
+  }
 }
 
 __global__ void rowsum_partials_kernel(const float* __restrict__ partial, float* __restrict__ nll, int B, int P,
@@ -220,16 +244,19 @@ int svk_dlogistic_nll_multi(const float* images6, int ch_off, const float* out6,
                             int H, int W, float* partial_ws, int64_t zs_part, int nets, hipStream_t st) {
   const int HW = H * W, P = dll_parts(HW);
   const int ppb = (HW + P - 1) / P;
-  dim3 grid(P, B, nets), block(256);
-  if (!grad)
-    hipLaunchKernelGGL((dlogistic_kernel<float, false>), grid, block, 0, st, images6, ch_off, out6,
-                       (float*)nullptr, 0.f, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
-  else if (grad_dtype == SV_BF16)
-    hipLaunchKernelGGL((dlogistic_kernel<bf16_t, true>), grid, block, 0, st, images6, ch_off, out6,
-                       (bf16_t*)grad, grad_scale, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
-  else if (grad_dtype == SV_F32)
-    hipLaunchKernelGGL((dlogistic_kernel<float, true>), grid, block, 0, st, images6, ch_off, out6,
-                       (float*)grad, grad_scale, partial_ws, HW, ppb, zs_out, zs_grad, zs_part);
+  const bool twin = nets == 2 && ch_off == 0;             // x | x-hat of one images6 record in one thread
+  dim3 grid(P, B, twin ? 1 : nets), block(256);
+#define SV_DLL_LAUNCH(TG_, GRAD_, g_, sc_)                                                                                  \
+  do {                                                                                                                      \
+    if (twin) hipLaunchKernelGGL((dlogistic_kernel<TG_, GRAD_, true>), grid, block, 0, st, images6, ch_off, out6, g_, sc_,  \
+                                 partial_ws, HW, ppb, zs_out, zs_grad, zs_part);                                            \
+    else hipLaunchKernelGGL((dlogistic_kernel<TG_, GRAD_, false>), grid, block, 0, st, images6, ch_off, out6, g_, sc_,      \
+                            partial_ws, HW, ppb, zs_out, zs_grad, zs_part);                                                 \
+  } while (0)
+  if (!grad) SV_DLL_LAUNCH(float, false, (float*)nullptr, 0.f);
+  else if (grad_dtype == SV_BF16) SV_DLL_LAUNCH(bf16_t, true, (bf16_t*)grad, grad_scale);
+  else if (grad_dtype == SV_F32) SV_DLL_LAUNCH(float, true, (float*)grad, grad_scale);
+#undef SV_DLL_LAUNCH
   else
     return SV_E_BADARG;
   SV_LAUNCH_CHECK();
