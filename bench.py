@@ -224,8 +224,8 @@ def decoder_stack(table, dtype, passes):
 
 # plan scope -> substrings of its HIP kernel symbol as rocprofv3 prints it (profiles/*_traffic.json keys)
 SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi16ELi4ELi4E"], "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
-                "dgrad.d4": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi6E"], "wgrad.d5": ["wgrad_tile_kernel<11, "],
-                "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
+                "fwd.d3": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi4E"], "fwd.e2": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi0E"],
+                "wgrad.d5": ["wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
 
 
 def main():
