@@ -268,6 +268,27 @@ void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srct
   a->P = a->Ktot / epp;
 }
 
+// Stride-2 layers whose four parity classes read the SAME dY window (k = 6, pad 2: rows / columns -1..1 of the class
+// grid in every class) run as ONE problem: the class weight images, laid back to back, are a [4*Cin][ntaps*gdy] image
+// of a stride-1 conv dY -> 4*Cin columns on the class grid, and column n = (class, channel) is stored to the class's
+// sub-pixel (TapGemmArgs::cls_n).  One staging of the dY tile and one A fragment then serve four classes.
+// -> false when the classes differ (k = 4: windows {0,-1} and {1,0}), the widths do not fit a 128-column tile, or the
+// caller's images are not contiguous (class_stride = elements between consecutive class images).
+bool svg_dgrad_merged_args(const sv_conv_desc* d, const int64_t* class_off, TapGemmArgs* a) {
+  static const bool off = getenv("SV_NO_CLS_MERGE") != nullptr;        // A/B: one problem per parity class
+  if (off || d->stride != 2 || (d->Cin & 7) || 4 * d->Cin > 128 || (4 * d->Cin) % 32) return false;
+  uint8_t srctap[SV_MAX_TAPS];
+  svg_dgrad_args(d, 0, a, srctap);
+  for (int c = 1; c < 4; ++c) {
+    TapGemmArgs b;
+    svg_dgrad_args(d, c, &b, srctap);
+    if (b.ntaps != a->ntaps || memcmp(b.dy, a->dy, a->ntaps) || memcmp(b.dx, a->dx, a->ntaps)) return false;
+    if (class_off[c] - class_off[c - 1] != svg_wprep_elems_class(d, 1, c - 1)) return false;
+  }
+  a->N = 4 * d->Cin; a->cls_n = d->Cin; a->ooy = 0; a->oox = 0;
+  return true;
+}
+
 void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   memset(a, 0, sizeof(*a));
   const int epp = svg_epp(d), cpad = svg_cin_pad(d);
@@ -418,6 +439,16 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
   if (ilog2_exact(svg_gdy(d)) < 0) return SV_E_UNSUPPORTED;
   const size_t esz = d->dtype == SV_BF16 ? 2 : 4;
   int64_t off = 0;
+  if (!dx_f32_atomic && svg_dgrad_classes(d) == 4) {      // classes with one shared window: one launch (cls_n)
+    int64_t coff[4] = {0, 0, 0, 0};
+    for (int c = 1; c < 4; ++c) coff[c] = coff[c - 1] + svg_wprep_elems_class(d, 1, c - 1);
+    TapGemmArgs a;
+    if (svg_dgrad_merged_args(d, coff, &a)) {
+      a.A = dy; a.Wt = w_dgrad; a.out = dx; a.mask = relu_mask;
+      rc = svk_conv_dispatch(a, d->dtype, svg_pick_cfg(a.N), (hipStream_t)stream);
+      if (rc != SV_E_UNSUPPORTED) return rc;
+    }
+  }
   for (int c = 0; c < svg_dgrad_classes(d); ++c) {
     TapGemmArgs a;
     uint8_t srctap[SV_MAX_TAPS];

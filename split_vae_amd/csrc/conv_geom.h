@@ -89,6 +89,7 @@ int svg_check(const sv_conv_desc* d);
 void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a);
 int svg_dgrad_classes(const sv_conv_desc* d);
 void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srctap[SV_MAX_TAPS]);
+bool svg_dgrad_merged_args(const sv_conv_desc* d, const int64_t* class_off, TapGemmArgs* a);   // all 4 classes as one problem
 void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a);
 void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs);
 void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);

@@ -30,6 +30,11 @@ struct TapGemmArgs {
   int ups;              // A is the LOW-RES tensor [B, IH/2, IW/2, lda]; the conv sees its 2x bilinear upsample
   int d2s;              // > 0: x-pixel-packed conv: column n = px*8 + co holds channel co < d2s of output pixel
                         // (oy, 2*ox + px); out is the unpacked [B, OHF, OWF, ldo] tensor
+  int cls_n;            // > 0: MERGED PARITY CLASSES of a stride-2 input gradient whose classes share one tap window (k = 6, pad 2:
+                        // every class reads dy rows / columns -1..1): ONE problem with N = 4 * cls_n columns, column n = class
+                        // (n / cls_n) channel (n % cls_n), class (ph, pw) = (c >> 1, c & 1) lands on output pixel
+                        // (OS * oy + ph, OS * ox + pw): the dY tile is staged once for all four classes and an A fragment feeds
+                        // 4x the MFMAs (tile kernel only)
   int adj;              // input gradient of a layer whose input is a 2x bilinear upsample, FUSED with the resize adjoint: `out`
                         // is the LOW-RES gradient [B, OHF/2, OWF/2, ldo], `mask` the low-res activation (ReLU gate, may be
                         // null).  Only the row-ring kernel implements it (SV_E_UNSUPPORTED elsewhere)
@@ -66,6 +71,7 @@ struct TileConvArgs {
   int dbg;                    // profiling ablation bits (SV_TC_DBG): 1 skip staging, 2 skip MFMA loop, 4 skip stores
   int ups;                    // input tile staged through the fused 2x bilinear upsample
   int d2s;                    // depth-to-space (x) epilogue of the pixel-packed conv: real channels per sub-pixel
+  int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };

@@ -408,6 +408,20 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   int m = 0, tap_cfg = svg_pick_cfg(L[0]->d.Cin);
   bool mixed = false;
   const int ncls = svg_dgrad_classes(&L[0]->d);
+  if (!adj && !f32_atomic && ncls == 4) {              // classes that share one dY window (e2): one problem per network
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+      ok = svg_dgrad_merged_args(&L[i]->d, L[i]->wd_off, &a[i]);
+      a[i].A = dy[i]; a[i].Wt = (char*)p->bp("warena") + L[i]->wd_off[0] * p->esz(); a[i].out = dx[i]; a[i].mask = mask[i];
+      fl += conv_flops(L[i]->d);
+    }
+    if (ok) {
+      Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+      const int rc = svk_conv_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(a[0].N), st);
+      if (rc != SV_E_UNSUPPORTED) return rc;
+    }
+    fl = 0;
+  }
   for (int i = 0; i < n; ++i) {
     fl += conv_flops(L[i]->d);
     for (int c = 0; c < ncls; ++c, ++m) {

@@ -304,8 +304,15 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
     const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
     if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
-    const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * (g.d2s ? 2 : g.OS) + g.oox;
-    const int64_t ob = (pix * g.ldo + n0) * oesz + c * psz;   // byte offset in the output tensor
+    int64_t ob;                                          // byte offset in the output tensor
+    if (g.cls_n) {                                       // merged parity classes: this piece's class picks the sub-pixel
+      const int n = n0 + c * (psz / oesz), cls = n / g.cls_n, ch = n - cls * g.cls_n;
+      const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + (cls >> 1)) * g.OWF + ox * g.OS + (cls & 1);
+      ob = (pix * g.ldo + ch) * oesz;
+    } else {
+      const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + g.ooy) * g.OWF + ox * (g.d2s ? 2 : g.OS) + g.oox;
+      ob = (pix * g.ldo + n0) * oesz + c * psz;
+    }
     if (psz == 16) {
       uint4 v = *(const uint4*)(sC + r * srow + c * 16);
       if (g.mask) {                                     // mask tensor has the output's type and indexing (never fp32)
@@ -355,6 +362,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
   if (t.ups && t.S != 1) return false;
   if (t.d2s && (t.N != 16 || !t.out_f32)) return false;
+  if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
   const int cin = (1 << t.cl2) * epp;
@@ -447,7 +455,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     memset(a, 0, sizeof(*a));
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
-    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s;
+    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;
@@ -544,7 +552,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   for (int i = 0; i < n && none_tile; ++i) {
     TileConvArgs b;
     int c;
-    none_tile = !(t[i].ups || t[i].d2s) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
+    none_tile = !(t[i].ups || t[i].d2s || t[i].cls_n) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
   }
   if (none_tile) {
     for (int i = 0; i < n; i += SV_TAP_MAX_MULTI) {
@@ -560,7 +568,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c)) {
       b.dbg = dbg;
       rc = svk_tile_conv(b, dtype, c, st);
-    } else if (t[i].ups || t[i].d2s) {
+    } else if (t[i].ups || t[i].d2s || t[i].cls_n) {
       rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor / has no depth-to-space store
     } else {
       rc = svk_tap_gemm(t[i], dtype, tap_cfg, st);

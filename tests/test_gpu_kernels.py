@@ -430,6 +430,35 @@ def test_row_ring_matches_tile_kernel_in_a_subprocess(lib_built, tmp_path):
         assert not np.array_equal(a, np.zeros_like(a))
 
 
+def test_merged_parity_classes_match_one_problem_per_class(lib_built, tmp_path):
+    """e2's input gradient (k 6, stride 2: the four parity classes read the same dY window) as ONE 128-column problem
+    with the class -> sub-pixel store, against one problem per class (SV_NO_CLS_MERGE=1), masked and unmasked, at a batch
+    with a ragged last tile: the same products in the same K order, so bit-exact."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "outs = []\n"
+        "for B in (1, 7):\n"
+        "    w = (torch.randn(6, 6, 32, 64, generator=g) * 0.03).cuda()\n"
+        "    dy = torch.randn(B, 8, 8, 64, generator=g).bfloat16().cuda()\n"
+        "    mask = torch.randn(B, 16, 16, 32, generator=g).bfloat16().cuda()\n"
+        "    c = ops.Conv2D(B, 16, 16, 32, 64, 6, 2, act='relu', dtype=torch.bfloat16); c.prep(w)\n"
+        "    outs += [c.dgrad(dy).float().cpu().numpy(), c.dgrad(dy, relu_mask=mask).float().cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env in (("merged", {}), ("classes", {"SV_NO_CLS_MERGE": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    for key in res[0].files:
+        assert np.array_equal(res[0][key], res[1][key]), key
+        assert np.count_nonzero(res[0][key]) > res[0][key].size // 4
+
+
 ADJ_LAYERS = [  # name, H (hi-res conv input = output size), Cin, Cout, k, y_f32
     ("d3_64", 16, 128, 64, 4, False),
     ("d4_64", 32, 64, 32, 6, False),
