@@ -313,7 +313,13 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   if (force_pc > 0 && force_pc < per_cu) per_cu = force_pc;
   // ablation bits: 1 skip the flush (+reduce), 2 skip input staging, 4 skip dY staging, 8 skip the MFMA loop
   static const int dbg = SV_DBG(getenv("SV_WT_DBG") ? atoi(getenv("SV_WT_DBG")) : (getenv("SV_WT_NOFLUSH") ? 1 : 0));
-  int msplit = (256 * per_cu + groups - 1) / groups;
+  // ONE resident round of workgroups over the whole launch (all n problems): every workgroup flushes one slab, so
+  // a second round doubles the slab writes and the reduce's reads for no extra parallelism (SV_WT_ROUNDS=2: the old
+  // one round PER PROBLEM, for A/B)
+  static const int rounds = getenv("SV_WT_ROUNDS") ? atoi(getenv("SV_WT_ROUNDS")) : 1;
+  const int share = rounds >= 2 ? 1 : n;
+  int msplit = (256 * per_cu + groups * share - 1) / (groups * share);
+  if (msplit < 1) msplit = 1;
   if (msplit > a[0].ntiles) msplit = a[0].ntiles;
   dim3 grid(msplit, groups, n), block(256 * NG);
   constexpr int PER = 4 * TPW * CIF * COF * 256;
