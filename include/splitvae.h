@@ -112,6 +112,14 @@ int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio, void* w_f
                            void* stream);
 int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                        void* y, void* stream);
+/* Same with a caller-owned workspace (sv_conv2d_fwd_workspace_bytes; 0 for most layers).  The bf16 decoder head
+ * (UpSampling2D(bilinear) -> Conv2D(6, 6x6, 'same'), vae/model.py:163-167 + d5) runs in POLYPHASE form: one 5x5 conv over
+ * the low-res tensor whose four output parities are four column classes, plus 1-D border terms for the taps that leave the
+ * zero-padded hi-res image; with a workspace those terms are computed first and added by the conv's epilogue, without one
+ * they are added to y with atomics afterwards (same result, slower). */
+int64_t sv_conv2d_fwd_workspace_bytes(const sv_conv_desc* d);
+int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* dx = conv-transpose(dy, w) * (mask>0 if mask!=NULL); dy[B,OH,OW,ldy], dx[B,H,W,ldx] (dtype).
  * dx_f32_atomic!=0: K is split over workgroups and dx (fp32, pre-zeroed) is accumulated atomically. */
 int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,

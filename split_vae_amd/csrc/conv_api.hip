@@ -14,6 +14,44 @@
 template <typename T>
 __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
                                            T* __restrict__ arena, int block_in_job) {
+  if (j.poly) {
+    // composite images of the polyphase head (conv_geom.h: svg_poly); source: the 6x6 HWIO master
+    const int total = j.rows * j.ntaps * j.inner;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* w = params + j.src_off;
+    const int ci = idx % j.inner;
+    float v = 0.f;
+    if (j.poly == 1) {
+      // [n = (py*2+px)*8 + co][t = (tx+2)*5 + (ty+2)][ci]: blend coefficient of hi-res tap k of parity p on low-res offset t:
+      // hi offset h = p + k - 2 from row 2i; even h = 2m: rows i+m-1 (.25), i+m (.75); odd h = 2m+1: i+m (.75), i+m+1 (.25)
+      const int t = (idx / j.inner) % 25, n = idx / (j.inner * 25);
+      const int co = n & 7, py = n >> 4, px = (n >> 3) & 1, tx = t / 5 - 2, ty = t % 5 - 2;
+      auto coef = [](int p, int k, int t) -> float {
+        const int h = p + k - 2, m = h >> 1;                      // arithmetic shift = floor
+        if (h & 1) return t == m ? 0.75f : t == m + 1 ? 0.25f : 0.f;
+        return t == m - 1 ? 0.25f : t == m ? 0.75f : 0.f;
+      };
+      if (co < j.Cout && ci < j.Cin)
+        for (int ky = 0; ky < 6; ++ky) {
+          const float cy = coef(py, ky, ty);
+          if (cy == 0.f) continue;
+          for (int kx = 0; kx < 6; ++kx) {
+            const float cx = coef(px, kx, tx);
+            if (cx != 0.f) v += cy * cx * w[((int64_t)(ky * 6 + kx) * j.Cin + ci) * j.Cout + co];
+          }
+        }
+    } else {
+      // border fix [cls][tap][n][ci] = -(sum over the excluded taps): classes 0..4 = hi-res rows 0, 1, 2H-3, 2H-2, 2H-1
+      // (tap = kx, the sum runs over the ky that leave the image: {0,1}, {0}, {5}, {4,5}, {3,4,5}); 5..9 = the columns
+      const int n = (idx / j.inner) & 15, tap = (idx / (j.inner * 16)) % 6, cls = idx / (j.inner * 96);
+      const int c5 = cls % 5, lo = c5 == 0 ? 0 : c5 == 1 ? 0 : c5 == 2 ? 5 : c5 == 3 ? 4 : 3, hi = c5 == 0 ? 1 : c5 == 1 ? 0 : 5;
+      if (n < j.Cout && ci < j.Cin)
+        for (int k = lo; k <= hi; ++k) v -= w[((int64_t)(cls < 5 ? k * 6 + tap : tap * 6 + k) * j.Cin + ci) * j.Cout + n];
+    }
+    arena[j.dst_off + idx] = from_f32<T>(v);
+    return;
+  }
   if (j.packx_kw) {
     const int total = j.rows * j.ntaps * j.inner;
     const int idx = block_in_job * 256 + threadIdx.x;
@@ -199,6 +237,18 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   a->N = d->Cout;
   a->OHF = OH; a->OWF = OW; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldy;
   a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1; a->ups = d->ups_in;
+  if (svg_poly(d)) {
+    // rows = LOW-RES pixels (i, j) of the [B, H/2, W/2, Cin] tensor; tap (ty, tx) in -2..2, x-major; 32 columns (py, px, co)
+    const int h = d->H / 2, w = d->W / 2;
+    a->M = d->B * h * w;
+    a->lOY = ilog2_exact(h); a->lOX = ilog2_exact(w); a->OY = h; a->OX = w;
+    a->IH = h; a->IW = w;
+    a->ntaps = 25; a->Ktot = 25 * cpad; a->P = a->Ktot / epp;
+    a->S = 1; a->SX = 1; a->N = 32; a->OS = 2; a->d2s = d->Cout; a->d2s_y = 1; a->clampin = 1; a->ups = 0;
+    for (int tx = 0; tx < 5; ++tx)
+      for (int ty = 0; ty < 5; ++ty) { a->dy[tx * 5 + ty] = (int8_t)(ty - 2); a->dx[tx * 5 + ty] = (int8_t)(tx - 2); }
+    return;
+  }
   if (svg_packx(d)) {
     // rows = output pixel pairs (y, 2X .. 2X+1); tap (ky, tx) reads input pixel (y + ky - pt, 2X + tx - pl)
     a->M = d->B * OH * (OW / 2);
@@ -352,6 +402,11 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
   j->inner = svg_cin_pad(d);
   j->inner_ld = j->inner; j->inner_off = 0;
   j->transpose = 0;
+  if (svg_poly(d)) {
+    j->ntaps = 25; j->rows = 32; j->poly = 1;
+    j->nblocks = (j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);
+    return;
+  }
   if (svg_packx(d)) {
     j->ntaps = d->KH * (d->KW + 1);
     j->rows = 16;
@@ -362,6 +417,14 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
     for (int kh = 0; kh < d->KH; ++kh)
       for (int kw = 0; kw < d->KW; ++kw) j->srctap[svg_fwd_tap(d, kh, kw)] = (uint8_t)(kh * d->KW + kw);
   j->nblocks = svg_prep_nblocks(j);
+}
+
+void svg_prep_job_polyfix(const sv_conv_desc* d, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  j->Cin = d->Cin; j->Cout = d->Cout;
+  j->rows = 160; j->ntaps = 6; j->inner = svg_cin_pad(d); j->inner_ld = j->inner;     // [10][6][16][Cin] (SV_POLY_FIX_ELEMS)
+  j->poly = 2;
+  j->nblocks = (j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);
 }
 
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
@@ -381,7 +444,7 @@ void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
   PrepJob j;
   if (for_dgrad) svg_prep_job_dgrad(d, cls, &j); else svg_prep_job_fwd(d, &j);
-  return (int64_t)j.rows * j.ntaps * j.inner;
+  return (int64_t)j.rows * j.ntaps * j.inner + (!for_dgrad && svg_poly(d) ? SV_POLY_FIX_ELEMS(svg_cin_pad(d)) : 0);
 }
 
 // ============================================================================ public API
@@ -404,6 +467,13 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
     svg_prep_job_fwd(d, &j);
     rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
     if (rc) return rc;
+    if (svg_poly(d)) {                                   // the border-fix image follows the composite image
+      const int64_t main_elems = (int64_t)j.rows * j.ntaps * j.inner;
+      svg_prep_job_polyfix(d, &j);
+      j.dst_off = main_elems;
+      rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
+      if (rc) return rc;
+    }
   }
   if (w_dgrad) {
     int64_t off = 0;
@@ -419,15 +489,39 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
   return SV_OK;
 }
 
-extern "C" int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
-                                  void* y, void* stream) {
+// Forward with an optional workspace.  The polyphase head (svg_poly) delivers its border terms through the workspace
+// (fix kernel first, added by the conv's epilogue); without one they are added to y with atomics after the conv.
+extern "C" int64_t sv_conv2d_fwd_workspace_bytes(const sv_conv_desc* d) {
+  if (svg_check(d) != SV_OK) return -1;
+  return svg_poly(d) ? svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) : 0;
+}
+
+extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
+                                     void* ws, int64_t ws_bytes, void* stream) {
   int rc = svg_check(d);
   if (rc != SV_OK) return rc;
   if (!x || !w_fwd || !y) return SV_E_BADARG;
   TapGemmArgs a;
   svg_fwd_args(d, &a);
   a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
-  return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  if (!svg_poly(d)) return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * 2;
+  float* yf = (float*)y;
+  float* fixbuf = ws && ws_bytes >= svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) ? (float*)ws : nullptr;
+  if (fixbuf) {
+    rc = svk_poly_fix_multi(1, &x, &wfix, nullptr, &fixbuf, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream);
+    if (rc) return rc;
+    a.fix = fixbuf;
+  }
+  rc = svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  if (rc == SV_OK && !fixbuf)
+    rc = svk_poly_fix_multi(1, &x, &wfix, &yf, nullptr, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                                  void* y, void* stream) {
+  return sv_conv2d_nhwc_fwd_ws(d, x, w_fwd, bias, y, nullptr, 0, stream);
 }
 
 extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dgrad,

@@ -33,6 +33,20 @@ static inline int svg_packx(const sv_conv_desc* d) {
          d->ldy == d->Cout && d->KH * (d->KW + 1) <= SV_MAX_TAPS && d->W >= 32 && d->H >= 16 &&
          svg_cin_pad(d) >= 16 && svg_cin_pad(d) <= 64;
 }
+// POLYPHASE form of the decoder head (2x bilinear upsample -> 6x6 SAME conv, Cout <= 8: vae/model.py:163-167 + d5).  The resize
+// is linear, so conv(U x) is a conv over the LOW-RES tensor: output pixel (2i+py, 2j+px) reads low-res rows i-2..i+2 and
+// columns j-2..j+2 through the composite weights W'[py,px][ty,tx] = sum_{ky,kx} Cy[py][ky][ty] Cx[px][kx][tx] w[ky,kx]
+// (Cy = the .25/.75 half-pixel blend coefficients): 25 taps x Cin instead of 42 x-packed taps, 32 columns (4 parities x
+// 8) instead of 16, a quarter of the pixels to stage and no blend arithmetic in the staging loop.  With the low-res input
+// edge-clamped (= the resize's own clamp) this equals the conv over the REPLICATE-padded upsampled image; the reference
+// zero-pads it, and the difference -- taps of the 5 hi-res border rows / columns that leave the image -- is 1-D convs
+// along the edges, subtracted by svk_poly_fix (poly_fix.hip).  bf16 only: the fp32 parity path keeps the direct form.
+static inline int svg_poly(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_POLY") != nullptr;           // A/B: the fused-upsample x-packed conv
+  return !off && svg_packx(d) && d->ups_in && d->KH == 6 && d->KW == 6 && d->Cin == svg_cin_pad(d) && d->Cin == 32 &&
+         d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1)) && d->act == SV_ACT_NONE;
+}
+#define SV_POLY_FIX_ELEMS(cin) (10 * 6 * 16 * (cin))                 // [10 border classes][6 taps][16 columns][Cin]
 // N tile selection of the tap GEMM: 0: 128, 1: 64, 2: 32, 3: 16 columns
 static inline int svg_pick_cfg(int N) {
   if (N % 128 == 0) return 0;
@@ -94,4 +108,5 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a);
 void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs);
 void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j);
+void svg_prep_job_polyfix(const sv_conv_desc* d, PrepJob* j);     // second forward job of a svg_poly layer (follows the main image)
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls);

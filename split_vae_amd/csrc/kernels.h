@@ -30,6 +30,11 @@ struct TapGemmArgs {
   int ups;              // A is the LOW-RES tensor [B, IH/2, IW/2, lda]; the conv sees its 2x bilinear upsample
   int d2s;              // > 0: x-pixel-packed conv: column n = px*8 + co holds channel co < d2s of output pixel
                         // (oy, 2*ox + px); out is the unpacked [B, OHF, OWF, ldo] tensor
+  int d2s_y;            // with d2s: N = 32 columns n = (py*2 + px)*8 + co of output pixel (2*oy + py, 2*ox + px): the POLYPHASE
+                        // form of (2x bilinear upsample -> conv): a plain conv over the LOW-RES tensor whose four output
+                        // parities are four column classes (conv_api.hip: svg_poly)
+  int clampin;          // input coordinates outside the image clamp to the edge (replicate) instead of reading zero
+  const float* fix;     // with d2s_y: border terms [B][10][max(OHF, OWF)][8] added by the epilogue (poly_fix.hip), or null
   int cls_n;            // > 0: MERGED PARITY CLASSES of a stride-2 input gradient whose classes share one tap window (k = 6, pad 2:
                         // every class reads dy rows / columns -1..1): ONE problem with N = 4 * cls_n columns, column n = class
                         // (n / cls_n) channel (n % cls_n), class (ph, pw) = (c >> 1, c & 1) lands on output pixel
@@ -72,6 +77,8 @@ struct TileConvArgs {
   int ups;                    // input tile staged through the fused 2x bilinear upsample
   int d2s;                    // depth-to-space (x) epilogue of the pixel-packed conv: real channels per sub-pixel
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
+  int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
+  const float* fix;           // TapGemmArgs::fix
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -159,12 +166,21 @@ struct PrepJob {
   int32_t transpose;   // 0: rows=co, inner=ci (forward); 1: rows=ci, inner=co (dgrad)
   int32_t packx_kw;    // > 0: forward image of the x-packed conv of a KH x packx_kw kernel: row n = px*8 + co,
                        // tap (ky, tx) of KH x (KW+1) <- source tap (ky, tx - px), zero outside the kernel
+  int32_t poly;        // 1: polyphase forward image of (2x bilinear upsample -> 6x6 conv) [32][25][Cin]; 2: its border-fix image
+                       // [10 classes][6 taps][16][Cin] (conv_api.hip: prep_poly)
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap
 };
 int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
                      int total_blocks, hipStream_t st);
+
+// border correction of the polyphase forward (poly_fix.hip): the out-of-image taps of the 5 hi-res border rows / columns.
+// fixbuf[i] != null: written to the workspace BEFORE the conv, whose epilogue adds it (TapGemmArgs::fix); else added to out6[i]
+// with atomics AFTER the conv.  n <= 2 twin problems per launch.
+int64_t svk_poly_fix_ws_bytes(int B, int h, int w);
+int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* out6, float* const* fixbuf, int B,
+                       int h, int w, int lda, int Cout, hipStream_t st);
 
 int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st);
 int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,

@@ -104,29 +104,43 @@ struct sv_lgvae_plan {
   // weight gradients on a second stream (they feed only Adam / the all-reduce; the input-gradient chain is the critical
   // path): fork = the side stream waits for the event recorded on the main stream when dY is ready, join before Adam and
   // at the end of every sv_lgvae_step call
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  enum { SIDE_MAX = 4 };
+  hipStream_t side[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // SV_SIDE_STREAMS of them, taken round-robin: the weight
+  hipEvent_t ev_fork = nullptr, ev_join[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // gradients of different layers are independent
+  int nside = 0, side_next = 0, side_slot = 0;   // side_slot: which stream (and which slab workspace) the last wgrad_stream() gave out
   bool side_pending = false;
   hipStream_t wgrad_stream(hipStream_t st) {
     static const bool off = getenv("SV_NO_SIDE") != nullptr;
+    side_slot = 0;
     if (off || (prof_on && prof_filter.empty())) return st;     // the full per-kernel table wants serial launches
     if (graph_on) return st;   // a captured fork/join replayed wrongly on ROCm 7.2 (corrupt gradients, then a crash): keep captures single-stream
-    if (!side) {
+    if (!nside) {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
-      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side = nullptr; return st; }
-      (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-      (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+      static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 1;
+      const int k = want < 1 ? 1 : want > SIDE_MAX ? SIDE_MAX : want;
+      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return st;
+      for (int i = 0; i < k; ++i) {
+        if (hipStreamCreateWithPriority(&side[i], hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side[i] = nullptr; break; }
+        (void)hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+        ++nside;
+      }
+      if (!nside) return st;
     }
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, ev_fork, 0) != hipSuccess) return st;
+    const int slot = side_next % nside;
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
+    side_next = slot + 1;
+    side_slot = slot;
     side_pending = true;
-    return side;
+    return side[slot];
   }
   int join_side(hipStream_t st) {
     if (!side_pending) return SV_OK;
     side_pending = false;
-    if (hipEventRecord(ev_join, side) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return (int)hipGetLastError();
+    side_next = 0;                     // every step hands the layers to the same streams
+    for (int i = 0; i < nside; ++i)
+      if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return (int)hipGetLastError();
     return SV_OK;
   }
   // captured steps (sv_lgvae_graph_enable): one executable graph per distinct (phase mask, buffers, baked scalars)
@@ -264,6 +278,14 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
       align(); L.wf_off = arena; j.dst_off = arena;
       arena += (int64_t)j.rows * j.ntaps * j.inner;
       push(j);
+      if (svg_poly(&L.d)) {                             // border-fix image of the polyphase head, right behind the composite image
+        PrepJob jf;
+        svg_prep_job_polyfix(&L.d, &jf);
+        jf.src_off = p->params[L.kparam].off;
+        jf.dst_off = arena;
+        arena += (int64_t)jf.rows * jf.ntaps * jf.inner;
+        push(jf);
+      }
       if (L.need_dgrad)
         for (int c = 0; c < svg_dgrad_classes(&L.d); ++c) {
           PrepJob jd;
@@ -319,7 +341,9 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->ws_bytes = 0;
   p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
   p->add_buf("warena", p->arena_elems * es);
-  p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI);
+  p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI * sv_lgvae_plan::SIDE_MAX);   // per side stream, per problem
+  p->add_buf("polyfix_x", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));   // border terms of the polyphase head (poly_fix.hip)
+  p->add_buf("polyfix_xh", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));
   p->add_buf("dyn", sizeof(SvDynArgs));
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
@@ -393,6 +417,19 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     fl += conv_flops(L[i]->d);
   }
   Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  if (svg_poly(&L[0]->d)) {
+    // polyphase head: the out-of-image taps of the border rows / columns go to a workspace first; the conv's epilogue adds them
+    const void* wfix[2];
+    float* fixbuf[2];
+    static const char* fb_name[2] = {"polyfix_x", "polyfix_xh"};
+    const sv_conv_desc& d = L[0]->d;
+    for (int i = 0; i < n; ++i) {
+      wfix[i] = (const char*)a[i].Wt + (int64_t)32 * 25 * svg_cin_pad(&L[i]->d) * p->esz();
+      fixbuf[i] = (float*)p->bp(fb_name[i]);
+      a[i].fix = fixbuf[i];
+    }
+    SV_TRY(svk_poly_fix_multi(n, x, wfix, nullptr, fixbuf, d.B, d.H / 2, d.W / 2, d.ldx, d.Cout, st));
+  }
   return svk_conv_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
 static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float* params, void* y, hipStream_t st) {
@@ -466,17 +503,20 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
                             float* grads, hipStream_t st) {
   WgradArgs a[SV_WGRAD_MAX_MULTI];
   double fl = 0;
-  const int64_t wsb = p->bbytes("wgrad_ws") / SV_WGRAD_MAX_MULTI;      // one partial-sum slab region per problem
+  const int64_t wsb = p->bbytes("wgrad_ws") / (SV_WGRAD_MAX_MULTI * sv_lgvae_plan::SIDE_MAX);   // one partial-sum slab region per stream and problem
+  const std::string ln = L[0]->name.substr(L[0]->name.find('.') + 1), nm = "wgrad." + ln;
+  // layers named in SV_WGRAD_MAIN (e.g. "d5,d4") keep their weight gradient on the main stream
+  static const char* on_main = getenv("SV_WGRAD_MAIN") ? getenv("SV_WGRAD_MAIN") : "";
+  if (strstr(on_main, ln.c_str())) p->side_slot = 0;
+  else st = p->wgrad_stream(st);
   for (int i = 0; i < n; ++i) {
     svg_wgrad_args(&L[i]->d, &a[i]);
     a[i].A = x[i]; a[i].dY = dy[i];
     a[i].dW = grads + p->params[L[i]->kparam].off;
     a[i].dbias = grads + p->params[L[i]->bparam].off;
-    a[i].ws = (float*)((char*)p->bp("wgrad_ws") + i * wsb); a[i].ws_bytes = wsb;
+    a[i].ws = (float*)((char*)p->bp("wgrad_ws") + (p->side_slot * SV_WGRAD_MAX_MULTI + i) * wsb); a[i].ws_bytes = wsb;
     fl += conv_flops(L[i]->d);
   }
-  const std::string nm = "wgrad." + L[0]->name.substr(L[0]->name.find('.') + 1);
-  st = p->wgrad_stream(st);
   Scope sc(p, st, nm, fl, 0);
   sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
@@ -801,12 +841,12 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   if (!p) return;
   for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto e : p->event_pool) (void)hipEventDestroy(e);
-  if (p->side) {
-    (void)hipStreamSynchronize(p->side);
-    (void)hipStreamDestroy(p->side);
-    (void)hipEventDestroy(p->ev_fork);
-    (void)hipEventDestroy(p->ev_join);
+  for (int i = 0; i < p->nside; ++i) {
+    (void)hipStreamSynchronize(p->side[i]);
+    (void)hipStreamDestroy(p->side[i]);
+    (void)hipEventDestroy(p->ev_join[i]);
   }
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (!p->graphs.empty()) (void)hipDeviceSynchronize();   // a replay may still be in flight
   for (auto& kv : p->graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);

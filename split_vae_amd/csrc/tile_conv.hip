@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
     const T* Ap = (const T*)g.A + ((phase << lcH) * EPP);
     if (g.ups) stage_tile_upsampled<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
+    else if (g.clampin) stage_tile_plain<T, NT, true>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
     else stage_tile_plain<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
   };
   stage(0);
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
   const int ncols = min(BN, g.N - n0);                  // real channels of this column tile
   const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
   // x-packed conv (fp32 head): the 16 columns (px, co<8) become 2*C contiguous floats of output pixels 2*ox, 2*ox+1
-  const int rowb = g.d2s ? 2 * g.d2s * 4 : ncols * oesz;   // output bytes per tile row
+  // (polyphase form, d2s_y: 32 columns (py, px, co<8) become two segments of 2*C floats: output rows 2*oy, 2*oy + 1)
+  const int rowb = g.d2s ? (g.d2s_y ? 4 : 2) * g.d2s * 4 : ncols * oesz;   // output bytes per tile row
   const int srow = ((rowb + 15) & ~15) + 16;            // LDS row pitch (padded)
   char* sC = smem;                                      // reuse: every LDS read finished at the loop's last barrier
   float bv[NF][4];
@@ -305,7 +307,11 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
     if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
     int64_t ob;                                          // byte offset in the output tensor
-    if (g.cls_n) {                                       // merged parity classes: this piece's class picks the sub-pixel
+    if (g.d2s_y) {                                       // polyphase: the row's first half is output row 2*oy, the second 2*oy + 1
+      const int pps = ppr_o >> 1, py = c >= pps ? 1 : 0;
+      const int64_t pix = ((int64_t)b * g.OHF + oy * 2 + py) * g.OWF + ox * 2;
+      ob = pix * g.ldo * oesz + (c - py * pps) * psz;
+    } else if (g.cls_n) {                                       // merged parity classes: this piece's class picks the sub-pixel
       const int n = n0 + c * (psz / oesz), cls = n / g.cls_n, ch = n - cls * g.cls_n;
       const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + (cls >> 1)) * g.OWF + ox * g.OS + (cls & 1);
       ob = (pix * g.ldo + ch) * oesz;
@@ -315,6 +321,23 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     }
     if (psz == 16) {
       uint4 v = *(const uint4*)(sC + r * srow + c * 16);
+      if (g.d2s_y && g.fix) {                           // polyphase head: border rows / columns take their out-of-image terms
+        const int pps = ppr_o >> 1, py = c >= pps ? 1 : 0, R = oy * 2 + py, L = g.OHF > g.OWF ? g.OHF : g.OWF;
+        auto bcls = [](int p, int n) { return p < 2 ? p : p >= n - 3 ? p - (n - 5) : -1; };   // 0, 1, n-3, n-2, n-1 -> 0..4
+        const int rc = bcls(R, g.OHF), cc0 = bcls(ox * 2, g.OWF), cc1 = bcls(ox * 2 + 1, g.OWF);
+        if (rc >= 0 || cc0 >= 0 || cc1 >= 0) {
+          float ve[4];
+          *(uint4*)ve = v;
+          const float* fb = g.fix + (int64_t)b * 10 * L * 8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int fi = (c - py * pps) * 4 + e, px = fi >= g.d2s ? 1 : 0, co = fi - px * g.d2s, cc = px ? cc1 : cc0;
+            if (rc >= 0) ve[e] += fb[((int64_t)rc * L + ox * 2 + px) * 8 + co];
+            if (cc >= 0) ve[e] += fb[((int64_t)(5 + cc) * L + R) * 8 + co];
+          }
+          v = *(uint4*)ve;
+        }
+      }
       if (g.mask) {                                     // mask tensor has the output's type and indexing (never fp32)
         const uint4 mv = *(const uint4*)((const char*)g.mask + ob);
         T ve[EPP], me[EPP];
@@ -361,7 +384,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.lOY < 0 || t.lOX < 0 || t.S > 2) return false;    // power-of-two grids, stride <= 2 (the tile maps shift and mask)
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
   if (t.ups && t.S != 1) return false;
-  if (t.d2s && (t.N != 16 || !t.out_f32)) return false;
+  if (t.d2s && ((t.N != 16 && !(t.N == 32 && t.d2s_y)) || !t.out_f32)) return false;
+  if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
+  if (t.clampin && (t.ups || t.S != 1)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
@@ -400,7 +425,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // try MF = 4 (256-row tile) then MF = 2 (128 rows); BN = 128 only with MF = 2, BN = 16/32 only with MF = 4
   static const char* mf2 = getenv("SV_TC_MF2");       // tuning knob: BN values (as letters a=16,b=32,c=64) forced to 128-row tiles
   for (int MF = 4; MF >= 2; MF -= 2) {
-    if (MF == 4 && BN == 128) continue;
+    // 256 x 128 tiles (SV_TC_BN128_MF4=1): half the weight streaming per output of the small-grid 128-column layers
+    static const bool big128 = getenv("SV_TC_BN128_MF4") != nullptr;
+    if (MF == 4 && BN == 128 && !(big128 && dtype == SV_BF16)) continue;
     if (MF == 4 && mf2 && strchr(mf2, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) continue;
     if (MF == 4 && BN == 32 && OY * OX <= 256 && t.OS == 2) continue;   // measured: e2's dgrad parity classes (16x16 grids) run 20 % faster on 128-row tiles
     const int BM = 64 * MF;
@@ -455,7 +482,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     memset(a, 0, sizeof(*a));
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
-    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n;
+    a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n; a->d2s_y = t.d2s_y; a->clampin = t.clampin; a->fix = t.fix;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;
@@ -490,6 +517,7 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
   if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
   if (dtype == SV_BF16) {
     switch (cfg) {
+      case 0: return launch_tile<bf16_t, 128, 4>(a, n, st);
       case 1: return launch_tile<bf16_t, 128, 2>(a, n, st);
       case 2: return launch_tile<bf16_t, 64, 4>(a, n, st);
       case 3: return launch_tile<bf16_t, 64, 2>(a, n, st);

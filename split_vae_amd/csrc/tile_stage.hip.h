@@ -24,7 +24,7 @@ __device__ __forceinline__ int tile_piece_off(const TileStageGeom& s, int pixel,
   return s.plane_bytes ? (c >> 1) * s.plane_bytes + pixel * 32 + (c & 1) * 16 : pixel * s.PS + c * 16;
 }
 
-template <typename T, int NT = 256>   // NT = threads of the workgroup
+template <typename T, int NT = 256, bool CLAMP = false>   // NT = threads of the workgroup; CLAMP: replicate the edge instead of zero
 __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base,
                                                  int ix_base, char* sIn, int tid) {
   constexpr int EPP = ElemTraits<T>::EPP;
@@ -37,7 +37,7 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
   for (int row = srow; row < nrows; row += rows_pp) {
     int bl = 0, iyl = row;
     while (iyl >= s.TIH) { iyl -= s.TIH; ++bl; }
-    const int iy = iy_base + iyl, b = b0 + bl;
+    const int iy = CLAMP ? min(max(iy_base + iyl, 0), s.IH - 1) : iy_base + iyl, b = b0 + bl;
     const bool rok = b < s.B && (unsigned)iy < (unsigned)s.IH;
     const T* src = Ab + ((int64_t)(b * s.IH + iy) * s.IW) * s.lda;
     const int prow = row * s.TIW;                      // first tile pixel of this row
@@ -46,7 +46,7 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = pc0 + u * LPR;
-        const int ixl = pc >> s.cl2, c = pc & (cpp - 1), ix = ix_base + ixl;
+        const int ixl = pc >> s.cl2, c = pc & (cpp - 1), ix = CLAMP ? min(max(ix_base + ixl, 0), s.IW - 1) : ix_base + ixl;
         v[u] = make_uint4(0, 0, 0, 0);
         if (pc < ppr && rok && (unsigned)ix < (unsigned)s.IW) v[u] = *(const uint4*)(src + (int64_t)ix * s.lda + c * EPP);
       }

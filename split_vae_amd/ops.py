@@ -157,12 +157,20 @@ class Conv2D:
         check(_lib.load().sv_conv2d_prep_weights(C.byref(self.desc), _p(w_hwio), _p(self.w_fwd), _p(self.w_dgrad),
                                                  _stream()), "sv_conv2d_prep_weights")
 
-    def fwd(self, x, bias, out=None):
+    def fwd(self, x, bias, out=None, workspace=True):
         d = self.desc
         y = out if out is not None else torch.empty((d.B, self.OH, self.OW, d.ldy),
                                                     dtype=torch.float32 if d.y_f32 else self.dtype, device=x.device)
-        check(_lib.load().sv_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(self.w_fwd), _p(bias), _p(y), _stream()),
-              "sv_conv2d_nhwc_fwd")
+        lib = _lib.load()
+        if workspace:                                   # polyphase head: border terms through a workspace (else atomics)
+            n = lib.sv_conv2d_fwd_workspace_bytes(C.byref(d))
+            if n > 0 and (getattr(self, "_fws", None) is None or self._fws.numel() < n or self._fws.device != x.device):
+                self._fws = torch.empty((n,), dtype=torch.uint8, device=x.device)
+            ws = self._fws if n > 0 else None
+            check(lib.sv_conv2d_nhwc_fwd_ws(C.byref(d), _p(x), _p(self.w_fwd), _p(bias), _p(y), _p(ws), n if n > 0 else 0,
+                                            _stream()), "sv_conv2d_nhwc_fwd_ws")
+        else:
+            check(lib.sv_conv2d_nhwc_fwd(C.byref(d), _p(x), _p(self.w_fwd), _p(bias), _p(y), _stream()), "sv_conv2d_nhwc_fwd")
         return y
 
     def dgrad(self, dy, relu_mask=None, f32_atomic=False, out=None):
