@@ -58,7 +58,9 @@ def main():
         P = lambda t: C.c_void_p(t.data_ptr())
         res = []
         if "fwd" in which:
-            t = timeit(lambda: lib.sv_conv2d_nhwc_fwd(C.byref(conv.desc), P(x), P(conv.w_fwd), P(bias), P(y), st()))
+            nws = lib.sv_conv2d_fwd_workspace_bytes(C.byref(conv.desc))
+            fws = torch.empty((max(nws, 16),), dtype=torch.uint8, device="cuda")
+            t = timeit(lambda: lib.sv_conv2d_nhwc_fwd_ws(C.byref(conv.desc), P(x), P(conv.w_fwd), P(bias), P(y), P(fws), nws, st()))
             res.append("fwd %7.1f us %6.0f TF/s" % (t, flops / t / 1e6))
         if "dgrad" in which and name != "e1":
             t = timeit(lambda: lib.sv_conv2d_nhwc_dgrad(C.byref(conv.desc), P(dy), P(conv.w_dgrad), None, P(dx), 0, st()))

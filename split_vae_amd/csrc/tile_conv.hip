@@ -301,17 +301,50 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
   if (SV_DBG(g.dbg) & 4) return;
   const int psz = (rowb & 15) ? 8 : 16;                 // piece size; rowb is a multiple of 8
   const int ppr_o = rowb / psz;
+  if (g.d2s_y) {
+    // POLYPHASE head (svg_poly): a tile row = the 2x2 output pixels of one low-res pixel: pieces 0..pps-1 go to output row
+    // 2*oy, the rest to 2*oy + 1.  Border rows / columns add their out-of-image terms, which poly_fix.hip wrote in this
+    // tensor's own layout (one aligned 16-B piece each); the loads of four pieces are issued before any is used.
+    const int C = g.d2s, pps = ppr_o >> 1, total = BM * ppr_o;
+    for (int q0 = tid; q0 < total; q0 += 4 * NT) {
+      float4 fr[4], fc[4];
+      int64_t ob[4];
+      int lo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u * NT;
+        const int r = q / ppr_o, c = q - r * ppr_o;
+        const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+        const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
+        lo[u] = (q < total && b < g.B && oy < g.OY && ox < g.OX) ? r * srow + c * 16 : -1;
+        const int py = c >= pps ? 1 : 0, R = oy * 2 + py, cs = c - py * pps;
+        ob[u] = (((int64_t)b * g.OHF + R) * g.OWF + ox * 2) * C * 4 + cs * 16;
+        fr[u] = fc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.fix && lo[u] >= 0) {
+          const int rc = R < 2 ? R : R >= g.OHF - 3 ? R - (g.OHF - 5) : -1;                    // rows 0, 1, H-3, H-2, H-1 -> 0..4
+          const int cg = ox == 0 ? 0 : ox == g.OX - 2 ? 1 : ox == g.OX - 1 ? 2 : -1;            // pixel pairs holding a border column
+          const float* fb = g.fix + (int64_t)b * (5 * g.OWF + 6 * g.OHF) * C;
+          if (rc >= 0) fr[u] = *(const float4*)(fb + ((int64_t)rc * g.OWF + ox * 2) * C + cs * 4);
+          if (cg >= 0) fc[u] = *(const float4*)(fb + (int64_t)5 * g.OWF * C + ((int64_t)R * 3 + cg) * 2 * C + cs * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (lo[u] < 0) continue;
+        float4 v = *(const float4*)(sC + lo[u]);
+        v.x += fr[u].x + fc[u].x; v.y += fr[u].y + fc[u].y; v.z += fr[u].z + fc[u].z; v.w += fr[u].w + fc[u].w;
+        *(float4*)((char*)g.out + ob[u]) = v;
+      }
+    }
+    return;
+  }
   for (int q = tid; q < BM * ppr_o; q += NT) {
     const int r = q / ppr_o, c = q - r * ppr_o;
     const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
     const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
     if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
     int64_t ob;                                          // byte offset in the output tensor
-    if (g.d2s_y) {                                       // polyphase: the row's first half is output row 2*oy, the second 2*oy + 1
-      const int pps = ppr_o >> 1, py = c >= pps ? 1 : 0;
-      const int64_t pix = ((int64_t)b * g.OHF + oy * 2 + py) * g.OWF + ox * 2;
-      ob = pix * g.ldo * oesz + (c - py * pps) * psz;
-    } else if (g.cls_n) {                                       // merged parity classes: this piece's class picks the sub-pixel
+    if (g.cls_n) {                                       // merged parity classes: this piece's class picks the sub-pixel
       const int n = n0 + c * (psz / oesz), cls = n / g.cls_n, ch = n - cls * g.cls_n;
       const int64_t pix = ((int64_t)b * g.OHF + oy * g.OS + (cls >> 1)) * g.OWF + ox * g.OS + (cls & 1);
       ob = (pix * g.ldo + ch) * oesz;
@@ -321,23 +354,6 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     }
     if (psz == 16) {
       uint4 v = *(const uint4*)(sC + r * srow + c * 16);
-      if (g.d2s_y && g.fix) {                           // polyphase head: border rows / columns take their out-of-image terms
-        const int pps = ppr_o >> 1, py = c >= pps ? 1 : 0, R = oy * 2 + py, L = g.OHF > g.OWF ? g.OHF : g.OWF;
-        auto bcls = [](int p, int n) { return p < 2 ? p : p >= n - 3 ? p - (n - 5) : -1; };   // 0, 1, n-3, n-2, n-1 -> 0..4
-        const int rc = bcls(R, g.OHF), cc0 = bcls(ox * 2, g.OWF), cc1 = bcls(ox * 2 + 1, g.OWF);
-        if (rc >= 0 || cc0 >= 0 || cc1 >= 0) {
-          float ve[4];
-          *(uint4*)ve = v;
-          const float* fb = g.fix + (int64_t)b * 10 * L * 8;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int fi = (c - py * pps) * 4 + e, px = fi >= g.d2s ? 1 : 0, co = fi - px * g.d2s, cc = px ? cc1 : cc0;
-            if (rc >= 0) ve[e] += fb[((int64_t)rc * L + ox * 2 + px) * 8 + co];
-            if (cc >= 0) ve[e] += fb[((int64_t)(5 + cc) * L + R) * 8 + co];
-          }
-          v = *(uint4*)ve;
-        }
-      }
       if (g.mask) {                                     // mask tensor has the output's type and indexing (never fp32)
         const uint4 mv = *(const uint4*)((const char*)g.mask + ob);
         T ve[EPP], me[EPP];
