@@ -34,6 +34,11 @@ struct TapGemmArgs {
                         // form of (2x bilinear upsample -> conv): a plain conv over the LOW-RES tensor whose four output
                         // parities are four column classes (conv_api.hip: svg_poly)
   int clampin;          // input coordinates outside the image clamp to the edge (replicate) instead of reading zero
+  // FUSED LOSS (with d2s_y, training step): the epilogue evaluates the discretised-logistic NLL of its pixels against
+  // nll_img (images6 [B,OHF,OWF,6], channels nll_ch..nll_ch+2), writes the gradient nll_gscale * d nll / d out6 to nll_grad
+  // ([B,OHF,OWF,8] bf16, what dlogistic_kernel would write) and one partial sum per (image, tile) to nll_part[b * tiles + tile];
+  // out is still written.  Needs one image per tile (OY * OX >= 256).
+  const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale;
   const float* fix;     // with d2s_y: border terms [B][10][max(OHF, OWF)][8] added by the epilogue (poly_fix.hip), or null
   int cls_n;            // > 0: MERGED PARITY CLASSES of a stride-2 input gradient whose classes share one tap window (k = 6, pad 2:
                         // every class reads dy rows / columns -1..1): ONE problem with N = 4 * cls_n columns, column n = class
@@ -79,6 +84,7 @@ struct TileConvArgs {
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
   const float* fix;           // TapGemmArgs::fix
+  const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale;   // TapGemmArgs: fused loss
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -201,6 +207,8 @@ int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* b
                         float* eps_out, float* z_mean, float* z_sig, float* z, void* z_lp, int z_dtype, int ldz,
                         int z_col, float* kl, int B, int L, uint64_t seed, uint64_t step, int stream_id,
                         int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn = nullptr);
+// per-image sums of P partials (fixed order): the tail of svk_dlogistic_nll_multi, also used after the fused loss epilogue
+int svk_nll_rowsum(const float* partial_ws, float* nll, int B, int P, int64_t zs_part, int64_t zs_nll, int nets, hipStream_t st);
 int svk_dlogistic_nll_multi(const float* images6, int ch_off, const float* out6, int64_t zs_out, float* nll,
                             int64_t zs_nll, void* grad, int64_t zs_grad, int grad_dtype, float grad_scale, int B,
                             int H, int W, float* partial_ws, int64_t zs_part, int nets, hipStream_t st);

@@ -100,6 +100,7 @@ struct sv_lgvae_plan {
   std::vector<PrepJob> jobs;
   int prep_blocks;
   int64_t arena_elems;
+  bool nll_fused = false;  // the last decoder forward evaluated the loss in the head's epilogue (nllpart_*, g5_* are valid)
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
   // weight gradients on a second stream (they feed only Adam / the all-reduce; the input-gradient chain is the critical
   // path): fork = the side stream waits for the event recorded on the main stream when dY is ready, join before Adam and
@@ -404,8 +405,9 @@ static double conv_flops(const sv_conv_desc& d) {
 
 // The x and x-hat networks have twin layers of identical geometry: n of them go out as ONE launch
 // (blockIdx.z picks the problem), which halves the per-launch fixed cost that dominates at B<=512.
+struct FusedNll { const float* images6; void* grad[2]; float* part[2]; float gscale; };   // loss in the head's epilogue (tile_conv.hip)
 static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const float* params,
-                          void* const* y, hipStream_t st) {
+                          void* const* y, hipStream_t st, const FusedNll* nll = nullptr) {
   TapGemmArgs a[2];
   double fl = 0;
   for (int i = 0; i < n; ++i) {
@@ -414,6 +416,10 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     a[i].Wt = (char*)p->bp("warena") + L[i]->wf_off * p->esz();
     a[i].bias = params + p->params[L[i]->bparam].off;
     a[i].out = y[i];
+    if (nll) {
+      a[i].nll_img = nll->images6; a[i].nll_ch = 3 * i; a[i].nll_grad = nll->grad[i]; a[i].nll_part = nll->part[i];
+      a[i].nll_gscale = nll->gscale;
+    }
     fl += conv_flops(L[i]->d);
   }
   Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
@@ -535,7 +541,9 @@ static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
                           (int)p->jobs.size(), p->prep_blocks, st);
 }
 
-static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_enc, bool do_dec, hipStream_t st) {
+static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_enc, bool do_dec, hipStream_t st,
+                         bool want_nll = false) {
+  p->nll_fused = false;
   const sv_lgvae_desc& d = p->d;
   const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
@@ -634,6 +642,17 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
           xs[k] = p->bp(hi_name[l] + sfx);
         }
       }
+      if (l == 2 && want_nll && svg_poly(&Ls[0]->d) && d.H * d.W >= 1024) {
+        // training step: the head's epilogue evaluates the loss of its own pixels (NLL partial sums + the gradient record
+        // g5), so dlogistic_kernel and its re-read of out6 drop out of the step (phase_loss then only sums the partials)
+        FusedNll f;
+        f.images6 = s->images6; f.gscale = 1.0f / (float)d.B;
+        f.grad[0] = p->bp("g5_x"); f.grad[1] = p->bp("g5_xh");
+        f.part[0] = (float*)p->bp("nllpart_x"); f.part[1] = (float*)p->bp("nllpart_xh");
+        const int rc = run_fwd_layers(p, 2, Ls, xs, s->params, ys, st, &f);
+        if (rc == SV_OK) { p->nll_fused = true; continue; }
+        if (rc != SV_E_UNSUPPORTED) return rc;
+      }
       SV_TRY(run_fwd_layers(p, 2, Ls, xs, s->params, ys, st));
     }
   }
@@ -643,7 +662,14 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
 static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_grad, hipStream_t st) {
   const sv_lgvae_desc& d = p->d;
   const char* en[2] = {"x", "xh"};
-  {
+  auto zs0 = [&](const char* kind, int64_t esz) {
+    return (int64_t)((char*)p->bp(std::string(kind) + "xh") - (char*)p->bp(std::string(kind) + "x")) / esz;
+  };
+  if (p->nll_fused && with_grad) {   // the head's epilogue left per-tile NLL sums and g5 (phase_forward): per-image sums only
+    const int HW = d.H * d.W;
+    SV_TRY(svk_nll_rowsum((const float*)p->bp("nllpart_x"), (float*)p->bp("nll_x"), d.B, HW > 1024 ? HW / 1024 : 1,
+                          zs0("nllpart_", 4), zs0("nll_", 4), 2, st));
+  } else {
     // algorithmic bytes: read x, m, log_scale (12 B/element) + write dm, dls (2 * esz B/element); both networks
     Scope sc(p, st, "dlogistic_nll", 0, 2.0 * d.B * d.H * d.W * 3 * (12.0 + (with_grad ? 2.0 * p->esz() : 0.0)));
     auto zs = [&](const char* kind, int64_t esz) {
@@ -886,7 +912,11 @@ extern "C" int sv_lgvae_buffer(const sv_lgvae_plan* p, const char* name, int64_t
 static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
   const int ph = s->phases;
   if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
-  if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, ph & SV_PHASE_FWD_ENCODERS, ph & SV_PHASE_FWD_DECODERS, st));
+  static const bool no_fused_nll = getenv("SV_NO_FUSED_NLL") != nullptr;    // A/B: dlogistic_kernel after the forward
+  const bool want_nll = !no_fused_nll && (ph & SV_PHASE_FWD_DECODERS) && (ph & SV_PHASE_LOSS) && s->grads && s->images6 &&
+                        p->d.dtype == SV_BF16;
+  if (!(ph & SV_PHASE_FORWARD)) p->nll_fused = false;
+  if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, ph & SV_PHASE_FWD_ENCODERS, ph & SV_PHASE_FWD_DECODERS, st, want_nll));
   if (ph & SV_PHASE_LOSS) {
     if (s->grads) {
       Scope sc(p, st, "zero_grads", 0, (double)p->nparams * 4);

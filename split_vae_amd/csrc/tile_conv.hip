@@ -16,6 +16,7 @@
 #include "common.hip.h"
 #include "kernels.h"
 #include "tile_stage.hip.h"
+#include "dlogistic.hip.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -306,6 +307,67 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     // 2*oy, the rest to 2*oy + 1.  Border rows / columns add their out-of-image terms, which poly_fix.hip wrote in this
     // tensor's own layout (one aligned 16-B piece each); the loads of four pieces are issued before any is used.
     const int C = g.d2s, pps = ppr_o >> 1, total = BM * ppr_o;
+    if constexpr (sizeof(T) == 2) {
+      if (g.nll_part) {
+        // FUSED LOSS: one thread per hi-res pixel (4 per tile row): its 6 outputs + border terms -> out6, the NLL of its three
+        // colour channels against the target image (vae/trainer.py:21-38, :127) and the bf16 gradient record; the tile's
+        // NLL sum goes to nll_part[image][tile] (summed per image in a fixed order by svk_nll_rowsum: deterministic).
+        const float* __restrict__ img = g.nll_img;
+        float* __restrict__ outp = (float*)g.out;
+        bf16_t* __restrict__ gp = (bf16_t*)g.nll_grad;
+        float nacc = 0.f;
+#pragma unroll 2
+        for (int hp = tid; hp < BM * 4; hp += NT) {
+          const int r = hp >> 2, sub = hp & 3, py = sub >> 1, px = sub & 1;
+          const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+          const int b = b0 + bl, oy = ty0 + ty, ox = tx0 + tx;
+          if (b >= g.B || oy >= g.OY || ox >= g.OX) continue;
+          const int R = oy * 2 + py, Cc = ox * 2 + px;
+          const int64_t pix = ((int64_t)b * g.OHF + R) * g.OWF + Cc;
+          const float x0 = img[pix * 6 + g.nll_ch], x1 = img[pix * 6 + g.nll_ch + 1], x2 = img[pix * 6 + g.nll_ch + 2];
+          const float* lp = (const float*)(sC + r * srow) + sub * 6;
+          f32x2 o01 = *(const f32x2*)lp, o23 = *(const f32x2*)(lp + 2), o45 = *(const f32x2*)(lp + 4);
+          if (g.fix) {
+            const int rc = R < 2 ? R : R >= g.OHF - 3 ? R - (g.OHF - 5) : -1;
+            const int cg = ox == 0 ? 0 : ox == g.OX - 2 ? 1 : ox == g.OX - 1 ? 2 : -1;
+            const float* fb = g.fix + (int64_t)b * (5 * g.OWF + 6 * g.OHF) * 6;
+            if (rc >= 0) {
+              const float* fp = fb + ((int64_t)rc * g.OWF + Cc) * 6;
+              o01 += *(const f32x2*)fp; o23 += *(const f32x2*)(fp + 2); o45 += *(const f32x2*)(fp + 4);
+            }
+            if (cg >= 0) {
+              const float* fp = fb + (int64_t)5 * g.OWF * 6 + (((int64_t)R * 3 + cg) * 2 + px) * 6;
+              o01 += *(const f32x2*)fp; o23 += *(const f32x2*)(fp + 2); o45 += *(const f32x2*)(fp + 4);
+            }
+          }
+          float* op = outp + pix * 6;
+          *(f32x2*)op = o01; *(f32x2*)(op + 2) = o23; *(f32x2*)(op + 4) = o45;
+          float n0, n1, n2, dm0, dm1, dm2, dl0, dl1, dl2;
+          dll_elem(x0, o01[0], o23[1], n0, dm0, dl0);        // channel k: mean o[k], log_scale o[3 + k] (vae/model.py:169)
+          dll_elem(x1, o01[1], o45[0], n1, dm1, dl1);
+          dll_elem(x2, o23[0], o45[1], n2, dm2, dl2);
+          nacc += (n0 + n1) + n2;
+          const float gs = g.nll_gscale;
+          bf16x8 v;
+          v[0] = (bf16_t)(dm0 * gs); v[1] = (bf16_t)(dm1 * gs); v[2] = (bf16_t)(dm2 * gs);
+          v[3] = (bf16_t)(dl0 * gs); v[4] = (bf16_t)(dl1 * gs); v[5] = (bf16_t)(dl2 * gs);
+          v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
+          *(bf16x8*)(gp + pix * 8) = v;
+        }
+        nacc = wave_sum(nacc);
+        __syncthreads();                                    // every read of the transposed tile is done: reuse its head
+        float* red = (float*)sC;
+        if (lane == 0) red[wave] = nacc;
+        __syncthreads();
+        if (tid == 0 && b0 < g.B) {
+          float s = 0.f;
+          for (int k = 0; k < NW; ++k) s += red[k];
+          const int tiles = g.tilesX * g.tilesY;
+          g.nll_part[(int64_t)b0 * tiles + (ty0 >> g.lTH) * g.tilesX + (tx0 >> g.lTW)] = s;
+        }
+        return;
+      }
+    }
     for (int q0 = tid; q0 < total; q0 += 4 * NT) {
       float4 fr[4], fc[4];
       int64_t ob[4];
@@ -332,7 +394,8 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
       for (int u = 0; u < 4; ++u) {
         if (lo[u] < 0) continue;
         float4 v = *(const float4*)(sC + lo[u]);
-        v.x += fr[u].x + fc[u].x; v.y += fr[u].y + fc[u].y; v.z += fr[u].z + fc[u].z; v.w += fr[u].w + fc[u].w;
+        v.x = (v.x + fr[u].x) + fc[u].x; v.y = (v.y + fr[u].y) + fc[u].y;       // row term first, then the column term: the
+        v.z = (v.z + fr[u].z) + fc[u].z; v.w = (v.w + fr[u].w) + fc[u].w;       // order of the fused-loss loop above (bitwise equal out6)
         *(float4*)((char*)g.out + ob[u]) = v;
       }
     }
@@ -403,6 +466,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s && ((t.N != 16 && !(t.N == 32 && t.d2s_y)) || !t.out_f32)) return false;
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
+  if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
@@ -445,13 +509,14 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     static const bool big128 = getenv("SV_TC_BN128_MF4") != nullptr;
     if (MF == 4 && BN == 128 && !(big128 && dtype == SV_BF16)) continue;
     if (MF == 4 && mf2 && strchr(mf2, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) continue;
-    if (MF == 4 && BN == 32 && OY * OX <= 256 && t.OS == 2) continue;   // measured: e2's dgrad parity classes (16x16 grids) run 20 % faster on 128-row tiles
+    if (MF == 4 && BN == 32 && OY * OX <= 256 && t.OS == 2 && !t.d2s_y) continue;   // measured: e2's dgrad parity classes (16x16 grids) run 20 % faster on 128-row tiles
     const int BM = 64 * MF;
     int lTH = 0;
     while ((1 << (lTW + lTH)) < BM && (1 << lTH) < OY) ++lTH;
     int lNB = 0;
     while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
     const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
+    if (t.nll_part && (BM != 256 || NB != 1)) return false;   // the fused loss writes one partial per 256-pixel tile of one image
     const int TIW = (TW - 1) * t.SX + (x_hi - x_lo) + 1, TIH = (TH - 1) * t.S + (y_hi - y_lo) + 1;
     // channel phases (see the kernel): halve the channels per staging pass while the tile alone would keep a CU at
     // <= 2 workgroups, the launch has several rounds of workgroups, and a phase keeps >= 32 B (two pieces) per pixel
@@ -499,6 +564,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
     a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n; a->d2s_y = t.d2s_y; a->clampin = t.clampin; a->fix = t.fix;
+    a->nll_img = t.nll_img; a->nll_grad = t.nll_grad; a->nll_part = t.nll_part; a->nll_ch = t.nll_ch; a->nll_gscale = t.nll_gscale;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;

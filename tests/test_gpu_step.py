@@ -144,6 +144,41 @@ def test_step_bf16_close_to_oracle(ops):
         assert cos > 0.995 and rel < 0.12, "grad %s: cosine %g relfro %g" % (name, cos, rel)
 
 
+@pytest.mark.parametrize("H,patch,B", [(32, 1, 5), (64, 8, 3)])
+def test_loss_fused_into_the_head_equals_the_separate_kernel(ops, H, patch, B):
+    """A training step evaluates the discretised-logistic loss in the decoder head's epilogue (tile_conv.hip: nll_part); the
+    same phases issued as two calls (forward, then loss + backward) run dlogistic_kernel on out6 instead.  Same element
+    function on the same fp32 outputs: the gradient records g5 are bitwise equal, the per-image NLL sums differ by fp32
+    summation order only, and so do the weight gradients (split-K atomics in the encoder)."""
+    from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM, PHASE_PREP, PHASE_FORWARD
+    x, perm, eps = make_inputs(B, H, patch, seed=11)
+    images = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), patch)
+    plan = ops.LGVaePlan(B, H, H, beta=40.0, dtype=torch.bfloat16)
+    P = flat_params(plan, np_ref.glorot_init(H, H, seed=3))
+    ex, eh = torch.from_numpy(eps[0]).cuda(), torch.from_numpy(eps[1]).cuda()
+    res = []
+    for split in (False, True):
+        G = torch.zeros_like(P)
+        rest = PHASE_ALL & ~PHASE_ADAM
+        if split:
+            plan.step(PHASE_PREP | PHASE_FORWARD, params=P, images6=images, eps_x=ex, eps_x_hat=eh)
+            rest &= ~(PHASE_PREP | PHASE_FORWARD)
+        plan.step(rest, params=P, grads=G, images6=images, eps_x=ex, eps_x_hat=eh)
+        torch.cuda.synchronize()
+        res.append({"g5x": plan.buffer("g5_x", torch.bfloat16, (B, H, H, 8)).clone(),
+                    "g5h": plan.buffer("g5_xh", torch.bfloat16, (B, H, H, 8)).clone(),
+                    "o6x": plan.buffer("out6_x", torch.float32, (B, H, H, 6)).clone(),
+                    "nll": plan.buffer("nll_x", torch.float32, (B,)).clone(),
+                    "losses": plan.buffer("losses", torch.float32, (8,)).clone(), "G": G})
+    a, b = res
+    assert torch.equal(a["o6x"], b["o6x"])
+    assert torch.equal(a["g5x"], b["g5x"]) and torch.equal(a["g5h"], b["g5h"])
+    assert float(a["g5x"].float().abs().max()) > 0
+    torch.testing.assert_close(a["nll"], b["nll"], rtol=1e-5, atol=0)
+    torch.testing.assert_close(a["losses"][:6], b["losses"][:6], rtol=1e-5, atol=0)
+    torch.testing.assert_close(a["G"], b["G"], rtol=1e-3, atol=1e-5 * float(b["G"].abs().max()))
+
+
 def test_step_forward_reproducible(ops):
     """Same inputs/seed twice: the decoder outputs are bitwise equal and the scalars agree to
     fp32 round-off (the encoder head's split-K uses fp32 atomics, so the KL terms may differ in
