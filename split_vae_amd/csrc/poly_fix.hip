@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
   const bf16_t* __restrict__ wfix = mg.wfix[blockIdx.y];
   float* __restrict__ out6 = mg.out6[blockIdx.y];
   float* __restrict__ fixbuf = mg.fixbuf[blockIdx.y];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction: as an SGPR the class loop below compiles to scalar branches.  (With a per-lane `wave` the
+  // fragment predicates became EXEC-masked regions around the MFMAs and their AGPR moves, and the kernel was not run-to-run
+  // reproducible once two workgroups shared a CU.)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int H2 = 2 * h, W2 = 2 * w;
   const int L = H2 > W2 ? H2 : W2, LW = L + 5;            // line index li = hi coordinate + 2, hi coordinate in -2 .. 2n+2
@@ -44,39 +48,27 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
   load_w(wave);
   const bf16_t* xb = x + (int64_t)b * h * w * lda;
   // ---- the four lines: [line][li][32 channels] bf16
-  for (int it0 = tid; it0 < 4 * LW * 4 && !(SV_DBG(dbg) & 1); it0 += 256 * 3) {   // three items per pass: their six loads are in flight together
-    uint4 a0[3], a1[3];
-    float fw[3];
-    int dst[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int it = it0 + k * 256;
-      const int ch = it & 3, li = (it >> 2) % LW, line = (it >> 2) / LW;
-      const bool is_row = line < 2;
-      const int n = is_row ? w : h;                        // low-res extent along the line
-      int u = li - 2;                                      // hi coordinate
-      dst[k] = it < 4 * LW * 4 ? ((line * LW + li) * 4 + ch) * 16 : -1;
-      a0[k] = a1[k] = make_uint4(0, 0, 0, 0);
-      fw[k] = 0.f;
-      if (dst[k] >= 0 && li < 2 * n + 5 && (is_row || (u >= 0 && u < 2 * n))) {
-        u = min(max(u, 0), 2 * n - 1);
-        const int m = u >> 1;
-        const int i0 = (u & 1) ? m : max(m - 1, 0), i1 = (u & 1) ? min(m + 1, n - 1) : m;
-        fw[k] = (u & 1) ? 0.25f : 0.75f;                   // weight of the second sample (common.hip.h: lerp2)
-        const int64_t o0 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * lda : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * lda;
-        const int64_t o1 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * lda : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * lda;
-        a0[k] = *(const uint4*)(xb + o0 + ch * 8); a1[k] = *(const uint4*)(xb + o1 + ch * 8);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (dst[k] < 0) continue;
+  for (int it = tid; it < 4 * LW * 4 && !(SV_DBG(dbg) & 1); it += 256) {
+    const int ch = it & 3, li = (it >> 2) % LW, line = (it >> 2) / LW;
+    const bool is_row = line < 2;
+    const int n = is_row ? w : h;                          // low-res extent along the line
+    int u = li - 2;                                        // hi coordinate
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (li < 2 * n + 5 && (is_row || (u >= 0 && u < 2 * n))) {
+      u = min(max(u, 0), 2 * n - 1);
+      const int m = u >> 1;
+      const int i0 = (u & 1) ? m : max(m - 1, 0), i1 = (u & 1) ? min(m + 1, n - 1) : m;
+      const float f = (u & 1) ? 0.25f : 0.75f;             // weight of the second sample (common.hip.h: lerp2)
+      const int64_t o0 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * lda : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * lda;
+      const int64_t o1 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * lda : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * lda;
+      const uint4 a0 = *(const uint4*)(xb + o0 + ch * 8), a1 = *(const uint4*)(xb + o1 + ch * 8);
       f32x2 p0[4], p1[4], r[4];
-      Piece<bf16_t>::unpack(a0[k], p0); Piece<bf16_t>::unpack(a1[k], p1);
+      Piece<bf16_t>::unpack(a0, p0); Piece<bf16_t>::unpack(a1, p1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = lerp2(p0[e], p1[e], fw[k]);
-      *(uint4*)(smem + dst[k]) = Piece<bf16_t>::pack(r);   // (zero inputs, weight 0: the zero entries of the column lines)
+      for (int e = 0; e < 4; ++e) r[e] = lerp2(p0[e], p1[e], f);
+      v = Piece<bf16_t>::pack(r);
     }
+    *(uint4*)(smem + ((line * LW + li) * 4 + ch) * 16) = v;
   }
   __syncthreads();
   // ---- classes 0..4: hi-res rows 0, 1, 2h-3, 2h-2, 2h-1 (tap = kx); 5..9: the columns (tap = ky)
