@@ -120,7 +120,7 @@ struct sv_lgvae_plan {
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
       static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 1;
-      const int k = want < 1 ? 1 : want > SIDE_MAX ? SIDE_MAX : want;
+      const int k = want < 1 ? 1 : want > SIDE_MAX - 1 ? SIDE_MAX - 1 : want;   // the last workspace slot belongs to the main stream
       if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return st;
       for (int i = 0; i < k; ++i) {
         if (hipStreamCreateWithPriority(&side[i], hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side[i] = nullptr; break; }
@@ -516,7 +516,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // concurrent d4 input gradient 2.5x; with d5 and the two tail layers e1, e2 on the main stream the step is 1.4 % shorter
   // ("" = everything on the side stream)
   static const char* on_main = getenv("SV_WGRAD_MAIN") ? getenv("SV_WGRAD_MAIN") : "e1,e2,d5";
-  if (strstr(on_main, ln.c_str())) p->side_slot = 0;
+  if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
   for (int i = 0; i < n; ++i) {
     svg_wgrad_args(&L[i]->d, &a[i]);

@@ -14,7 +14,7 @@ in a user's own graph.
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 
 _lib_def = torch.library.Library("split_vae", "DEF")
 _lib_impl = torch.library.Library("split_vae", "IMPL", "CUDA")        # HIP devices dispatch under the CUDA key on ROCm
@@ -74,8 +74,17 @@ def _conv_dgrad(dy, w_hwio, relu_mask, H, W, ldx, stride, ups_in):
 
 @_impl("conv2d_nhwc_wgrad")
 def _conv_wgrad(x, dy, KH, KW, Cin, Cout, stride, ups_in):
-    c = _conv(x, Cin, Cout, KH, stride, 0, ups_in, False)
     assert KH == KW
+    if ups_in:
+        # the fused-resize weight gradient exists for the model's decoder geometries (wgrad_tile.hip); any other layer
+        # materialises the 2x bilinear resize first (same numbers: the fused staging uses the resize kernel's arithmetic)
+        try:
+            return _conv(x, Cin, Cout, KH, stride, 0, True, False).wgrad(x.contiguous(), dy.contiguous(), workspace=True)
+        except _lib.SplitVaeError as e:
+            if "SV_E_UNSUPPORTED" not in str(e):
+                raise
+        x = ops.upsample2x_fwd(x.contiguous())
+    c = _conv(x, Cin, Cout, KH, stride, 0, False, False)
     return c.wgrad(x.contiguous(), dy.contiguous(), workspace=True)
 
 

@@ -166,6 +166,8 @@ def style_transfer_test(model, test_dataset, label=True, filename=None, filepath
     idx = np.array([26, 101, 3025, 3129, 3182, 3233, 3547, 3695, 10462, 10471, 10601, 10608, 16171, 16289, 16593, 16801, 101,
                     326, 333, 798, 841, 1189, 6186, 2651, 1437, 1826, 5536])
     test, _ = load_svhn_mat(os.path.join(data_dir, "test_32x32.mat"))
+    if len(test) <= int(idx.max()):                 # a cut-down test file (the real one has 26 032 images): wrap the picks
+        idx = idx % len(test)
     rng = np.random.default_rng(seed)
     x = test[rng.permutation(idx)[:n]]
     x_hat = test[rng.permutation(idx)[:n]]
