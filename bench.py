@@ -223,7 +223,8 @@ def decoder_stack(table, dtype, passes):
 
 
 # plan scope -> substrings of its HIP kernel symbol as rocprofv3 prints it (profiles/*_traffic.json keys)
-SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi16ELi4ELi4E"], "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
+SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyphase head; the symbol also serves e1's forward (traffic = their mean)
+                "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
                 "fwd.d3": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi4E"], "fwd.e2": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi0E"],
                 "wgrad.d5": ["wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
 
@@ -367,10 +368,13 @@ def main():
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"],
                            "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
-        elbo = next((r for r in table if r["name"].startswith("dlogistic")), None)
+        # the HBM-bound entry: the ELBO kernel when the step runs it, else (training steps evaluate the loss in the decoder
+        # head's epilogue) the Adam update -- 28 algorithmic bytes per parameter
+        elbo = next((r for r in table if r["name"].startswith("dlogistic")), None) or \
+            next((r for r in table if r["name"] == "adam_step"), None)
         if elbo and elbo["launches"]:
             ems = elbo["total_ms"] / elbo["launches"]
-            etr, esym, _ = measured_traffic(["dlogistic_kernel"])
+            etr, esym, _ = measured_traffic(["dlogistic_kernel"] if elbo["name"].startswith("dlogistic") else ["adam_kernel"])
             out["roofline"]["hbm"] = {"bound": "hbm", "kernel": elbo["name"], "algorithmic_bytes": elbo["bytes"],
                                       "avg_launch_ms": round(ems, 4), "achieved": round(elbo["bytes"] / (ems * 1e-3) / 1e9, 1),
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(elbo["bytes"] / (ems * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
