@@ -354,7 +354,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
   const bool slab = a[0].ws != nullptr;                         // halving the slabs is the point; atomics keep NG = 1
   // measured per layer (B = 512): e2 -13 %, d2 -8 %, e1 -4 %, d3 0; d4 / d5 (the longest MFMA sections) lose
   // 5-12 % to the lockstep of the two groups, so the wide-tile layers keep two independent workgroups per CU
-  static const char* ng2 = getenv("SV_WT_NG2") ? getenv("SV_WT_NG2") : "356";     // layer ids (see the table above)
+  static const char* ng2 = getenv("SV_WT_NG2") ? getenv("SV_WT_NG2") : "3456";     // layer ids (see the table above)
   const bool want = strchr(ng2, '0' + a[0].layer_id) != nullptr;
   if (!ng1 && want && slab && two <= 160 * 1024 && HFB <= 160 * 1024 && a[0].ntiles >= 64)
     return launch_wt_ng<TPW, CIF, COF, KC, 2>(a, n, groups, st, ev_mid);
@@ -392,7 +392,8 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   static const char* hiocc = getenv("SV_WT_HIOCC") ? getenv("SV_WT_HIOCC") : "6";
   const bool hi = strchr(hiocc, '0' + id) != nullptr;
   if (narrow) CW = 16;
-  if (!skip && id == 4) return SV_E_UNSUPPORTED;   // measured: e3 (8x8 output grid) is no faster here than on the im2col GEMM
+  // (e3 stayed on the im2col GEMM in round 1 -- "no faster here"; with one resident round of workgroups per launch and the
+  // two-group form it is: 0.097 -> 0.064 ms incl. the reduce, B = 512.  SV_WGRAD_IM2COL_IDS=4 restores the GEMM.)
   // every layer takes the two-stage flush when a workspace is given: even d5 (6 of 16 slab columns
   // real) and e1 (3 of 16 rows real) beat the fp32 atomics (d5: 183 -> 133 us) since the reduce runs at HBM speed
   const bool allow_slab = true;
