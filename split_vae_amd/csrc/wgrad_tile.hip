@@ -387,7 +387,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   // 16-channel slices for d4 / d3 / packed d5: half the accumulators per wave, so three workgroups (3 waves per
   // SIMD) fit per CU instead of two; e1 fits four.  Measured together: 185.5k -> 188.7k images/s (SV_WT_CW16= /
   // SV_WT_HIOCC= with an empty list restore the wide variants).
-  static const char* cw16 = getenv("SV_WT_CW16") ? getenv("SV_WT_CW16") : "127";
+  static const char* cw16 = getenv("SV_WT_CW16") ? getenv("SV_WT_CW16") : "17";   // (round 2: d3 (id 2) back on 32-channel slices, step -1.3 %)
   const bool narrow = strchr(cw16, '0' + id) && (id == 1 || id == 2 || id == 7);
   static const char* hiocc = getenv("SV_WT_HIOCC") ? getenv("SV_WT_HIOCC") : "6";
   const bool hi = strchr(hiocc, '0' + id) != nullptr;
