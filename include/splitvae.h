@@ -85,6 +85,18 @@ int sv_upsample2x_fwd(const void* in, void* out, int32_t dtype, int32_t B, int32
 int sv_upsample2x_bwd(const void* g_hi, const void* y_lo_mask, void* g_lo, int32_t dtype,
                       int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 
+/* ---------------------------------------------------------------- SPLIT-SPAIR: spatial transformer (fp32)
+ * Replaces spair.utils.STN.call + bilinear_sampler + get_pixel_value (spair/utils.py:119-200, :202-272, :274-330) and the
+ * gradient tape.gradient takes through them.  z_where [B,Hc,Wc,4] pre-activations; inverse = 0: img [B,H,W,C] -> one
+ * [Ho,Wo,C] glimpse per cell, out [B,Hc*Wc,Ho,Wo,C]; inverse = 1 (the renderer's STN): img [B,Hc*Wc,H,W,C] -> each object
+ * pasted on its own [Ho,Wo,C] canvas.  bbox (may be NULL) = obj_bbox_mask [B,Hc*Wc,4].  Backward: g_img (same shape as img,
+ * ZERO IT FIRST: scatter-added with atomics), g_z_where [B,Hc,Wc,4]. */
+int sv_stn_sample_fwd(const float* img, const float* z_where, float* out, float* bbox, int32_t B, int32_t Hc, int32_t Wc,
+                      int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t inverse, void* stream);
+int sv_stn_sample_bwd(const float* img, const float* z_where, const float* g_out, float* g_img, float* g_z_where, int32_t B,
+                      int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t inverse,
+                      void* stream);
+
 /* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
  * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the
  * Conv2DBackpropInput / Conv2DBackpropFilter / BiasAddGrad / ReluGrad nodes of tape.gradient

@@ -72,11 +72,14 @@ def stn_constants(H_obj, W_obj, H_out, W_out, dtype=torch.float64):
     return grid, f32(bias_tx), f32(bias_ty)
 
 
-def bilinear_sampler(img, batch_grids):
+def bilinear_sampler(img, batch_grids, inverse=False):
     """STN.bilinear_sampler, forward (non-inverse) form (:202-272): img [B,H,W,C], batch_grids [B,B',2,Ho,Wo] (x then y in
     [-1,1]) -> [B,B',Ho,Wo,C].  Order of operations as the reference: x1 = floor(x)+1 BEFORE the clamps, so at the right /
     bottom border both corners clamp to the last pixel and the weights (x1-x), (x-x0) are taken from the CLAMPED corners."""
-    B, H, W, C = img.shape
+    if inverse:                                               # img [B,B',H,W,C]: every cell samples its own image (:290-308)
+        B, Bp, H, W, C = img.shape
+    else:
+        B, H, W, C = img.shape
     x = batch_grids[:, :, 0]
     y = batch_grids[:, :, 1]
     x = 0.5 * (x + 1.0) * (W - 1)
@@ -91,12 +94,16 @@ def bilinear_sampler(img, batch_grids):
     wd = (x - x0) * (y - y0)
     xi0, xi1, yi0, yi1 = x0.long(), x1.long(), y0.long(), y1.long()
     bidx = torch.arange(B).view(B, 1, 1, 1).expand_as(xi0)
-    g = lambda yy, xx: img[bidx, yy, xx]                       # get_pixel_value (:274-330): gather_nd on (b, y, x)
+    if inverse:
+        pidx = torch.arange(Bp).view(1, Bp, 1, 1).expand_as(xi0)
+        g = lambda yy, xx: img[bidx, pidx, yy, xx]             # gather_nd on (b, b', y, x)
+    else:
+        g = lambda yy, xx: img[bidx, yy, xx]                   # get_pixel_value (:274-330): gather_nd on (b, y, x)
     Ia, Ib, Ic, Id = g(yi0, xi0), g(yi1, xi0), g(yi0, xi1), g(yi1, xi1)
     return wa[..., None] * Ia + wb[..., None] * Ib + wc[..., None] * Ic + wd[..., None] * Id
 
 
-def stn_forward(x, z_where, H_out=32, W_out=32):
+def stn_forward(x, z_where, H_out=32, W_out=32, inverse=False):
     """STN.call, forward form (:119-200): x [B,H,W,C], z_where [B,Hc,Wc,4] -> (glimpses [B,Hc*Wc,H_out,W_out,C],
     obj_bbox_mask [B,Hc*Wc,4])."""
     B, Hc, Wc, _ = z_where.shape
@@ -108,11 +115,14 @@ def stn_forward(x, z_where, H_out=32, W_out=32):
     bh, bw = (sy / 2.0)[..., None], (sx / 2.0)[..., None]
     bty, btx = (ty[..., None] + 1.0) / 2.0, (tx[..., None] + 1.0) / 2.0
     bbox = torch.cat([bty - bh, btx - bw, bty + bh, btx + bw], dim=-1).reshape(B, Hc * Wc, 4)
+    if inverse:                                               # the renderer's STN (:158-162)
+        tx = -tx / (sx + 1e-5); ty = -ty / (sy + 1e-5)
+        sx = 1 / (sx + 1e-5); sy = 1 / (sy + 1e-5)
     sx, sy, tx, ty = (t.reshape(B, Hc * Wc) for t in (sx, sy, tx, ty))
     zeros = torch.zeros_like(sx)
     A = torch.stack([torch.stack([sx, zeros, tx], dim=2), torch.stack([zeros, sy, ty], dim=2)], dim=2)     # [B,B',2,3]
     batch_grids = (A @ grid[None, None]).reshape(B, Hc * Wc, 2, H_out, W_out)
-    return bilinear_sampler(x, batch_grids), bbox
+    return bilinear_sampler(x, batch_grids, inverse), bbox
 
 
 # --------------------------------------------------------------------------------------------- z_pres KL (spair/trainer.py)

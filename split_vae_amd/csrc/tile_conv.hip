@@ -584,7 +584,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : 0) + (wslots > 2 ? 128 : 0);
     // 256-row tiles that leave room for at most two workgroups per CU: 8 waves share the tile
     static const char* nw8 = getenv("SV_TC_NW8");       // tuning knob: BN classes (a=16, b=32, c=64) run with 8-wave workgroups
-    if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) *cfg_out = 16 + cfgN;
+    if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : BN == 64 ? 'c' : 'd')) *cfg_out = 16 + cfgN;
     return true;
   }
   return false;
@@ -614,6 +614,7 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
       case 64 + 2: return launch_tile<bf16_t, 64, 4, 4, 6>(a, n, st);     // KH = 6
       case 64 + 4: return launch_tile<bf16_t, 32, 4, 4, 6>(a, n, st);
       case 64 + 6: return launch_tile<bf16_t, 16, 4, 4, 6>(a, n, st);
+      case 16: return launch_tile<bf16_t, 128, 2, 8>(a, n, st);   // (SV_TC_BN128_MF4=1 SV_TC_NW8=d)
       case 17: return launch_tile<bf16_t, 64, 2, 8>(a, n, st);
       case 18: return launch_tile<bf16_t, 32, 2, 8>(a, n, st);
       case 19: return launch_tile<bf16_t, 16, 2, 8>(a, n, st);

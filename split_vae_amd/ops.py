@@ -132,6 +132,32 @@ def upsample2x_bwd(g_hi, y_lo_mask=None):
     return out
 
 
+# ------------------------------------------------------------------ SPLIT-SPAIR spatial transformer (spair/utils.py:119-330)
+def stn_sample(img, z_where, Ho, Wo, inverse=False):
+    """STN.call: img [B,H,W,C] (inverse: [B,B',H,W,C]) fp32, z_where [B,Hc,Wc,4] -> (out [B,B',Ho,Wo,C], obj_bbox_mask [B,B',4])."""
+    B, Hc, Wc, _ = z_where.shape
+    H, W, Cc = img.shape[-3:]
+    assert img.dtype == torch.float32 and z_where.dtype == torch.float32
+    assert tuple(img.shape[:-3]) == ((B, Hc * Wc) if inverse else (B,))
+    out = torch.empty((B, Hc * Wc, Ho, Wo, Cc), dtype=torch.float32, device=img.device)
+    bbox = torch.empty((B, Hc * Wc, 4), dtype=torch.float32, device=img.device)
+    check(_lib.load().sv_stn_sample_fwd(_p(img.contiguous()), _p(z_where.contiguous()), _p(out), _p(bbox), B, Hc, Wc, H, W, Cc, Ho, Wo,
+                                        1 if inverse else 0, _stream()), "sv_stn_sample_fwd")
+    return out, bbox
+
+
+def stn_sample_bwd(img, z_where, g_out, inverse=False):
+    """-> (g_img like img, g_z_where like z_where) for the upstream gradient g_out [B,B',Ho,Wo,C]."""
+    B, Hc, Wc, _ = z_where.shape
+    H, W, Cc = img.shape[-3:]
+    Ho, Wo = g_out.shape[2:4]
+    g_img = torch.zeros_like(img)
+    g_z = torch.empty_like(z_where)
+    check(_lib.load().sv_stn_sample_bwd(_p(img.contiguous()), _p(z_where.contiguous()), _p(g_out.contiguous()), _p(g_img), _p(g_z), B, Hc,
+                                        Wc, H, W, Cc, Ho, Wo, 1 if inverse else 0, _stream()), "sv_stn_sample_bwd")
+    return g_img, g_z
+
+
 # ------------------------------------------------------------------ K3-K10 conv (vae/model.py:36-38,:153-156)
 class Conv2D:
     """One Conv2D(padding='same') layer instance on the MFMA path (forward, dgrad, wgrad)."""

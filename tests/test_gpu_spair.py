@@ -86,3 +86,58 @@ def test_unsupported_geometries_are_refused(ops):
         ops.Conv2D(4, 50, 50, 8, 8, 4, 3)                       # stride must divide the extent
     with pytest.raises(_lib.SplitVaeError):
         ops.Conv2D(4, 48, 48, 8, 8, 4, 4)                       # strides 1..3
+
+
+# ------------------------------------------------------------------ spatial transformer (spair/utils.py:119-330)
+STN_CASES = [  # name, inverse, image extent, channels, output extent
+    ("glimpses", False, 48, 3, 32),      # STN(H_img=32...) on the [32,48,48,3] canvas: one 32x32 glimpse per cell
+    ("render", True, 32, 4, 48),         # the renderer's inverse STN: each object's rgb+alpha pasted on a 48x48 canvas
+]
+
+
+def _stn_inputs(inverse, Hi, C, seed):
+    rng = np.random.default_rng(seed)
+    Bs, Hc = 5, 4
+    shape = (Bs, Hc * Hc, Hi, Hi, C) if inverse else (Bs, Hi, Hi, C)
+    img = torch.from_numpy(rng.uniform(0, 1, shape).astype(np.float32))
+    z = torch.from_numpy((rng.standard_normal((Bs, Hc, Hc, 4)) * 1.5).astype(np.float32))
+    return img, z
+
+
+@pytest.mark.parametrize("case", STN_CASES, ids=lambda c: c[0])
+def test_stn_forward_matches_oracle(ops, case):
+    """Affine grid + 4-tap gather + obj_bbox_mask against the restatement, both STN directions.  fp32 on the device vs fp64:
+    the output is continuous in the sampling point, so a floor() that lands on the other side of an integer in fp32 moves the
+    value by O(eps) only."""
+    name, inverse, Hi, C, Ho = case
+    img, z = _stn_inputs(inverse, Hi, C, 1)
+    out, bbox = ops.stn_sample(img.cuda(), z.cuda(), Ho, Ho, inverse=inverse)
+    ref, rbox = spair_ref.stn_forward(img.double(), z.double(), Ho, Ho, inverse=inverse)
+    assert tuple(out.shape) == tuple(ref.shape)
+    # inverse form: sampling coordinates are scaled by 1/sx (up to ~1e5 when a cell's box collapses): fp32 coordinate error
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=0, atol=2e-3 if inverse else 2e-5)
+    assert float((out.double().cpu() - ref).norm() / ref.norm()) < (2e-4 if inverse else 1e-5)
+    torch.testing.assert_close(bbox.double().cpu(), rbox, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", STN_CASES, ids=lambda c: c[0])
+def test_stn_backward_matches_autograd_of_the_oracle(ops, case):
+    """g_img (scatter of the four tap weights) and g_z_where (through the tap weights; floor / clip carry none) against
+    torch autograd of the fp64 restatement."""
+    name, inverse, Hi, C, Ho = case
+    img, z = _stn_inputs(inverse, Hi, C, 2)
+    if inverse:
+        z = z * 0.5                                       # keep 1/sx moderate: the comparison is about the chain rule
+    rng = np.random.default_rng(3)
+    g = torch.from_numpy(rng.standard_normal((img.shape[0], 16, Ho, Ho, C)).astype(np.float32))
+    ri, rz = img.double().requires_grad_(True), z.double().requires_grad_(True)
+    ref, _ = spair_ref.stn_forward(ri, rz, Ho, Ho, inverse=inverse)
+    (ref * g.double()).sum().backward()
+    g_img, g_z = ops.stn_sample_bwd(img.cuda(), z.cuda(), g.cuda(), inverse=inverse)
+    ei = float((g_img.double().cpu() - ri.grad).norm() / ri.grad.norm())
+    ez = float((g_z.double().cpu() - rz.grad).norm() / rz.grad.norm())
+    assert ei < (1e-3 if inverse else 1e-5), ei
+    assert ez < (2e-2 if inverse else 1e-3), ez          # a sampling point within fp32 eps of an integer takes the other cell's slope
+    # run-to-run: g_z_where is reduced in a fixed order
+    _, g_z2 = ops.stn_sample_bwd(img.cuda(), z.cuda(), g.cuda(), inverse=inverse)
+    assert torch.equal(g_z, g_z2)
