@@ -97,6 +97,18 @@ int sv_stn_sample_bwd(const float* img, const float* z_where, const float* g_out
                       int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t inverse,
                       void* stream);
 
+/* SPLIT-SPAIR: Renderer.call (spair/spair.py:534-579), fp32.  obj [B,B',H,W,C+1] = every object's rgb + alpha on its own
+ * canvas (sv_stn_sample_fwd, inverse = 1), bg [B,H,W,C], z_depth / z_pres / z_pres_logits [B,B'] -> out [B,H,W,C]; B' <= 16,
+ * C <= 4.  training != 0: z_pres as given and `noise` [B,B',H,W,C] (the GaussianNoise(0.01) draw, may be NULL) added to the
+ * object images before their clip; training == 0: z_pres = max(round(sigmoid(z_pres_logits)), 1e-8), noise must be NULL.
+ * Backward (training form): g_obj like obj, g_bg like bg, g_z_pres / g_z_depth [B,B'] (all written, none accumulated). */
+int sv_spair_render_fwd(const float* obj, const float* bg, const float* z_depth, const float* z_pres,
+                        const float* z_pres_logits, const float* noise, float* out, int32_t B, int32_t Bp, int32_t H,
+                        int32_t W, int32_t C, int32_t training, void* stream);
+int sv_spair_render_bwd(const float* obj, const float* bg, const float* z_depth, const float* z_pres, const float* noise,
+                        const float* g_out, float* g_obj, float* g_bg, float* g_z_pres, float* g_z_depth, int32_t B,
+                        int32_t Bp, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
  * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the
  * Conv2DBackpropInput / Conv2DBackpropFilter / BiasAddGrad / ReluGrad nodes of tape.gradient

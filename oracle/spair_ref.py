@@ -173,3 +173,30 @@ def compute_z_pres_kl_yolo_air(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_
             so_far = so_far + sample
             i += 1
     return tf_mean_sum(torch.stack(kls, dim=1))       # [B, cells, 1]
+
+
+# --------------------------------------------------------------------------------------------- Renderer (spair/spair.py:534-579)
+def renderer(obj_full_recon_unnorm, background_img, z_depth, z_pres, z_pres_logits, training=False, noise=None, num_channel=3):
+    """Renderer.call: obj_full_recon_unnorm [B,B',H,W,C+1] (every object's rgb + alpha on its own canvas, from the inverse STN),
+    background_img [B,H,W,C], z_depth / z_pres / z_pres_logits [B,Hc,Wc,1] -> canvas_with_bg [B,H,W,C].
+    training: z_pres as given and GaussianNoise(0.01) on the object images (`noise` = that N(0, 0.01) draw, or None for no
+    noise); else z_pres = max(round(sigmoid(logits)), 1e-8) and no noise."""
+    B, Bp = obj_full_recon_unnorm.shape[:2]
+    if not training:
+        z_pres = torch.sigmoid(z_pres_logits)
+    z_depth = z_depth.reshape(B, Bp, 1, 1, 1)
+    z_pres = z_pres.reshape(B, Bp, 1, 1, 1)
+    if not training:
+        z_pres = torch.maximum(torch.round(z_pres), torch.full_like(z_pres, 1e-8))
+    obj_img = obj_full_recon_unnorm[..., :num_channel]
+    obj_alpha = torch.clamp(obj_full_recon_unnorm[..., num_channel:], 1e-8, 1.0)
+    transparency_map = z_pres * obj_alpha
+    importance_map = z_pres * obj_alpha * (torch.sigmoid(-z_depth) + 0.5)
+    if training and noise is not None:
+        obj_img = obj_img + noise
+    obj_img = torch.clamp(obj_img, 0.0, 1.0)
+    unnorm_canvas = (importance_map * obj_img).sum(dim=1)
+    normalise_const = importance_map.sum(dim=1)
+    normalised_canvas = unnorm_canvas / (normalise_const + 1e-8)
+    normalised_alpha_canvas = (transparency_map * importance_map).sum(dim=1) / (normalise_const + 1e-8)
+    return normalised_alpha_canvas * normalised_canvas + (1.0 - normalised_alpha_canvas) * background_img

@@ -158,6 +158,30 @@ def stn_sample_bwd(img, z_where, g_out, inverse=False):
     return g_img, g_z
 
 
+def spair_render(obj, bg, z_depth, z_pres=None, z_pres_logits=None, training=False, noise=None):
+    """Renderer.call (spair/spair.py:534-579): obj [B,B',H,W,C+1], bg [B,H,W,C], z_* [B,Hc,Wc,1] -> canvas [B,H,W,C]."""
+    B, Bp, H, W, C1 = obj.shape
+    out = torch.empty((B, H, W, C1 - 1), dtype=torch.float32, device=obj.device)
+    f = lambda t: None if t is None else t.reshape(B, Bp).contiguous()
+    check(_lib.load().sv_spair_render_fwd(_p(obj.contiguous()), _p(bg.contiguous()), _p(f(z_depth)), _p(f(z_pres)), _p(f(z_pres_logits)),
+                                          _p(None if noise is None else noise.contiguous()), _p(out), B, Bp, H, W, C1 - 1,
+                                          1 if training else 0, _stream()), "sv_spair_render_fwd")
+    return out
+
+
+def spair_render_bwd(obj, bg, z_depth, z_pres, g_out, noise=None):
+    """-> (g_obj, g_bg, g_z_pres [B,B'], g_z_depth [B,B']) of the training-form renderer."""
+    B, Bp, H, W, C1 = obj.shape
+    g_obj, g_bg = torch.empty_like(obj), torch.empty_like(bg)
+    g_zp = torch.empty((B, Bp), dtype=torch.float32, device=obj.device)
+    g_zd = torch.empty_like(g_zp)
+    f = lambda t: t.reshape(B, Bp).contiguous()
+    check(_lib.load().sv_spair_render_bwd(_p(obj.contiguous()), _p(bg.contiguous()), _p(f(z_depth)), _p(f(z_pres)),
+                                          _p(None if noise is None else noise.contiguous()), _p(g_out.contiguous()), _p(g_obj), _p(g_bg),
+                                          _p(g_zp), _p(g_zd), B, Bp, H, W, C1 - 1, _stream()), "sv_spair_render_bwd")
+    return g_obj, g_bg, g_zp, g_zd
+
+
 # ------------------------------------------------------------------ K3-K10 conv (vae/model.py:36-38,:153-156)
 class Conv2D:
     """One Conv2D(padding='same') layer instance on the MFMA path (forward, dgrad, wgrad)."""
