@@ -114,3 +114,41 @@ def test_concrete_kl_and_count_prior():
                                          torch.full((B, H, W, 1), 4.0, dtype=torch.float64), prior_prob, temp)
     assert float(kl_on) > 1.0 and math.isfinite(float(kl_on))
     assert float(S.tf_safe_log(torch.tensor(0.0))) == float(torch.log(torch.tensor(1e-8)))       # log(0 + 1e-8), never the replacement
+
+
+def test_renderer_known_answers():
+    """Renderer.call (spair/spair.py:534-579): one opaque present object hides the background wherever its alpha is 1; an absent
+    object (test form, sigmoid(logit) < 0.5 -> z_pres 1e-8) leaves the background; two equally deep objects average."""
+    B, H, C = 1, 4, 3
+    bg = torch.full((B, H, H, C), 0.25, dtype=torch.float64)
+    obj = torch.zeros((B, 2, H, H, C + 1), dtype=torch.float64)
+    obj[:, 0, ..., :C] = 0.75; obj[:, 0, ..., C] = 1.0            # object 0: opaque, colour 0.75
+    obj[:, 1, ..., :C] = 0.5; obj[:, 1, ..., C] = 1e-8            # object 1: transparent
+    zd = torch.zeros((B, 1, 2, 1), dtype=torch.float64)
+    zp = torch.ones((B, 1, 2, 1), dtype=torch.float64)
+    out = S.renderer(obj, bg, zd, zp, None, training=True)
+    assert torch.allclose(out, torch.full_like(out, 0.75), atol=1e-6)
+    logits = torch.tensor([-5.0, -5.0], dtype=torch.float64).reshape(B, 1, 2, 1)
+    out = S.renderer(obj, bg, zd, None, logits, training=False)
+    assert torch.allclose(out, bg, atol=1e-6)
+    obj[:, 1, ..., C] = 1.0                                        # both opaque, same depth: importance-weighted mean
+    out = S.renderer(obj, bg, zd, zp, None, training=True)
+    assert torch.allclose(out, torch.full_like(out, 0.625), atol=1e-6)
+    zd2 = torch.tensor([-20.0, 20.0], dtype=torch.float64).reshape(B, 1, 2, 1)     # object 0 in front: sigmoid(-z) + .5 = 1.5 vs .5
+    out = S.renderer(obj, bg, zd2, zp, None, training=True)
+    assert torch.allclose(out, torch.full_like(out, (1.5 * 0.75 + 0.5 * 0.5) / 2.0), atol=1e-6)
+
+
+def test_inverse_stn_pastes_the_object_inside_its_box():
+    """The renderer's STN (inverse form, spair/utils.py:158-162): a constant object lands on the canvas inside obj_bbox_mask
+    and the canvas is ~0 well outside it only where the sampler's clipped corners coincide (its border quirk keeps the edge
+    value elsewhere) -- here: the centre of the box carries the object's value."""
+    B, Hc = 1, 4
+    z = torch.zeros((B, Hc, Hc, 4), dtype=torch.float64)
+    obj = torch.ones((B, Hc * Hc, 32, 32, 1), dtype=torch.float64)
+    out, bbox = S.stn_forward(obj, z, 48, 48, inverse=True)
+    assert tuple(out.shape) == (B, 16, 48, 48, 1)
+    for cell in (0, 5, 15):
+        y0, x0, y1, x1 = (bbox[0, cell] * 47).tolist()
+        cy, cx = int(round((y0 + y1) / 2)), int(round((x0 + x1) / 2))
+        assert abs(float(out[0, cell, cy, cx, 0]) - 1.0) < 1e-9
