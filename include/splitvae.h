@@ -77,6 +77,13 @@ int sv_reparam_kl_bwd(const float* dz, int32_t ld_dz, const float* dz2, int32_t 
 int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t t, float grad_scale, void* stream);
 
+/* The same with Keras `clipnorm` (SPLIT-SPAIR: Adam(..., clipnorm=1.0), spair/main.py:109): every gradient tensor is scaled by
+ * clipnorm / max(||g * grad_scale||_2, clipnorm) first (tf.clip_by_norm).  tensor_off: DEVICE array of n_tensors+1 element
+ * offsets into the flat buffers; norm_ws: DEVICE scratch of 32*n_tensors floats.  Deterministic (fixed-order norms). */
+int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
+                          float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
+                          float grad_scale, void* stream);
+
 /* ---------------------------------------------------------------- K10a: bilinear 2x
  * Replaces tf.image.resize(x,[2H,2W]) (vae/model.py:163,:165,:167; bilinear, half-pixel centres,
  * edge clamp) and its adjoint (ResizeBilinearGrad) fused with the ReLU mask of the producer. */
@@ -108,6 +115,14 @@ int sv_spair_render_fwd(const float* obj, const float* bg, const float* z_depth,
 int sv_spair_render_bwd(const float* obj, const float* bg, const float* z_depth, const float* z_pres, const float* noise,
                         const float* g_out, float* g_obj, float* g_bg, float* g_z_pres, float* g_z_depth, int32_t B,
                         int32_t Bp, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* SPLIT-SPAIR: compute_z_pres_kl_yolo_air + concrete_binary_sample_kl (spair/trainer.py:28-42, :45-94), fp32: the sequential
+ * count-prior KL of the n_cells <= 16 presence variables, cells in raster order.  z_pres / z_pres_logits / z_pres_pre_sigmoid
+ * [B,n_cells] -> kl [B] (per-image sums: tf_mean_sum = their batch mean); g_pre_sigmoid / g_logits (may be NULL) =
+ * grad_scale * d kl_b / d input (the prior depends on the thresholded samples only: no gradient to z_pres). */
+int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
+                      float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob, float temperature,
+                      float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
  * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the

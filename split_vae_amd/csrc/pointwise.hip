@@ -395,6 +395,58 @@ extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_
   return svk_adam_step(p, g, m, v, n, lr, beta1, beta2, eps, t, grad_scale, nullptr, (hipStream_t)stream);
 }
 
+// ---- Adam with Keras `clipnorm` (spair/main.py:109: Adam(..., clipnorm=1.0)): every gradient TENSOR is scaled by
+// clipnorm / max(||g||_2, clipnorm) (tf.clip_by_norm) before the update.  Pass 1: 32 partial sums of squares per tensor
+// (fixed strides); pass 2: a workgroup column per tensor adds them in a fixed order and applies the update -- deterministic.
+#define SV_CLIP_PARTS 32
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ off,
+                                                    float* __restrict__ parts, float gscale) {
+  const int t = blockIdx.y;
+  const int64_t lo = off[t], hi = off[t + 1];
+  float s = 0.f;
+  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)SV_CLIP_PARTS * 256) {
+    const float v = g[i] * gscale;
+    s += v * v;
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[(int64_t)t * SV_CLIP_PARTS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, const int64_t* __restrict__ off,
+                                                        const float* __restrict__ parts, float clipnorm, float alpha,
+                                                        float omb1, float omb2, float eps, float gscale) {
+  const int t = blockIdx.y;
+  float ss = 0.f;
+  for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];
+  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
+  const int64_t lo = off[t], hi = off[t + 1];
+  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
+    const float gc = g[i] * sc;
+    float mi = m[i], vi = v[i];
+    mi = mi + (gc - mi) * omb1;
+    vi = vi + (gc * gc - vi) * omb2;
+    p[i] = p[i] - alpha * mi / (sqrtf(vi) + eps);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
+extern "C" int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
+                                     float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
+                                     float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !tensor_off || !norm_ws || n_tensors < 1 || t <= 0 || !(clipnorm > 0.f)) return SV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const double alpha = svk_adam_alpha(lr, beta1, beta2, t);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SV_CLIP_PARTS, n_tensors), dim3(256), 0, st, g, tensor_off, norm_ws, grad_scale);
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(64, n_tensors), dim3(256), 0, st, p, g, m, v, tensor_off, norm_ws, clipnorm,
+                     (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 __global__ void set_dyn_kernel(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha) {
   dyn->seed = seed; dyn->step = step; dyn->sample_offset = sample_offset; dyn->adam_alpha = adam_alpha; dyn->pad = 0.f;
 }

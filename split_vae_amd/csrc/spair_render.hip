@@ -135,3 +135,74 @@ extern "C" int sv_spair_render_bwd(const float* obj, const float* bg, const floa
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ============================================================================ sequential z_pres KL (spair/trainer.py:28-42, :45-94)
+// compute_z_pres_kl_yolo_air: the cells are visited in raster order; the prior odds of cell i follow from the count
+// distribution over 0..n objects conditioned on the cells switched on so far (z_pres > 0.5).  One thread per image carries
+// the (n+1)-entry distribution through the n <= 16 cells -- the recurrence is serial by construction and tiny.  The prior
+// depends on the SAMPLES only (comparisons, no gradient), so the tape's gradient reaches the posterior logits and the
+// pre-sigmoid sample alone:  d kl / d y = 2T (e_q/(1+e_q+eps) - e_p/(1+e_p+eps)),  d kl / d q = 1 - 2 e_q/(1+e_q+eps),
+// e_x = exp(-yT + x).  kl [B] = per-image sums (tf_mean_sum's inner sum); gradients are scaled by grad_scale (1/B for the mean).
+namespace {
+__device__ __forceinline__ float safe_log(float v) {       // tf_safe_log (:97-101)
+  const float l = logf(v + 1e-8f);
+  return (isnan(l) || isinf(l)) ? -100.f : l;
+}
+__global__ __launch_bounds__(64) void zpres_kl_kernel(const float* __restrict__ z_pres, const float* __restrict__ logits,
+                                                      const float* __restrict__ pre, float* __restrict__ kl,
+                                                      float* __restrict__ g_pre, float* __restrict__ g_logits, int B, int n,
+                                                      float prior_prob, float T, float gscale) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float dist[MAXBP + 1];
+  const float cpp = 1.f - prior_prob;
+  float norm = 0.f;
+#pragma unroll
+  for (int k = 0; k <= MAXBP; ++k) {
+    dist[k] = k <= n ? (1.f - cpp) * powf(cpp, (float)k) : 0.f;
+    norm += dist[k];
+  }
+  norm = fmaxf(norm, 1e-6f);
+#pragma unroll
+  for (int k = 0; k <= MAXBP; ++k) dist[k] /= norm;
+  float so_far = 0.f, total = 0.f;
+  const float lt = logf(T + 1e-8f);
+  for (int i = 0; i < n; ++i) {
+    float pz = 0.f;
+    const float inv = 1.f / (float)(n - i);
+#pragma unroll
+    for (int k = 0; k <= MAXBP; ++k) pz += dist[k] * (fmaxf((float)k - so_far, 0.f) * inv);
+    const float p = safe_log(pz) - safe_log(1.f - pz);     // prior log-odds
+    const float y = pre[(int64_t)b * n + i], q = logits[(int64_t)b * n + i];
+    const float eq = expf(-y * T + q), ep = expf(-y * T + p);
+    const float log_post = lt - y * T + q - 2.f * logf(1.f + eq + 1e-8f);
+    const float log_prior = lt - y * T + p - 2.f * logf(1.f + ep + 1e-8f);
+    total += log_post - log_prior;
+    if (g_pre) g_pre[(int64_t)b * n + i] = gscale * 2.f * T * (eq / (1.f + eq + 1e-8f) - ep / (1.f + ep + 1e-8f));
+    if (g_logits) g_logits[(int64_t)b * n + i] = gscale * (1.f - 2.f * eq / (1.f + eq + 1e-8f));
+    const float s = z_pres[(int64_t)b * n + i] > 0.5f ? 1.f : 0.f;
+    float nn = 0.f;
+#pragma unroll
+    for (int k = 0; k <= MAXBP; ++k) {
+      const float pg = fmaxf((float)k - so_far, 0.f) * inv;
+      dist[k] = (s * pg + (1.f - s) * (1.f - pg)) * dist[k];
+      nn += dist[k];
+    }
+    nn = fmaxf(nn, 1e-6f);
+#pragma unroll
+    for (int k = 0; k <= MAXBP; ++k) dist[k] /= nn;
+    so_far += s;
+  }
+  kl[b] = total;
+}
+}  // namespace
+
+extern "C" int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
+                                 float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob,
+                                 float temperature, float grad_scale, void* stream) {
+  if (!z_pres || !z_pres_logits || !z_pres_pre_sigmoid || !kl || B < 1 || n_cells < 1 || n_cells > MAXBP) return SV_E_BADARG;
+  hipLaunchKernelGGL(zpres_kl_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, z_pres, z_pres_logits,
+                     z_pres_pre_sigmoid, kl, g_pre_sigmoid, g_logits, B, n_cells, prior_prob, temperature, grad_scale);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

@@ -182,6 +182,29 @@ def spair_render_bwd(obj, bg, z_depth, z_pres, g_out, noise=None):
     return g_obj, g_bg, g_zp, g_zd
 
 
+def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature, grad_scale=None):
+    """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94): inputs [B,H,W,1] -> (kl [B] per-image sums, g_pre_sigmoid, g_logits)
+    with the gradients of mean_b(kl_b) (grad_scale = 1/B) unless grad_scale is given."""
+    B = z_pres.shape[0]
+    n = z_pres[0].numel()
+    f = lambda t: t.reshape(B, n).contiguous()
+    kl = torch.empty((B,), dtype=torch.float32, device=z_pres.device)
+    g_pre, g_log = torch.empty((B, n), dtype=torch.float32, device=z_pres.device), torch.empty((B, n), dtype=torch.float32, device=z_pres.device)
+    check(_lib.load().sv_spair_zpres_kl(_p(f(z_pres)), _p(f(z_pres_logits)), _p(f(z_pres_pre_sigmoid)), _p(kl), _p(g_pre), _p(g_log), B, n,
+                                        float(prior_prob), float(temperature), 1.0 / B if grad_scale is None else float(grad_scale),
+                                        _stream()), "sv_spair_zpres_kl")
+    return kl, g_pre.reshape(z_pres.shape), g_log.reshape(z_pres.shape)
+
+
+def adam_step_clipnorm(p, g, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """Keras Adam(clipnorm=...) over flat buffers; tensor_off: int64 device tensor of n_tensors+1 offsets."""
+    nt = tensor_off.numel() - 1
+    ws = torch.empty((32 * nt,), dtype=torch.float32, device=p.device)
+    check(_lib.load().sv_adam_step_clipnorm(_p(p), _p(g), _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
+                                            float(beta1), float(beta2), float(eps), int(t), float(grad_scale), _stream()),
+          "sv_adam_step_clipnorm")
+
+
 # ------------------------------------------------------------------ K3-K10 conv (vae/model.py:36-38,:153-156)
 class Conv2D:
     """One Conv2D(padding='same') layer instance on the MFMA path (forward, dgrad, wgrad)."""

@@ -184,3 +184,50 @@ def test_renderer_backward_matches_autograd_of_the_oracle(ops, with_noise):
         assert err < 1e-4, (name, err)
     again = ops.spair_render_bwd(obj.cuda(), bg.cuda(), zd.cuda(), zp.cuda(), g.cuda(), noise=None if nz is None else nz.cuda())
     assert all(torch.equal(a, b) for a, b in zip(got, again))      # fixed-order reductions: run-to-run identical
+
+
+# ------------------------------------------------------------------ z_pres KL and clipnorm Adam
+@pytest.mark.parametrize("prior_prob,temp", [(0.1, 1.0), (0.5, 2.5), (0.01, 0.5)])
+def test_zpres_kl_and_its_gradient(ops, prior_prob, temp):
+    """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94) on the device: per-image sums against the fp64 restatement, the
+    gradients against its autograd (the count prior sees thresholded samples only: no gradient to z_pres)."""
+    rng = np.random.default_rng(int(prior_prob * 1000))
+    Bs = 32
+    pre = torch.from_numpy(rng.standard_normal((Bs, 4, 4, 1)).astype(np.float32) * 2)
+    logits = torch.from_numpy(rng.standard_normal((Bs, 4, 4, 1)).astype(np.float32) * 2)
+    zp = torch.sigmoid(pre)
+    zp[0] = 0.9; zp[1] = 0.1                               # all on / all off: the count recursion's extremes
+    kl, g_pre, g_log = ops.spair_zpres_kl(zp.cuda(), logits.cuda(), pre.cuda(), prior_prob, temp)
+    rp, rl = pre.double().requires_grad_(True), logits.double().requires_grad_(True)
+    ref = spair_ref.compute_z_pres_kl_yolo_air(zp.double(), rl, rp, prior_prob, temp)
+    ref.backward()
+    assert abs(float(kl.double().mean()) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-5
+    torch.testing.assert_close(g_pre.double().cpu(), rp.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(g_log.double().cpu(), rl.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_adam_with_clipnorm_matches_keras_formula(ops):
+    """Adam(clipnorm=1.0) (spair/main.py:109): per-TENSOR tf.clip_by_norm, then the Keras update; three steps, tensors whose
+    norm is above and below the threshold, a ragged table."""
+    rng = np.random.default_rng(9)
+    sizes = [7, 4096, 33, 100000, 1]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(off[-1])
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    P, M, V = (torch.from_numpy(a.copy()).cuda() for a in (p, m, v))
+    OFF = torch.from_numpy(off).cuda()
+    lr, b1, b2, eps, clip = 1e-3, 0.9, 0.999, 1e-7, 1.0
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32) * np.repeat([0.01, 1.0, 0.2, 0.001, 5.0], sizes).astype(np.float32)
+        ops.adam_step_clipnorm(P, torch.from_numpy(g).cuda(), M, V, OFF, clip, t, lr, b1, b2, eps)
+        g64 = g.astype(np.float64)
+        for a, b in zip(off[:-1], off[1:]):
+            nrm = np.sqrt((g64[a:b] ** 2).sum())
+            g64[a:b] *= clip / max(nrm, clip)
+        m64 += (g64 - m64) * (1 - b1); v64 += (g64 * g64 - v64) * (1 - b2)
+        alpha = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        p64 -= alpha * m64 / (np.sqrt(v64) + eps)
+    np.testing.assert_allclose(P.cpu().numpy(), p64, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(M.cpu().numpy(), m64, rtol=2e-5, atol=1e-8)
