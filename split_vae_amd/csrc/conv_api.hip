@@ -208,7 +208,6 @@ int svg_check(const sv_conv_desc* d) {
   // its stride-3 layer, spair/spair.py:382-384) on the im2col kernels, whose row decode divides.  Strided layers need the
   // stride to divide the extent (the input gradient iterates H/s x W/s parity classes).
   if (d->stride > 1 && ((d->H % d->stride) || (d->W % d->stride))) return SV_E_UNSUPPORTED;
-  if (d->stride == 2 && ((d->KH & 1) || (d->KW & 1))) return SV_E_UNSUPPORTED;
   if (d->ldx < d->Cin || d->ldx % 8) return SV_E_BADARG;
   if (ilog2_exact(svg_cin_pad(d)) < 0) return SV_E_UNSUPPORTED;      // K pieces per tap: a power of two (the input gradient
                                                                    // contracts over Cout instead: checked there)

@@ -231,3 +231,35 @@ def test_adam_with_clipnorm_matches_keras_formula(ops):
         p64 -= alpha * m64 / (np.sqrt(v64) + eps)
     np.testing.assert_allclose(P.cpu().numpy(), p64, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(M.cpu().numpy(), m64, rtol=2e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ ImageEncoder / ImageDecoder geometry (spair/spair.py:113-160)
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("H,Cin,Cout", [(48, 3, 32), (24, 32, 64), (12, 64, 128), (32, 3, 32), (16, 32, 64)])
+def test_odd_kernel_stride_2_layers(ops, H, Cin, Cout, dtype, rtol):
+    """Conv2D(kernel_size=3, strides=2, padding='same') of SPAIR's ImageEncoder (48 -> 24 -> 12 -> 6; TF pads 0 before / 1 after)
+    and the same layer on power-of-two extents: forward, input gradient (parity classes with 4 / 2 / 2 / 1 taps) and weight
+    gradient against the fp64 reference."""
+    rng = np.random.default_rng(H + Cin)
+    Bs, k, s = 8, 3, 2
+    x = torch.from_numpy(rng.standard_normal((Bs, H, H, Cin)).astype(np.float32)).to(dtype)
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(Bs, H, H, Cin, Cout, k, s, act="relu", dtype=dtype)
+    conv.prep(w.cuda())
+    xg = _pad8(x).cuda()
+    y = conv.fwd(xg, b.cuda())
+    wr, xr, br = w.to(dtype).double().requires_grad_(True), x.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch_ref.conv2d_same(xr, wr, br, s, "relu")
+    assert tuple(y.shape[1:3]) == tuple(yr.shape[1:3]) == (H // 2, H // 2)
+    torch.testing.assert_close(y[..., :Cout].double().cpu(), yr.detach(), rtol=rtol, atol=rtol * float(yr.abs().max()))
+    dy = torch.from_numpy(rng.standard_normal(tuple(yr.shape)).astype(np.float32)).to(dtype)
+    pre = torch_ref.conv2d_same(xr, wr, br, s, None)
+    pre.backward(dy.double())
+    dyg = _pad8(dy).cuda()
+    dw, db = conv.wgrad(xg, dyg)
+    torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=rtol, atol=rtol * float(wr.grad.abs().max()))
+    torch.testing.assert_close(db.double().cpu(), br.grad, rtol=rtol, atol=rtol * float(br.grad.abs().max()))
+    if Cin >= 8:
+        dx = conv.dgrad(dyg)
+        torch.testing.assert_close(dx[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=rtol * float(xr.grad.abs().max()))
