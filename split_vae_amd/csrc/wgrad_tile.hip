@@ -324,7 +324,12 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   // small batches: a workgroup should own several tiles before it pays for a slab flush (the slab is as large for one tile as
   // for forty: at 64 images per network d2's 512 one-tile workgroups wrote and re-read 67 MB of partial sums)
   static const int min_tiles = getenv("SV_WT_MIN_TILES") ? atoi(getenv("SV_WT_MIN_TILES")) : 4;   // B = 64: 0.768 -> 0.746 ms; 8: worse (too few workgroups)
-  if (min_tiles > 1 && msplit > (a[0].ntiles + min_tiles - 1) / min_tiles) msplit = (a[0].ntiles + min_tiles - 1) / min_tiles;
+  if (min_tiles > 1) {
+    int cand = (a[0].ntiles + min_tiles - 1) / min_tiles;
+    const int floor_wgs = (256 + groups * n - 1) / (groups * n);     // ... but never fewer than one workgroup per CU in the launch
+    if (cand < floor_wgs) cand = floor_wgs;                          // (SVHN-32, 64 images: 4 tiles per workgroup left 32 workgroups: +5 %)
+    if (msplit > cand) msplit = cand;
+  }
   dim3 grid(msplit, groups, n), block(256 * NG);
   constexpr int PER = 4 * TPW * CIF * COF * 256;
   const int64_t need = (int64_t)msplit * groups * PER * 4;
