@@ -473,7 +473,12 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   const int cin = (1 << t.cl2) * epp;
   // N tile
   int BN, cfgN;
-  if (t.N % 128 == 0) { BN = 128; cfgN = 0; }
+  // small launches (up to 256-image shards): a 128-column layer whose 128-row tiles give at most about one workgroup per CU
+  // runs on 64-column tiles instead -- twice the workgroups, half the weight streaming each (SV_TC_SMALL_WGS: the threshold)
+  static const int small_wgs = getenv("SV_TC_SMALL_WGS") ? atoi(getenv("SV_TC_SMALL_WGS")) : 300;   // measured: helps up to 256 such workgroups (B = 256: -1.6 %, 128: -3.6 %, 64: -3.4 %), hurts at 512 (+1.8 %)
+  const int64_t wgs128 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 128);
+  const bool small = t.N % 128 == 0 && wgs128 < small_wgs && dtype == SV_BF16 && !t.cls_n;
+  if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
   else if (t.N % 64 == 0) { BN = 64; cfgN = 1; }
   else if (t.N % 32 == 0) { BN = 32; cfgN = 2; }
   else if (t.N <= 16) { BN = 16; cfgN = 3; }
@@ -509,6 +514,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     static const bool big128 = getenv("SV_TC_BN128_MF4") != nullptr;
     if (MF == 4 && BN == 128 && !(big128 && dtype == SV_BF16)) continue;
     if (MF == 4 && mf2 && strchr(mf2, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')) continue;
+    if (MF == 4 && small) continue;                       // (128-row tiles: the point is more workgroups)
     if (MF == 4 && BN == 32 && OY * OX <= 256 && t.OS == 2 && !t.d2s_y) continue;   // measured: e2's dgrad parity classes (16x16 grids) run 20 % faster on 128-row tiles
     const int BM = 64 * MF;
     int lTH = 0;
