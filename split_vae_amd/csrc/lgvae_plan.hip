@@ -515,7 +515,10 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // the critical path of the backward pass (it ends ~0.3 ms after the last input gradient), and d5's weight gradient slows the
   // concurrent d4 input gradient 2.5x; with d5 and the two tail layers e1, e2 on the main stream the step is 1.4 % shorter
   // ("" = everything on the side stream)
-  static const char* on_main = getenv("SV_WGRAD_MAIN") ? getenv("SV_WGRAD_MAIN") : "e1,e2,d5";
+  // Batch dependence (re-measured per shard size): d5 on the main stream pays from ~768 images per launch (B = 512: -0.4 %)
+  // and costs below that (B = 256: +0.6 %, 128: +4 %, 64: +2 %); e1 / e2 on the main stream pay at every size.
+  static const char* on_main_env = getenv("SV_WGRAD_MAIN");
+  const char* on_main = on_main_env ? on_main_env : (n * L[0]->d.B >= 768 ? "e1,e2,d5" : "e1,e2");
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
   for (int i = 0; i < n; ++i) {
