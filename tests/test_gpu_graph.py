@@ -63,9 +63,10 @@ def test_replayed_steps_equal_eager_steps(ops, dtype, monkeypatch):
         assert float(d.max()) <= 2.1e-3 * (t + 1), (t, float(d.max()))
         frac, frac0 = float((d > 1e-5).float().mean()), float((d0 > 1e-5).float().mean())
         # (two eager runs share one launch schedule and are often bit-identical; the replay runs the weight gradients on
-        # the main stream, another valid order of the same atomics, and bf16 amplifies it: 2 % was seen, a stale
-        # scalar gives ~100 %)
-        assert frac <= 3 * frac0 + (2e-2 if dtype == "f32" else 1e-1), (t, frac, frac0)
+        # the main stream, another valid order of the same atomics, and bf16 + Adam's sign-like update amplify it: 2-14 %
+        # of the elements were seen to sit more than 1e-5 apart by the third step (scripts/dbg_e3race.py: the gradients of
+        # the two schedules agree to 1e-5 relative, like two runs of one schedule); a stale scalar gives ~100 %)
+        assert frac <= 3 * frac0 + (2e-2 if dtype == "f32" else 0.3), (t, frac, frac0)
     assert pe.graph_count() == 0 and pg.graph_count() == 1            # eager / eager, capture, then replays
     assert not torch.equal(hist[2], hist[3])                          # consecutive replays draw different noise
     assert np.isfinite(float(lg[5]))
