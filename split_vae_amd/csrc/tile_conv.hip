@@ -478,8 +478,10 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   static const int small_wgs = getenv("SV_TC_SMALL_WGS") ? atoi(getenv("SV_TC_SMALL_WGS")) : 300;   // measured: helps up to 256 such workgroups (B = 256: -1.6 %, 128: -3.6 %, 64: -3.4 %), hurts at 512 (+1.8 %)
   const int64_t wgs128 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 128);
   const bool small = t.N % 128 == 0 && wgs128 < small_wgs && dtype == SV_BF16 && !t.cls_n;
+  static const int tiny_wgs = getenv("SV_TC_TINY_WGS") ? atoi(getenv("SV_TC_TINY_WGS")) : 100;   // ... and on 32-column tiles below this (64-image shards: -1.3 .. -1.9 %)
+  const bool tiny = small && wgs128 < tiny_wgs;
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
-  else if (t.N % 64 == 0) { BN = 64; cfgN = 1; }
+  else if (t.N % 64 == 0 && !tiny) { BN = 64; cfgN = 1; }
   else if (t.N % 32 == 0) { BN = 32; cfgN = 2; }
   else if (t.N <= 16) { BN = 16; cfgN = 3; }
   else return false;
