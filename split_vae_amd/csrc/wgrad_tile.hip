@@ -22,7 +22,7 @@
 #include "conv_geom.h"
 
 #ifndef SV_WT_PF
-#define SV_WT_PF 4      // LDS prefetch depth (fragments) of the transposed A-operand reads
+#define SV_WT_PF 3      // LDS prefetch depth (fragments) of the transposed A-operand reads (re-measured round 2: 3 beats 4 by 0.5 % of the step, 1-2 and 6-8 lose)
 #endif
 
 __device__ __forceinline__ short4_t tr16(const char* p) {
