@@ -28,6 +28,12 @@ _lib_def.define("reparam_kl_fwd(Tensor pre, Tensor bias, Tensor? eps, int seed, 
 _lib_def.define("reparam_kl_bwd(Tensor dz, Tensor z_mean, Tensor z_sig, Tensor eps, float kl_scale) -> Tensor")
 _lib_def.define("upsample2x_bwd(Tensor g_hi, Tensor? relu_mask) -> Tensor")
 _lib_def.define("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps, float grad_scale) -> ()")
+# SPLIT-SPAIR operators (fp32; spair/utils.py:119-330, spair/spair.py:534-579, spair/trainer.py:28-94)
+_lib_def.define("stn_sample_fwd(Tensor img, Tensor z_where, int Ho, int Wo, bool inverse) -> (Tensor, Tensor)")
+_lib_def.define("stn_sample_bwd(Tensor img, Tensor z_where, Tensor g_out, bool inverse) -> (Tensor, Tensor)")
+_lib_def.define("spair_render_fwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor? z_pres, Tensor? z_pres_logits, Tensor? noise, bool training) -> Tensor")
+_lib_def.define("spair_render_bwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor z_pres, Tensor? noise, Tensor g_out) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib_def.define("spair_zpres_kl(Tensor z_pres, Tensor z_pres_logits, Tensor z_pres_pre_sigmoid, float prior_prob, float temperature) -> (Tensor, Tensor, Tensor)")
 
 ACT = {None: 0, "none": 0, "relu": 1}
 
@@ -200,3 +206,91 @@ def reparam_kl(pre, bias, eps):
     sd, before bias and softplus), bias [2L], eps [B,L] -> (z, kl [B] per-image terms, z_mean, z_sig); differentiable in
     pre and bias through z and a uniformly weighted kl."""
     return _ReparamKlFn.apply(pre, bias, eps)
+
+
+# ---------------------------------------------------------------------------------------------- SPLIT-SPAIR operators
+@_impl("stn_sample_fwd")
+def _stn_fwd(img, z_where, Ho, Wo, inverse):
+    return ops.stn_sample(img, z_where, Ho, Wo, inverse=inverse)
+
+
+@_impl("stn_sample_bwd")
+def _stn_bwd(img, z_where, g_out, inverse):
+    return ops.stn_sample_bwd(img, z_where, g_out, inverse=inverse)
+
+
+@_impl("spair_render_fwd")
+def _render_fwd(obj, bg, z_depth, z_pres, z_pres_logits, noise, training):
+    return ops.spair_render(obj, bg, z_depth, z_pres=z_pres, z_pres_logits=z_pres_logits, training=training, noise=noise)
+
+
+@_impl("spair_render_bwd")
+def _render_bwd(obj, bg, z_depth, z_pres, noise, g_out):
+    return ops.spair_render_bwd(obj, bg, z_depth, z_pres, g_out, noise=noise)
+
+
+@_impl("spair_zpres_kl")
+def _zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
+    return ops.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature, grad_scale=1.0)
+
+
+class _StnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, z_where, Ho, Wo, inverse):
+        out, bbox = torch.ops.split_vae.stn_sample_fwd(img, z_where, Ho, Wo, inverse)
+        ctx.save_for_backward(img, z_where)
+        ctx.inverse = inverse
+        ctx.mark_non_differentiable(bbox)          # obj_bbox_mask only feeds metrics / drawings in the reference
+        return out, bbox
+
+    @staticmethod
+    def backward(ctx, g_out, _g_bbox):
+        img, z_where = ctx.saved_tensors
+        g_img, g_z = torch.ops.split_vae.stn_sample_bwd(img, z_where, g_out.contiguous(), ctx.inverse)
+        return g_img, g_z, None, None, None
+
+
+def stn_sample(img, z_where, Ho, Wo, inverse=False):
+    """STN.call (spair/utils.py:119-200): glimpses / pasted objects [B,B',Ho,Wo,C] and obj_bbox_mask; differentiable in img
+    and z_where."""
+    return _StnFn.apply(img, z_where, Ho, Wo, inverse)
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, bg, z_depth, z_pres, noise):
+        out = torch.ops.split_vae.spair_render_fwd(obj, bg, z_depth, z_pres, None, noise, True)
+        ctx.save_for_backward(obj, bg, z_depth, z_pres, noise)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        obj, bg, z_depth, z_pres, noise = ctx.saved_tensors
+        g_obj, g_bg, g_zp, g_zd = torch.ops.split_vae.spair_render_bwd(obj, bg, z_depth, z_pres, noise, g_out.contiguous())
+        return g_obj, g_bg, g_zd.reshape(z_depth.shape), g_zp.reshape(z_pres.shape), None
+
+
+def spair_render(obj, bg, z_depth, z_pres, noise=None):
+    """Renderer.call, training form (spair/spair.py:534-579); differentiable in obj, bg, z_depth, z_pres.  (The test form
+    rounds the presences: call torch.ops.split_vae.spair_render_fwd with training=False.)"""
+    return _RenderFn.apply(obj, bg, z_depth, z_pres, noise)
+
+
+class _ZpresKlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
+        kl, g_pre, g_log = torch.ops.split_vae.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature)
+        ctx.save_for_backward(g_pre, g_log)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g_kl):
+        g_pre, g_log = ctx.saved_tensors
+        w = g_kl.view(-1, *([1] * (g_pre.dim() - 1)))
+        return None, g_log * w, g_pre * w, None, None     # no gradient to z_pres: the count prior sees thresholded samples only
+
+
+def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
+    """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94) as per-image sums kl [B] (tf_mean_sum = kl.mean()); differentiable
+    in the logits and the pre-sigmoid sample."""
+    return _ZpresKlFn.apply(z_pres, z_pres_logits, z_pres_pre_sigmoid, float(prior_prob), float(temperature))

@@ -96,3 +96,46 @@ def test_scramble_and_adam_ops(lib_built):
     torch.ops.split_vae.adam_step(p, g, m, v, 1, 1e-3, 0.9, 0.999, 1e-7, 1.0)
     want = p0.double() - 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9) * (0.1 * g.double()) / ((0.001 * g.double() ** 2).sqrt() + 1e-7)
     torch.testing.assert_close(p.double(), want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_spair_ops_compose_in_one_autograd_graph(lib_built):
+    """glimpses = STN(x, z_where); objects pasted back with the inverse STN; Renderer over a background; xent + z_pres KL
+    loss; backward through all of it -- against torch autograd of the fp64 oracle composition (spair/utils.py:119-330,
+    spair/spair.py:534-579, spair/trainer.py:45-101)."""
+    from oracle import spair_ref as S
+    from split_vae_amd import torch_ops as T
+    g = torch.Generator().manual_seed(3)
+    B, Hc = 4, 4
+    x = torch.rand(B, 48, 48, 3, generator=g)
+    z_where = torch.randn(B, Hc, Hc, 4, generator=g) * 0.7
+    z_depth = torch.randn(B, Hc, Hc, 1, generator=g)
+    pre = torch.randn(B, Hc, Hc, 1, generator=g)
+    logits = torch.randn(B, Hc, Hc, 1, generator=g)
+    bg = torch.rand(B, 48, 48, 3, generator=g)
+    alpha = torch.rand(B, 16, 32, 32, 1, generator=g)
+
+    def graph(stn, render, zkl, t):
+        x_, zw, zd, pr, lg, bg_ = t
+        glimpses, _ = stn(x_, zw, 32, 32, False)                             # [B,16,32,32,3]
+        obj = torch.cat([glimpses, alpha.to(glimpses)], dim=-1)              # rgb from the glimpses + a fixed alpha
+        pasted, _ = stn(obj, zw, 48, 48, True)                               # [B,16,48,48,4]
+        zp = torch.sigmoid(pr)
+        canvas = render(pasted, bg_, zd, zp)
+        recon = -(x_ * torch.log(canvas + 1e-8) + (1 - x_) * torch.log(1 - canvas + 1e-8)).sum(dim=(1, 2, 3)).mean()
+        return recon + zkl(zp, lg, pr)
+
+    r = [t.double().requires_grad_(True) for t in (x, z_where, z_depth, pre, logits, bg)]
+    ref = graph(lambda a, b, h, w, inv: S.stn_forward(a, b, h, w, inverse=inv),
+                lambda o, b_, zd, zp: S.renderer(o, b_, zd, zp, None, training=True),
+                lambda zp, lg, pr: S.compute_z_pres_kl_yolo_air(zp, lg, pr, 0.3, 1.5), r)
+    ref.backward()
+    d = [t.cuda().requires_grad_(True) for t in (x, z_where, z_depth, pre, logits, bg)]
+    got = graph(lambda a, b, h, w, inv: T.stn_sample(a, b, h, w, inv),
+                lambda o, b_, zd, zp: T.spair_render(o, b_, zd, zp),
+                lambda zp, lg, pr: T.spair_zpres_kl(zp, lg, pr, 0.3, 1.5).mean(), d)
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref))
+    for name, a, b in zip(("x", "z_where", "z_depth", "pre_sigmoid", "logits", "bg"), d, r):
+        err = float((a.grad.double().cpu() - b.grad).norm() / b.grad.norm())
+        assert err < 5e-3, (name, err)
