@@ -190,7 +190,9 @@ int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, 
 
 int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st);
 int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,
-                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st);
+                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st,
+                        const float* part_x = nullptr, const float* part_xh = nullptr, int P = 0);   // part_*: per-tile NLL partials (fused loss)
+
 // Step-varying scalars of a captured step (hipGraph replay, lgvae_plan.hip): the kernels that consume them read this
 // device record instead of their launch arguments when `dyn` is non-null; svk_set_dyn writes it before each replay.
 struct SvDynArgs {
@@ -199,6 +201,15 @@ struct SvDynArgs {
   float adam_alpha;       // lr * sqrt(1 - beta2^t) / (1 - beta1^t)
   float pad;
 };
+// both networks' heads in one launch (index 0 = x, 1 = x-hat; Philox stream id = the index)
+int svk_reparam_kl_fwd_twin(const float* const* pre, const float* const* bias_mean, const float* const* bias_sd,
+                            const float* const* eps, float* const* eps_out, float* const* z_mean, float* const* z_sig,
+                            float* const* z, void* z_lp, int z_dtype, int ldz, const int* z_col, float* const* kl, int B,
+                            const int* L, uint64_t seed, uint64_t step, int64_t sample_offset, hipStream_t st,
+                            const SvDynArgs* dyn = nullptr);
+int svk_reparam_kl_bwd_twin(const float* const* dz, const int* ld_dz, const float* const* dz2, const int* ld_dz2,
+                            const float* const* z_mean, const float* const* z_sig, const float* const* eps, float kl_scale,
+                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st);
 int svk_set_dyn(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha, hipStream_t st);
 double svk_adam_alpha(float lr, float beta1, float beta2, int64_t t);
 int svk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -597,6 +597,25 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     else
       for (int e = 0; e < 2; ++e) SV_TRY(svk_tap_gemm(a[e], dt, cfgs[e], st));   // latent sizes with different tiles
   }
+  static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;   // A/B: one launch per network for the small pointwise kernels
+  if (do_enc && !d.external_global_encoder && !no_twin) {
+    // both networks' Sampling + KL in one launch
+    Scope sc(p, st, "reparam_kl_fwd", 0, (double)B * (Lg + Ll) * 16);
+    const float *pre[2], *bm[2], *bs[2], *eps[2];
+    float *eo[2], *zm[2], *zs[2], *zz[2], *kl[2];
+    const int zc[2] = {0, Lg}, LL[2] = {Lg, Ll};
+    for (int e = 0; e < 2; ++e) {
+      const std::string sfx = en[e];
+      const Layer& Lh = p->enc[e][3];
+      pre[e] = (const float*)p->bp("pre_" + sfx);
+      bm[e] = s->params + p->params[Lh.kparam + 1].off; bs[e] = s->params + p->params[Lh.kparam + 3].off;
+      eps[e] = e == 0 ? s->eps_x : s->eps_x_hat;
+      eo[e] = (float*)p->bp("eps_" + sfx); zm[e] = (float*)p->bp("z_mean_" + sfx); zs[e] = (float*)p->bp("z_sig_" + sfx);
+      zz[e] = (float*)p->bp("z_" + sfx); kl[e] = (float*)p->bp("kl_" + sfx);
+    }
+    SV_TRY(svk_reparam_kl_fwd_twin(pre, bm, bs, eps, eo, zm, zs, zz, p->bp("zcat"), dt, Lc, zc, kl, B, LL, s->seed, s->step,
+                                   s->sample_offset, st, p->dyn));
+  } else
   for (int e = d.external_global_encoder ? 1 : 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
     const int L = e == 0 ? Lg : Ll;
@@ -668,10 +687,9 @@ static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_g
   auto zs0 = [&](const char* kind, int64_t esz) {
     return (int64_t)((char*)p->bp(std::string(kind) + "xh") - (char*)p->bp(std::string(kind) + "x")) / esz;
   };
-  if (p->nll_fused && with_grad) {   // the head's epilogue left per-tile NLL sums and g5 (phase_forward): per-image sums only
-    const int HW = d.H * d.W;
-    SV_TRY(svk_nll_rowsum((const float*)p->bp("nllpart_x"), (float*)p->bp("nll_x"), d.B, HW > 1024 ? HW / 1024 : 1,
-                          zs0("nllpart_", 4), zs0("nll_", 4), 2, st));
+  const bool from_parts = p->nll_fused && with_grad;   // the head's epilogue left per-tile NLL sums and g5 (phase_forward): finalize_losses
+                                                       // forms the per-image sums itself (fixed order), no separate kernel
+  if (from_parts) {
   } else {
     // algorithmic bytes: read x, m, log_scale (12 B/element) + write dm, dls (2 * esz B/element); both networks
     Scope sc(p, st, "dlogistic_nll", 0, 2.0 * d.B * d.H * d.W * 3 * (12.0 + (with_grad ? 2.0 * p->esz() : 0.0)));
@@ -682,9 +700,12 @@ static int phase_loss(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool with_g
                                    zs("nll_", 4), with_grad ? p->bp("g5_x") : nullptr, zs("g5_", (int64_t)p->esz()), d.dtype,
                                    1.0f / (float)d.B, d.B, d.H, d.W, (float*)p->bp("nllpart_x"), zs("nllpart_", 4), 2, st));
   }
+  const int HWp = d.H * d.W;
   SV_TRY(svk_finalize_losses((const float*)p->bp("nll_x"), (const float*)p->bp("nll_xh"), (const float*)p->bp("kl_x"),
                              (const float*)p->bp("kl_xh"), d.B, d.beta, (float*)p->bp("losses"),
-                             (float*)p->bp("metric_acc"), s->accumulate_metrics, st));
+                             (float*)p->bp("metric_acc"), s->accumulate_metrics, st,
+                             from_parts ? (const float*)p->bp("nllpart_x") : nullptr,
+                             from_parts ? (const float*)p->bp("nllpart_xh") : nullptr, HWp > 1024 ? HWp / 1024 : 1));
   return SV_OK;
 }
 
@@ -771,6 +792,17 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
   const int e0 = d.external_global_encoder ? 1 : 0;
   if (do_heads) {
     Scope sc(p, st, "reparam_kl_bwd", 0, 0);
+    static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;
+    if (!e0 && !no_twin) {
+      const float* dz[2] = {(const float*)p->bp("gz_x"), (const float*)p->bp("gz_x") + Lg};
+      const float* dz2[2] = {nullptr, (const float*)p->bp("gz_xh")};
+      const int ld[2] = {Lc, Lc}, ld2[2] = {0, Ll}, LL[2] = {Lg, Ll};
+      const float* zm[2] = {(const float*)p->bp("z_mean_x"), (const float*)p->bp("z_mean_xh")};
+      const float* zs[2] = {(const float*)p->bp("z_sig_x"), (const float*)p->bp("z_sig_xh")};
+      const float* ep[2] = {(const float*)p->bp("eps_x"), (const float*)p->bp("eps_xh")};
+      void* gp[2] = {p->bp("ghead_x"), p->bp("ghead_xh")};
+      SV_TRY(svk_reparam_kl_bwd_twin(dz, ld, dz2, ld2, zm, zs, ep, kl_scale, gp, dt, B, LL, st));
+    } else {
     if (!e0)
       SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x"), Lc, nullptr, 0, (const float*)p->bp("z_mean_x"),
                                (const float*)p->bp("z_sig_x"), (const float*)p->bp("eps_x"), kl_scale, p->bp("ghead_x"),
@@ -778,6 +810,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
     SV_TRY(sv_reparam_kl_bwd((const float*)p->bp("gz_x") + Lg, Lc, (const float*)p->bp("gz_xh"), Ll,
                              (const float*)p->bp("z_mean_xh"), (const float*)p->bp("z_sig_xh"),
                              (const float*)p->bp("eps_xh"), kl_scale, p->bp("ghead_xh"), dt, B, Ll, st));
+    }
   }
   if (do_heads) {
     // heads: two Keras kernels/biases per network -> wgrad problems on the column halves of ghead, all in one launch

@@ -230,16 +230,23 @@ extern "C" int sv_dlogistic_nll(const float* images6, int32_t ch_off, const floa
 }
 
 // ============================================================================ A4 + A7 reparam / KL
+struct ReparamFwdArgs {
+  const float *pre, *bias_mean, *bias_sd, *eps;
+  float *eps_out, *z_mean, *z_sig, *z;
+  void* z_lp;
+  float* kl;
+  int ldz, z_col, L, stream_id;
+};
 template <typename TZ>
-__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
-    const float* __restrict__ pre, const float* __restrict__ bias_mean, const float* __restrict__ bias_sd,
-    const float* __restrict__ eps, float* __restrict__ eps_out, float* __restrict__ z_mean, float* __restrict__ z_sig,
-    float* __restrict__ z, TZ* __restrict__ z_lp, int ldz, int z_col, float* __restrict__ kl, int B,
-    int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset, const SvDynArgs* __restrict__ dyn) {
+__device__ __forceinline__ void reparam_kl_fwd_body(const ReparamFwdArgs& g, int B, uint64_t seed, uint64_t step, int64_t sample_offset) {
+  const float* __restrict__ pre = g.pre; const float* __restrict__ bias_mean = g.bias_mean; const float* __restrict__ bias_sd = g.bias_sd;
+  const float* __restrict__ eps = g.eps;
+  float* __restrict__ eps_out = g.eps_out; float* __restrict__ z_mean = g.z_mean; float* __restrict__ z_sig = g.z_sig;
+  float* __restrict__ z = g.z; TZ* __restrict__ z_lp = (TZ*)g.z_lp; float* __restrict__ kl = g.kl;
+  const int ldz = g.ldz, z_col = g.z_col, L = g.L, stream_id = g.stream_id;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (b >= B) return;
-  if (dyn) { seed = dyn->seed; step = dyn->step; sample_offset = dyn->sample_offset; }   // captured step (graph replay)
   Philox ph(seed ^ 0xe9515eedULL);
   const uint64_t gs = (uint64_t)(sample_offset + b);
   float acc = 0.f;
@@ -267,6 +274,41 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
   }
   acc = wave_sum(acc);
   if (lane == 0) kl[b] = -0.5f * acc;
+}
+
+template <typename TZ>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
+    const float* __restrict__ pre, const float* __restrict__ bias_mean, const float* __restrict__ bias_sd,
+    const float* __restrict__ eps, float* __restrict__ eps_out, float* __restrict__ z_mean, float* __restrict__ z_sig,
+    float* __restrict__ z, TZ* __restrict__ z_lp, int ldz, int z_col, float* __restrict__ kl, int B,
+    int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset, const SvDynArgs* __restrict__ dyn) {
+  if (dyn) { seed = dyn->seed; step = dyn->step; sample_offset = dyn->sample_offset; }   // captured step (graph replay)
+  const ReparamFwdArgs g = {pre, bias_mean, bias_sd, eps, eps_out, z_mean, z_sig, z, (void*)z_lp, kl, ldz, z_col, L, stream_id};
+  reparam_kl_fwd_body<TZ>(g, B, seed, step, sample_offset);
+}
+
+// the x and x-hat heads in one launch (blockIdx.y picks the network): one dependent launch less on the critical path
+struct ReparamFwdTwin { ReparamFwdArgs a[2]; };
+template <typename TZ>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_twin_kernel(const ReparamFwdTwin t, int B, uint64_t seed, uint64_t step,
+                                                                  int64_t sample_offset, const SvDynArgs* __restrict__ dyn) {
+  if (dyn) { seed = dyn->seed; step = dyn->step; sample_offset = dyn->sample_offset; }
+  reparam_kl_fwd_body<TZ>(t.a[blockIdx.y], B, seed, step, sample_offset);
+}
+
+int svk_reparam_kl_fwd_twin(const float* const* pre, const float* const* bias_mean, const float* const* bias_sd,
+                            const float* const* eps, float* const* eps_out, float* const* z_mean, float* const* z_sig,
+                            float* const* z, void* z_lp, int z_dtype, int ldz, const int* z_col, float* const* kl, int B,
+                            const int* L, uint64_t seed, uint64_t step, int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn) {
+  ReparamFwdTwin t;
+  for (int e = 0; e < 2; ++e)
+    t.a[e] = {pre[e], bias_mean[e], bias_sd[e], eps[e], eps_out[e], z_mean[e], z_sig[e], z[e], z_lp, kl[e], ldz, z_col[e], L[e], e};
+  dim3 grid((B + 3) / 4, 2), block(256);
+  if (z_dtype == SV_BF16) hipLaunchKernelGGL((reparam_kl_fwd_twin_kernel<bf16_t>), grid, block, 0, st, t, B, seed, step, sample_offset, dyn);
+  else if (z_dtype == SV_F32) hipLaunchKernelGGL((reparam_kl_fwd_twin_kernel<float>), grid, block, 0, st, t, B, seed, step, sample_offset, dyn);
+  else return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 int svk_reparam_kl_fwd2(const float* pre, const float* bias_mean, const float* bias_sd, const float* eps,
@@ -315,6 +357,43 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
     g_pre[(int64_t)b * 2 * L + j] = from_f32<TG>(dmu);
     g_pre[(int64_t)b * 2 * L + L + j] = from_f32<TG>(dpre);
   }
+}
+
+struct ReparamBwdArgs { const float *dz, *dz2, *z_mean, *z_sig, *eps; void* g_pre; int ld_dz, ld_dz2, L; };
+struct ReparamBwdTwin { ReparamBwdArgs a[2]; };
+template <typename TG>
+__global__ __launch_bounds__(256) void reparam_kl_bwd_twin_kernel(const ReparamBwdTwin t, float kl_scale, int B) {
+  const ReparamBwdArgs& g = t.a[blockIdx.y];
+  const int L = g.L;
+  const int64_t total = (int64_t)B * L;
+  TG* __restrict__ g_pre = (TG*)g.g_pre;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), j = (int)(i - (int64_t)b * L);
+    float gg = g.dz[(int64_t)b * g.ld_dz + j];
+    if (g.dz2) gg += g.dz2[(int64_t)b * g.ld_dz2 + j];
+    const float mu = g.z_mean[i], sg = g.z_sig[i], e = g.eps[i];
+    const float dmu = gg + kl_scale * mu;
+    const float dsg = gg * e + kl_scale * (sg - 1.f / sg);
+    const float dpre = dsg * (1.f - expf(-sg));          // as reparam_kl_bwd_kernel
+    g_pre[(int64_t)b * 2 * L + j] = from_f32<TG>(dmu);
+    g_pre[(int64_t)b * 2 * L + L + j] = from_f32<TG>(dpre);
+  }
+}
+int svk_reparam_kl_bwd_twin(const float* const* dz, const int* ld_dz, const float* const* dz2, const int* ld_dz2,
+                            const float* const* z_mean, const float* const* z_sig, const float* const* eps, float kl_scale,
+                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st) {
+  ReparamBwdTwin t;
+  int Lmax = 0;
+  for (int e = 0; e < 2; ++e) {
+    t.a[e] = {dz[e], dz2[e], z_mean[e], z_sig[e], eps[e], g_pre[e], ld_dz[e], ld_dz2[e], L[e]};
+    Lmax = L[e] > Lmax ? L[e] : Lmax;
+  }
+  dim3 grid((unsigned)(((int64_t)B * Lmax + 255) / 256), 2), block(256);
+  if (g_dtype == SV_BF16) hipLaunchKernelGGL((reparam_kl_bwd_twin_kernel<bf16_t>), grid, block, 0, st, t, kl_scale, B);
+  else if (g_dtype == SV_F32) hipLaunchKernelGGL((reparam_kl_bwd_twin_kernel<float>), grid, block, 0, st, t, kl_scale, B);
+  else return SV_E_BADARG;
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 extern "C" int sv_reparam_kl_bwd(const float* dz, int32_t ld_dz, const float* dz2, int32_t ld_dz2,
@@ -617,15 +696,24 @@ int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t 
 }
 
 // the five scalars of vae/trainer.py:127-135 (+ total) and the running means of :140-144
-__global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __restrict__ nll_x,
-                                                              const float* __restrict__ nll_xh,
+// part_x / part_xh != null (the loss was evaluated in the decoder head's epilogue): the per-image NLL sums are formed here from
+// the P per-tile partials of each image, in index order (what rowsum_partials_kernel does), and written to nll_x / nll_xh
+__global__ __launch_bounds__(256) void finalize_losses_kernel(float* __restrict__ nll_x,
+                                                              float* __restrict__ nll_xh,
                                                               const float* __restrict__ kl_x,
                                                               const float* __restrict__ kl_xh, int B,
                                                               float beta, float* __restrict__ losses,
-                                                              float* __restrict__ metric_acc, int accumulate) {
+                                                              float* __restrict__ metric_acc, int accumulate,
+                                                              const float* __restrict__ part_x,
+                                                              const float* __restrict__ part_xh, int P) {
   __shared__ float red[4][4];
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (part_x) {
+      float sx = 0.f, sh = 0.f;
+      for (int i = 0; i < P; ++i) { sx += part_x[(int64_t)b * P + i]; sh += part_xh[(int64_t)b * P + i]; }
+      nll_x[b] = sx; nll_xh[b] = sh;
+    }
     a[0] += nll_x[b]; a[1] += nll_xh[b]; a[2] += kl_x[b]; a[3] += kl_xh[b];
   }
 #pragma unroll
@@ -651,9 +739,10 @@ __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __res
 }
 
 int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,
-                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, st, nll_x, nll_xh, kl_x, kl_xh, B,
-                     beta, losses, metric_acc, accumulate);
+                        int B, float beta, float* losses, float* metric_acc, int accumulate, hipStream_t st,
+                        const float* part_x, const float* part_xh, int P) {
+  hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, st, (float*)nll_x, (float*)nll_xh, kl_x, kl_xh, B,
+                     beta, losses, metric_acc, accumulate, part_x, part_xh, P);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
