@@ -1,0 +1,87 @@
+"""CPU check of the algebra behind the polyphase decoder head (csrc/conv_api.hip prep_poly, csrc/poly_fix.hip):
+
+    Conv2D(6x6, 'same')(UpSampling2D(bilinear)(x))  ==  polyphase 5x5 conv over the edge-clamped low-res x  -  border terms
+
+in float64 numpy, with the resize and the conv taken from the oracle restatement of the reference (vae/model.py:163-169).  The
+composite weights, the ten border classes and the line construction are written here exactly as the device code builds them, so
+a mistake in the derivation (coefficients, parity / tap order, excluded-tap sets, replicate vs zero line extension) fails on CPU."""
+import numpy as np
+import torch
+
+from oracle import torch_ref
+
+
+def _coef(p, k, t):
+    """blend coefficient of hi-res tap k (0..5) of output parity p on the low-res offset t (-2..2): prep_poly's lambda."""
+    h = p + k - 2
+    m = h >> 1                                   # floor
+    if h & 1:
+        return 0.75 if t == m else 0.25 if t == m + 1 else 0.0
+    return 0.25 if t == m - 1 else 0.75 if t == m else 0.0
+
+
+def _line_up(v):
+    """1-D 2x bilinear upsample with half-pixel centres and edge clamp (the fix kernel's line build): [n, C] -> [2n, C]."""
+    n = v.shape[0]
+    out = np.zeros((2 * n, v.shape[1]))
+    for u in range(2 * n):
+        m = u >> 1
+        if u & 1:
+            i0, i1, f = m, min(m + 1, n - 1), 0.25
+        else:
+            i0, i1, f = max(m - 1, 0), m, 0.75
+        out[u] = v[i0] + (v[i1] - v[i0]) * f
+    return out
+
+
+def test_polyphase_identity_with_border_terms():
+    rng = np.random.default_rng(0)
+    B, h, C, Co = 2, 8, 5, 6
+    x = rng.standard_normal((B, h, h, C))
+    w = rng.standard_normal((6, 6, C, Co)) * 0.2
+    bias = rng.standard_normal(Co)
+    ref = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.from_numpy(x)), torch.from_numpy(w), torch.from_numpy(bias), 1, None).numpy()
+    H = 2 * h
+    # ---- composite weights W'[py,px][ty,tx] and the polyphase conv over the edge-clamped input
+    out = np.zeros((B, H, H, Co))
+    xp = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)), mode="edge")
+    for py in range(2):
+        for px in range(2):
+            Wc = np.zeros((5, 5, C, Co))
+            for ty in range(-2, 3):
+                for tx in range(-2, 3):
+                    for ky in range(6):
+                        for kx in range(6):
+                            c = _coef(py, ky, ty) * _coef(px, kx, tx)
+                            if c:
+                                Wc[ty + 2, tx + 2] += c * w[ky, kx]
+            for i in range(h):
+                for j in range(h):
+                    win = xp[:, i:i + 5, j:j + 5, :]                       # low-res rows i-2..i+2, cols j-2..j+2 (clamped)
+                    out[:, 2 * i + py, 2 * j + px] = np.einsum("byxc,yxco->bo", win, Wc) + bias
+    # ---- border terms: classes (edge coordinate, excluded taps); rows use the replicate-extended first / last upsampled row,
+    # columns the zero-extended first / last upsampled column (poly_fix.hip)
+    classes = [(0, (0, 1)), (1, (0,)), (H - 3, (5,)), (H - 2, (4, 5)), (H - 1, (3, 4, 5))]
+    for b in range(B):
+        top, bot = _line_up(x[b, 0]), _line_up(x[b, h - 1])                 # [H, C]
+        left, right = _line_up(x[b, :, 0]), _line_up(x[b, :, h - 1])
+        for edge, excl in classes:
+            rline = top if edge < 2 else bot
+            cline = left if edge < 2 else right
+            for pos in range(H):
+                for tap in range(6):
+                    q = pos + tap - 2
+                    rv = rline[min(max(q, 0), H - 1)]                       # replicate beyond the ends
+                    cv = cline[q] if 0 <= q < H else np.zeros(C)            # zero beyond the ends
+                    for k in excl:
+                        out[b, edge, pos] -= rv @ w[k, tap]                 # row class: excluded ky = k, tap = kx
+                        out[b, pos, edge] -= cv @ w[tap, k]                 # column class: excluded kx = k, tap = ky
+    np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_composite_coefficients_are_a_partition_of_unity():
+    """each hi-res tap draws weight 1 from its two low-res neighbours, and only offsets -2..2 are touched"""
+    for p in range(2):
+        for k in range(6):
+            assert abs(sum(_coef(p, k, t) for t in range(-2, 3)) - 1.0) < 1e-15
+            assert all(_coef(p, k, t) == 0.0 for t in (-4, -3, 3, 4))
