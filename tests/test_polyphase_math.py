@@ -85,3 +85,57 @@ def test_composite_coefficients_are_a_partition_of_unity():
         for k in range(6):
             assert abs(sum(_coef(p, k, t) for t in range(-2, 3)) - 1.0) < 1e-15
             assert all(_coef(p, k, t) == 0.0 for t in (-4, -3, 3, 4))
+
+
+def test_polyphase_weight_gradient_identity():
+    """The same algebra for Conv2DBackpropFilter (DESIGN.md "Next kernel lever"): dW = P(dW') - dW_frame with dW' the weight
+    gradient of the polyphase conv on the LOW-RES grid (edge-clamped input, dY read as its space-to-depth view), P the
+    transpose of the composite-weight map, dW_frame the out-of-image taps of the five border rows / columns (1-D weight
+    gradients along the fix lines).  Checked against autograd of the oracle's resize + conv."""
+    rng = np.random.default_rng(1)
+    B, h, C, Co = 2, 8, 4, 3
+    H = 2 * h
+    x = rng.standard_normal((B, h, h, C))
+    w = rng.standard_normal((6, 6, C, Co)) * 0.2
+    dy = rng.standard_normal((B, H, H, Co))
+    wt = torch.from_numpy(w).requires_grad_(True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.from_numpy(x)), wt, torch.zeros(Co, dtype=torch.float64), 1, None)
+    (y * torch.from_numpy(dy)).sum().backward()
+    want = wt.grad.numpy()
+    # dW'[py,px][ty,tx][ci,co] = sum_{b,i,j} x~[b, i+ty, j+tx, ci] * dy[b, 2i+py, 2j+px, co]
+    xp = np.pad(x, ((0, 0), (2, 2), (2, 2), (0, 0)), mode="edge")
+    dWp = np.zeros((2, 2, 5, 5, C, Co))
+    for py in range(2):
+        for px in range(2):
+            dys = dy[:, py::2, px::2, :]                                     # [B, h, h, Co]
+            for ty in range(5):
+                for tx in range(5):
+                    dWp[py, px, ty, tx] = np.einsum("bijc,bijo->co", xp[:, ty:ty + h, tx:tx + h, :], dys)
+    # projection P: dW[ky,kx] = sum Cy[py][ky][ty] Cx[px][kx][tx] dW'[py,px][ty,tx]
+    dW = np.zeros_like(w)
+    for ky in range(6):
+        for kx in range(6):
+            for py in range(2):
+                for px in range(2):
+                    for ty in range(-2, 3):
+                        for tx in range(-2, 3):
+                            c = _coef(py, ky, ty) * _coef(px, kx, tx)
+                            if c:
+                                dW[ky, kx] += c * dWp[py, px, ty + 2, tx + 2]
+    # frame: the taps of the border rows / columns that leave the image
+    classes = [(0, (0, 1)), (1, (0,)), (H - 3, (5,)), (H - 2, (4, 5)), (H - 1, (3, 4, 5))]
+    for b in range(B):
+        top, bot = _line_up(x[b, 0]), _line_up(x[b, h - 1])
+        left, right = _line_up(x[b, :, 0]), _line_up(x[b, :, h - 1])
+        for edge, excl in classes:
+            rline = top if edge < 2 else bot
+            cline = left if edge < 2 else right
+            for pos in range(H):
+                for tap in range(6):
+                    q = pos + tap - 2
+                    rv = rline[min(max(q, 0), H - 1)]
+                    cv = cline[q] if 0 <= q < H else np.zeros(C)
+                    for k in excl:
+                        dW[k, tap] -= np.outer(rv, dy[b, edge, pos])         # row class: ky = k, kx = tap
+                        dW[tap, k] -= np.outer(cv, dy[b, pos, edge])         # column class: ky = tap, kx = k
+    np.testing.assert_allclose(dW, want, rtol=1e-9, atol=1e-9)
