@@ -475,7 +475,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   int BN, cfgN;
   // small launches (up to 256-image shards): a 128-column layer whose 128-row tiles give at most about one workgroup per CU
   // runs on 64-column tiles instead -- twice the workgroups, half the weight streaming each (SV_TC_SMALL_WGS: the threshold)
-  static const int small_wgs = getenv("SV_TC_SMALL_WGS") ? atoi(getenv("SV_TC_SMALL_WGS")) : 300;   // measured: helps up to 256 such workgroups (B = 256: -1.6 %, 128: -3.6 %, 64: -3.4 %), hurts at 512 (+1.8 %)
+  static const int small_wgs = getenv("SV_TC_SMALL_WGS") ? atoi(getenv("SV_TC_SMALL_WGS")) : 200;   // (per problem) measured: helps at 128 such workgroups per network (B = 256: -1.6 %; 128: -3.6 %, 64: -3.4 %), hurts at 256 (B = 512: +1.8 %)
   const int64_t wgs128 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 128);
   const bool small = t.N % 128 == 0 && wgs128 < small_wgs && dtype == SV_BF16 && !t.cls_n;
   static const int tiny_wgs = getenv("SV_TC_TINY_WGS") ? atoi(getenv("SV_TC_TINY_WGS")) : 100;   // ... and on 32-column tiles below this (64-image shards: -1.3 .. -1.9 %)
