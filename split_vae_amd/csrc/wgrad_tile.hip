@@ -425,8 +425,11 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c; a.layer_id = id;
-  static const bool contig = getenv("SV_WT_STRIDED") == nullptr;
-  a.contig = contig ? 1 : 0;
+  // tile walk of a workgroup: a contiguous run (neighbours share halos in one XCD's L2) or strided by the grid.  Re-measured per
+  // layer (round 2): strided wins for the layers listed in SV_WT_STRIDED_IDS (SV_WT_STRIDED=1: every layer)
+  static const bool all_strided = getenv("SV_WT_STRIDED") != nullptr;
+  static const char* strided_ids = getenv("SV_WT_STRIDED_IDS") ? getenv("SV_WT_STRIDED_IDS") : "567";   // d5 (x-packed), e2, e1: -0.6 % of the step (almost all of it d5)
+  a.contig = (all_strided || strchr(strided_ids, '0' + id)) ? 0 : 1;
   a.CW = CW; a.ncg = cin / CW;
   a.cl2 = ilog2_exact(CW / 8);
   a.lTW = lTW; a.lTH = lTH; a.lNB = lNB; a.OY = OY; a.OX = OX;
