@@ -181,6 +181,15 @@ int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d);
 int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw,
                             float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight gradient of the bf16 decoder head (UpSampling2D(bilinear) -> Conv2D(6x6), vae/model.py:163-169) in POLYPHASE form: the
+ * weight gradient of the 5x5 low-res conv (no blend arithmetic, a quarter of the pixels staged), projected back onto the 6x6
+ * kernel, minus the out-of-image taps of the five border rows / columns (tests/test_polyphase_math.py).  Same result
+ * as sv_conv2d_nhwc_wgrad on the same layer to bf16 accuracy (closer to the fp64 gradient: the upsampled activations are never
+ * rounded).  Workspace: sv_conv2d_wgrad_poly_workspace_bytes (0 = the layer has no polyphase form), ZEROED before its first use. */
+int64_t sv_conv2d_wgrad_poly_workspace_bytes(const sv_conv_desc* d);
+int sv_conv2d_nhwc_wgrad_poly(const sv_conv_desc* d, const void* x_lo, const void* dy, float* dw, float* dbias, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- F3: input files (host side, no device work)
  * CRC-32C of the TFRecord framing the reference's CelebA files use (tf.io.TFRecordWriter at vae/data.py:93-100,
  * TFRecordDataset at :123-131): record = uint64 length | masked_crc32c(length) | data | masked_crc32c(data),

@@ -96,6 +96,8 @@ SYMBOLS = {
     "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sv_conv2d_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sv_conv2d_nhwc_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "sv_conv2d_wgrad_poly_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
+    "sv_conv2d_nhwc_wgrad_poly": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sv_crc32c": (C.c_uint32, [_vp, _i64]),
     "sv_masked_crc32c": (C.c_uint32, [_vp, _i64]),
     "sv_gm_param_count": (_i64, [C.POINTER(GmDesc)]),

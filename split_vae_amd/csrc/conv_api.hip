@@ -586,6 +586,45 @@ extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const 
   return svk_wgrad_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
 }
 
+// Main term of the polyphase weight gradient of a svg_poly layer (poly_wgrad.hip, tests/test_polyphase_math.py):
+// dWp[t = (tx+2)*5 + (ty+2)][ci][(py*2+px)*8 + co] = sum x~[i+ty, j+tx, ci] dy[2i+py, 2j+px, co] on the LOW-RES grid (tile kernel id 8)
+void svg_poly_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int h = d->H / 2, w = d->W / 2, cpad = svg_cin_pad(d);
+  a->M = d->B * h * w; a->lOY = ilog2_exact(h); a->lOX = ilog2_exact(w); a->OY = h; a->OX = w;
+  a->IH = h; a->IW = w; a->lda = d->ldx; a->S = 1; a->SX = 1;
+  a->ldy = 32; a->ycols = 32; a->cl2 = ilog2_exact(cpad / 8);
+  a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = 32; a->ntaps = 25; a->Nrows = 25 * cpad;
+  a->clampin = 1; a->dy_s2d = 1; a->assign = 1; a->msplit = a->M;
+  for (int tx = 0; tx < 5; ++tx)
+    for (int ty = 0; ty < 5; ++ty) { a->dy[tx * 5 + ty] = (int8_t)(ty - 2); a->dx[tx * 5 + ty] = (int8_t)(tx - 2); }
+}
+
+
+// The polyphase weight gradient as one call (tests, micro-benchmarks; the training plan sequences the same kernels): dw / dbias
+// accumulated like sv_conv2d_nhwc_wgrad; workspace of sv_conv2d_wgrad_poly_workspace_bytes, whose first use must find it zeroed.
+extern "C" int64_t sv_conv2d_wgrad_poly_workspace_bytes(const sv_conv_desc* d) {
+  if (svg_check(d) != SV_OK) return -1;
+  if (!svg_poly(d)) return 0;
+  return SV_WGRAD_WS_BYTES + svk_poly_wgrad_ws_floats(svg_cin_pad(d), SV_POLY_WGRAD_NWG) * 4;
+}
+extern "C" int sv_conv2d_nhwc_wgrad_poly(const sv_conv_desc* d, const void* x_lo, const void* dy, float* dw, float* dbias, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!svg_poly(d)) return SV_E_UNSUPPORTED;
+  if (!x_lo || !dy || !dw || !workspace || workspace_bytes < sv_conv2d_wgrad_poly_workspace_bytes(d)) return SV_E_BADARG;
+  float* pw = (float*)((char*)workspace + SV_WGRAD_WS_BYTES);
+  const int Cin = svg_cin_pad(d);
+  WgradArgs a;
+  svg_poly_wgrad_args(d, &a);
+  a.A = x_lo; a.dY = dy; a.dW = pw; a.dbias = pw + 25 * Cin * 32; a.ws = (float*)workspace; a.ws_bytes = SV_WGRAD_WS_BYTES;
+  rc = svk_wgrad_tile(a, (hipStream_t)stream);
+  if (rc) return rc;
+  return svk_poly_wgrad_finish(1, &x_lo, &dy, &pw, &dw, &dbias, d->B, d->H / 2, d->W / 2, d->ldx, Cin, d->Cout, SV_POLY_WGRAD_NWG,
+                               (hipStream_t)stream);
+}
+
 extern "C" int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d) {
   if (svg_check(d) != SV_OK) return -1;
   return SV_WGRAD_WS_BYTES;

@@ -109,6 +109,8 @@ int svg_dgrad_classes(const sv_conv_desc* d);
 void svg_dgrad_args(const sv_conv_desc* d, int cls, TapGemmArgs* a, uint8_t srctap[SV_MAX_TAPS]);
 bool svg_dgrad_merged_args(const sv_conv_desc* d, const int64_t* class_off, TapGemmArgs* a);   // all 4 classes as one problem
 void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a);
+void svg_poly_wgrad_args(const sv_conv_desc* d, WgradArgs* a);      // main term of the polyphase weight gradient (svg_poly layers)
+#define SV_POLY_WGRAD_NWG 256
 void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs);
 void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j);

@@ -113,6 +113,9 @@ struct WgradArgs {
   int Cin_pad, Cin_real, N, Nrows;   // Nrows = ntaps*Cin_pad (padded wrow count)
   int ntaps, msplit;  // msplit = rows of m per blockIdx.z slice (multiple of the m-step)
   int ups;            // A is the low-res tensor, the layer input is its 2x bilinear upsample (tile kernel only)
+  int clampin;        // input coordinates outside the image clamp to the edge (polyphase weight gradient; tile kernel only)
+  int dy_s2d;         // dY is the hi-res gradient [B, 2*OY, 2*OX, 8] read as its space-to-depth view [B, OY, OX, 32]
+  int assign;         // slab path: the reduce WRITES dW (every element has one owner) instead of adding to it
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
   hipEvent_t ev_mid[2];   // profiling: when set, both are recorded after the main kernel, before the slab reduce
@@ -146,6 +149,7 @@ struct WgradTileArgs {
   int in_bytes, dy_bytes;
   int dbg;                  // ablation: 1 = skip the atomic flush
   int ups;                  // fused 2x bilinear upsample of the input
+  int clampin, dy_s2d, assign;   // WgradArgs::clampin / dy_s2d / assign
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];
@@ -187,6 +191,11 @@ int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob*
 int64_t svk_poly_fix_ws_bytes(int B, int h, int w);
 int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* out6, float* const* fixbuf, int B,
                        int h, int w, int lda, int Cout, hipStream_t st);
+
+// polyphase weight gradient of the decoder head, the small terms (poly_wgrad.hip)
+int64_t svk_poly_wgrad_ws_floats(int Cin, int nwg);
+int svk_poly_wgrad_finish(int n, const void* const* x_lo, const void* const* dy, float* const* ws, float* const* dW, float* const* dbias,
+                          int B, int h, int w, int lda, int Cin, int Cout, int nwg, hipStream_t st);
 
 int svk_split_pad(const float* images6, void* x8, void* xh8, int dtype, int64_t npix, hipStream_t st);
 int svk_finalize_losses(const float* nll_x, const float* nll_xh, const float* kl_x, const float* kl_xh,

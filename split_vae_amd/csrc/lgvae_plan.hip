@@ -345,6 +345,8 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI * sv_lgvae_plan::SIDE_MAX);   // per side stream, per problem
   p->add_buf("polyfix_x", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));   // border terms of the polyphase head (poly_fix.hip)
   p->add_buf("polyfix_xh", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));
+  p->add_buf("polyw_x", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);        // polyphase weight gradient of the head: dW', dbias', frame slabs
+  p->add_buf("polyw_xh", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);
   p->add_buf("dyn", sizeof(SvDynArgs));
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
@@ -521,6 +523,28 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   const char* on_main = on_main_env ? on_main_env : (n * L[0]->d.B >= 768 ? "e1,e2,d5" : "e1,e2");
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
+  // the decoder head's weight gradient in polyphase form (poly_wgrad.hip) from ~512 images per launch (its three small
+  // kernels cost more than they save below that: 16 images 42 vs 20 us; 1024 images 132 vs 184 us)
+  static const bool no_pw = getenv("SV_NO_POLY_WGRAD") != nullptr;
+  static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 512;
+  if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2) {
+    static const char* pw_name[2] = {"polyw_x", "polyw_xh"};
+    float* pw[2];
+    float *dwv[2], *dbv[2];
+    const int Cin = svg_cin_pad(&L[0]->d);
+    for (int i = 0; i < n; ++i) {
+      svg_poly_wgrad_args(&L[i]->d, &a[i]);
+      pw[i] = (float*)p->bp(pw_name[i]);
+      a[i].A = x[i]; a[i].dY = dy[i]; a[i].dW = pw[i]; a[i].dbias = pw[i] + 25 * Cin * 32;
+      a[i].ws = (float*)((char*)p->bp("wgrad_ws") + (p->side_slot * SV_WGRAD_MAX_MULTI + i) * wsb); a[i].ws_bytes = wsb;
+      dwv[i] = grads + p->params[L[i]->kparam].off; dbv[i] = grads + p->params[L[i]->bparam].off;
+      fl += conv_flops(L[i]->d);
+    }
+    Scope sc(p, st, nm, fl, 0);
+    SV_TRY(svk_wgrad_tile_multi(a, n, st));
+    const sv_conv_desc& d = L[0]->d;
+    return svk_poly_wgrad_finish(n, x, dy, pw, dwv, dbv, d.B, d.H / 2, d.W / 2, d.ldx, Cin, d.Cout, SV_POLY_WGRAD_NWG, st);
+  }
   for (int i = 0; i < n; ++i) {
     svg_wgrad_args(&L[i]->d, &a[i]);
     a[i].A = x[i]; a[i].dY = dy[i];
@@ -929,6 +953,10 @@ extern "C" int sv_lgvae_plan_bind(sv_lgvae_plan* p, void* workspace, int64_t byt
   hipError_t e = hipMemcpyAsync(p->bp("jobs"), p->jobs.data(), p->jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(p->bp("metric_acc"), 0, 32, st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(p->bp("polyw_x"), 0, (size_t)p->bbytes("polyw_x"), st);   // dbias' accumulates from zero
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(p->bp("polyw_xh"), 0, (size_t)p->bbytes("polyw_xh"), st);
   if (e != hipSuccess) return (int)e;
   e = hipStreamSynchronize(st);   // the job table lives in plan-owned host memory: finish the copy now
   if (e != hipSuccess) return (int)e;

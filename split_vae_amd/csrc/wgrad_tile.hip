@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
       const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
       if ((SV_DBG(g.dbg) & 2) || !has) {}
       else if (g.ups) stage_tile_upsampled<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
+      else if (g.clampin) stage_tile_plain<bf16_t, 256, true>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
       else stage_tile_plain<bf16_t>(Ab, sg, b0, iy_base, ix_base, sIn, tid);
     }
     // ---- stage dY patch
@@ -127,7 +128,11 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (b < g.B) v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 8);
+      if (b < g.B) {
+        if (g.dy_s2d)   // piece c = parity (py, px) of the hi-res [B, 2*OY, 2*OX, 8] gradient
+          v = *(const uint4*)(Yb + (((int64_t)b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 1)) * (2 * g.OX) + 2 * (tx0 + tx) + (c & 1)) * 8);
+        else v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 8);
+      }
       *(uint4*)(sDy + r * g.YS + c * 16) = v;
     }
     __syncthreads();
@@ -256,7 +261,7 @@ bias_part:
 template <int TPW, int CIF, int COF>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMulti m, int msplit, int groups, int ncg,
                                                            int CW, int Cin_real, int N, int ntaps, int fold_kw,
-                                                           int fold_c, int pairx) {
+                                                           int fold_c, int pairx, int assign) {
   const float* __restrict__ slab = m.slab[blockIdx.z];
   float* __restrict__ dW = m.dW[blockIdx.z];
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
     if (di < 0) continue;
     // folded: the two pixel-parity columns of a tap pair land on one element from two threads; two
     // atomic adds onto the zeroed gradient commute exactly, so the result is still run-to-run identical
-    if (fold_kw) atomicAdd(dW + di, sv[k]); else dW[di] += sv[k];
+    if (fold_kw) atomicAdd(dW + di, sv[k]); else if (assign) dW[di] = sv[k]; else dW[di] += sv[k];
   }
 }
 
@@ -349,7 +354,7 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1)) {
     hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
-                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c, a[0].pairx);
+                       a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c, a[0].pairx, a[0].assign);
     SV_LAUNCH_CHECK();
   }
   return SV_OK;
@@ -391,6 +396,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   else if (nt == 36 && cin == 32 && cout == 64) { id = 5; BM = 128; CW = 16; TT = 36; }    // e2
   else if (nt == 36 && cin == 8 && cout == 32) { id = 6; BM = 256; CW = 8; TT = 36; }      // e1 (taps halved below: pairx)
   else if (nt == 42 && cin == 32 && cout == 16 && w.fold_kw) { id = 7; BM = 256; CW = 32; TT = 42; }   // d5, x-packed
+  else if (nt == 25 && cin == 32 && cout == 32 && w.dy_s2d) { id = 8; BM = 256; CW = 16; TT = 25; }     // d5, polyphase (low-res grid)
   else return SV_E_UNSUPPORTED;
   if (skip && strchr(skip, '0' + id)) return SV_E_UNSUPPORTED;
   // 16-channel slices for d4 / d3 / packed d5: half the accumulators per wave, so three workgroups (3 waves per
@@ -425,6 +431,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   memset(&a, 0, sizeof(a));
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c; a.layer_id = id;
+  a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.assign = w.assign;
   // tile walk of a workgroup: a contiguous run (neighbours share halos in one XCD's L2) or strided by the grid.  Re-measured per
   // layer (round 2): strided wins for the layers listed in SV_WT_STRIDED_IDS (SV_WT_STRIDED=1: every layer)
   static const bool all_strided = getenv("SV_WT_STRIDED") != nullptr;
@@ -485,6 +492,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
     case 6: if (KC == 8 && pairx && hi) return launch_wt_ng<5, 1, 2, 8, 1, 4>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8 && pairx) return launch_wt<5, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8) return launch_wt<9, 1, 2, 8>(av, n, groups, st, wv[0].ev_mid); break;
+    case 8: if (KC == 8) return launch_wt_ng<7, 1, 2, 8, 1, 3>(av, n, groups, st, wv[0].ev_mid); break;
     case 7: if (KC == 8 && narrow) return launch_wt_ng<11, 1, 1, 8, 1, 3>(av, n, groups, st, wv[0].ev_mid);
             if (KC == 8) return launch_wt<11, 2, 1, 8>(av, n, groups, st, wv[0].ev_mid); break;
   }

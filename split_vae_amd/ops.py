@@ -290,6 +290,23 @@ class Conv2D:
                   "sv_conv2d_nhwc_wgrad")
         return dw, db
 
+    def wgrad_poly(self, x_lo, dy, dw=None, db=None):
+        """Polyphase weight gradient of the decoder head (sv_conv2d_nhwc_wgrad_poly); None when the layer has no such form."""
+        d = self.desc
+        lib = _lib.load()
+        n = lib.sv_conv2d_wgrad_poly_workspace_bytes(C.byref(d))
+        if n <= 0:
+            return None
+        if getattr(self, "_pws", None) is None or self._pws.numel() < n or self._pws.device != x_lo.device:
+            self._pws = torch.zeros((n,), dtype=torch.uint8, device=x_lo.device)
+        if dw is None:
+            dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x_lo.device)
+        if db is None:
+            db = torch.zeros((d.Cout,), dtype=torch.float32, device=x_lo.device)
+        check(lib.sv_conv2d_nhwc_wgrad_poly(C.byref(d), _p(x_lo), _p(dy), _p(dw), _p(db), _p(self._pws), n, _stream()),
+              "sv_conv2d_nhwc_wgrad_poly")
+        return dw, db
+
 
 # ------------------------------------------------------------------ the whole-step plan
 class LGVaePlan:

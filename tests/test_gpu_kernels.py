@@ -575,3 +575,32 @@ def test_d5_input_gradient_ignores_stale_lds(ops):
         f32conv.fwd(xin, torch.zeros(64, device="cuda"))           # NaN / Inf operands through LDS on every CU
         again = conv.dgrad(dy)
         assert torch.equal(again, first)
+
+
+@pytest.mark.parametrize("B", [2, 9])
+@pytest.mark.parametrize("H", [32, 64])
+def test_polyphase_weight_gradient_of_the_head(ops, H, B):
+    """Conv2DBackpropFilter + BiasAddGrad of the decoder head in polyphase form (poly_wgrad.hip; the algebra is pinned on CPU
+    by tests/test_polyphase_math.py) against autograd of the fp64 resize -> conv on the same bf16 operands, and against the
+    direct fused-upsample kernel; run-to-run identical weights (fixed-order slabs; the bias uses atomics)."""
+    rng = np.random.default_rng(H + B)
+    Cin, Cout, k = 32, 6, 6
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16()
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, 8)).astype(np.float32)).bfloat16()
+    dy[..., Cout:] = 0
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.bfloat16, y_f32=True, ups_in=True)
+    conv.prep(torch.zeros(k, k, Cin, Cout).cuda())
+    dw, db = conv.wgrad_poly(x_lo.cuda(), dy.cuda())
+    wt = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(x_lo.double()), wt, bt, 1, None)
+    (y * dy[..., :Cout].double()).sum().backward()
+    assert float((dw.double().cpu() - wt.grad).norm() / wt.grad.norm()) < 2e-3
+    torch.testing.assert_close(db.double().cpu(), bt.grad, rtol=1e-4, atol=1e-4 * float(bt.grad.abs().max()))
+    for ky, kx in ((0, 0), (0, 5), (5, 0), (5, 5), (2, 2), (3, 1)):                 # corner taps carry the largest frame terms
+        a, r = dw[ky, kx].double().cpu(), wt.grad[ky, kx]
+        assert float((a - r).norm() / r.norm()) < 5e-3, (ky, kx)
+    dw0, db0 = conv.wgrad(x_lo.cuda(), dy.cuda(), workspace=True)
+    assert float((dw - dw0).norm() / dw0.norm()) < 6e-3
+    dw2, _ = conv.wgrad_poly(x_lo.cuda(), dy.cuda())
+    assert torch.equal(dw, dw2)
