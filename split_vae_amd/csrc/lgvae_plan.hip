@@ -523,10 +523,10 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   const char* on_main = on_main_env ? on_main_env : (n * L[0]->d.B >= 768 ? "e1,e2,d5" : "e1,e2");
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
-  // the decoder head's weight gradient in polyphase form (poly_wgrad.hip) from ~512 images per launch (its three small
+  // the decoder head's weight gradient in polyphase form (poly_wgrad.hip) from ~768 images per launch (its three small
   // kernels cost more than they save below that: 16 images 42 vs 20 us; 1024 images 132 vs 184 us)
   static const bool no_pw = getenv("SV_NO_POLY_WGRAD") != nullptr;
-  static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 512;
+  static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 768;   // (512 images per launch: +0.4 %; 1024: -1.0 %)
   if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2) {
     static const char* pw_name[2] = {"polyw_x", "polyw_xh"};
     float* pw[2];
