@@ -595,7 +595,7 @@ void svg_poly_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   a->IH = h; a->IW = w; a->lda = d->ldx; a->S = 1; a->SX = 1;
   a->ldy = 32; a->ycols = 32; a->cl2 = ilog2_exact(cpad / 8);
   a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = 32; a->ntaps = 25; a->Nrows = 25 * cpad;
-  a->clampin = 1; a->dy_s2d = 1; a->assign = 1; a->msplit = a->M;
+  a->clampin = 1; a->dy_s2d = 8; a->assign = 1; a->msplit = a->M;
   for (int tx = 0; tx < 5; ++tx)
     for (int ty = 0; ty < 5; ++ty) { a->dy[tx * 5 + ty] = (int8_t)(ty - 2); a->dx[tx * 5 + ty] = (int8_t)(tx - 2); }
 }

@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
       const int b = b0 + bl;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (b < g.B) {
-        if (g.dy_s2d)   // piece c = parity (py, px) of the hi-res [B, 2*OY, 2*OX, 8] gradient
-          v = *(const uint4*)(Yb + (((int64_t)b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 1)) * (2 * g.OX) + 2 * (tx0 + tx) + (c & 1)) * 8);
+        if (g.dy_s2d) {   // dy_s2d = channels per hi-res pixel (8 / 32): piece c = (parity (py, px), 16-B piece within the pixel)
+          const int pp = g.dy_s2d >> 3, par = c / pp, sub = c - par * pp;
+          v = *(const uint4*)(Yb + (((int64_t)b * 2 * g.OY + 2 * (ty0 + ty) + (par >> 1)) * (2 * g.OX) + 2 * (tx0 + tx) + (par & 1)) * g.dy_s2d + sub * 8);
+        }
         else v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 8);
       }
       *(uint4*)(sDy + r * g.YS + c * 16) = v;
