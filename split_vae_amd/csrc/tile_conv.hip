@@ -30,7 +30,15 @@
 // with row-window reuse (YR = KH) the 16-column kernel steps one whole filter column (KH taps x 4 pieces), the wider
 // ones two taps (their weight tiles are BN x PPS x 16 B x 2 buffers of LDS)
 static __host__ __device__ constexpr int tile_pps(int BN, int YR = 0) {
-  return YR ? (BN == 16 ? YR * 4 : 8) : BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8;
+  return YR ? (BN == 16 || YR == 5 ? YR * 4 : 8) : BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8;   // (KH = 5: a step = one filter column, 20 pieces)
+}
+
+// position of weight piece q of row n inside its LDS row: XOR swizzle within each 8-piece group (a trailing group of 4 pieces,
+// PPS = 20, swizzles within 4) -- the rows of a fragment then start on different banks
+template <int PPS>
+__device__ __forceinline__ int wpiece(int q, int n) {
+  if constexpr (PPS % 8 == 0) return q ^ (n & 7);
+  else return (q & ~7) == (PPS & ~7) ? (q & ~3) | ((q & 3) ^ (n & 3)) : q ^ (n & 7);
 }
 
 template <typename T> struct MmaOpT;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
 #pragma unroll
     for (int i = 0; i < BRN; ++i) {
       const int n = r0 + RPP * i;
-      if (n < BN && r0 < RPP) *(uint4*)(sB + slot * (BN * RB) + n * RB + ((pp ^ (n & 7)) << 4)) = rb[i];   // XOR swizzle within each 8-piece group
+      if (n < BN && r0 < RPP) *(uint4*)(sB + slot * (BN * RB) + n * RB + (wpiece<PPS>(pp, n) << 4)) = rb[i];   // swizzled (wpiece)
     }
   };
   const int nk = (gdbg & 2) ? 0 : (gP + PPS - 1) / PPS;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const int n = j * 16 + lr;
-        bfr[j] = *(const uint4*)(cB + n * RB + (((kk * 4 + lg) ^ (n & 7)) << 4));
+        bfr[j] = *(const uint4*)(cB + n * RB + (wpiece<PPS>(kk * 4 + lg, n) << 4));
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i)
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
               const int n = j * 16 + lr;
-              bfr[j] = *(const uint4*)(cB + n * RB + (((kk * 4 + lg) ^ (n & 7)) << 4));
+              bfr[j] = *(const uint4*)(cB + n * RB + (wpiece<PPS>(kk * 4 + lg, n) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MF; ++i)
@@ -538,7 +546,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
         !(yr_off && (yr_off[0] == '1' || strchr(yr_off, BN == 16 ? 'a' : BN == 32 ? 'b' : 'c')))) {
       int kh = 1;
       while (kh < t.ntaps && t.dx[kh] == t.dx[0]) ++kh;
-      bool ok = (kh == 4 || kh == 6) && t.ntaps % kh == 0;
+      static const bool yr5 = getenv("SV_TC_YR5") != nullptr;         // A/B (off: measured 0.155 vs 0.141 ms for the polyphase head -- a step is one
+                                                                       // whole 5-tap column, 20 pieces: 128 VGPRs, 7 spilled, bigger weight slots)
+      bool ok = (kh == 4 || kh == 6 || (kh == 5 && yr5 && BN == 32)) && t.ntaps % kh == 0;
       for (int i = 0; i < t.ntaps && ok; ++i)
         ok = t.dx[i] == t.dx[i / kh * kh] && t.dy[i] == t.dy[0] + i % kh && t.dy[0] == y_lo;
       if (ok) yr = kh;
@@ -589,7 +599,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->act = t.act; a->out_f32 = t.out_f32; a->ntaps = t.ntaps; a->ups = t.ups;
     memcpy(a->dy, t.dy, sizeof(a->dy));
     memcpy(a->dx, t.dx, sizeof(a->dx));
-    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : 0) + (wslots > 2 ? 128 : 0);
+    *cfg_out = cfgN * 2 + (MF == 4 ? 0 : 1) + (yr == 4 ? 32 : yr == 6 ? 64 : yr == 5 ? 96 : 0) + (wslots > 2 ? 128 : 0);
     // 256-row tiles that leave room for at most two workgroups per CU: 8 waves share the tile
     static const char* nw8 = getenv("SV_TC_NW8");       // tuning knob: BN classes (a=16, b=32, c=64) run with 8-wave workgroups
     if (MF == 4 && dtype == SV_BF16 && nw8 && strchr(nw8, BN == 16 ? 'a' : BN == 32 ? 'b' : BN == 64 ? 'c' : 'd')) *cfg_out = 16 + cfgN;
@@ -619,6 +629,7 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
       case 32 + 2: return launch_tile<bf16_t, 64, 4, 4, 4>(a, n, st);     // row-window reuse, KH = 4
       case 32 + 4: return launch_tile<bf16_t, 32, 4, 4, 4>(a, n, st);
       case 32 + 6: return launch_tile<bf16_t, 16, 4, 4, 4>(a, n, st);
+      case 96 + 4: return launch_tile<bf16_t, 32, 4, 4, 5>(a, n, st);     // KH = 5 (polyphase head)
       case 64 + 2: return launch_tile<bf16_t, 64, 4, 4, 6>(a, n, st);     // KH = 6
       case 64 + 4: return launch_tile<bf16_t, 32, 4, 4, 6>(a, n, st);
       case 64 + 6: return launch_tile<bf16_t, 16, 4, 4, 6>(a, n, st);
