@@ -78,6 +78,7 @@ def cpu(B, steps=6):
 if __name__ == "__main__":
     batches = [int(a) for a in sys.argv[1:]] or [64, 512]
     for B in batches:
-        for dt in ("bf16", "f32"):
+        for dt in os.environ.get("GM_DTYPES", "bf16,f32").split(","):
             gpu(B, dt)
-    cpu(64)
+    if not os.environ.get("GM_NO_CPU"):
+        cpu(64)

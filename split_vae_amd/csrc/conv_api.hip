@@ -503,7 +503,21 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
   TapGemmArgs a;
   svg_fwd_args(d, &a);
   a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
-  if (!svg_poly(d)) return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  if (!svg_poly(d)) {
+    // dense layers (1x1 on a 1x1 grid) with an fp32 pre-activation output: a [B, Cin] x [Cin, Cout] GEMM whose tile grid is a
+    // handful of workgroups (SPLIT-GMVAE's y_block / prior / posterior layers, vae/model.py:54-75) -- split K into the zeroed output
+    static const bool no_sk = getenv("SV_NO_DENSE_SPLITK") != nullptr;
+    if (!no_sk && d->y_f32 && d->act == SV_ACT_NONE && d->H == 1 && d->W == 1 && d->KH == 1 && d->KW == 1 && !d->ups_in) {
+      int cfg = svg_pick_cfg(d->Cout);
+      const int sk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
+      if (sk > 1) {
+        if (hipMemsetAsync(y, 0, (size_t)d->B * d->ldy * sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+        a.splitk = sk;
+        return svk_tap_gemm(a, d->dtype, cfg, (hipStream_t)stream);
+      }
+    }
+    return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+  }
   const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * 2;
   float* yf = (float*)y;
   float* fixbuf = ws && ws_bytes >= svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) ? (float*)ws : nullptr;

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int nl = j * 16 + lg * 4 + e;
-          bv[j][e] = (g.bias && n0 + nl < g.N) ? g.bias[n0 + nl] : 0.f;
+          bv[j][e] = (g.bias && n0 + nl < g.N && zi == 0) ? g.bias[n0 + nl] : 0.f;   // split-K: the first K slice carries the bias
         }
       const bool relu = g.act == SV_ACT_RELU;
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
       }
       __syncthreads();
       if (g.splitk > 1) {
-        // fp32 partial sums (no bias / activation / mask: checked at launch): one dword per lane,
+        // fp32 partial sums (no activation / mask: checked at launch; the bias rides on K slice 0): one dword per lane,
         // consecutive lanes on consecutive channels, so an atomic instruction covers whole 128-B lines
         const float rinv = 1.0f / (float)ncols;
         for (int q = tid; q < BM * ncols; q += 256) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
         float v = acc[i][j][e];
         const int64_t o = pix * g.ldo + n;
         if (g.splitk > 1) {
-          atomicAdd((float*)g.out + o, v);
+          atomicAdd((float*)g.out + o, (g.bias && zi == 0) ? v + g.bias[n] : v);
           continue;
         }
         if (g.bias) v += g.bias[n];
@@ -299,7 +299,7 @@ int svk_tap_gemm_multi(const TapGemmArgs* a, int n, int dtype, int cfg, hipStrea
   if (n < 1 || n > SV_TAP_MAX_MULTI) return SV_E_BADARG;
   for (int i = 0; i < n; ++i) {
     if (a[i].ntaps > SV_MAX_TAPS || a[i].splitk < 1) return SV_E_BADARG;
-    if (a[i].splitk > 1 && (!a[i].out_f32 || a[i].bias || a[i].act != SV_ACT_NONE || a[i].mask)) return SV_E_BADARG;
+    if (a[i].splitk > 1 && (!a[i].out_f32 || a[i].act != SV_ACT_NONE || a[i].mask)) return SV_E_BADARG;
   }
   if (dtype == SV_BF16) {
     switch (cfg) {
