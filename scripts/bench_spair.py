@@ -1,0 +1,43 @@
+"""SPLIT-SPAIR / SPAIR train step (config 5: 48x48 canvases, 4x4 cells, batch 32; README.md:93) on one MI355X.
+Usage: python scripts/bench_spair.py [batch ...]     (one JSON line per model)"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from split_vae_amd import spair, spair_main, spair_trainer
+from split_vae_amd.augmentation import Augmentator
+
+MODELS = {
+    "lg_spair (README.md:93)": dict(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+                                    split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True),
+    "bg_spair (README.md:87)": dict(model="bg_spair", latent_size=64, bg_latent_size=4, dense_bg=True, z_bg_beta=10.0),
+    "spair (defaults)": dict(model="spair"),
+}
+
+
+def run(name, kw, B, steps=30, warmup=5):
+    cfg = spair_main.default_config(**kw)
+    model = spair.get_model(cfg, seed=0)
+    x, _ = spair_main.synthetic_canvases(B, seed=1)
+    images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x) if cfg.model == "lg_spair" else x
+    opt = spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0)
+    for i in range(warmup):
+        spair_trainer.train_step(model, images, opt, i, cfg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        spair_trainer.train_step(model, images, opt, warmup + i, cfg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"what": "SPAIR train step (fwd+losses+bwd+clipnorm Adam)", "model": name, "device": "MI355X", "dtype": "f32", "batch": B,
+                      "params": model.count_params(), "images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    for B in [int(a) for a in sys.argv[1:]] or [32]:
+        for name, kw in MODELS.items():
+            run(name, kw, B)

@@ -264,8 +264,12 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
   // a pixel-major tile that is written out with 16-byte row-contiguous stores (8-byte for the
   // 6-channel fp32 head), ReLU mask applied there.  (The first version stored 2-byte scalars and
   // re-loaded the bias per element behind a branch: 32 dependent global loads per tile, a 35 us floor.)
-  const int ncols = min(BN, g.N - n0);                  // real channels of this column tile
   const int oesz = g.out_f32 ? 4 : (int)sizeof(T);
+  // channels stored by this column tile: the real ones and -- when their bytes are not a multiple of the 8-byte store piece (a
+  // 3-channel input gradient: SPAIR's glimpse encoder) -- the zero pad channels up to the tensor's pitch (weight rows >= N are
+  // zero, the bias is skipped); the plan rejects layers whose pitch leaves no such room
+  const int Nst = (!g.d2s && !g.cls_n && ((g.N * oesz) & 7)) ? min(g.ldo, (g.N + 7) & ~7) : g.N;
+  const int ncols = min(BN, Nst - n0);
   // x-packed conv (fp32 head): the 16 columns (px, co<8) become 2*C contiguous floats of output pixels 2*ox, 2*ox+1
   // (polyphase form, d2s_y: 32 columns (py, px, co<8) become two segments of 2*C floats: output rows 2*oy, 2*oy + 1)
   const int rowb = g.d2s ? (g.d2s_y ? 4 : 2) * g.d2s * 4 : ncols * oesz;   // output bytes per tile row
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     for (int e = 0; e < 4; ++e) {
       const int nl = j * 16 + lg * 4 + e;
       const int bi = g.d2s ? (nl & 7) : n0 + nl;
-      bv[j][e] = (g.bias && nl < ncols && (!g.d2s || bi < g.d2s)) ? g.bias[bi] : 0.f;
+      bv[j][e] = (g.bias && nl < ncols && n0 + nl < g.N && (!g.d2s || bi < g.d2s)) ? g.bias[bi] : 0.f;
     }
   const bool relu = g.act == SV_ACT_RELU;
 #pragma unroll
@@ -477,6 +481,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
+  if (!t.d2s && !t.cls_n) {                             // the epilogue stores 8- / 16-byte pieces (see Nst in the kernel)
+    const int oe = t.out_f32 ? 4 : (dtype == SV_BF16 ? 2 : 4);
+    const int nst = ((t.N * oe) & 7) ? (t.ldo < ((t.N + 7) & ~7) ? t.ldo : ((t.N + 7) & ~7)) : t.N;
+    if ((nst * oe) & 7) return false;
+  }
   const int esz = dtype == SV_BF16 ? 2 : 4, epp = 16 / esz;
   const int cin = (1 << t.cl2) * epp;
   // N tile

@@ -1,0 +1,199 @@
+"""SPAIR / SPLIT-SPAIR losses, step closures and loop (spair/trainer.py of 51616/split-vae) on the device operators.
+
+`train_step(model, images, optimizer, step, config)` = spair/trainer.py:136-234: forward (training=True), the loss assembly of
+the configured model, the gradient of every variable (torch autograd over the `split_vae::*` operators, which pair each forward
+kernel with its hand-written adjoint), and tf.keras.optimizers.Adam(lr, clipnorm=1.0) (spair/main.py:109) as ONE pair of launches
+over the model's flat variable buffer (sv_adam_step_clipnorm).  The sequential 16-cell count-prior KL of z_pres is one kernel
+(spair_render.hip: sv_spair_zpres_kl); the Gaussian KLs and the cross-entropy are torch elementwise reductions.
+"""
+import time
+
+import torch
+
+from . import ops, torch_ops as T
+
+TRAIN_METRIC_NAMES = ['x_recon_train_loss', 'z_zoom_kl_train_loss', 'z_what_kl_train_loss', 'z_where_kl_train_loss',
+                      'z_depth_kl_train_loss', 'z_pres_kl_train_loss', 'z_bg_kl_train_loss', 'z_l_kl_train_loss',
+                      'x_hat_recon_train_loss']                                                    # spair/trainer.py:125-126
+TEST_METRIC_NAMES = [n.replace('_train_', '_test_') for n in TRAIN_METRIC_NAMES] + ['MAE test', 'MAPE test']   # :128-129
+
+
+def tf_safe_log(value, replacement_value=-100.0):
+    """spair/trainer.py:97-101."""
+    lv = torch.log(value + 1e-8)
+    return torch.where(torch.isnan(lv) | torch.isinf(lv), torch.full_like(lv, replacement_value), lv)
+
+
+def tf_mean_sum(t):
+    """:107-109: average over the batch, sum over everything else."""
+    return t.reshape(t.shape[0], -1).sum(dim=1).mean()
+
+
+def xent_loss(label, pred):
+    """:103-104."""
+    return -(label * tf_safe_log(pred) + (1.0 - label) * tf_safe_log(1.0 - pred))
+
+
+def kl_divergence(z_mean, z_sig):
+    """:13-21 (rank 2 and rank 4 inputs: sum over all but the batch axis)."""
+    if z_mean.dim() not in (2, 4):
+        raise NotImplementedError('This KL shape is not implemented')
+    z_log_var = tf_safe_log(z_sig * z_sig)
+    return tf_mean_sum(-0.5 * (1 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)))
+
+
+def kl_divergence_two_gauss(mean1, sig1, mean2, sig2):
+    """:23-24."""
+    return tf_mean_sum(tf_safe_log(sig2) - tf_safe_log(sig1) + (sig1 * sig1 + (mean1 - mean2) ** 2) / (2 * sig2 * sig2) - 0.5)
+
+
+def compute_z_pres_kl_yolo_air(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
+    """:45-94 as one kernel (per-image sums) + the batch mean."""
+    return T.spair_zpres_kl(z_pres.contiguous(), z_pres_logits.contiguous(), z_pres_pre_sigmoid.contiguous(), prior_prob, temperature).mean()
+
+
+class ClipnormAdam:
+    """tf.keras.optimizers.Adam(learning_rate, clipnorm=...) (spair/main.py:109) over a model's flat variable buffer."""
+
+    def __init__(self, learning_rate=1e-4, clipnorm=1.0, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.clipnorm = learning_rate, clipnorm
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.iterations = 0
+        self._slots = None
+
+    def apply_gradients(self, model, grads):
+        st = model.store
+        if self._slots is None:
+            self._slots = (torch.zeros_like(st.flat), torch.zeros_like(st.flat), torch.empty_like(st.flat))
+        m, v, g = self._slots
+        torch.cat([x.reshape(-1) for x in grads], out=g)
+        self.iterations += 1
+        ops.adam_step_clipnorm(st.flat, g, m, v, st.tensor_off, self.clipnorm, self.iterations, float(self.learning_rate),
+                               self.beta_1, self.beta_2, self.epsilon)
+
+
+def _unpack(config, out):
+    names = ["x_recon", "z_what", "z_what_mean", "z_what_sigma", "z_where", "z_where_mean", "z_where_sigma", "z_depth", "z_depth_mean",
+             "z_depth_sigma", "z_pres", "z_pres_logits", "z_pres_pre_sigmoid", "all_glimpses", "obj_recon_unnorm", "obj_recon_alpha",
+             "obj_full_recon_unnorm", "obj_bbox_mask"]
+    if config.model == "lg_spair":
+        names += ["z_bg", "z_bg_mean", "z_bg_sig", "x_hat_recon", "z_l", "z_l_mean", "z_l_sig"]
+    elif config.model == "bg_spair":
+        names += ["z_bg", "z_bg_mean", "z_bg_sig"]
+    return dict(zip(names, out))
+
+
+def compute_losses(config, images, out, step, training=True):
+    """The loss assembly of train_step (:142-228; training=True) or test_step (:243-293) -> (total_loss | None, [losses])."""
+    o = _unpack(config, out)
+    lg = config.model == "lg_spair"
+    x = images[..., :3]                                               # :148-151 (spair / bg_spair canvases have 3 channels)
+    x_recon_loss = tf_mean_sum(xent_loss(x, o["x_recon"]))
+    anneal = min(1.0, (step + 1) / config.z_pres_anneal_step) if training else 1.0
+    z_pres_kl = compute_z_pres_kl_yolo_air(o["z_pres"], o["z_pres_logits"], o["z_pres_pre_sigmoid"], 0.99 * anneal, config.tau)
+    zm, zs = o["z_where_mean"], o["z_where_sigma"]
+    zoom_mean = torch.full_like(zm[..., :2], config.prior_z_zoom + (config.prior_z_zoom_start * (1 - anneal) if training else 0.0))
+    zoom_kl = kl_divergence_two_gauss(zm[..., :2], zs[..., :2], zoom_mean, torch.full_like(zs[..., :2], 0.5))
+    what_kl = kl_divergence(o["z_what_mean"], o["z_what_sigma"])
+    where_kl = kl_divergence(zm[..., 2:], zs[..., 2:])
+    depth_kl = kl_divergence(o["z_depth_mean"], o["z_depth_sigma"])
+    losses = [x_recon_loss, zoom_kl, what_kl, where_kl, depth_kl, z_pres_kl]
+    if not training:                                                                               # test_step :262-285
+        if lg:
+            losses += [kl_divergence(torch.cat([o["z_bg_mean"], o["z_l_mean"]], dim=1), torch.cat([o["z_bg_sig"], o["z_l_sig"]], dim=1)),
+                       kl_divergence(o["z_l_mean"], o["z_l_sig"]), tf_mean_sum(xent_loss(images[..., 3:], o["x_hat_recon"]))]
+        elif config.model == "bg_spair":
+            losses += [kl_divergence(o["z_bg_mean"], o["z_bg_sig"]), torch.zeros((), device=x.device), torch.zeros((), device=x.device)]
+        return None, losses
+    rw = config.reconstruction_weight
+    obj = lambda wk: config.z_what_beta * wk + depth_kl + where_kl + zoom_kl + z_pres_kl
+    annealed_beta = min(config.beta, config.beta * (step + 1.0) / config.anneal_until)
+    if lg:
+        x_hat_recon_loss = tf_mean_sum(xent_loss(images[..., 3:], o["x_hat_recon"]))
+        z_l_kl = kl_divergence(o["z_l_mean"], o["z_l_sig"])
+        if not config.split_z_l:                                                                   # :176-195
+            if config.concat_z_bg:
+                z_bg_kl = kl_divergence(torch.cat([o["z_bg_mean"], o["z_l_mean"]], dim=1), torch.cat([o["z_bg_sig"], o["z_l_sig"]], dim=1))
+            else:
+                z_bg_kl = kl_divergence(o["z_bg_mean"], o["z_bg_sig"])
+            if config.concat_z_what:
+                tile = lambda t: t[:, None, None, :].expand(-1, 4, 4, -1)
+                what_kl = kl_divergence(torch.cat([o["z_what_mean"], tile(o["z_l_mean"])], dim=-1),
+                                        torch.cat([o["z_what_sigma"], tile(o["z_l_sig"])], dim=-1))
+            total = config.z_bg_beta * z_bg_kl + rw * x_recon_loss + config.beta * obj(what_kl) + x_hat_recon_loss
+        else:                                                                                      # :197-207
+            z_bg_kl = kl_divergence(o["z_bg_mean"], o["z_bg_sig"])
+            total = config.z_bg_beta * z_bg_kl + config.z_l_beta * z_l_kl + x_hat_recon_loss + rw * x_recon_loss + config.beta * obj(what_kl)
+        losses += [z_bg_kl, z_l_kl, x_hat_recon_loss]
+    elif config.model == "bg_spair":                                                               # :222-228
+        z_bg_kl = kl_divergence(o["z_bg_mean"], o["z_bg_sig"])
+        losses.append(z_bg_kl)
+        total = config.z_bg_beta * z_bg_kl + rw * x_recon_loss + annealed_beta * obj(what_kl)
+    else:                                                                                          # :165-167
+        total = rw * x_recon_loss + annealed_beta * obj(what_kl)
+    return total, losses
+
+
+def train_step(model, images, optimizer, step, config, noise=None, return_grads=False):
+    """spair/trainer.py:136-234.  `noise`: pinned random draws by name (tests); default = the model's device generator."""
+    out = model(images, training=True, noise=noise)
+    total_loss, losses = compute_losses(config, images, out, float(step), training=True)
+    variables = [v for _, v in model.trainable_variables]
+    grads = torch.autograd.grad(total_loss, variables, allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, variables)]
+    optimizer.apply_gradients(model, grads)
+    o = tuple(t.detach() if torch.is_tensor(t) else t for t in out)
+    res = o[:17] + o[18:]                                              # the reference drops obj_bbox_mask from the step's return (:230-232)
+    return (res, [l.detach() for l in losses], total_loss.detach(), grads) if return_grads else (res, [l.detach() for l in losses])
+
+
+@torch.no_grad()
+def test_step(model, images, config, labels=None, noise=None):
+    """spair/trainer.py:236-308 (the reference evaluates with model(images, training=True) too)."""
+    out = model(images, training=True, noise=noise)
+    _, losses = compute_losses(config, images, out, 0.0, training=False)
+    if labels is not None:
+        pred_count = torch.round(torch.sigmoid(out[11])).sum(dim=(1, 2, 3))
+        lab = labels.to(pred_count)
+        losses.append((lab - pred_count).abs().mean())
+        losses.append(100.0 * ((lab - pred_count).abs() / lab.abs().clamp_min(1e-7)).mean())
+    return out[:17] + out[18:], losses
+
+
+def train_spair(model, optimizer, dataset, train_dataset, test_dataset, config, log=print):
+    """spair/trainer.py:112-424 without the matplotlib grids: the step loop, the 1000-step metric logs, save_weights at the end."""
+    sums, n = None, 0
+    start = time.time()
+    history = []
+    every = int(config.log_every or 1000)
+    for step, images in enumerate(train_dataset):
+        _, losses = train_step(model, images, optimizer, step, config)
+        vals = torch.stack([l.float() for l in losses])
+        sums = vals if sums is None else sums + vals
+        n += 1
+        if step % every == 0:
+            torch.cuda.synchronize()
+            log('Training time: {:.2f}'.format(time.time() - start))
+            tr = dict(zip(TRAIN_METRIC_NAMES, (sums / n).tolist()))
+            log('Training step:', step)
+            log(tr)
+            sums, n = None, 0
+            rec = {"step": step, "train": tr}
+            for test_num, test_ds in enumerate(test_dataset or []):
+                ts, tn = None, 0
+                for batch in test_ds:
+                    imgs, labels = batch if isinstance(batch, (tuple, list)) else (batch, None)
+                    _, tl = test_step(model, imgs, config, labels)
+                    tv = torch.stack([l.float() for l in tl])
+                    ts = tv if ts is None else ts + tv
+                    tn += 1
+                if tn:
+                    te = dict(zip([nm + str(test_num) for nm in TEST_METRIC_NAMES], (ts / tn).tolist()))
+                    log(te)
+                    rec["test" + str(test_num)] = te
+            history.append(rec)
+            start = time.time()
+        if step >= config.training_steps:
+            log('Training done!')
+            break
+    return history

@@ -26,6 +26,7 @@ _lib_def.define("conv2d_nhwc_wgrad(Tensor x, Tensor dy, int KH, int KW, int Cin,
 _lib_def.define("dlogistic_nll(Tensor images6, int ch_off, Tensor out6, float grad_scale, bool bf16_grad) -> (Tensor, Tensor)")
 _lib_def.define("reparam_kl_fwd(Tensor pre, Tensor bias, Tensor? eps, int seed, int step, int stream_id, int sample_offset) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 _lib_def.define("reparam_kl_bwd(Tensor dz, Tensor z_mean, Tensor z_sig, Tensor eps, float kl_scale) -> Tensor")
+_lib_def.define("upsample2x_fwd(Tensor x) -> Tensor")
 _lib_def.define("upsample2x_bwd(Tensor g_hi, Tensor? relu_mask) -> Tensor")
 _lib_def.define("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps, float grad_scale) -> ()")
 # SPLIT-SPAIR operators (fp32; spair/utils.py:119-330, spair/spair.py:534-579, spair/trainer.py:28-94)
@@ -113,6 +114,11 @@ def _reparam_bwd(dz, z_mean, z_sig, eps, kl_scale):
     return ops.reparam_kl_bwd(dz.contiguous(), z_mean, z_sig, eps, kl_scale, torch.float32)
 
 
+@_impl("upsample2x_fwd")
+def _ups_fwd(x):
+    return ops.upsample2x_fwd(x.contiguous())
+
+
 @_impl("upsample2x_bwd")
 def _ups_bwd(g_hi, relu_mask):
     return ops.upsample2x_bwd(g_hi.contiguous(), relu_mask)
@@ -147,7 +153,12 @@ class _Conv2dFn(torch.autograd.Function):
         H, W = x.shape[1] * (2 if ups_in else 1), x.shape[2] * (2 if ups_in else 1)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.split_vae.conv2d_nhwc_dgrad(gy, w, None, H, W, x.shape[-1], stride, ups_in)
+            gy_d, w_d = gy, w
+            P = 1 << (gy.shape[-1] - 1).bit_length()
+            if P != gy.shape[-1]:                                     # the input-gradient kernels index dY by a power-of-two pixel pitch
+                gy_d = torch.nn.functional.pad(gy, (0, P - gy.shape[-1]))          # (SPAIR's 100-channel z3): zero channels, zero filters
+                w_d = torch.nn.functional.pad(w, (0, P - Cout))
+            gx = torch.ops.split_vae.conv2d_nhwc_dgrad(gy_d, w_d, None, H, W, x.shape[-1], stride, ups_in)
             if ups_in:                                                # adjoint of the fused bilinear resize
                 gx = torch.ops.split_vae.upsample2x_bwd(gx, None)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
@@ -206,6 +217,22 @@ def reparam_kl(pre, bias, eps):
     sd, before bias and softplus), bias [2L], eps [B,L] -> (z, kl [B] per-image terms, z_mean, z_sig); differentiable in
     pre and bias through z and a uniformly weighted kl."""
     return _ReparamKlFn.apply(pre, bias, eps)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return torch.ops.split_vae.upsample2x_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.ops.split_vae.upsample2x_bwd(g.contiguous(), None)
+
+
+def upsample2x(x):
+    """tf.image.resize to twice the size (bilinear, half-pixel centres; vae/model.py:163-167, spair/spair.py:175-180) as its own
+    op, for layers whose geometry the fused-resize conv (ups_in) does not cover.  x NHWC, channels % 8 == 0 (fp32: % 4)."""
+    return _Upsample2xFn.apply(x)
 
 
 # ---------------------------------------------------------------------------------------------- SPLIT-SPAIR operators

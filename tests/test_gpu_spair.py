@@ -260,6 +260,7 @@ def test_odd_kernel_stride_2_layers(ops, H, Cin, Cout, dtype, rtol):
     dw, db = conv.wgrad(xg, dyg)
     torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=rtol, atol=rtol * float(wr.grad.abs().max()))
     torch.testing.assert_close(db.double().cpu(), br.grad, rtol=rtol, atol=rtol * float(br.grad.abs().max()))
-    if Cin >= 8:
-        dx = conv.dgrad(dyg)
-        torch.testing.assert_close(dx[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=rtol * float(xr.grad.abs().max()))
+    # Cin = 3: the glimpse encoder's first layer (spair/spair.py:250) -- its input gradient reaches z_where through the STN
+    dx = conv.dgrad(dyg)
+    torch.testing.assert_close(dx[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=rtol * float(xr.grad.abs().max()))
+    assert float(dx[..., Cin:].abs().max()) == 0.0 if Cin % 8 else True

@@ -1,0 +1,126 @@
+"""SPAIR / SPLIT-SPAIR assembled on the device operators (split_vae_amd/spair.py, spair_trainer.py) against the fp64 CPU
+restatement of spair/spair.py + spair/trainer.py (oracle/spair_model_ref.py): same variables, same pinned random draws ->
+every returned tensor, every loss term, the gradient of every variable and one clipnorm-Adam step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "spair": dict(model="spair"),
+    "bg_spair": dict(model="bg_spair", latent_size=64, bg_latent_size=4),
+    # README.md:93 (SPLIT-SPAIR on Multi-Bird, solid background)
+    "lg_spair_readme": dict(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+                            split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True),
+    # the conv image encoders / decoders, the backbone concat and the un-split loss branch
+    "lg_spair_conv": dict(model="lg_spair", latent_size=32, bg_latent_size=8, local_latent_size=16, concat_backbone=True,
+                          concat_z_what=True),
+}
+OUT_NAMES = ["x_recon", "z_what", "z_what_mean", "z_what_sigma", "z_where", "z_where_mean", "z_where_sigma", "z_depth", "z_depth_mean",
+             "z_depth_sigma", "z_pres", "z_pres_logits", "z_pres_pre_sigmoid", "all_glimpses", "obj_recon_unnorm", "obj_recon_alpha",
+             "obj_full_recon_unnorm", "obj_bbox_mask", "z_bg", "z_bg_mean", "z_bg_sig", "x_hat_recon", "z_l", "z_l_mean", "z_l_sig"]
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_spair_step_matches_oracle(lib_built, name):
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    cfg = R.default_config(**CONFIGS[name])
+    B, step = 3, 41
+    chans = 6 if cfg.model == "lg_spair" else 3
+    g = torch.Generator().manual_seed(11)
+    images = torch.rand(B, 48, 48, chans, generator=g)
+    p = R.init_params(cfg, seed=5)
+    noise = R.draw_noise(cfg, B, seed=7)
+    for v in p.values():
+        v.requires_grad_(True)
+    ref = R.forward(p, cfg, images.double(), noise, training=True)
+    total_ref, losses_ref = R.losses(cfg, images.double(), ref, step)
+    grads_ref = torch.autograd.grad(total_ref, list(p.values()), allow_unused=True)
+    # the same restatement in fp32 on the CPU: how far fp32 rounding alone moves each gradient (the cross-entropy of a canvas
+    # without a background -- model 'spair', bg_recon = 0 -- divides by predictions near 1e-8: some sums cancel by 1e4 and more)
+    p32 = {k: v.detach().float().requires_grad_(True) for k, v in p.items()}
+    ref32 = R.forward(p32, cfg, images, {k: v.float() for k, v in noise.items()}, training=True)
+    grads32 = torch.autograd.grad(R.losses(cfg, images, ref32, step)[0], list(p32.values()), allow_unused=True)
+
+    model = spair.get_model(dotdict(cfg), seed=0)
+    assert [n for n, _ in model.trainable_variables] == list(p.keys())
+    model.set_weights({k: v.detach().numpy() for k, v in p.items()})
+    before = model.store.flat.clone()
+    dn = {k: v.float().cuda() for k, v in noise.items()}
+    opt = spair_trainer.ClipnormAdam(learning_rate=1e-3, clipnorm=1.0)
+    res, losses, total, grads = spair_trainer.train_step(model, images.cuda(), opt, step, dotdict(cfg), noise=dn, return_grads=True)
+    # outputs (the step's return drops obj_bbox_mask; the model's call keeps it)
+    names = [n for n in OUT_NAMES[:17] + OUT_NAMES[18:] if n in ref]
+    assert len(res) == len(names)
+    for n, t in zip(names, res):
+        assert tuple(t.shape) == tuple(ref[n].shape), n
+        assert _rel(t, ref[n].detach()) < 2e-4, (n, _rel(t, ref[n].detach()))
+    assert len(losses) == len(losses_ref)
+    for i, (a, b) in enumerate(zip(losses, losses_ref)):
+        assert abs(float(a) - float(b)) <= 2e-4 * max(1.0, abs(float(b))), (i, float(a), float(b))
+    assert abs(float(total) - float(total_ref)) <= 2e-4 * abs(float(total_ref))
+    worst = 0.0
+    for (n, _), ga, gb, g32 in zip(model.trainable_variables, grads, grads_ref, grads32):
+        if gb is None:
+            assert float(ga.abs().max()) == 0.0, n
+            continue
+        e = float((ga.double().cpu() - gb).norm() / gb.norm().clamp_min(1e-12))
+        e32 = float((g32.double() - gb).norm() / gb.norm().clamp_min(1e-12))
+        worst = max(worst, e)
+        assert e < max(1e-3, 3.0 * e32), (n, e, e32)          # no worse than the CPU's own fp32 evaluation of the same graph
+    # Adam(clipnorm=1): the oracle's update from ITS gradients vs the flat-buffer kernel pair
+    pl = [v.detach().clone() for v in p.values()]
+    m = [torch.zeros_like(v) for v in pl]
+    vv = [torch.zeros_like(v) for v in pl]
+    R.clipnorm_adam_(pl, [gb if gb is not None else torch.zeros_like(v) for gb, v in zip(grads_ref, pl)], m, vv, 1, lr=1e-3, clipnorm=1.0)
+    upd_ref = torch.cat([(a - b.detach()).reshape(-1) for a, b in zip(pl, p.values())])
+    upd = (model.store.flat - before).double().cpu()
+    assert float((upd - upd_ref).norm() / upd_ref.norm()) < 2e-2          # first Adam step = lr * sign-like: tiny gradients flip easily
+    assert float(upd.abs().max()) <= 1e-3 * 1.0001
+
+
+def test_spair_eval_forward_and_test_step(lib_built):
+    """training=False: the Renderer rounds sigmoid(z_pres_logits) (spair/spair.py:549-558); test_step's metric list."""
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    cfg = R.default_config(**CONFIGS["lg_spair_readme"])
+    B = 2
+    images = torch.rand(B, 48, 48, 6, generator=torch.Generator().manual_seed(2))
+    p = R.init_params(cfg, seed=1)
+    noise = R.draw_noise(cfg, B, seed=3)
+    ref = R.forward(p, cfg, images.double(), noise, training=False)
+    model = spair.get_model(dotdict(cfg))
+    model.set_weights({k: v.numpy() for k, v in p.items()})
+    dn = {k: v.float().cuda() for k, v in noise.items()}
+    with torch.no_grad():
+        out = model(images.cuda(), training=False, noise=dn)
+    assert _rel(out[0], ref["x_recon"]) < 2e-4
+    labels = torch.tensor([3.0, 5.0]).cuda()
+    res, losses = spair_trainer.test_step(model, images.cuda(), dotdict(cfg), labels=labels, noise=dn)
+    assert len(losses) == len(spair_trainer.TEST_METRIC_NAMES) and len(res) == 24
+    assert all(bool(torch.isfinite(l)) for l in losses)
+
+
+def test_spair_training_reduces_the_loss(lib_built):
+    """30 steps of SPLIT-SPAIR on one fixed batch with the device generator's noise: the total loss falls."""
+    from split_vae_amd import spair, spair_trainer, spair_main
+    cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, split_z_l=True,
+                                    concat_z_what=True, dense_local=True, dense_bg=True)
+    model = spair.get_model(cfg, seed=4)
+    images = torch.rand(8, 48, 48, 6, generator=torch.Generator().manual_seed(5)).cuda()
+    opt = spair_trainer.ClipnormAdam(learning_rate=1e-3, clipnorm=1.0)
+    tot = []
+    for step in range(30):
+        _, _, total, _ = spair_trainer.train_step(model, images, opt, step, cfg, return_grads=True)
+        tot.append(float(total))
+    assert np.isfinite(tot).all()
+    assert np.mean(tot[-5:]) < 0.9 * np.mean(tot[:5]), tot

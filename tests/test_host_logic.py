@@ -265,3 +265,22 @@ def test_png_writer_round_trip(tmp_path):
     assert np.array_equal(back, np.clip(np.rint(canvas * 255), 0, 255).astype(np.uint8))
     grid = viz._tile(np.arange(4 * 2 * 3 * 3, dtype=np.float32).reshape(4, 2, 3, 3), 2, 2)
     assert grid.shape == (4, 6, 3) and np.array_equal(grid[:2, 3:], np.arange(18, 36, dtype=np.float32).reshape(2, 3, 3))
+
+
+def test_spair_cli_flags_match_reference():
+    """spair/main.py:19-50: same names, types and defaults; README.md:93's SPLIT-SPAIR command parses."""
+    from split_vae_amd.spair_main import build_parser, default_config
+    a = build_parser().parse_args([])
+    want = dict(learning_rate=1e-4, beta=0.5, dataset='cub_solid_fixed', channel=3, training_steps=100000, batch_size=32, runs=1, tau=0.8,
+                object_size=32, latent_size=128, no_label=False, anneal_until=1.0, z_pres_anneal_step=10000.0, prior_z_zoom=0.0,
+                prior_z_zoom_start=10.0, reconstruction_weight=1.0, bg_latent_size=4, local_latent_size=64, z_bg_beta=10.0, z_l_beta=0.1,
+                z_what_beta=0.1, allow_growth=False, model='spair', patch_size=4, augmentation='scramble', split_z_l=False, dense_bg=False,
+                dense_local=False, concat_bg=False, concat_z_what=False, concat_backbone=False)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    b = build_parser().parse_args("--dataset cub_solid_fixed --z_bg_beta 10 --patch_size 8 --latent_size 64 --bg_latent_size 4 "
+                                  "--local_latent_size 4 --model lg_spair -split_z_l -concat_z_what -dense_local -dense_bg "
+                                  "--training_steps 200000".split())
+    assert (b.model, b.split_z_l, b.concat_z_what, b.dense_local, b.dense_bg, b.local_latent_size) == ("lg_spair", True, True, True, True, 4)
+    c = default_config(model="lg_spair")
+    assert c.concat_z_bg is None and c.bg_model is None and c.image_size == [48, 48, 3]     # keys no flag defines read as None
