@@ -79,7 +79,7 @@ int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* The same with Keras `clipnorm` (SPLIT-SPAIR: Adam(..., clipnorm=1.0), spair/main.py:109): every gradient tensor is scaled by
  * clipnorm / max(||g * grad_scale||_2, clipnorm) first (tf.clip_by_norm).  tensor_off: DEVICE array of n_tensors+1 element
- * offsets into the flat buffers; norm_ws: DEVICE scratch of 32*n_tensors floats.  Deterministic (fixed-order norms). */
+ * offsets into the flat buffers; norm_ws: DEVICE scratch of 128*n_tensors floats.  Deterministic (fixed-order norms). */
 int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
                           float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
                           float grad_scale, void* stream);
@@ -96,10 +96,13 @@ int sv_upsample2x_bwd(const void* g_hi, const void* y_lo_mask, void* g_lo, int32
  * Replaces spair.utils.STN.call + bilinear_sampler + get_pixel_value (spair/utils.py:119-200, :202-272, :274-330) and the
  * gradient tape.gradient takes through them.  z_where [B,Hc,Wc,4] pre-activations; inverse = 0: img [B,H,W,C] -> one
  * [Ho,Wo,C] glimpse per cell, out [B,Hc*Wc,Ho,Wo,C]; inverse = 1 (the renderer's STN): img [B,Hc*Wc,H,W,C] -> each object
- * pasted on its own [Ho,Wo,C] canvas.  bbox (may be NULL) = obj_bbox_mask [B,Hc*Wc,4].  Backward: g_img (same shape as img,
- * ZERO IT FIRST: scatter-added with atomics), g_z_where [B,Hc,Wc,4]. */
+ * pasted on its own [Ho,Wo,C] canvas.  bbox (may be NULL) = obj_bbox_mask [B,Hc*Wc,4].  Backward: g_z_where [B,Hc,Wc,4] and
+ * g_img (same shape as img; may be NULL when the image takes no gradient).  g_img is scatter-ADDED with atomics -- zero it
+ * first -- unless sv_stn_bwd_overwrites(H, W, C, inverse) is 1 (inverse form, small objects: each cell's gradient is
+ * accumulated in LDS and stored whole). */
 int sv_stn_sample_fwd(const float* img, const float* z_where, float* out, float* bbox, int32_t B, int32_t Hc, int32_t Wc,
                       int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t inverse, void* stream);
+int sv_stn_bwd_overwrites(int32_t H, int32_t W, int32_t C, int32_t inverse);
 int sv_stn_sample_bwd(const float* img, const float* z_where, const float* g_out, float* g_img, float* g_z_where, int32_t B,
                       int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t inverse,
                       void* stream);
@@ -123,6 +126,14 @@ int sv_spair_render_bwd(const float* obj, const float* bg, const float* z_depth,
 int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
                       float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob, float temperature,
                       float grad_scale, void* stream);
+
+/* SPLIT-SPAIR: the per-image loss sums of spair/trainer.py with their gradients, fp32, one launch each (spair_loss.hip):
+ *   mode 0: xent_loss :103-104, a = label, b = prediction;  mode 1: kl_divergence :13-21, a = z_mean, b = z_sig;
+ *   mode 2: kl_divergence_two_gauss :23-24 against the constant prior N(prior_mean, prior_sig) (:156-157), a = mean, b = sig.
+ * a, b [B,n] -> sums [B] (tf_mean_sum :107-109 = their batch mean); ga / gb [B,n] (may be NULL) = the per-element derivatives
+ * (mode 0: ga is ignored).  tf_safe_log :97-101 semantics (log(v + 1e-8); NaN / inf -> -100, no gradient). */
+int sv_spair_loss(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
+                  float prior_mean, float prior_sig, void* stream);
 
 /* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
  * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the

@@ -40,4 +40,5 @@ def run(name, kw, B, steps=30, warmup=5):
 if __name__ == "__main__":
     for B in [int(a) for a in sys.argv[1:]] or [32]:
         for name, kw in MODELS.items():
-            run(name, kw, B)
+            if os.environ.get("SPAIR_ONLY", "") in name:
+                run(name, kw, B)

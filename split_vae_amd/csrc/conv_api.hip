@@ -495,6 +495,16 @@ extern "C" int64_t sv_conv2d_fwd_workspace_bytes(const sv_conv_desc* d) {
   return svg_poly(d) ? svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) : 0;
 }
 
+// im2col tile for a layer the tile kernel does not plan (non-power-of-two grids, stride 3: SPAIR's backbone): when the
+// 128-row tiles of svg_pick_cfg leave most of the 256 CUs idle, 64 x 32 tiles (tap-GEMM cfg 4) give 8x the workgroups.
+static int svg_im2col_cfg(const TapGemmArgs& a, int cfg) {
+  static const bool off = getenv("SV_NO_SMALL_IM2COL") != nullptr;
+  static const int BMt[4] = {128, 128, 256, 256}, BNt[4] = {128, 64, 32, 16};
+  if (off || cfg > 2 || (a.N % 32) || a.splitk > 1) return cfg;
+  const int64_t tiles = (int64_t)((a.M + BMt[cfg] - 1) / BMt[cfg]) * ((a.N + BNt[cfg] - 1) / BNt[cfg]);
+  return tiles < 256 ? 4 : cfg;
+}
+
 extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
                                      void* ws, int64_t ws_bytes, void* stream) {
   int rc = svg_check(d);
@@ -516,7 +526,7 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
         return svk_tap_gemm(a, d->dtype, cfg, (hipStream_t)stream);
       }
     }
-    return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
+    return svk_conv_dispatch(a, d->dtype, svg_im2col_cfg(a, svg_pick_cfg(d->Cout)), (hipStream_t)stream);
   }
   const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * 2;
   float* yf = (float*)y;
@@ -565,7 +575,7 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
     if (dx_f32_atomic) {
       a.out_f32 = 1;
       a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
-    }
+    } else cfg = svg_im2col_cfg(a, cfg);
     rc = svk_conv_dispatch(a, d->dtype, cfg, (hipStream_t)stream);
     if (rc) return rc;
     off += svg_wprep_elems_class(d, 1, c);

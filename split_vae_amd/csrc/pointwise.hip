@@ -475,9 +475,9 @@ extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_
 }
 
 // ---- Adam with Keras `clipnorm` (spair/main.py:109: Adam(..., clipnorm=1.0)): every gradient TENSOR is scaled by
-// clipnorm / max(||g||_2, clipnorm) (tf.clip_by_norm) before the update.  Pass 1: 32 partial sums of squares per tensor
+// clipnorm / max(||g||_2, clipnorm) (tf.clip_by_norm) before the update.  Pass 1: 128 partial sums of squares per tensor
 // (fixed strides); pass 2: a workgroup column per tensor adds them in a fixed order and applies the update -- deterministic.
-#define SV_CLIP_PARTS 32
+#define SV_CLIP_PARTS 128
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ off,
                                                     float* __restrict__ parts, float gscale) {
   const int t = blockIdx.y;
@@ -520,7 +520,7 @@ extern "C" int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* 
   const double alpha = svk_adam_alpha(lr, beta1, beta2, t);
   hipLaunchKernelGGL(sumsq_kernel, dim3(SV_CLIP_PARTS, n_tensors), dim3(256), 0, st, g, tensor_off, norm_ws, grad_scale);
   SV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adam_clip_kernel, dim3(64, n_tensors), dim3(256), 0, st, p, g, m, v, tensor_off, norm_ws, clipnorm,
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(256, n_tensors), dim3(256), 0, st, p, g, m, v, tensor_off, norm_ws, clipnorm,
                      (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale);
   SV_LAUNCH_CHECK();
   return SV_OK;

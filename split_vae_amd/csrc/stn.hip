@@ -13,9 +13,13 @@
 // obj_bbox_mask [B,B',4] = (bty - sy/2, btx - sx/2, bty + sy/2, btx + sx/2), bt = (t + 1)/2, from the NON-inverted values.
 //
 // One thread per output pixel, all C channels (C = 3 image / 4 object channels: the gather is HBM- and latency-bound).
-// Backward: g_img is scatter-added with fp32 atomics (zero it first); g_z_where is reduced per (b, cell) in the workgroup
-// (one workgroup per cell: wave shuffles + LDS, fixed order) -- floor / clip carry no gradient, exactly as tf.floor /
-// tf.clip_by_value at interior points.
+// Backward: g_z_where is reduced per (b, cell) in the workgroup (one workgroup per cell: wave shuffles + LDS, fixed order) --
+// floor / clip carry no gradient, exactly as tf.floor / tf.clip_by_value at interior points.  g_img (optional: the glimpse
+// STN reads the input image, which takes no gradient) is a scatter-add:
+//   inverse form, object <= SV_STN_LDS_FLOATS: every (b, cell) workgroup owns its object's gradient -- accumulated in LDS (ds_add_f32) and
+//     written out once with plain coalesced stores (the buffer need not be zeroed);
+//   otherwise: fp32 atomics into the zeroed global buffer (the 16 cells of an image overlap).
+// Taps with zero weight (the 48x48 canvas pixels outside the pasted 32x32 object: both corners clipped) scatter nothing.
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -56,16 +60,23 @@ __device__ __forceinline__ StnTap stn_tap(float xn, float yn, int H, int W) {
 }
 __device__ __forceinline__ float lin(int i, int n) { return n > 1 ? -1.f + 2.f * (float)i / (float)(n - 1) : -1.f; }   // np.linspace(-1, 1, n)[i]
 
+#define SV_STN_LDS_FLOATS 8192                                     // 32 KB: an object_size 32 rgb+alpha rendering is 4096 floats
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void stn_kernel(const float* __restrict__ img, const float* __restrict__ z_where,
                                                   float* __restrict__ out, float* __restrict__ bbox,
                                                   const float* __restrict__ g_out, float* __restrict__ g_img,
                                                   float* __restrict__ g_z, int Bp, int Hc, int Wc, int H, int W, int C,
-                                                  int Ho, int Wo, int inverse) {
+                                                  int Ho, int Wo, int inverse, int lds_acc) {
+  extern __shared__ float sacc[];                              // BWD, lds_acc: this object's gradient [H*W*C]
   const int cell = blockIdx.x, b = blockIdx.y;                 // one workgroup per (image, cell)
+  if (BWD && lds_acc) {
+    for (int i = threadIdx.x; i < H * W * C; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+  }
   const StnCell c = stn_cell(z_where + ((int64_t)b * Bp + cell) * 4, cell, Hc, Wc, inverse);
   const float* ib = img + ((int64_t)b * (inverse ? Bp : 1) + (inverse ? cell : 0)) * H * W * C;
-  float* gib = BWD ? g_img + ((int64_t)b * (inverse ? Bp : 1) + (inverse ? cell : 0)) * H * W * C : nullptr;
+  float* gib = (BWD && g_img) ? g_img + ((int64_t)b * (inverse ? Bp : 1) + (inverse ? cell : 0)) * H * W * C : nullptr;
   const int64_t ob = ((int64_t)b * Bp + cell) * Ho * Wo * C;
   if (!BWD && bbox && threadIdx.x == 0) {
     float* bb = bbox + ((int64_t)b * Bp + cell) * 4;
@@ -91,14 +102,26 @@ __global__ __launch_bounds__(256) void stn_kernel(const float* __restrict__ img,
         const float Ia = pa[k], Ib = pb[k], Ic = pc[k], Id = pd[k];
         dx += g * (t.wy0 * (Ic - Ia) + t.wy1 * (Id - Ib));
         dy += g * (t.wx0 * (Ib - Ia) + t.wx1 * (Id - Ic));
-        atomicAdd(gib + ((int64_t)t.y0 * W + t.x0) * C + k, g * wa);
-        atomicAdd(gib + ((int64_t)t.y1 * W + t.x0) * C + k, g * wb);
-        atomicAdd(gib + ((int64_t)t.y0 * W + t.x1) * C + k, g * wc);
-        atomicAdd(gib + ((int64_t)t.y1 * W + t.x1) * C + k, g * wd);
+        if (!gib) continue;
+        if (lds_acc) {
+          if (wa != 0.f) atomicAdd(sacc + (t.y0 * W + t.x0) * C + k, g * wa);
+          if (wb != 0.f) atomicAdd(sacc + (t.y1 * W + t.x0) * C + k, g * wb);
+          if (wc != 0.f) atomicAdd(sacc + (t.y0 * W + t.x1) * C + k, g * wc);
+          if (wd != 0.f) atomicAdd(sacc + (t.y1 * W + t.x1) * C + k, g * wd);
+        } else {
+          if (wa != 0.f) atomicAdd(gib + ((int64_t)t.y0 * W + t.x0) * C + k, g * wa);
+          if (wb != 0.f) atomicAdd(gib + ((int64_t)t.y1 * W + t.x0) * C + k, g * wb);
+          if (wc != 0.f) atomicAdd(gib + ((int64_t)t.y0 * W + t.x1) * C + k, g * wc);
+          if (wd != 0.f) atomicAdd(gib + ((int64_t)t.y1 * W + t.x1) * C + k, g * wd);
+        }
       }
       const float dxn = dx * 0.5f * (float)(W - 1), dyn = dy * 0.5f * (float)(H - 1);
       gsx += dxn * gx; gtx += dxn; gsy += dyn * gy; gty += dyn;
     }
+  }
+  if (BWD && lds_acc) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * W * C; i += 256) gib[i] = sacc[i];
   }
   if (BWD) {
     __shared__ float red[4][4];
@@ -140,19 +163,25 @@ extern "C" int sv_stn_sample_fwd(const float* img, const float* z_where, float* 
   const int rc = stn_check(B, Hc, Wc, H, W, C, Ho, Wo);
   if (rc) return rc;
   hipLaunchKernelGGL((stn_kernel<false>), dim3(Hc * Wc, B), dim3(256), 0, (hipStream_t)stream, img, z_where, out, bbox,
-                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, Hc * Wc, Hc, Wc, H, W, C, Ho, Wo, inverse ? 1 : 0);
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr, Hc * Wc, Hc, Wc, H, W, C, Ho, Wo, inverse ? 1 : 0, 0);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_stn_bwd_overwrites(int32_t H, int32_t W, int32_t C, int32_t inverse) {
+  return inverse && (int64_t)H * W * C <= SV_STN_LDS_FLOATS ? 1 : 0;
 }
 
 extern "C" int sv_stn_sample_bwd(const float* img, const float* z_where, const float* g_out, float* g_img, float* g_z_where,
                                  int32_t B, int32_t Hc, int32_t Wc, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                                  int32_t inverse, void* stream) {
-  if (!img || !z_where || !g_out || !g_img || !g_z_where) return SV_E_BADARG;
+  if (!img || !z_where || !g_out || !g_z_where) return SV_E_BADARG;
   const int rc = stn_check(B, Hc, Wc, H, W, C, Ho, Wo);
   if (rc) return rc;
-  hipLaunchKernelGGL((stn_kernel<true>), dim3(Hc * Wc, B), dim3(256), 0, (hipStream_t)stream, img, z_where, (float*)nullptr,
-                     (float*)nullptr, g_out, g_img, g_z_where, Hc * Wc, Hc, Wc, H, W, C, Ho, Wo, inverse ? 1 : 0);
+  const int lds_acc = g_img && sv_stn_bwd_overwrites(H, W, C, inverse);
+  hipLaunchKernelGGL((stn_kernel<true>), dim3(Hc * Wc, B), dim3(256), lds_acc ? (size_t)H * W * C * sizeof(float) : 0, (hipStream_t)stream,
+                     img, z_where, (float*)nullptr, (float*)nullptr, g_out, g_img, g_z_where, Hc * Wc, Hc, Wc, H, W, C, Ho, Wo,
+                     inverse ? 1 : 0, lds_acc);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

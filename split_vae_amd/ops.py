@@ -146,12 +146,15 @@ def stn_sample(img, z_where, Ho, Wo, inverse=False):
     return out, bbox
 
 
-def stn_sample_bwd(img, z_where, g_out, inverse=False):
-    """-> (g_img like img, g_z_where like z_where) for the upstream gradient g_out [B,B',Ho,Wo,C]."""
+def stn_sample_bwd(img, z_where, g_out, inverse=False, need_img=True):
+    """-> (g_img like img | None, g_z_where like z_where) for the upstream gradient g_out [B,B',Ho,Wo,C]."""
     B, Hc, Wc, _ = z_where.shape
     H, W, Cc = img.shape[-3:]
     Ho, Wo = g_out.shape[2:4]
-    g_img = torch.zeros_like(img)
+    lib = _lib.load()
+    g_img = None
+    if need_img:
+        g_img = torch.empty_like(img) if lib.sv_stn_bwd_overwrites(H, W, Cc, 1 if inverse else 0) else torch.zeros_like(img)
     g_z = torch.empty_like(z_where)
     check(_lib.load().sv_stn_sample_bwd(_p(img.contiguous()), _p(z_where.contiguous()), _p(g_out.contiguous()), _p(g_img), _p(g_z), B, Hc,
                                         Wc, H, W, Cc, Ho, Wo, 1 if inverse else 0, _stream()), "sv_stn_sample_bwd")
@@ -196,10 +199,27 @@ def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temper
     return kl, g_pre.reshape(z_pres.shape), g_log.reshape(z_pres.shape)
 
 
+SPAIR_LOSS_MODES = {"xent": 0, "kl": 1, "kl_prior": 2}
+
+
+def spair_loss(mode, a, b, prior_mean=0.0, prior_sig=1.0, grads=True):
+    """Per-image loss sums of spair/trainer.py (xent_loss / kl_divergence / kl_divergence_two_gauss vs a constant prior) over
+    a, b [B, ...] fp32 -> (sums [B], ga | None, gb | None) with the per-element derivatives (xent: gb only)."""
+    B = a.shape[0]
+    n = a[0].numel()
+    a2, b2 = a.reshape(B, n).contiguous(), b.reshape(B, n).contiguous()
+    sums = torch.empty((B,), dtype=torch.float32, device=a.device)
+    ga = torch.empty_like(a2) if grads and mode != "xent" else None
+    gb = torch.empty_like(b2) if grads else None
+    check(_lib.load().sv_spair_loss(SPAIR_LOSS_MODES[mode], _p(a2), _p(b2), _p(sums), _p(ga), _p(gb), B, n, float(prior_mean),
+                                    float(prior_sig), _stream()), "sv_spair_loss")
+    return sums, (None if ga is None else ga.reshape(a.shape)), (None if gb is None else gb.reshape(b.shape))
+
+
 def adam_step_clipnorm(p, g, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
     """Keras Adam(clipnorm=...) over flat buffers; tensor_off: int64 device tensor of n_tensors+1 offsets."""
     nt = tensor_off.numel() - 1
-    ws = torch.empty((32 * nt,), dtype=torch.float32, device=p.device)
+    ws = torch.empty((128 * nt,), dtype=torch.float32, device=p.device)
     check(_lib.load().sv_adam_step_clipnorm(_p(p), _p(g), _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
                                             float(beta1), float(beta2), float(eps), int(t), float(grad_scale), _stream()),
           "sv_adam_step_clipnorm")
@@ -223,12 +243,15 @@ class Conv2D:
         self.nf, self.nd = nf, nd
         self.w_fwd = self.w_dgrad = None
 
-    def prep(self, w_hwio):
+    def prep(self, w_hwio, fwd=True, dgrad=True):
+        """The kernels' weight images from the Keras HWIO kernel (either may be skipped: a forward-only or gradient-only call)."""
         dev = w_hwio.device
-        self.w_fwd = torch.empty((self.nf,), dtype=self.dtype, device=dev)
-        self.w_dgrad = torch.empty((self.nd,), dtype=self.dtype, device=dev)
-        check(_lib.load().sv_conv2d_prep_weights(C.byref(self.desc), _p(w_hwio), _p(self.w_fwd), _p(self.w_dgrad),
-                                                 _stream()), "sv_conv2d_prep_weights")
+        if fwd:
+            self.w_fwd = torch.empty((self.nf,), dtype=self.dtype, device=dev)
+        if dgrad:
+            self.w_dgrad = torch.empty((self.nd,), dtype=self.dtype, device=dev)
+        check(_lib.load().sv_conv2d_prep_weights(C.byref(self.desc), _p(w_hwio), _p(self.w_fwd if fwd else None),
+                                                 _p(self.w_dgrad if dgrad else None), _stream()), "sv_conv2d_prep_weights")
 
     def fwd(self, x, bias, out=None, workspace=True):
         d = self.desc

@@ -18,6 +18,8 @@ TRAIN_METRIC_NAMES = ['x_recon_train_loss', 'z_zoom_kl_train_loss', 'z_what_kl_t
 TEST_METRIC_NAMES = [n.replace('_train_', '_test_') for n in TRAIN_METRIC_NAMES] + ['MAE test', 'MAPE test']   # :128-129
 
 
+# The three reductions below run as one kernel each with their gradients (spair_loss.hip: sv_spair_loss); the elementwise
+# restatements next to them (tf_safe_log, xent_loss) keep the reference's names for callers that want the per-element maps.
 def tf_safe_log(value, replacement_value=-100.0):
     """spair/trainer.py:97-101."""
     lv = torch.log(value + 1e-8)
@@ -38,13 +40,19 @@ def kl_divergence(z_mean, z_sig):
     """:13-21 (rank 2 and rank 4 inputs: sum over all but the batch axis)."""
     if z_mean.dim() not in (2, 4):
         raise NotImplementedError('This KL shape is not implemented')
-    z_log_var = tf_safe_log(z_sig * z_sig)
-    return tf_mean_sum(-0.5 * (1 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)))
+    return T.spair_kl(z_mean.contiguous(), z_sig.contiguous()).mean()
 
 
 def kl_divergence_two_gauss(mean1, sig1, mean2, sig2):
-    """:23-24."""
+    """:23-24.  mean2 / sig2: python scalars (the constant zoom prior of :156-157: one kernel) or tensors (composed)."""
+    if not torch.is_tensor(mean2) and not torch.is_tensor(sig2):
+        return T.spair_kl_prior(mean1.contiguous(), sig1.contiguous(), mean2, sig2).mean()
     return tf_mean_sum(tf_safe_log(sig2) - tf_safe_log(sig1) + (sig1 * sig1 + (mean1 - mean2) ** 2) / (2 * sig2 * sig2) - 0.5)
+
+
+def xent_mean_sum(label, pred):
+    """tf_mean_sum(xent_loss(label, pred)) (:148, :186) as one kernel."""
+    return T.spair_xent(label.contiguous(), pred.contiguous()).mean()
 
 
 def compute_z_pres_kl_yolo_air(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
@@ -88,12 +96,12 @@ def compute_losses(config, images, out, step, training=True):
     o = _unpack(config, out)
     lg = config.model == "lg_spair"
     x = images[..., :3]                                               # :148-151 (spair / bg_spair canvases have 3 channels)
-    x_recon_loss = tf_mean_sum(xent_loss(x, o["x_recon"]))
+    x_recon_loss = xent_mean_sum(x, o["x_recon"])
     anneal = min(1.0, (step + 1) / config.z_pres_anneal_step) if training else 1.0
     z_pres_kl = compute_z_pres_kl_yolo_air(o["z_pres"], o["z_pres_logits"], o["z_pres_pre_sigmoid"], 0.99 * anneal, config.tau)
     zm, zs = o["z_where_mean"], o["z_where_sigma"]
-    zoom_mean = torch.full_like(zm[..., :2], config.prior_z_zoom + (config.prior_z_zoom_start * (1 - anneal) if training else 0.0))
-    zoom_kl = kl_divergence_two_gauss(zm[..., :2], zs[..., :2], zoom_mean, torch.full_like(zs[..., :2], 0.5))
+    zoom_mean = config.prior_z_zoom + (config.prior_z_zoom_start * (1 - anneal) if training else 0.0)       # :156, anneals to prior_z_zoom
+    zoom_kl = kl_divergence_two_gauss(zm[..., :2], zs[..., :2], zoom_mean, 0.5)
     what_kl = kl_divergence(o["z_what_mean"], o["z_what_sigma"])
     where_kl = kl_divergence(zm[..., 2:], zs[..., 2:])
     depth_kl = kl_divergence(o["z_depth_mean"], o["z_depth_sigma"])
@@ -101,7 +109,7 @@ def compute_losses(config, images, out, step, training=True):
     if not training:                                                                               # test_step :262-285
         if lg:
             losses += [kl_divergence(torch.cat([o["z_bg_mean"], o["z_l_mean"]], dim=1), torch.cat([o["z_bg_sig"], o["z_l_sig"]], dim=1)),
-                       kl_divergence(o["z_l_mean"], o["z_l_sig"]), tf_mean_sum(xent_loss(images[..., 3:], o["x_hat_recon"]))]
+                       kl_divergence(o["z_l_mean"], o["z_l_sig"]), xent_mean_sum(images[..., 3:], o["x_hat_recon"])]
         elif config.model == "bg_spair":
             losses += [kl_divergence(o["z_bg_mean"], o["z_bg_sig"]), torch.zeros((), device=x.device), torch.zeros((), device=x.device)]
         return None, losses
@@ -109,7 +117,7 @@ def compute_losses(config, images, out, step, training=True):
     obj = lambda wk: config.z_what_beta * wk + depth_kl + where_kl + zoom_kl + z_pres_kl
     annealed_beta = min(config.beta, config.beta * (step + 1.0) / config.anneal_until)
     if lg:
-        x_hat_recon_loss = tf_mean_sum(xent_loss(images[..., 3:], o["x_hat_recon"]))
+        x_hat_recon_loss = xent_mean_sum(images[..., 3:], o["x_hat_recon"])
         z_l_kl = kl_divergence(o["z_l_mean"], o["z_l_sig"])
         if not config.split_z_l:                                                                   # :176-195
             if config.concat_z_bg:

@@ -31,10 +31,12 @@ _lib_def.define("upsample2x_bwd(Tensor g_hi, Tensor? relu_mask) -> Tensor")
 _lib_def.define("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, int t, float lr, float beta1, float beta2, float eps, float grad_scale) -> ()")
 # SPLIT-SPAIR operators (fp32; spair/utils.py:119-330, spair/spair.py:534-579, spair/trainer.py:28-94)
 _lib_def.define("stn_sample_fwd(Tensor img, Tensor z_where, int Ho, int Wo, bool inverse) -> (Tensor, Tensor)")
-_lib_def.define("stn_sample_bwd(Tensor img, Tensor z_where, Tensor g_out, bool inverse) -> (Tensor, Tensor)")
+_lib_def.define("stn_sample_bwd(Tensor img, Tensor z_where, Tensor g_out, bool inverse, bool need_img) -> (Tensor, Tensor)")
 _lib_def.define("spair_render_fwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor? z_pres, Tensor? z_pres_logits, Tensor? noise, bool training) -> Tensor")
 _lib_def.define("spair_render_bwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor z_pres, Tensor? noise, Tensor g_out) -> (Tensor, Tensor, Tensor, Tensor)")
 _lib_def.define("spair_zpres_kl(Tensor z_pres, Tensor z_pres_logits, Tensor z_pres_pre_sigmoid, float prior_prob, float temperature) -> (Tensor, Tensor, Tensor)")
+
+_lib_def.define("spair_loss(str mode, Tensor a, Tensor b, float prior_mean, float prior_sig) -> (Tensor, Tensor, Tensor)")
 
 ACT = {None: 0, "none": 0, "relu": 1}
 
@@ -64,7 +66,7 @@ def _conv_fwd(x, w_hwio, bias, stride, act, ups_in, y_f32):
     w_hwio [KH,KW,Cin,Cout] fp32 Keras layout -> y [B,OH,OW,ldy] (ldy = Cout rounded up to 8, or Cout fp32 when y_f32)."""
     KH, KW, Cin, Cout = w_hwio.shape
     c = _conv(x, Cin, Cout, KH, stride, act, ups_in, y_f32)
-    c.prep(w_hwio.contiguous())
+    c.prep(w_hwio.contiguous(), dgrad=False)
     if bias is None:
         bias = torch.zeros((Cout,), dtype=torch.float32, device=x.device)
     return c.fwd(x.contiguous(), bias.contiguous())
@@ -75,7 +77,7 @@ def _conv_dgrad(dy, w_hwio, relu_mask, H, W, ldx, stride, ups_in):
     """dL/dx of the conv for x [B,H,W,ldx] (H, W: the conv's logical input size, i.e. hi-res when ups_in)."""
     KH, KW, Cin, Cout = w_hwio.shape
     c = _conv(dy, Cin, Cout, KH, stride, 0, ups_in, False, H=H, W=W)
-    c.prep(w_hwio.contiguous())
+    c.prep(w_hwio.contiguous(), fwd=False)
     return c.dgrad(dy.contiguous(), relu_mask)
 
 
@@ -242,8 +244,9 @@ def _stn_fwd(img, z_where, Ho, Wo, inverse):
 
 
 @_impl("stn_sample_bwd")
-def _stn_bwd(img, z_where, g_out, inverse):
-    return ops.stn_sample_bwd(img, z_where, g_out, inverse=inverse)
+def _stn_bwd(img, z_where, g_out, inverse, need_img):
+    g_img, g_z = ops.stn_sample_bwd(img, z_where, g_out, inverse=inverse, need_img=need_img)
+    return (g_img if need_img else img.new_empty((0,))), g_z
 
 
 @_impl("spair_render_fwd")
@@ -273,8 +276,9 @@ class _StnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_bbox):
         img, z_where = ctx.saved_tensors
-        g_img, g_z = torch.ops.split_vae.stn_sample_bwd(img, z_where, g_out.contiguous(), ctx.inverse)
-        return g_img, g_z, None, None, None
+        need_img = ctx.needs_input_grad[0]                   # the glimpse STN reads the input image: no gradient, no scatter
+        g_img, g_z = torch.ops.split_vae.stn_sample_bwd(img, z_where, g_out.contiguous(), ctx.inverse, need_img)
+        return (g_img if need_img else None), g_z, None, None, None
 
 
 def stn_sample(img, z_where, Ho, Wo, inverse=False):
@@ -321,3 +325,39 @@ def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temper
     """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94) as per-image sums kl [B] (tf_mean_sum = kl.mean()); differentiable
     in the logits and the pre-sigmoid sample."""
     return _ZpresKlFn.apply(z_pres, z_pres_logits, z_pres_pre_sigmoid, float(prior_prob), float(temperature))
+
+
+@_impl("spair_loss")
+def _spair_loss(mode, a, b, prior_mean, prior_sig):
+    sums, ga, gb = ops.spair_loss(mode, a, b, prior_mean, prior_sig)
+    return sums, (ga if ga is not None else a.new_empty((0,))), gb
+
+
+class _SpairLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mode, a, b, prior_mean, prior_sig):
+        sums, ga, gb = torch.ops.split_vae.spair_loss(mode, a, b, prior_mean, prior_sig)
+        ctx.save_for_backward(ga, gb)
+        ctx.has_ga = mode != "xent"
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        ga, gb = ctx.saved_tensors
+        w = g_sums.view(-1, *([1] * (gb.dim() - 1)))
+        return None, (ga * w if ctx.has_ga and ctx.needs_input_grad[1] else None), gb * w, None, None
+
+
+def spair_xent(label, pred):
+    """Per-image sums of xent_loss (spair/trainer.py:103-104) [B]; differentiable in pred."""
+    return _SpairLossFn.apply("xent", label, pred, 0.0, 1.0)
+
+
+def spair_kl(z_mean, z_sig):
+    """Per-image sums of kl_divergence's integrand (spair/trainer.py:13-21) [B]; differentiable in both."""
+    return _SpairLossFn.apply("kl", z_mean, z_sig, 0.0, 1.0)
+
+
+def spair_kl_prior(mean, sig, prior_mean, prior_sig):
+    """Per-image sums of kl_divergence_two_gauss (spair/trainer.py:23-24) against the constant prior N(prior_mean, prior_sig)."""
+    return _SpairLossFn.apply("kl_prior", mean, sig, float(prior_mean), float(prior_sig))

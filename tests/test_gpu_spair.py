@@ -264,3 +264,38 @@ def test_odd_kernel_stride_2_layers(ops, H, Cin, Cout, dtype, rtol):
     dx = conv.dgrad(dyg)
     torch.testing.assert_close(dx[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=rtol * float(xr.grad.abs().max()))
     assert float(dx[..., Cin:].abs().max()) == 0.0 if Cin % 8 else True
+
+
+@pytest.mark.parametrize("mode", ["xent", "kl", "kl_prior"])
+def test_loss_reductions_and_their_gradients(ops, mode):
+    """sv_spair_loss: xent_loss / kl_divergence / kl_divergence_two_gauss (spair/trainer.py:13-24, :103-109) as per-image sums with
+    gradients, against autograd of the fp64 restatement -- including predictions at exactly 0 and 1 (tf_safe_log's 1e-8)."""
+    from oracle import spair_model_ref as R
+    g = torch.Generator().manual_seed(4)
+    B, shape = 5, (6, 7, 3)
+    if mode == "xent":
+        a = torch.rand(B, *shape, generator=g)
+        b = torch.rand(B, *shape, generator=g)
+        b.view(-1)[:4] = torch.tensor([0.0, 1.0, 1e-9, 1 - 1e-7])
+        f = lambda x, y: R.xent_loss(x, y)
+    elif mode == "kl":
+        a = torch.randn(B, *shape, generator=g)
+        b = torch.nn.functional.softplus(torch.randn(B, *shape, generator=g))
+        f = lambda x, y: -0.5 * (1 + spair_ref.tf_safe_log(y * y) - x * x - torch.exp(spair_ref.tf_safe_log(y * y)))
+    else:
+        a = torch.randn(B, *shape, generator=g)
+        b = torch.nn.functional.softplus(torch.randn(B, *shape, generator=g) - 1.0)
+        pm, ps = 3.7, 0.5
+        f = lambda x, y: (spair_ref.tf_safe_log(torch.full_like(y, ps)) - spair_ref.tf_safe_log(y) + (y * y + (x - pm) ** 2) / (2 * ps * ps) - 0.5)
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    t = f(ar, br).reshape(B, -1).sum(dim=1)
+    w = torch.rand(B, generator=g).double()
+    (t * w).sum().backward()
+    sums, ga, gb = ops.spair_loss(mode, a.cuda(), b.cuda(), *((pm, ps) if mode == "kl_prior" else ()))
+    torch.testing.assert_close(sums.double().cpu(), t.detach(), rtol=2e-5, atol=1e-4)
+    wv = w.view(B, 1, 1, 1)
+    torch.testing.assert_close(gb.double().cpu() * wv, br.grad, rtol=2e-5, atol=1e-5 * float(br.grad.abs().max()))
+    if mode == "xent":
+        assert ga is None
+    else:
+        torch.testing.assert_close(ga.double().cpu() * wv, ar.grad, rtol=2e-5, atol=1e-5 * float(ar.grad.abs().max()))
