@@ -84,6 +84,13 @@ int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const in
                           float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
                           float grad_scale, void* stream);
 
+/* hipGraph-replay form: the step size alpha = lr*sqrt(1-b2^t)/(1-b1^t) is read from DEVICE memory (alpha_dev, one float the
+ * caller refreshes before each replay with sv_adam_alpha(lr, beta1, beta2, t)); alpha_dev == NULL = the call above. */
+int sv_adam_step_clipnorm_dyn(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
+                              float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
+                              const float* alpha_dev, float grad_scale, void* stream);
+float sv_adam_alpha(float lr, float beta1, float beta2, int64_t t);
+
 /* ---------------------------------------------------------------- K10a: bilinear 2x
  * Replaces tf.image.resize(x,[2H,2W]) (vae/model.py:163,:165,:167; bilinear, half-pixel centres,
  * edge clamp) and its adjoint (ResizeBilinearGrad) fused with the ReLU mask of the producer. */
@@ -127,6 +134,12 @@ int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const flo
                       float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob, float temperature,
                       float grad_scale, void* stream);
 
+/* hipGraph-replay form: prior_prob_dev (may be NULL) = one DEVICE float that overrides prior_prob (the prior anneals with the
+ * step, spair/trainer.py:153). */
+int sv_spair_zpres_kl_dyn(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
+                          float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob,
+                          const float* prior_prob_dev, float temperature, float grad_scale, void* stream);
+
 /* SPLIT-SPAIR: the per-image loss sums of spair/trainer.py with their gradients, fp32, one launch each (spair_loss.hip):
  *   mode 0: xent_loss :103-104, a = label, b = prediction;  mode 1: kl_divergence :13-21, a = z_mean, b = z_sig;
  *   mode 2: kl_divergence_two_gauss :23-24 against the constant prior N(prior_mean, prior_sig) (:156-157), a = mean, b = sig.
@@ -134,6 +147,10 @@ int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const flo
  * (mode 0: ga is ignored).  tf_safe_log :97-101 semantics (log(v + 1e-8); NaN / inf -> -100, no gradient). */
 int sv_spair_loss(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
                   float prior_mean, float prior_sig, void* stream);
+/* hipGraph-replay form: prior_mean_dev (may be NULL) = one DEVICE float that overrides prior_mean (mode 2: the zoom prior
+ * anneals with the step, spair/trainer.py:156). */
+int sv_spair_loss_dyn(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
+                      float prior_mean, const float* prior_mean_dev, float prior_sig, void* stream);
 
 /* ---------------------------------------------------------------- K3-K10: NHWC conv (implicit GEMM on MFMA)
  * Replaces tf.keras.layers.Conv2D(padding='same') forward (vae/model.py:36-38,:153-156) and the

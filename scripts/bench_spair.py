@@ -25,15 +25,17 @@ def run(name, kw, B, steps=30, warmup=5):
     x, _ = spair_main.synthetic_canvases(B, seed=1)
     images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x) if cfg.model == "lg_spair" else x
     opt = spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0)
+    graphed = not os.environ.get("SPAIR_EAGER")
+    step_fn = spair_trainer.GraphedTrainStep(model, opt, cfg, images) if graphed else (lambda im, st: spair_trainer.train_step(model, im, opt, st, cfg))
     for i in range(warmup):
-        spair_trainer.train_step(model, images, opt, i, cfg)
+        step_fn(images, i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        spair_trainer.train_step(model, images, opt, warmup + i, cfg)
+        step_fn(images, warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"what": "SPAIR train step (fwd+losses+bwd+clipnorm Adam)", "model": name, "device": "MI355X", "dtype": "f32", "batch": B,
+    print(json.dumps({"what": "SPAIR train step (fwd+losses+bwd+clipnorm Adam)", "launch": "hipGraph replay" if graphed else "eager", "model": name, "device": "MI355X", "dtype": "f32", "batch": B,
                       "params": model.count_params(), "images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}), flush=True)
 
 

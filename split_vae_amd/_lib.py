@@ -81,6 +81,11 @@ SYMBOLS = {
     "sv_upsample2x_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_upsample2x_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_stn_sample_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_spair_loss_dyn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp, C.c_float, _vp]),
+    "sv_spair_zpres_kl_dyn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp, C.c_float, C.c_float, _vp]),
+    "sv_adam_step_clipnorm_dyn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            _i64, _vp, C.c_float, _vp]),
+    "sv_adam_alpha": (C.c_float, [C.c_float, C.c_float, C.c_float, _i64]),
     "sv_spair_loss": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sv_stn_bwd_overwrites": (C.c_int, [_i32, _i32, _i32, _i32]),
     "sv_stn_sample_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

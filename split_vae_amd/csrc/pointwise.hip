@@ -496,8 +496,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, const int64_t* __restrict__ off,
                                                         const float* __restrict__ parts, float clipnorm, float alpha,
-                                                        float omb1, float omb2, float eps, float gscale) {
+                                                        float omb1, float omb2, float eps, float gscale,
+                                                        const float* __restrict__ alpha_dev) {
   const int t = blockIdx.y;
+  if (alpha_dev) alpha = *alpha_dev;                           // hipGraph replay: the bias-corrected step size of iteration t
   float ss = 0.f;
   for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];
   const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
@@ -512,16 +514,24 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
   }
 }
 
+extern "C" float sv_adam_alpha(float lr, float beta1, float beta2, int64_t t) { return (float)svk_adam_alpha(lr, beta1, beta2, t); }
+
 extern "C" int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
                                      float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
                                      float grad_scale, void* stream) {
+  return sv_adam_step_clipnorm_dyn(p, g, m, v, tensor_off, n_tensors, norm_ws, clipnorm, lr, beta1, beta2, eps, t, nullptr, grad_scale, stream);
+}
+
+extern "C" int sv_adam_step_clipnorm_dyn(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
+                                         float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
+                                         const float* alpha_dev, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || !tensor_off || !norm_ws || n_tensors < 1 || t <= 0 || !(clipnorm > 0.f)) return SV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const double alpha = svk_adam_alpha(lr, beta1, beta2, t);
   hipLaunchKernelGGL(sumsq_kernel, dim3(SV_CLIP_PARTS, n_tensors), dim3(256), 0, st, g, tensor_off, norm_ws, grad_scale);
   SV_LAUNCH_CHECK();
   hipLaunchKernelGGL(adam_clip_kernel, dim3(256, n_tensors), dim3(256), 0, st, p, g, m, v, tensor_off, norm_ws, clipnorm,
-                     (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale);
+                     (float)alpha, 1.f - beta1, 1.f - beta2, eps, grad_scale, alpha_dev);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -21,8 +21,10 @@ __device__ __forceinline__ float safe_log(float v, bool& ok) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void spair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ sums,
-                                                         float* __restrict__ ga, float* __restrict__ gb, int n, float m2, float s2) {
+                                                         float* __restrict__ ga, float* __restrict__ gb, int n, float m2, float s2,
+                                                         const float* __restrict__ m2_dev) {
   const int64_t base = (int64_t)blockIdx.x * n;
+  if (MODE == 2 && m2_dev) m2 = *m2_dev;                       // hipGraph replay: the annealed prior mean lives in device memory
   bool ok2;
   const float ls2 = MODE == 2 ? safe_log(s2, ok2) : 0.f, inv2 = MODE == 2 ? 1.0f / (2.0f * s2 * s2) : 0.f;
   float acc = 0.f;
@@ -59,14 +61,19 @@ __global__ __launch_bounds__(256) void spair_loss_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int sv_spair_loss(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
-                             float prior_mean, float prior_sig, void* stream) {
+extern "C" int sv_spair_loss_dyn(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
+                                 float prior_mean, const float* prior_mean_dev, float prior_sig, void* stream) {
   if (!a || !b || !sums || B < 1 || n < 1 || mode < 0 || mode > 2) return SV_E_BADARG;
   if (mode == 2 && !(prior_sig > 0.f)) return SV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 0) hipLaunchKernelGGL((spair_loss_kernel<0>), dim3(B), dim3(256), 0, st, a, b, sums, (float*)nullptr, gb, n, 0.f, 1.f);
-  else if (mode == 1) hipLaunchKernelGGL((spair_loss_kernel<1>), dim3(B), dim3(256), 0, st, a, b, sums, ga, gb, n, 0.f, 1.f);
-  else hipLaunchKernelGGL((spair_loss_kernel<2>), dim3(B), dim3(256), 0, st, a, b, sums, ga, gb, n, prior_mean, prior_sig);
+  if (mode == 0) hipLaunchKernelGGL((spair_loss_kernel<0>), dim3(B), dim3(256), 0, st, a, b, sums, (float*)nullptr, gb, n, 0.f, 1.f, (const float*)nullptr);
+  else if (mode == 1) hipLaunchKernelGGL((spair_loss_kernel<1>), dim3(B), dim3(256), 0, st, a, b, sums, ga, gb, n, 0.f, 1.f, (const float*)nullptr);
+  else hipLaunchKernelGGL((spair_loss_kernel<2>), dim3(B), dim3(256), 0, st, a, b, sums, ga, gb, n, prior_mean, prior_sig, prior_mean_dev);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+
+extern "C" int sv_spair_loss(int32_t mode, const float* a, const float* b, float* sums, float* ga, float* gb, int32_t B, int32_t n,
+                             float prior_mean, float prior_sig, void* stream) {
+  return sv_spair_loss_dyn(mode, a, b, sums, ga, gb, B, n, prior_mean, nullptr, prior_sig, stream);
 }

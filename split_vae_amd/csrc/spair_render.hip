@@ -151,9 +151,10 @@ __device__ __forceinline__ float safe_log(float v) {       // tf_safe_log (:97-1
 __global__ __launch_bounds__(64) void zpres_kl_kernel(const float* __restrict__ z_pres, const float* __restrict__ logits,
                                                       const float* __restrict__ pre, float* __restrict__ kl,
                                                       float* __restrict__ g_pre, float* __restrict__ g_logits, int B, int n,
-                                                      float prior_prob, float T, float gscale) {
+                                                      float prior_prob, float T, float gscale, const float* __restrict__ prior_dev) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
+  if (prior_dev) prior_prob = *prior_dev;                      // hipGraph replay: the annealed prior lives in device memory
   float dist[MAXBP + 1];
   const float cpp = 1.f - prior_prob;
   float norm = 0.f;
@@ -197,12 +198,19 @@ __global__ __launch_bounds__(64) void zpres_kl_kernel(const float* __restrict__ 
 }
 }  // namespace
 
+extern "C" int sv_spair_zpres_kl_dyn(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
+                                     float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob,
+                                     const float* prior_prob_dev, float temperature, float grad_scale, void* stream) {
+  if (!z_pres || !z_pres_logits || !z_pres_pre_sigmoid || !kl || B < 1 || n_cells < 1 || n_cells > MAXBP) return SV_E_BADARG;
+  hipLaunchKernelGGL(zpres_kl_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, z_pres, z_pres_logits,
+                     z_pres_pre_sigmoid, kl, g_pre_sigmoid, g_logits, B, n_cells, prior_prob, temperature, grad_scale, prior_prob_dev);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_spair_zpres_kl(const float* z_pres, const float* z_pres_logits, const float* z_pres_pre_sigmoid, float* kl,
                                  float* g_pre_sigmoid, float* g_logits, int32_t B, int32_t n_cells, float prior_prob,
                                  float temperature, float grad_scale, void* stream) {
-  if (!z_pres || !z_pres_logits || !z_pres_pre_sigmoid || !kl || B < 1 || n_cells < 1 || n_cells > MAXBP) return SV_E_BADARG;
-  hipLaunchKernelGGL(zpres_kl_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, z_pres, z_pres_logits,
-                     z_pres_pre_sigmoid, kl, g_pre_sigmoid, g_logits, B, n_cells, prior_prob, temperature, grad_scale);
-  SV_LAUNCH_CHECK();
-  return SV_OK;
+  return sv_spair_zpres_kl_dyn(z_pres, z_pres_logits, z_pres_pre_sigmoid, kl, g_pre_sigmoid, g_logits, B, n_cells, prior_prob, nullptr,
+                               temperature, grad_scale, stream);
 }

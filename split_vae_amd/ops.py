@@ -185,6 +185,15 @@ def spair_render_bwd(obj, bg, z_depth, z_pres, g_out, noise=None):
     return g_obj, g_bg, g_zp, g_zd
 
 
+def _dev_scalar(v):
+    """(python float, device pointer | None): a scalar given as a 1-element fp32 device tensor is read by the kernel at run
+    time (hipGraph replays see its current value)."""
+    if torch.is_tensor(v):
+        assert v.dtype == torch.float32 and v.numel() == 1 and v.is_cuda
+        return 0.0, v
+    return float(v), None
+
+
 def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature, grad_scale=None):
     """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94): inputs [B,H,W,1] -> (kl [B] per-image sums, g_pre_sigmoid, g_logits)
     with the gradients of mean_b(kl_b) (grad_scale = 1/B) unless grad_scale is given."""
@@ -193,9 +202,10 @@ def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temper
     f = lambda t: t.reshape(B, n).contiguous()
     kl = torch.empty((B,), dtype=torch.float32, device=z_pres.device)
     g_pre, g_log = torch.empty((B, n), dtype=torch.float32, device=z_pres.device), torch.empty((B, n), dtype=torch.float32, device=z_pres.device)
-    check(_lib.load().sv_spair_zpres_kl(_p(f(z_pres)), _p(f(z_pres_logits)), _p(f(z_pres_pre_sigmoid)), _p(kl), _p(g_pre), _p(g_log), B, n,
-                                        float(prior_prob), float(temperature), 1.0 / B if grad_scale is None else float(grad_scale),
-                                        _stream()), "sv_spair_zpres_kl")
+    pp, pp_dev = _dev_scalar(prior_prob)
+    check(_lib.load().sv_spair_zpres_kl_dyn(_p(f(z_pres)), _p(f(z_pres_logits)), _p(f(z_pres_pre_sigmoid)), _p(kl), _p(g_pre), _p(g_log), B, n,
+                                            pp, _p(pp_dev), float(temperature), 1.0 / B if grad_scale is None else float(grad_scale),
+                                            _stream()), "sv_spair_zpres_kl")
     return kl, g_pre.reshape(z_pres.shape), g_log.reshape(z_pres.shape)
 
 
@@ -211,18 +221,25 @@ def spair_loss(mode, a, b, prior_mean=0.0, prior_sig=1.0, grads=True):
     sums = torch.empty((B,), dtype=torch.float32, device=a.device)
     ga = torch.empty_like(a2) if grads and mode != "xent" else None
     gb = torch.empty_like(b2) if grads else None
-    check(_lib.load().sv_spair_loss(SPAIR_LOSS_MODES[mode], _p(a2), _p(b2), _p(sums), _p(ga), _p(gb), B, n, float(prior_mean),
-                                    float(prior_sig), _stream()), "sv_spair_loss")
+    pm, pm_dev = _dev_scalar(prior_mean)
+    check(_lib.load().sv_spair_loss_dyn(SPAIR_LOSS_MODES[mode], _p(a2), _p(b2), _p(sums), _p(ga), _p(gb), B, n, pm, _p(pm_dev),
+                                        float(prior_sig), _stream()), "sv_spair_loss")
     return sums, (None if ga is None else ga.reshape(a.shape)), (None if gb is None else gb.reshape(b.shape))
 
 
-def adam_step_clipnorm(p, g, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-    """Keras Adam(clipnorm=...) over flat buffers; tensor_off: int64 device tensor of n_tensors+1 offsets."""
+def adam_alpha(lr, beta1, beta2, t):
+    """Keras Adam's bias-corrected step size of iteration t (what sv_adam_step* computes from lr and t)."""
+    return float(_lib.load().sv_adam_alpha(float(lr), float(beta1), float(beta2), int(t)))
+
+
+def adam_step_clipnorm(p, g, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, alpha_dev=None):
+    """Keras Adam(clipnorm=...) over flat buffers; tensor_off: int64 device tensor of n_tensors+1 offsets.  alpha_dev: a
+    1-element device tensor holding adam_alpha(lr, beta1, beta2, t) -- read at run time instead of (lr, t) (hipGraph replay)."""
     nt = tensor_off.numel() - 1
     ws = torch.empty((128 * nt,), dtype=torch.float32, device=p.device)
-    check(_lib.load().sv_adam_step_clipnorm(_p(p), _p(g), _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
-                                            float(beta1), float(beta2), float(eps), int(t), float(grad_scale), _stream()),
-          "sv_adam_step_clipnorm")
+    check(_lib.load().sv_adam_step_clipnorm_dyn(_p(p), _p(g), _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
+                                                float(beta1), float(beta2), float(eps), int(t), _p(alpha_dev), float(grad_scale),
+                                                _stream()), "sv_adam_step_clipnorm")
 
 
 # ------------------------------------------------------------------ K3-K10 conv (vae/model.py:36-38,:153-156)

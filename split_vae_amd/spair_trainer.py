@@ -44,8 +44,9 @@ def kl_divergence(z_mean, z_sig):
 
 
 def kl_divergence_two_gauss(mean1, sig1, mean2, sig2):
-    """:23-24.  mean2 / sig2: python scalars (the constant zoom prior of :156-157: one kernel) or tensors (composed)."""
-    if not torch.is_tensor(mean2) and not torch.is_tensor(sig2):
+    """:23-24.  mean2: a python scalar or a 1-element device tensor, sig2: a python scalar (the constant zoom prior of
+    :156-157: one kernel); full tensors take the composed expression."""
+    if (not torch.is_tensor(mean2) or mean2.numel() == 1) and not torch.is_tensor(sig2):
         return T.spair_kl_prior(mean1.contiguous(), sig1.contiguous(), mean2, sig2).mean()
     return tf_mean_sum(tf_safe_log(sig2) - tf_safe_log(sig1) + (sig1 * sig1 + (mean1 - mean2) ** 2) / (2 * sig2 * sig2) - 0.5)
 
@@ -69,15 +70,21 @@ class ClipnormAdam:
         self.iterations = 0
         self._slots = None
 
-    def apply_gradients(self, model, grads):
+    def alpha(self, t):
+        return ops.adam_alpha(self.learning_rate, self.beta_1, self.beta_2, t)
+
+    def apply_gradients(self, model, grads, alpha_dev=None):
+        """alpha_dev: 1-element device tensor with alpha(iterations + 1) -- the captured (hipGraph) step reads the step size from it
+        and the caller advances `iterations` per replay."""
         st = model.store
         if self._slots is None:
             self._slots = (torch.zeros_like(st.flat), torch.zeros_like(st.flat), torch.empty_like(st.flat))
         m, v, g = self._slots
         torch.cat([x.reshape(-1) for x in grads], out=g)
-        self.iterations += 1
-        ops.adam_step_clipnorm(st.flat, g, m, v, st.tensor_off, self.clipnorm, self.iterations, float(self.learning_rate),
-                               self.beta_1, self.beta_2, self.epsilon)
+        if alpha_dev is None:
+            self.iterations += 1
+        ops.adam_step_clipnorm(st.flat, g, m, v, st.tensor_off, self.clipnorm, max(self.iterations, 1), float(self.learning_rate),
+                               self.beta_1, self.beta_2, self.epsilon, alpha_dev=alpha_dev)
 
 
 def _unpack(config, out):
@@ -91,17 +98,26 @@ def _unpack(config, out):
     return dict(zip(names, out))
 
 
-def compute_losses(config, images, out, step, training=True):
-    """The loss assembly of train_step (:142-228; training=True) or test_step (:243-293) -> (total_loss | None, [losses])."""
+def step_scalars(config, step, training=True):
+    """The step-dependent constants of train_step (:153, :156, :165-167): prior_z_pres_prob, the zoom prior's mean and the
+    annealed beta of the spair / bg_spair objectives; test_step (:247-250) uses their final values."""
+    anneal = min(1.0, (step + 1) / config.z_pres_anneal_step) if training else 1.0
+    return {"prior_prob": 0.99 * anneal,
+            "zoom_mean": config.prior_z_zoom + (config.prior_z_zoom_start * (1 - anneal) if training else 0.0),
+            "annealed_beta": min(config.beta, config.beta * (step + 1.0) / config.anneal_until)}
+
+
+def compute_losses(config, images, out, step, training=True, dyn=None):
+    """The loss assembly of train_step (:142-228; training=True) or test_step (:243-293) -> (total_loss | None, [losses]).
+    dyn: step_scalars as 1-element device tensors (the captured step reads them at replay time) instead of `step`."""
     o = _unpack(config, out)
     lg = config.model == "lg_spair"
+    sc = dyn if dyn is not None else step_scalars(config, step, training)
     x = images[..., :3]                                               # :148-151 (spair / bg_spair canvases have 3 channels)
     x_recon_loss = xent_mean_sum(x, o["x_recon"])
-    anneal = min(1.0, (step + 1) / config.z_pres_anneal_step) if training else 1.0
-    z_pres_kl = compute_z_pres_kl_yolo_air(o["z_pres"], o["z_pres_logits"], o["z_pres_pre_sigmoid"], 0.99 * anneal, config.tau)
+    z_pres_kl = compute_z_pres_kl_yolo_air(o["z_pres"], o["z_pres_logits"], o["z_pres_pre_sigmoid"], sc["prior_prob"], config.tau)
     zm, zs = o["z_where_mean"], o["z_where_sigma"]
-    zoom_mean = config.prior_z_zoom + (config.prior_z_zoom_start * (1 - anneal) if training else 0.0)       # :156, anneals to prior_z_zoom
-    zoom_kl = kl_divergence_two_gauss(zm[..., :2], zs[..., :2], zoom_mean, 0.5)
+    zoom_kl = kl_divergence_two_gauss(zm[..., :2], zs[..., :2], sc["zoom_mean"], 0.5)
     what_kl = kl_divergence(o["z_what_mean"], o["z_what_sigma"])
     where_kl = kl_divergence(zm[..., 2:], zs[..., 2:])
     depth_kl = kl_divergence(o["z_depth_mean"], o["z_depth_sigma"])
@@ -115,7 +131,9 @@ def compute_losses(config, images, out, step, training=True):
         return None, losses
     rw = config.reconstruction_weight
     obj = lambda wk: config.z_what_beta * wk + depth_kl + where_kl + zoom_kl + z_pres_kl
-    annealed_beta = min(config.beta, config.beta * (step + 1.0) / config.anneal_until)
+    annealed_beta = sc["annealed_beta"]
+    if torch.is_tensor(annealed_beta):
+        annealed_beta = annealed_beta.reshape(())
     if lg:
         x_hat_recon_loss = xent_mean_sum(images[..., 3:], o["x_hat_recon"])
         z_l_kl = kl_divergence(o["z_l_mean"], o["z_l_sig"])
@@ -155,6 +173,61 @@ def train_step(model, images, optimizer, step, config, noise=None, return_grads=
     return (res, [l.detach() for l in losses], total_loss.detach(), grads) if return_grads else (res, [l.detach() for l in losses])
 
 
+class GraphedTrainStep:
+    """train_step captured once into a hipGraph (torch.cuda.graph over the same operators) and replayed: the ~700 launches of a
+    step cost one graph launch on the host.  The step-dependent scalars (step_scalars, Adam's step size) live in a 4-float
+    device buffer refreshed before every replay; the batch is copied into a static buffer; the random draws come from torch's
+    default device generator (graph-safe).  Returns the static output tensors of the captured step (overwritten by the next
+    replay: clone what must be kept)."""
+
+    def __init__(self, model, optimizer, config, images_like, warmup=3, noise=None):
+        self.model, self.optimizer, self.config, self.noise = model, optimizer, config, noise      # noise: pinned draws (tests)
+        self.images = torch.empty_like(images_like)
+        self.images.copy_(images_like)
+        self.dyn = torch.zeros((4,), dtype=torch.float32, device=images_like.device)
+        self._views = {"prior_prob": self.dyn[0:1], "zoom_mean": self.dyn[1:2], "annealed_beta": self.dyn[2:3]}
+        model.generator = None                                            # default generator: its Philox offset advances per replay
+        self._stage(0)
+        st = model.store
+        saved = st.flat.clone()                                           # the warm-up steps are real steps: undone below
+        saved_mv = [t.clone() for t in optimizer._slots[:2]] if optimizer._slots is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                     # allocator / lazy-init warm-up off the capture stream
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        st.flat.copy_(saved)
+        for i, t in enumerate(optimizer._slots[:2]):
+            t.copy_(saved_mv[i]) if saved_mv is not None else t.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs, self.losses, self.total = self._body()
+
+    def _stage(self, step):
+        sc = step_scalars(self.config, float(step), True)
+        self.dyn.copy_(torch.tensor([sc["prior_prob"], sc["zoom_mean"], sc["annealed_beta"],
+                                     self.optimizer.alpha(self.optimizer.iterations + 1)], dtype=torch.float32), non_blocking=True)
+
+    def _body(self):
+        out = self.model(self.images, training=True, noise=self.noise)
+        total, losses = compute_losses(self.config, self.images, out, 0.0, training=True, dyn=self._views)
+        variables = [v for _, v in self.model.trainable_variables]
+        grads = torch.autograd.grad(total, variables, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, variables)]
+        self.optimizer.apply_gradients(self.model, grads, alpha_dev=self.dyn[3:4])
+        o = tuple(t.detach() for t in out)
+        return o[:17] + o[18:], [l.detach() for l in losses], total.detach()
+
+    def __call__(self, images, step):
+        self.images.copy_(images, non_blocking=True)
+        self._stage(step)
+        self.graph.replay()
+        self.optimizer.iterations += 1
+        return self.outputs, self.losses
+
+
 @torch.no_grad()
 def test_step(model, images, config, labels=None, noise=None):
     """spair/trainer.py:236-308 (the reference evaluates with model(images, training=True) too)."""
@@ -174,8 +247,14 @@ def train_spair(model, optimizer, dataset, train_dataset, test_dataset, config, 
     start = time.time()
     history = []
     every = int(config.log_every or 1000)
+    graphed = None
     for step, images in enumerate(train_dataset):
-        _, losses = train_step(model, images, optimizer, step, config)
+        if config.graph:                                                  # one hipGraph replay per step (GraphedTrainStep)
+            if graphed is None:
+                graphed = GraphedTrainStep(model, optimizer, config, images)
+            _, losses = graphed(images, step)
+        else:
+            _, losses = train_step(model, images, optimizer, step, config)
         vals = torch.stack([l.float() for l in losses])
         sums = vals if sums is None else sums + vals
         n += 1

@@ -34,9 +34,9 @@ _lib_def.define("stn_sample_fwd(Tensor img, Tensor z_where, int Ho, int Wo, bool
 _lib_def.define("stn_sample_bwd(Tensor img, Tensor z_where, Tensor g_out, bool inverse, bool need_img) -> (Tensor, Tensor)")
 _lib_def.define("spair_render_fwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor? z_pres, Tensor? z_pres_logits, Tensor? noise, bool training) -> Tensor")
 _lib_def.define("spair_render_bwd(Tensor obj, Tensor bg, Tensor z_depth, Tensor z_pres, Tensor? noise, Tensor g_out) -> (Tensor, Tensor, Tensor, Tensor)")
-_lib_def.define("spair_zpres_kl(Tensor z_pres, Tensor z_pres_logits, Tensor z_pres_pre_sigmoid, float prior_prob, float temperature) -> (Tensor, Tensor, Tensor)")
+_lib_def.define("spair_zpres_kl(Tensor z_pres, Tensor z_pres_logits, Tensor z_pres_pre_sigmoid, float prior_prob, float temperature, Tensor? prior_prob_dev=None) -> (Tensor, Tensor, Tensor)")
 
-_lib_def.define("spair_loss(str mode, Tensor a, Tensor b, float prior_mean, float prior_sig) -> (Tensor, Tensor, Tensor)")
+_lib_def.define("spair_loss(str mode, Tensor a, Tensor b, float prior_mean, float prior_sig, Tensor? prior_mean_dev=None) -> (Tensor, Tensor, Tensor)")
 
 ACT = {None: 0, "none": 0, "relu": 1}
 
@@ -260,8 +260,9 @@ def _render_bwd(obj, bg, z_depth, z_pres, noise, g_out):
 
 
 @_impl("spair_zpres_kl")
-def _zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
-    return ops.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature, grad_scale=1.0)
+def _zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature, prior_prob_dev=None):
+    return ops.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob if prior_prob_dev is None else prior_prob_dev,
+                              temperature, grad_scale=1.0)
 
 
 class _StnFn(torch.autograd.Function):
@@ -310,7 +311,9 @@ def spair_render(obj, bg, z_depth, z_pres, noise=None):
 class _ZpresKlFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
-        kl, g_pre, g_log = torch.ops.split_vae.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature)
+        dev = prior_prob if torch.is_tensor(prior_prob) else None      # a device scalar: read at run time (hipGraph replay)
+        kl, g_pre, g_log = torch.ops.split_vae.spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, 0.0 if dev is not None else prior_prob,
+                                                              temperature, dev)
         ctx.save_for_backward(g_pre, g_log)
         return kl
 
@@ -324,19 +327,21 @@ class _ZpresKlFn(torch.autograd.Function):
 def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temperature):
     """compute_z_pres_kl_yolo_air (spair/trainer.py:45-94) as per-image sums kl [B] (tf_mean_sum = kl.mean()); differentiable
     in the logits and the pre-sigmoid sample."""
-    return _ZpresKlFn.apply(z_pres, z_pres_logits, z_pres_pre_sigmoid, float(prior_prob), float(temperature))
+    return _ZpresKlFn.apply(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob if torch.is_tensor(prior_prob) else float(prior_prob),
+                            float(temperature))
 
 
 @_impl("spair_loss")
-def _spair_loss(mode, a, b, prior_mean, prior_sig):
-    sums, ga, gb = ops.spair_loss(mode, a, b, prior_mean, prior_sig)
+def _spair_loss(mode, a, b, prior_mean, prior_sig, prior_mean_dev=None):
+    sums, ga, gb = ops.spair_loss(mode, a, b, prior_mean if prior_mean_dev is None else prior_mean_dev, prior_sig)
     return sums, (ga if ga is not None else a.new_empty((0,))), gb
 
 
 class _SpairLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, a, b, prior_mean, prior_sig):
-        sums, ga, gb = torch.ops.split_vae.spair_loss(mode, a, b, prior_mean, prior_sig)
+        dev = prior_mean if torch.is_tensor(prior_mean) else None
+        sums, ga, gb = torch.ops.split_vae.spair_loss(mode, a, b, 0.0 if dev is not None else prior_mean, prior_sig, dev)
         ctx.save_for_backward(ga, gb)
         ctx.has_ga = mode != "xent"
         return sums
@@ -360,4 +365,4 @@ def spair_kl(z_mean, z_sig):
 
 def spair_kl_prior(mean, sig, prior_mean, prior_sig):
     """Per-image sums of kl_divergence_two_gauss (spair/trainer.py:23-24) against the constant prior N(prior_mean, prior_sig)."""
-    return _SpairLossFn.apply("kl_prior", mean, sig, float(prior_mean), float(prior_sig))
+    return _SpairLossFn.apply("kl_prior", mean, sig, prior_mean if torch.is_tensor(prior_mean) else float(prior_mean), float(prior_sig))

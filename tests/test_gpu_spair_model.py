@@ -124,3 +124,37 @@ def test_spair_training_reduces_the_loss(lib_built):
         tot.append(float(total))
     assert np.isfinite(tot).all()
     assert np.mean(tot[-5:]) < 0.9 * np.mean(tot[:5]), tot
+
+
+@pytest.mark.parametrize("name", ["spair", "lg_spair_readme"])
+def test_graphed_step_equals_eager_steps(lib_built, name):
+    """GraphedTrainStep (one hipGraph replay per step, step-dependent scalars in device memory) against the eager train_step: same
+    pinned draws, steps 7..10 of the annealing schedule -> the same losses and variables (up to the order of fp32 atomics)."""
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    cfg = dotdict(R.default_config(**CONFIGS[name]))
+    cfg.z_pres_anneal_step, cfg.anneal_until = 20.0, 15.0               # so that every annealed scalar moves over these steps
+    B = 4
+    images = torch.rand(B, 48, 48, 6 if cfg.model == "lg_spair" else 3, generator=torch.Generator().manual_seed(3)).cuda()
+    noise = {k: v.float().cuda() for k, v in R.draw_noise(cfg, B, seed=9).items()}
+    runs = []
+    for graphed in (False, True):
+        model = spair.get_model(cfg, seed=2)
+        opt = spair_trainer.ClipnormAdam(learning_rate=1e-3, clipnorm=1.0)
+        step_fn = spair_trainer.GraphedTrainStep(model, opt, cfg, images, noise=noise) if graphed else None
+        hist = []
+        for step in range(7, 11):
+            if graphed:
+                _, losses = step_fn(images, step)
+            else:
+                _, losses = spair_trainer.train_step(model, images, opt, step, cfg, noise=noise)
+            hist.append([float(l) for l in losses])
+        assert opt.iterations == 4
+        runs.append((hist, model.store.flat.clone()))
+    (h0, p0), (h1, p1) = runs
+    for a, b in zip(h0, h1):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (a, b)
+    assert float((p0 - p1).norm() / p0.norm()) < 1e-5
+    assert h0[0][1] != h0[-1][1]                                        # the zoom prior really annealed over these steps
