@@ -126,6 +126,13 @@ int sv_spair_render_bwd(const float* obj, const float* bg, const float* z_depth,
                         const float* g_out, float* g_obj, float* g_bg, float* g_z_pres, float* g_z_depth, int32_t B,
                         int32_t Bp, int32_t H, int32_t W, int32_t C, void* stream);
 
+/* The same with a workspace of sv_spair_render_bwd_workspace_floats(B, H, W) floats: a workgroup per 256-pixel chunk instead of
+ * one per image (288 instead of 32 workgroups at batch 32); the chunks' partial g_z sums are added in chunk order (deterministic). */
+int64_t sv_spair_render_bwd_workspace_floats(int32_t B, int32_t H, int32_t W);
+int sv_spair_render_bwd_ws(const float* obj, const float* bg, const float* z_depth, const float* z_pres, const float* noise,
+                           const float* g_out, float* g_obj, float* g_bg, float* g_z_pres, float* g_z_depth, int32_t B,
+                           int32_t Bp, int32_t H, int32_t W, int32_t C, float* ws, int64_t ws_floats, void* stream);
+
 /* SPLIT-SPAIR: compute_z_pres_kl_yolo_air + concrete_binary_sample_kl (spair/trainer.py:28-42, :45-94), fp32: the sequential
  * count-prior KL of the n_cells <= 16 presence variables, cells in raster order.  z_pres / z_pres_logits / z_pres_pre_sigmoid
  * [B,n_cells] -> kl [B] (per-image sums: tf_mean_sum = their batch mean); g_pre_sigmoid / g_logits (may be NULL) =

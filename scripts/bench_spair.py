@@ -39,8 +39,38 @@ def run(name, kw, B, steps=30, warmup=5):
                       "params": model.count_params(), "images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}), flush=True)
 
 
+def cpu(name, kw, B, steps=3):
+    """The fp32 torch-CPU restatement (oracle/spair_model_ref.py: forward + losses + autograd + clipnorm Adam) on the host cores."""
+    from oracle import spair_model_ref as R
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, 0, torch.float32)
+    for v in p.values():
+        v.requires_grad_(True)
+    images = torch.rand(B, 48, 48, 6 if cfg.model == "lg_spair" else 3)
+    m = [torch.zeros_like(v) for v in p.values()]
+    vv = [torch.zeros_like(v) for v in p.values()]
+    ts = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        o = R.forward(p, cfg, images, R.draw_noise(cfg, B, i, torch.float32), training=True)
+        total, _ = R.losses(cfg, images, o, i)
+        g = torch.autograd.grad(total, list(p.values()), allow_unused=True)
+        with torch.no_grad():
+            R.clipnorm_adam_(list(p.values()), [x if x is not None else torch.zeros_like(v) for x, v in zip(g, p.values())], m, vv, i + 1)
+        ts.append(time.perf_counter() - t0)
+    dt = min(ts[1:])
+    print(json.dumps({"what": "SPAIR train step, torch-CPU restatement (oracle)", "model": name, "device": "host CPU", "cores": cores, "dtype": "f32",
+                      "batch": B, "images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     for B in [int(a) for a in sys.argv[1:]] or [32]:
         for name, kw in MODELS.items():
             if os.environ.get("SPAIR_ONLY", "") in name:
                 run(name, kw, B)
+    if os.environ.get("SPAIR_CPU"):
+        for name, kw in MODELS.items():
+            if os.environ.get("SPAIR_ONLY", "") in name:
+                cpu(name, kw, 32)

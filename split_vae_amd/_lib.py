@@ -91,6 +91,8 @@ SYMBOLS = {
     "sv_stn_sample_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_spair_render_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_spair_render_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_spair_render_bwd_workspace_floats": (_i64, [_i32, _i32, _i32]),
+    "sv_spair_render_bwd_ws": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "sv_spair_zpres_kl": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _f, _f, _vp]),
     "sv_adam_step_clipnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _f, _f, _f, _f, _f, _i64, _f, _vp]),
     "sv_conv2d_wprep_elems": (_i64, [C.POINTER(ConvDesc), _i32]),

@@ -7,10 +7,12 @@
 // training = 0: z_pres = max(round(sigmoid(z_pres_logits)), 1e-8), no noise (the reference's test-time rendering).
 // obj [B,B',H,W,C+1] (the inverse STN's output), bg [B,H,W,C], z_* [B,B'] -> out [B,H,W,C].
 //
-// One workgroup per image, a thread per pixel looping the B' <= 16 objects (their 4-float records are strided by the
-// canvas size: a latency-bound gather of B'(C+1) floats per pixel).  Backward: the same pass recomputes the forward sums,
-// writes g_obj / g_bg per pixel (clip gates as tf.clip_by_value: gradient inside [min, max] only) and reduces
-// g_z_pres / g_z_depth per object over the image in a fixed order (lane shuffles, then the four waves through LDS).
+// A workgroup per 256-pixel chunk of an image (grid = chunks x B: 288 workgroups at batch 32 instead of 32), a thread per pixel
+// looping the B' <= 16 objects (their 4-float records are strided by the canvas size: a latency-bound gather of B'(C+1)
+// floats per pixel).  Backward: the same pass recomputes the forward sums, writes g_obj / g_bg per pixel (clip gates as
+// tf.clip_by_value: gradient inside [min, max] only) and reduces g_z_pres / g_z_depth per object over the chunk in a fixed
+// order (lane shuffles, then the four waves through LDS); the chunks' partial sums go to a workspace that a second tiny kernel adds
+// in chunk order (deterministic).  Without a workspace (sv_spair_render_bwd) one workgroup walks the whole image.
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -24,8 +26,8 @@ __global__ __launch_bounds__(256) void spair_render_kernel(const float* __restri
                                                            float* __restrict__ out, const float* __restrict__ g_out,
                                                            float* __restrict__ g_obj, float* __restrict__ g_bg,
                                                            float* __restrict__ g_zp, float* __restrict__ g_zd, int Bp, int HW,
-                                                           int C, int training) {
-  const int b = blockIdx.x;
+                                                           int C, int training, float* __restrict__ part) {
+  const int b = blockIdx.y;
   __shared__ float s_zp[MAXBP], s_s[MAXBP], s_ds[MAXBP];
   __shared__ float red[4][2 * MAXBP];
   if (threadIdx.x < Bp) {
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void spair_render_kernel(const float* __restri
   float azp[MAXBP], azd[MAXBP];
 #pragma unroll
   for (int k = 0; k < MAXBP; ++k) azp[k] = azd[k] = 0.f;
-  for (int p = threadIdx.x; p < HW; p += 256) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
     float N = 0.f, T = 0.f, U[MAXC] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < Bp; ++k) {
       const float* q = ob + k * cell_stride + (int64_t)p * C1;
@@ -104,12 +106,25 @@ __global__ __launch_bounds__(256) void spair_render_kernel(const float* __restri
     if (threadIdx.x < 2 * MAXBP) {
       const int k = threadIdx.x & (MAXBP - 1);
       const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-      if (k < Bp) {
+      if (part) part[((int64_t)b * gridDim.x + blockIdx.x) * 2 * MAXBP + threadIdx.x] = v;     // chunk partials: render_finish_kernel
+      else if (k < Bp) {
         if (threadIdx.x < MAXBP) { if (g_zp) g_zp[(int64_t)b * Bp + k] = training ? v : 0.f; }
         else g_zd[(int64_t)b * Bp + k] = v;
       }
     }
   }
+}
+// g_z_pres / g_z_depth [B,Bp] = the chunk partials added in chunk order
+__global__ __launch_bounds__(64) void render_finish_kernel(const float* __restrict__ part, float* __restrict__ g_zp, float* __restrict__ g_zd,
+                                                           int Bp, int chunks) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= 2 * MAXBP) return;
+  const int k = t & (MAXBP - 1);
+  if (k >= Bp) return;
+  float v = 0.f;
+  for (int c = 0; c < chunks; ++c) v += part[((int64_t)b * chunks + c) * 2 * MAXBP + t];
+  if (t < MAXBP) g_zp[(int64_t)b * Bp + k] = v;
+  else g_zd[(int64_t)b * Bp + k] = v;
 }
 }  // namespace
 
@@ -118,9 +133,9 @@ extern "C" int sv_spair_render_fwd(const float* obj, const float* bg, const floa
                                    int32_t W, int32_t C, int32_t training, void* stream) {
   if (!obj || !bg || !z_depth || !out || B < 1 || Bp < 1 || Bp > MAXBP || C < 1 || C > MAXC || H < 1 || W < 1) return SV_E_BADARG;
   if ((training && !z_pres) || (!training && !z_pres_logits) || (!training && noise)) return SV_E_BADARG;
-  hipLaunchKernelGGL((spair_render_kernel<false>), dim3(B), dim3(256), 0, (hipStream_t)stream, obj, bg, z_depth, z_pres,
+  hipLaunchKernelGGL((spair_render_kernel<false>), dim3((H * W + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, obj, bg, z_depth, z_pres,
                      z_pres_logits, noise, out, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     (float*)nullptr, Bp, H * W, C, training ? 1 : 0);
+                     (float*)nullptr, Bp, H * W, C, training ? 1 : 0, (float*)nullptr);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -130,8 +145,27 @@ extern "C" int sv_spair_render_bwd(const float* obj, const float* bg, const floa
                                    float* g_z_depth, int32_t B, int32_t Bp, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!obj || !bg || !z_depth || !z_pres || !g_out || !g_obj || !g_bg || !g_z_pres || !g_z_depth) return SV_E_BADARG;
   if (B < 1 || Bp < 1 || Bp > MAXBP || C < 1 || C > MAXC || H < 1 || W < 1) return SV_E_BADARG;
-  hipLaunchKernelGGL((spair_render_kernel<true>), dim3(B), dim3(256), 0, (hipStream_t)stream, obj, bg, z_depth, z_pres,
-                     (const float*)nullptr, noise, (float*)nullptr, g_out, g_obj, g_bg, g_z_pres, g_z_depth, Bp, H * W, C, 1);
+  hipLaunchKernelGGL((spair_render_kernel<true>), dim3(1, B), dim3(256), 0, (hipStream_t)stream, obj, bg, z_depth, z_pres,
+                     (const float*)nullptr, noise, (float*)nullptr, g_out, g_obj, g_bg, g_z_pres, g_z_depth, Bp, H * W, C, 1, (float*)nullptr);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+extern "C" int64_t sv_spair_render_bwd_workspace_floats(int32_t B, int32_t H, int32_t W) {
+  return B < 1 || H < 1 || W < 1 ? 0 : (int64_t)B * ((H * W + 255) / 256) * 2 * MAXBP;
+}
+
+extern "C" int sv_spair_render_bwd_ws(const float* obj, const float* bg, const float* z_depth, const float* z_pres, const float* noise,
+                                      const float* g_out, float* g_obj, float* g_bg, float* g_z_pres, float* g_z_depth, int32_t B,
+                                      int32_t Bp, int32_t H, int32_t W, int32_t C, float* ws, int64_t ws_floats, void* stream) {
+  if (!obj || !bg || !z_depth || !z_pres || !g_out || !g_obj || !g_bg || !g_z_pres || !g_z_depth) return SV_E_BADARG;
+  if (B < 1 || Bp < 1 || Bp > MAXBP || C < 1 || C > MAXC || H < 1 || W < 1) return SV_E_BADARG;
+  if (!ws || ws_floats < sv_spair_render_bwd_workspace_floats(B, H, W)) return SV_E_BADARG;
+  const int chunks = (H * W + 255) / 256;
+  hipLaunchKernelGGL((spair_render_kernel<true>), dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, obj, bg, z_depth, z_pres,
+                     (const float*)nullptr, noise, (float*)nullptr, g_out, g_obj, g_bg, g_z_pres, g_z_depth, Bp, H * W, C, 1, ws);
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(render_finish_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ws, g_z_pres, g_z_depth, Bp, chunks);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

@@ -179,9 +179,12 @@ def spair_render_bwd(obj, bg, z_depth, z_pres, g_out, noise=None):
     g_zp = torch.empty((B, Bp), dtype=torch.float32, device=obj.device)
     g_zd = torch.empty_like(g_zp)
     f = lambda t: t.reshape(B, Bp).contiguous()
-    check(_lib.load().sv_spair_render_bwd(_p(obj.contiguous()), _p(bg.contiguous()), _p(f(z_depth)), _p(f(z_pres)),
-                                          _p(None if noise is None else noise.contiguous()), _p(g_out.contiguous()), _p(g_obj), _p(g_bg),
-                                          _p(g_zp), _p(g_zd), B, Bp, H, W, C1 - 1, _stream()), "sv_spair_render_bwd")
+    lib = _lib.load()
+    n = lib.sv_spair_render_bwd_workspace_floats(B, H, W)
+    ws = torch.empty((n,), dtype=torch.float32, device=obj.device)
+    check(lib.sv_spair_render_bwd_ws(_p(obj.contiguous()), _p(bg.contiguous()), _p(f(z_depth)), _p(f(z_pres)),
+                                     _p(None if noise is None else noise.contiguous()), _p(g_out.contiguous()), _p(g_obj), _p(g_bg),
+                                     _p(g_zp), _p(g_zd), B, Bp, H, W, C1 - 1, _p(ws), n, _stream()), "sv_spair_render_bwd_ws")
     return g_obj, g_bg, g_zp, g_zd
 
 

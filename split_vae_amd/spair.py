@@ -106,6 +106,10 @@ class Conv2D(_Layer):
         self.fused = resize_in                   # cleared when the fused-resize kernel does not cover this geometry
 
     def __call__(self, x):
+        if self.kernel.shape[0] == 1 and self.strides == 1 and not self.resize_in:
+            # a 1x1 convolution IS a Dense layer over the pixels (the backbone's z1 / z2 / z3 on the 4x4 cell grid): a plain library GEMM
+            y = torch.addmm(self.bias, x.reshape(-1, self.cin), self.kernel.view(self.cin, self.cout)).reshape(*x.shape[:-1], self.cout)
+            return _activation(y, self.activation)
         if x.shape[-1] != _r8(self.cin):                             # the kernels read 8-channel pixel pitches (pad channels zero)
             x = F.pad(x, (0, _r8(self.cin) - x.shape[-1]))
         act = "relu" if self.activation == "relu" else None
