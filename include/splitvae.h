@@ -360,6 +360,10 @@ enum { SV_PHASE_PREP = 1,           /* fp32 master weights -> MFMA-ready images 
        SV_PHASE_BWD_ENC_HEADS = 32, /* reparam adjoint, e4_mean/e4_sd gradients, dgrad into a3 */
        SV_PHASE_BWD_ENC_CONVS = 64, /* e3, e2, e1 gradients */
        SV_PHASE_ADAM = 128,
+       SV_PHASE_NO_RECON = 256,     /* modifier: a call that runs the decoders, the loss and its gradients together evaluates the loss in
+                                       the head conv's epilogue; the reconstruction tensors out6_x / out6_xh (x_mean | x_log_scale) are
+                                       then dead -- train_step_lg_vae (vae/trainer.py:121-144) returns nothing -- and with this bit they
+                                       are not stored (100 MB of HBM writes per 512-image step).  Losses and gradients are unchanged. */
        SV_PHASE_FORWARD = 6, SV_PHASE_BACKWARD = 112, SV_PHASE_ALL = 255 };
 
 typedef struct {

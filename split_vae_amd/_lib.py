@@ -14,6 +14,7 @@ SV_ACT_NONE, SV_ACT_RELU, SV_ACT_ELU = 0, 1, 2
 PHASE_PREP, PHASE_FWD_ENCODERS, PHASE_FWD_DECODERS, PHASE_LOSS = 1, 2, 4, 8
 PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM = 16, 32, 64, 128
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
+PHASE_NO_RECON = 256      # modifier: the fused-loss training step does not store out6_x / out6_xh (include/splitvae.h)
 PHASE_INFER = PHASE_PREP | PHASE_FORWARD
 
 STATUS = {0: "SV_OK", -1: "SV_E_BADARG", -2: "SV_E_UNSUPPORTED", -3: "SV_E_WORKSPACE", -4: "SV_E_STATE"}

@@ -39,6 +39,7 @@ struct TapGemmArgs {
   // ([B,OHF,OWF,8] bf16, what dlogistic_kernel would write) and one partial sum per (image, tile) to nll_part[b * tiles + tile];
   // out is still written.  Needs one image per tile (OY * OX >= 256).
   const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale;
+  int nll_noout;              // fused loss: the reconstruction (out6) is not stored (SV_PHASE_NO_RECON: dead after the loss in a training step)
   const float* fix;     // with d2s_y: border terms [B][10][max(OHF, OWF)][8] added by the epilogue (poly_fix.hip), or null
   int cls_n;            // > 0: MERGED PARITY CLASSES of a stride-2 input gradient whose classes share one tap window (k = 6, pad 2:
                         // every class reads dy rows / columns -1..1): ONE problem with N = 4 * cls_n columns, column n = class
@@ -84,7 +85,7 @@ struct TileConvArgs {
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
   const float* fix;           // TapGemmArgs::fix
-  const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale;   // TapGemmArgs: fused loss
+  const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale; int nll_noout;   // TapGemmArgs: fused loss
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };

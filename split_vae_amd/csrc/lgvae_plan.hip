@@ -407,7 +407,7 @@ static double conv_flops(const sv_conv_desc& d) {
 
 // The x and x-hat networks have twin layers of identical geometry: n of them go out as ONE launch
 // (blockIdx.z picks the problem), which halves the per-launch fixed cost that dominates at B<=512.
-struct FusedNll { const float* images6; void* grad[2]; float* part[2]; float gscale; };   // loss in the head's epilogue (tile_conv.hip)
+struct FusedNll { const float* images6; void* grad[2]; float* part[2]; float gscale; int noout; };   // loss in the head's epilogue (tile_conv.hip)
 static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const float* params,
                           void* const* y, hipStream_t st, const FusedNll* nll = nullptr) {
   TapGemmArgs a[2];
@@ -420,7 +420,7 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     a[i].out = y[i];
     if (nll) {
       a[i].nll_img = nll->images6; a[i].nll_ch = 3 * i; a[i].nll_grad = nll->grad[i]; a[i].nll_part = nll->part[i];
-      a[i].nll_gscale = nll->gscale;
+      a[i].nll_gscale = nll->gscale; a[i].nll_noout = nll->noout;
     }
     fl += conv_flops(L[i]->d);
   }
@@ -692,7 +692,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
         // training step: the head's epilogue evaluates the loss of its own pixels (NLL partial sums + the gradient record
         // g5), so dlogistic_kernel and its re-read of out6 drop out of the step (phase_loss then only sums the partials)
         FusedNll f;
-        f.images6 = s->images6; f.gscale = 1.0f / (float)d.B;
+        f.images6 = s->images6; f.gscale = 1.0f / (float)d.B; f.noout = (s->phases & SV_PHASE_NO_RECON) ? 1 : 0;
         f.grad[0] = p->bp("g5_x"); f.grad[1] = p->bp("g5_xh");
         f.part[0] = (float*)p->bp("nllpart_x"); f.part[1] = (float*)p->bp("nllpart_xh");
         const int rc = run_fwd_layers(p, 2, Ls, xs, s->params, ys, st, &f);

@@ -352,8 +352,10 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
               o01 += *(const f32x2*)fp; o23 += *(const f32x2*)(fp + 2); o45 += *(const f32x2*)(fp + 4);
             }
           }
-          float* op = outp + pix * 6;
-          *(f32x2*)op = o01; *(f32x2*)(op + 2) = o23; *(f32x2*)(op + 4) = o45;
+          if (!g.nll_noout) {
+            float* op = outp + pix * 6;
+            *(f32x2*)op = o01; *(f32x2*)(op + 2) = o23; *(f32x2*)(op + 4) = o45;
+          }
           float n0, n1, n2, dm0, dm1, dm2, dl0, dl1, dl2;
           dll_elem(x0, o01[0], o23[1], n0, dm0, dl0);        // channel k: mean o[k], log_scale o[3 + k] (vae/model.py:169)
           dll_elem(x1, o01[1], o45[0], n1, dm1, dl1);
@@ -591,7 +593,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
     a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n; a->d2s_y = t.d2s_y; a->clampin = t.clampin; a->fix = t.fix;
-    a->nll_img = t.nll_img; a->nll_grad = t.nll_grad; a->nll_part = t.nll_part; a->nll_ch = t.nll_ch; a->nll_gscale = t.nll_gscale;
+    a->nll_img = t.nll_img; a->nll_grad = t.nll_grad; a->nll_part = t.nll_part; a->nll_ch = t.nll_ch; a->nll_gscale = t.nll_gscale; a->nll_noout = t.nll_noout;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
     a->tilesX = OX / TW; a->tilesY = OY / TH;

@@ -13,7 +13,7 @@ import torch
 
 from . import dist as svdist
 from ._lib import (PHASE_ADAM, PHASE_ALL, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS,
-                   PHASE_FORWARD, PHASE_LOSS, PHASE_PREP)
+                   PHASE_FORWARD, PHASE_LOSS, PHASE_NO_RECON, PHASE_PREP)
 from .model import LGVae
 
 METRIC_NAMES = ["x_recon_loss", "x_kl_loss", "x_hat_recon_loss", "x_hat_kl_loss", "total_kl_loss"]
@@ -59,10 +59,13 @@ def _check_images(model, images):
         raise ValueError("images must be contiguous fp32 on the HIP device")
 
 
-def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0, accumulate_metrics=True):
+def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0, accumulate_metrics=True, keep_recon=True):
     """train_step_lg_vae (vae/trainer.py:120-144): forward, total = recon_x + recon_x_hat +
     beta*KL, gradients of the 40 variables, Adam update, metric update.  `images` [B,H,W,6] fp32
-    on the device.  eps=(eps_x, eps_x_hat) pins the Sampling noise; default = Philox stream."""
+    on the device.  eps=(eps_x, eps_x_hat) pins the Sampling noise; default = Philox stream.
+    keep_recon=False: the reference's step returns nothing and the loss is evaluated inside the head conv, so the
+    reconstruction tensors (plan buffers out6_x / out6_xh) are dead and are not stored (SV_PHASE_NO_RECON); the training
+    loop and bench.py run this way.  Losses, gradients and the update are identical either way."""
     from .gm import LGGMVae
     if isinstance(model, LGGMVae):
         raise TypeError("LGGMVae trains with gm.train_step_lg_gm_vae (vae/trainer.py:297-299 picks the step by model class)")
@@ -80,11 +83,12 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
               beta2=optimizer.beta_2, adam_eps=optimizer.epsilon, t=optimizer.iterations,
               accumulate_metrics=accumulate_metrics)
     model._calls += 1
+    nr = 0 if keep_recon else PHASE_NO_RECON
     if reducer is None or reducer.world == 1:
-        plan.step(PHASE_ALL, **kw)
+        plan.step(PHASE_ALL | nr, **kw)
         return plan
     # data parallel: launch each bucket's all-reduce as soon as the phase that fills it is enqueued
-    plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS, **kw)
+    plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS | nr, **kw)
     reducer.launch(model.grad_flat, "decoders")
     plan.step(PHASE_BWD_ENC_HEADS, **kw)
     reducer.launch(model.grad_flat, "enc_heads")
@@ -128,7 +132,7 @@ def train_local_global_autoencoder(model, optimizer, dataset, train_dataset, tes
     log_every = int(config.get("log_every") or 10000)
     for step, train_data in enumerate(train_dataset):
         images = train_data[0] if config.label else train_data
-        plan = train_step(model, images, optimizer)
+        plan = train_step(model, images, optimizer, keep_recon=False)
         if metrics is None:
             metrics = StepMetrics(plan)
         if step % log_every == 0:

@@ -224,3 +224,32 @@ def test_other_geometries_match_oracle_losses(ops, H, L):
     for name, off, shape in plan.param_table:
         g = G[off:off + int(np.prod(shape))]
         assert torch.isfinite(g).all() and float(g.abs().max()) > 0, name
+
+
+@pytest.mark.gpu
+def test_step_without_stored_reconstructions_is_the_same_step(lib_built):
+    """SV_PHASE_NO_RECON: the training step with the loss fused into the head conv does not write out6_x / out6_xh; the five
+    losses, gradients and updated variables are equal up to the step's own run-to-run atomics order."""
+    import torch
+    from split_vae_amd import data, trainer
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+    B, H = 64, 64
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    img = Augmentator("scramble", size=8, seed=1).augment(x)
+    outs = []
+    for keep in (True, False):
+        m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="bf16", device=torch.device("cuda"), seed=3)
+        m.beta = 120.0
+        opt = Adam(learning_rate=1e-4)
+        plan = trainer.train_step(m, img, opt, keep_recon=keep)
+        torch.cuda.synchronize()
+        o6 = plan.buffer("out6_x", torch.float32, (B, H, H, 6)).clone()
+        outs.append((trainer.last_losses(plan), m.grad_flat.clone(), m.flat.clone(), o6))
+    (l0, g0, p0, o0), (l1, g1, p1, o1) = outs
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), k
+    # (the split-K atomics of the heads / d1 reorder fp32 sums from run to run: equal up to that, not bitwise)
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-4 and float((p0 - p1).norm() / p0.norm()) < 1e-3   # (first Adam step = lr * sign-like: near-zero gradients flip)
+    assert float(o0.abs().max()) > 0 and float(o1.abs().max()) == 0.0      # stored / never written (the workspace starts zeroed)
