@@ -32,6 +32,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")     # before any HIP call: see split_vae_amd/__init__.py (a 4th hardware queue slows the DP step)
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
@@ -153,7 +154,8 @@ class Workload:
         self.aug = Augmentator("scramble", size=self.patch, seed=1)
         self.off = rank * B
         self.x = data.synthetic_images(B, H, H, seed=0, device=dev, sample_offset=self.off)   # resident in HBM
-        self.reducer = reducer_cls(self.model.param_table, self.model.n_params) if (reducer_cls and world > 1) else None
+        # SV_DIST_FORCE=1: the data-parallel path (phase split + bucketed RCCL all-reduce) with a world of one rank
+        self.reducer = reducer_cls(self.model.param_table, self.model.n_params) if (reducer_cls and (world > 1 or os.environ.get("SV_DIST_FORCE"))) else None
 
     def step(self):
         from split_vae_amd import trainer
@@ -258,7 +260,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report one as the other" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); none visible")
-    backend = torch.distributed.get_backend() if world > 1 else None
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
     dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real N-GPU node; lets a gloo dry run share one GPU
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -296,7 +298,7 @@ def main():
     plan.profile_enable(False)
 
     extra = {}
-    if world > 1:
+    if w.reducer is not None:
         # per-bucket all-reduce time, alone on the chip (what the backward has to hide)
         ar = {}
         for name in w.reducer.buckets:
@@ -313,7 +315,7 @@ def main():
         extra["dist_backend"] = "sv_comm (RCCL through the C ABI)" if native else backend
         extra["allreduce_ms"] = ar
         extra["allreduce_bytes"] = {k: int(sum(e - b for b, e in v) * 4) for k, v in w.reducer.buckets.items()}
-        if not args.global_batch and 512 % world == 0 and H == 64:
+        if world > 1 and not args.global_batch and 512 % world == 0 and H == 64:
             # the strong-scaling row of config 4: global batch 512 split over the ranks (64 per GPU at N = 8)
             ws = Workload(64, 512 // world, args.dtype, dev, rank, world, svdist.make_reducer)
             ks = max(args.steps, 100)
@@ -338,7 +340,7 @@ def main():
         rows["long_run"] = {"steps": 400, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
 
     if rank != 0:
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
     value = world * B * args.steps / dt
@@ -389,7 +391,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -20,7 +20,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # SV_DIST_FORCE=1: take the distributed path with ONE rank too (process group, phase split, bucketed all-reduce over a world
+    # of 1) -- how the RCCL path is exercised on a single-GPU box (tests/test_gpu_dist.py)
+    if (world > 1 or os.environ.get("SV_DIST_FORCE")) and not dist.is_initialized():
         if backend is None:      # SV_DIST_BACKEND=gloo: several ranks sharing one GPU (tests); RCCL wants one device per rank
             backend = os.environ.get("SV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend in ("nccl", "sv_comm"):
@@ -69,7 +71,7 @@ def param_buckets(param_table, n_params):
 def make_reducer(param_table, n_params):
     """GradReducer over torch.distributed (default: backend nccl = RCCL) or, with SV_DIST_BACKEND=sv_comm, NativeGradReducer
     over the C ABI's own RCCL communicator."""
-    if os.environ.get("SV_DIST_BACKEND") == "sv_comm" and dist.is_initialized() and dist.get_world_size() > 1:
+    if os.environ.get("SV_DIST_BACKEND") == "sv_comm" and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SV_DIST_FORCE")):
         return NativeGradReducer(param_table, n_params)
     return GradReducer(param_table, n_params)
 
@@ -103,6 +105,8 @@ class NativeGradReducer:
             n = len(spans)
             self._ranges[k] = ((C.c_int64 * n)(*[b for b, _ in spans]), (C.c_int64 * n)(*[e for _, e in spans]), n)
         self._dirty = False
+        self.force = True
+        self.mode = os.environ.get("SV_DP_MODE", "overlap")             # 'overlap' (bucketed, behind the backward) | 'single'
 
     @property
     def grad_scale(self):
@@ -114,6 +118,14 @@ class NativeGradReducer:
         b, e, n = self._ranges[bucket]
         _lib.check(self.lib.sv_comm_allreduce_ranges(self.handle, self.C.c_void_p(flat.data_ptr()), b, e, n,
                                                      self.C.c_void_p(self.stream.cuda_stream)), "sv_comm_allreduce_ranges")
+        self._dirty = True
+
+    def launch_all(self, flat):
+        """mode 'single': the whole flat buffer as one all-reduce."""
+        from . import _lib
+        self.stream.wait_stream(torch.cuda.current_stream())
+        _lib.check(self.lib.sv_comm_allreduce(self.handle, self.C.c_void_p(flat.data_ptr()), flat.numel(),
+                                              self.C.c_void_p(self.stream.cuda_stream)), "sv_comm_allreduce")
         self._dirty = True
 
     def wait(self):
@@ -136,9 +148,17 @@ class GradReducer:
 
     def __init__(self, param_table, n_params, group=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(os.environ.get("SV_DIST_FORCE")) and dist.is_initialized()
         self.group = group
         self.buckets = param_buckets(param_table, n_params)
         self._pending = []
+        self.mode = os.environ.get("SV_DP_MODE", "overlap")             # 'overlap' (bucketed, behind the backward) | 'single'
+
+    def launch_all(self, flat):
+        """mode 'single': the whole flat buffer as one all-reduce."""
+        if self.world == 1 and not self.force:
+            return
+        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     @property
     def grad_scale(self):
@@ -146,7 +166,7 @@ class GradReducer:
 
     def launch(self, flat, bucket):
         """Enqueue the all-reduce of one bucket (call right after the phase that produced it)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for b, e in self.buckets[bucket]:
             self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -84,8 +84,16 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
               accumulate_metrics=accumulate_metrics)
     model._calls += 1
     nr = 0 if keep_recon else PHASE_NO_RECON
-    if reducer is None or reducer.world == 1:
+    if reducer is None or (reducer.world == 1 and not getattr(reducer, "force", False)):
         plan.step(PHASE_ALL | nr, **kw)
+        return plan
+    if getattr(reducer, "mode", "overlap") == "single":
+        # one all-reduce of the whole gradient buffer between the backward and Adam: nothing overlaps, but there is one
+        # cross-stream hand-over instead of four and the backward runs as in the single-GPU step
+        plan.step((PHASE_ALL & ~PHASE_ADAM) | nr, **kw)
+        reducer.launch_all(model.grad_flat)
+        reducer.wait()
+        plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
         return plan
     # data parallel: launch each bucket's all-reduce as soon as the phase that fills it is enqueued
     plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS | nr, **kw)

@@ -25,7 +25,7 @@ def main():
     opt = Adam(learning_rate=1e-3)
     aug = Augmentator("scramble", size=patch, seed=1)
     x = data.synthetic_images(hi - lo, H, H, seed=0, device="cuda", sample_offset=lo)
-    reducer = svdist.make_reducer(model.param_table, model.n_params) if world > 1 else None
+    reducer = svdist.make_reducer(model.param_table, model.n_params) if (world > 1 or os.environ.get("SV_DIST_FORCE")) else None
     losses = []
     for _ in range(steps):
         img = aug.augment(x, sample_offset=lo)
@@ -34,7 +34,7 @@ def main():
         losses.append(plan.buffer("losses", torch.float32, (8,)).cpu().numpy().copy())
     if rank == 0:
         np.savez(out, params=model.flat.cpu().numpy(), grads=model.grad_flat.cpu().numpy(), losses=np.stack(losses))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -23,12 +23,14 @@ def _free_port():
     return p
 
 
-def _run(world, out, gb=32, steps=3, backend="gloo"):
+def _run(world, out, gb=32, steps=3, backend="gloo", force=False):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r) if backend == "nccl" else "0", WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SV_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if force:
+            env["SV_DIST_FORCE"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps)],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -61,6 +63,19 @@ def test_two_ranks_over_rccl_equal_one(lib_built, tmp_path, backend):
     g1, g2 = one["grads"], two["grads"] / 2.0
     assert np.linalg.norm(g1 - g2) <= 2e-3 * np.linalg.norm(g1)
     assert np.linalg.norm(one["params"] - two["params"]) <= 5e-2 * np.linalg.norm(one["params"] - _init_params())
+
+
+@pytest.mark.parametrize("backend", ["nccl", "sv_comm"])
+def test_one_rank_through_the_rccl_path_equals_the_plain_step(lib_built, tmp_path, backend):
+    """The production data-parallel path on the ONE device of this box (SV_DIST_FORCE=1): process group on the `nccl` backend
+    (= RCCL) resp. the library's own communicator, the four-call phase split of train_step, the three gradient buckets all-reduced
+    asynchronously over a world of one rank, 1/world inside Adam -- against the plain single-call step."""
+    one = _run(1, str(tmp_path / "one.npz"))
+    dp = _run(1, str(tmp_path / "dp.npz"), backend=backend, force=True)
+    g1, g2 = one["grads"], dp["grads"]
+    assert np.linalg.norm(g1 - g2) <= 2e-3 * np.linalg.norm(g1)
+    assert np.linalg.norm(one["params"] - dp["params"]) <= 5e-2 * np.linalg.norm(one["params"] - _init_params())
+    assert np.allclose(one["losses"], dp["losses"], rtol=1e-4, atol=1e-4)
 
 
 def test_sv_comm_single_rank_on_the_device(lib_built):
