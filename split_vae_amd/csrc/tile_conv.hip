@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
   // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
   // workgroups instead of paying the ~10 us fixed latency of a launch each
   const TileConvArgs& g = mg.a[blockIdx.z];
+  if (SV_DBG(g.dbg) & 32) return;                     // ablation build only: the cost of dispatching the grid
   constexpr int NT = 64 * NW, WM = 16 * MF, BM = NW * WM, NF = BN / 16;
   // 16-B pieces of K per step.  128 B per weight row normally; the 16-column kernel takes 512-B steps:
   // its steps are otherwise 8 MFMAs per wave between two barriers (21 -> 6 steps for the packed d5)
