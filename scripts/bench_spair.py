@@ -20,7 +20,7 @@ MODELS = {
 
 
 def run(name, kw, B, steps=30, warmup=5):
-    cfg = spair_main.default_config(**kw)
+    cfg = spair_main.default_config(dtype=os.environ.get("SPAIR_DTYPE", "f32"), **kw)
     model = spair.get_model(cfg, seed=0)
     x, _ = spair_main.synthetic_canvases(B, seed=1)
     images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x) if cfg.model == "lg_spair" else x
@@ -35,7 +35,7 @@ def run(name, kw, B, steps=30, warmup=5):
         step_fn(images, warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(json.dumps({"what": "SPAIR train step (fwd+losses+bwd+clipnorm Adam)", "launch": "hipGraph replay" if graphed else "eager", "model": name, "device": "MI355X", "dtype": "f32", "batch": B,
+    print(json.dumps({"what": "SPAIR train step (fwd+losses+bwd+clipnorm Adam)", "launch": "hipGraph replay" if graphed else "eager", "model": name, "device": "MI355X", "dtype": cfg.dtype, "batch": B,
                       "params": model.count_params(), "images_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3)}), flush=True)
 
 

@@ -34,6 +34,7 @@ class VarStore:
     def __init__(self):
         self.spec = []            # (name, shape)
         self.flat = None
+        self.convs = []           # the Conv2D layers (their compute dtype is a model-wide switch)
 
     def add(self, name, shape):
         self.spec.append((name, tuple(shape)))
@@ -104,6 +105,8 @@ class Conv2D(_Layer):
         super().__init__(store, name, (k, k, cin, cout))
         self.cin, self.cout, self.strides, self.activation, self.resize_in = cin, cout, strides, activation, resize_in
         self.fused = resize_in                   # cleared when the fused-resize kernel does not cover this geometry
+        store.convs.append(self)
+        self.compute_dtype = torch.float32       # torch.bfloat16: bf16 MFMA operands, fp32 accumulation and fp32 master weights
 
     def __call__(self, x):
         if self.kernel.shape[0] == 1 and self.strides == 1 and not self.resize_in:
@@ -112,6 +115,8 @@ class Conv2D(_Layer):
             return _activation(y, self.activation)
         if x.shape[-1] != _r8(self.cin):                             # the kernels read 8-channel pixel pitches (pad channels zero)
             x = F.pad(x, (0, _r8(self.cin) - x.shape[-1]))
+        if self.compute_dtype != torch.float32:
+            x = x.to(self.compute_dtype)                             # (autograd casts the input gradient back)
         act = "relu" if self.activation == "relu" else None
         y = None
         if self.fused:
@@ -127,6 +132,8 @@ class Conv2D(_Layer):
             y = T.conv2d(x, self.kernel, self.bias, self.strides, act, False, False)
         if y.shape[-1] != self.cout:
             y = y[..., :self.cout]
+        if y.dtype != torch.float32:
+            y = y.float()
         return y if act else _activation(y, self.activation)
 
 
@@ -350,9 +357,14 @@ class Renderer:
 
 
 class _Model:
-    def _finish(self, store, device, seed):
+    def _finish(self, store, device, seed, dtype="f32"):
         self.store = store
         store.finalize(device, seed)
+        # dtype 'bf16': the spatial convolutions run on the bf16 MFMA kernels (fp32 accumulation, fp32 master weights, fp32
+        # activations between layers); everything else stays fp32.  'f32' (default) is the reference's precision.
+        self.dtype = dtype
+        for c in store.convs:
+            c.compute_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.device = torch.device(device)
         self.generator = torch.Generator(device=device).manual_seed(seed + 1)
 
@@ -398,7 +410,7 @@ class SPAIR(_Model):
         self.bg_model = BackgroundModel(store, image_size, config.bg_latent_size) if config.model == "bg_spair" else None
         self.bg_latent_size = config.bg_latent_size
         self.renderer = Renderer(C)
-        self._finish(store, device, seed)
+        self._finish(store, device, seed, config.dtype or "f32")
 
     def __call__(self, inputs, training=False, noise=None):
         nz = _Noise(noise, self.device, self.generator)
@@ -430,7 +442,7 @@ class LGSPAIR(_Model):
         self.bg_decoder = ImageDecoder(store, image_size, Lbg + (Ll if self.concat_z_bg else 0), "bg_decoder", bool(config.dense_bg))
         self.x_hat_encoder = ImageEncoder(store, image_size, Ll, "x_hat_encoder", bool(config.dense_local))
         self.x_hat_decoder = ImageDecoder(store, image_size, Ll, "x_hat_decoder", bool(config.dense_local))
-        self._finish(store, device, seed)
+        self._finish(store, device, seed, config.dtype or "f32")
 
     def __call__(self, inputs, training=False, noise=None):
         nz = _Noise(noise, self.device, self.generator)

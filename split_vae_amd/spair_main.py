@@ -6,7 +6,7 @@
 The Multi-Bird canvases are synthesised by the reference from CUB mask blobs that are not in its repository (spair/data.py:14-15),
 so the only data source here is --synthetic: 48x48x3 canvases in [0,1] (the shape get_cub_dataset reports, spair/data.py:258-278)
 with 0-5 soft-edged blobs on a solid background and the blob count as the label.
-Extra flags (not in the reference): --synthetic, --seed, --log_every, --graph.
+Extra flags (not in the reference): --synthetic, --seed, --log_every, --graph, --dtype.
 """
 import argparse
 
@@ -35,6 +35,8 @@ def build_parser():
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log_every", type=int, default=1000)
+    ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
+                    help="bf16: the spatial convolutions on the bf16 MFMA kernels (fp32 accumulation / master weights); f32 = the reference's precision")
     ap.add_argument("--graph", action="store_true", help="capture the train step into a hipGraph and replay it (spair_trainer.GraphedTrainStep)")
     return ap
 

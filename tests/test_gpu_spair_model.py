@@ -158,3 +158,36 @@ def test_graphed_step_equals_eager_steps(lib_built, name):
             assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (a, b)
     assert float((p0 - p1).norm() / p0.norm()) < 1e-5
     assert h0[0][1] != h0[-1][1]                                        # the zoom prior really annealed over these steps
+
+
+def test_bf16_convolutions_track_the_fp32_model(lib_built):
+    """dtype='bf16': the spatial convolutions on the bf16 MFMA kernels (fp32 accumulation, fp32 master weights).  Same variables and
+    draws as the fp32 model: outputs within bf16 rounding of it (stated: 3e-2 of each tensor's norm), the loss terms within 2e-2,
+    gradients within 0.15 of the fp32 gradient's norm per variable group, and 30 training steps still reduce the loss."""
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    cfg = R.default_config(**CONFIGS["lg_spair_conv"])
+    B, step = 4, 10
+    images = torch.rand(B, 48, 48, 6, generator=torch.Generator().manual_seed(1)).cuda()
+    noise = {k: v.float().cuda() for k, v in R.draw_noise(cfg, B, seed=2).items()}
+    res = {}
+    for dt in ("f32", "bf16"):
+        c = dotdict(cfg, dtype=dt)
+        model = spair.get_model(c, seed=6)
+        opt = spair_trainer.ClipnormAdam(learning_rate=1e-3)
+        out, losses, total, grads = spair_trainer.train_step(model, images, opt, step, c, noise=noise, return_grads=True)
+        res[dt] = (out, [float(l) for l in losses], torch.cat([g.reshape(-1) for g in grads]))
+    for a, b in zip(res["bf16"][0], res["f32"][0]):
+        assert _rel(a, b) < 3e-2
+    for a, b in zip(res["bf16"][1], res["f32"][1]):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (a, b)
+    assert _rel(res["bf16"][2], res["f32"][2]) < 0.15
+    c = dotdict(cfg, dtype="bf16")
+    model = spair.get_model(c, seed=4)
+    opt = spair_trainer.ClipnormAdam(learning_rate=1e-3)
+    tot = []
+    for s in range(30):
+        _, _, total, _ = spair_trainer.train_step(model, images, opt, s, c, return_grads=True)
+        tot.append(float(total))
+    assert np.isfinite(tot).all() and np.mean(tot[-5:]) < 0.9 * np.mean(tot[:5]), tot
