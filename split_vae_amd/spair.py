@@ -108,14 +108,16 @@ class Conv2D(_Layer):
         store.convs.append(self)
         self.compute_dtype = torch.float32       # torch.bfloat16: bf16 MFMA operands, fp32 accumulation and fp32 master weights
 
-    def __call__(self, x):
+    def __call__(self, x, out_lp=False):
+        """out_lp: with bf16 compute, hand the bf16 activation to the caller as it is (the next layer is another convolution that
+        would cast it straight back: saves the two casts and their adjoints per pair of layers)."""
         if self.kernel.shape[0] == 1 and self.strides == 1 and not self.resize_in:
             # a 1x1 convolution IS a Dense layer over the pixels (the backbone's z1 / z2 / z3 on the 4x4 cell grid): a plain library GEMM
             y = torch.addmm(self.bias, x.reshape(-1, self.cin), self.kernel.view(self.cin, self.cout)).reshape(*x.shape[:-1], self.cout)
             return _activation(y, self.activation)
         if x.shape[-1] != _r8(self.cin):                             # the kernels read 8-channel pixel pitches (pad channels zero)
             x = F.pad(x, (0, _r8(self.cin) - x.shape[-1]))
-        if self.compute_dtype != torch.float32:
+        if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)                             # (autograd casts the input gradient back)
         act = "relu" if self.activation == "relu" else None
         y = None
@@ -132,7 +134,7 @@ class Conv2D(_Layer):
             y = T.conv2d(x, self.kernel, self.bias, self.strides, act, False, False)
         if y.shape[-1] != self.cout:
             y = y[..., :self.cout]
-        if y.dtype != torch.float32:
+        if y.dtype != torch.float32 and not (out_lp and (act or self.activation is None)):
             y = y.float()
         return y if act else _activation(y, self.activation)
 
@@ -179,7 +181,7 @@ class ImageEncoder:
 
     def __call__(self, x, eps):
         B = x.shape[0]
-        h = self.e2(self.e1(x.reshape(B, -1))) if self.dense else self.e3(self.e2(self.e1(x))).reshape(B, -1)
+        h = self.e2(self.e1(x.reshape(B, -1))) if self.dense else self.e3(self.e2(self.e1(x, out_lp=True), out_lp=True)).reshape(B, -1)
         z_mean, z_sig = self.z_mu(h), self.z_sigma(h)
         return _sample(z_mean, z_sig, eps), z_mean, z_sig
 
@@ -206,7 +208,7 @@ class ImageDecoder:
         if self.dense:
             return self.d3(self.d2(self.d1(z))).reshape(-1, H, W, C)
         x = self.d1(z).reshape(-1, H // 8, W // 8, 128)
-        return self.d5(self.d4(self.d3(self.d2(x))))
+        return self.d5(self.d4(self.d3(self.d2(x, out_lp=True), out_lp=True)))      # d4's sigmoid is a torch op: fp32 from there
 
 
 class BackgroundModel:
@@ -233,7 +235,7 @@ class ObjEncoder:
 
     def __call__(self, glimpses, eps):
         g = glimpses.reshape(-1, *glimpses.shape[2:])
-        x = self.conv2(self.conv1(g))
+        x = self.conv2(self.conv1(g, out_lp=True))
         h = self.dense1(x.reshape(x.shape[0], -1))
         mean, sig = self.z_what_mu(h), self.z_what_sigma(h)
         return _sample(mean, sig, eps), mean, sig
@@ -253,7 +255,7 @@ class ObjDecoder:
     def __call__(self, z_what):
         S = self.object_size
         x = self.d1(self.d0(z_what)).reshape(-1, S // 4, S // 4, 32)
-        x = self.d5(self.d3(self.d2(x)))
+        x = self.d5(self.d3(self.d2(x, out_lp=True), out_lp=True))
         return torch.sigmoid(x[..., :self.num_channel]), torch.sigmoid(x[..., self.num_channel:])
 
 
@@ -289,7 +291,7 @@ class Encoder:
     def __call__(self, inputs, noise, training=False):
         x, z_l = inputs if isinstance(inputs, (list, tuple)) else (inputs, None)
         B = x.shape[0]
-        z = self.z3(self.z2(self.z1(self.conv3(self.conv2(self.conv1(x))))))
+        z = self.z3(self.z2(self.z1(self.conv3(self.conv2(self.conv1(x, out_lp=True), out_lp=True)))))
         Hc, Wc = z.shape[1], z.shape[2]
         n = B * Hc * Wc
         fv = z.reshape(n, z.shape[-1])
