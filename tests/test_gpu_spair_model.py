@@ -191,3 +191,19 @@ def test_bf16_convolutions_track_the_fp32_model(lib_built):
         _, _, total, _ = spair_trainer.train_step(model, images, opt, s, c, return_grads=True)
         tot.append(float(total))
     assert np.isfinite(tot).all() and np.mean(tot[-5:]) < 0.9 * np.mean(tot[:5]), tot
+
+
+@pytest.mark.parametrize("extra", [[], ["--graph", "--dtype", "bf16"]], ids=["eager_f32", "graph_bf16"])
+def test_spair_cli_trains_on_synthetic_canvases(lib_built, capsys, extra):
+    """python -m split_vae_amd.spair_main with README.md:93's SPLIT-SPAIR flags on synthetic canvases: a few steps, the 9 train and
+    11 test metrics logged under the reference's names (spair/trainer.py:125-129)."""
+    from split_vae_amd import spair_main, spair_trainer
+    hist = spair_main.main("--dataset cub_solid_fixed --z_bg_beta 10 --patch_size 8 --latent_size 64 --bg_latent_size 4 --local_latent_size 4 "
+                           "--model lg_spair -split_z_l -concat_z_what -dense_local -dense_bg --training_steps 4 --log_every 2 --batch_size 8 "
+                           "--synthetic".split() + extra)
+    out = capsys.readouterr().out
+    assert "Training done!" in out and "Total params: 31885347" in out
+    assert [h["step"] for h in hist] == [0, 2, 4]
+    assert list(hist[-1]["train"]) == spair_trainer.TRAIN_METRIC_NAMES
+    assert list(hist[-1]["test0"]) == [n + "0" for n in spair_trainer.TEST_METRIC_NAMES]
+    assert all(np.isfinite(v) for v in hist[-1]["train"].values())
