@@ -159,7 +159,8 @@ class Workload:
 
     def step(self):
         from split_vae_amd import trainer
-        images = self.aug.augment(self.x, sample_offset=self.off)
+        # plan=: the augmentation kernel also writes the step's padded low-precision inputs (one pass over the batch less)
+        images = self.aug.augment(self.x, sample_offset=self.off, plan=None if os.environ.get("SV_BENCH_NO_STAGED") else self.model.plan(self.x.shape[0]))
         # keep_recon=False: like the reference's step (returns nothing), the reconstructions die inside the fused loss
         return trainer.train_step(self.model, images, self.opt, reducer=self.reducer, sample_offset=self.off,
                                   keep_recon=os.environ.get("SV_BENCH_KEEP_RECON") is not None)

@@ -34,6 +34,11 @@ const char* sv_version(void);
  * perm[n]); images6[B,H,W,6] fp32 = [x | x_aug].  Pure index bookkeeping: bit-exact. */
 int sv_scramble_gather(const float* x, const int32_t* perm, float* images6,
                        int32_t B, int32_t H, int32_t W, int32_t patch, void* stream);
+/* The same, also writing the two zero-padded 8-channel NHWC tensors (x | x_aug, sv_dtype `dtype`) the first encoder layers of
+ * sv_lgvae_step read -- pass the plan's in8_x / in8_xh buffers (sv_lgvae_buffer) and SV_PHASE_INPUTS_STAGED to the step: images6 is
+ * read once less and the step's split / pad pass drops out (vae/main.py:57-61 + vae/model.py:190 in one kernel). */
+int sv_scramble_gather_staged(const float* x, const int32_t* perm, float* images6, void* x8, void* xh8, int32_t dtype, int32_t B,
+                              int32_t H, int32_t W, int32_t patch, void* stream);
 /* tf.random.shuffle (augmentation.py:49) stand-in: one uniform permutation per image from a
  * counter-based Philox stream keyed by (seed, step, global sample index = sample_offset + b),
  * so 1-GPU and N-GPU runs draw identical permutations.  n_patch <= 4096. */
@@ -364,6 +369,8 @@ enum { SV_PHASE_PREP = 1,           /* fp32 master weights -> MFMA-ready images 
                                        the head conv's epilogue; the reconstruction tensors out6_x / out6_xh (x_mean | x_log_scale) are
                                        then dead -- train_step_lg_vae (vae/trainer.py:121-144) returns nothing -- and with this bit they
                                        are not stored (100 MB of HBM writes per 512-image step).  Losses and gradients are unchanged. */
+       SV_PHASE_INPUTS_STAGED = 512, /* modifier: the plan buffers in8_x / in8_xh already hold this call's images6 as padded 8-channel
+                                       tensors in the plan's dtype (written by sv_scramble_gather_staged): the split / pad pass is skipped */
        SV_PHASE_FORWARD = 6, SV_PHASE_BACKWARD = 112, SV_PHASE_ALL = 255 };
 
 typedef struct {

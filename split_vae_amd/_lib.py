@@ -14,6 +14,7 @@ SV_ACT_NONE, SV_ACT_RELU, SV_ACT_ELU = 0, 1, 2
 PHASE_PREP, PHASE_FWD_ENCODERS, PHASE_FWD_DECODERS, PHASE_LOSS = 1, 2, 4, 8
 PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM = 16, 32, 64, 128
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
+PHASE_INPUTS_STAGED = 512  # modifier: in8_x / in8_xh were written by sv_scramble_gather_staged (include/splitvae.h)
 PHASE_NO_RECON = 256      # modifier: the fused-loss training step does not store out6_x / out6_xh (include/splitvae.h)
 PHASE_INFER = PHASE_PREP | PHASE_FORWARD
 
@@ -62,6 +63,7 @@ _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_fl
 SYMBOLS = {
     "sv_version": (C.c_char_p, []),
     "sv_scramble_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sv_scramble_gather_staged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_random_perm": (C.c_int, [_vp, _i32, _i32, _u64, _u64, _i64, _vp]),
     "sv_dlogistic_nll": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f, _i32, _i32, _i32, _vp, _vp]),
     "sv_dlogistic_nll_workspace_bytes": (_i64, [_i32, _i32, _i32]),

@@ -23,7 +23,7 @@ class Augmentator(object):
         else:
             raise ValueError("unknown augmentation type %r" % (type,))
 
-    def scramble(self, x, perm=None, sample_offset=0):
+    def scramble(self, x, perm=None, sample_offset=0, plan=None):
         """x[B,H,W,3] (or [H,W,3]) fp32 on the device -> concat([x, x_aug], axis=-1).
         perm[B,(H/size)^2] int32 makes the shuffle explicit (the reference draws it from TF's
         unseeded RNG, augmentation.py:49); by default it comes from the counter-based Philox
@@ -39,7 +39,14 @@ class Augmentator(object):
         if perm is None:
             perm = ops.random_perm(B, (H // self.size) * (W // self.size), self.seed, self._step, sample_offset, x.device)
             self._step += 1
-        out = ops.scramble_gather(x.contiguous(), perm.to(torch.int32).contiguous(), self.size)
+        staged = None
+        if plan is not None and not single and (plan.desc.B, plan.desc.H, plan.desc.W) == (B, H, W):
+            # the training plan's padded input buffers are written by the same kernel (ops.scramble_gather, staged=): train_step
+            # recognises the returned tensor and skips its split / pad pass
+            staged = (plan.buffer("in8_x", plan.dtype, (B, H, W, 8)), plan.buffer("in8_xh", plan.dtype, (B, H, W, 8)))
+        out = ops.scramble_gather(x.contiguous(), perm.to(torch.int32).contiguous(), self.size, staged=staged)
+        if staged is not None:
+            out._sv_staged_plan = plan
         return out[0] if single else out
 
     def no_op(self, x):

@@ -31,6 +31,60 @@ __global__ __launch_bounds__(256) void scramble_kernel(const float* __restrict__
   }
 }
 
+// The same gather that also writes what the step's split_pad would derive from images6: the two 8-channel (zero padded) NHWC
+// tensors the first encoder layers read, in the plan's contraction dtype -- images6 is then read once less and split_pad drops out.
+template <typename T>
+__global__ __launch_bounds__(256) void scramble_staged_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm,
+                                                              float* __restrict__ out, T* __restrict__ x8, T* __restrict__ xh8,
+                                                              int B, int H, int W, int s, int G) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int xw = (int)(idx % W);
+    const int64_t t = idx / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int r = y / s, i = y - r * s, c = xw / s, j = xw - c * s;
+    const int p = perm[(int64_t)b * G * G + r * G + c];
+    const int pr = p / G, pc = p - pr * G;
+    const float* src0 = x + idx * 3;
+    const float* src1 = x + (((int64_t)b * H + pr * s + i) * W + pc * s + j) * 3;
+    float* dst = out + idx * 6;
+    const float a0 = src0[0], a1 = src0[1], a2 = src0[2];
+    const float b0 = src1[0], b1 = src1[1], b2 = src1[2];
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
+    T u[8], w[8];
+    u[0] = from_f32<T>(a0); u[1] = from_f32<T>(a1); u[2] = from_f32<T>(a2);
+    w[0] = from_f32<T>(b0); w[1] = from_f32<T>(b1); w[2] = from_f32<T>(b2);
+#pragma unroll
+    for (int e = 3; e < 8; ++e) { u[e] = from_f32<T>(0.f); w[e] = from_f32<T>(0.f); }
+    if constexpr (sizeof(T) == 2) {
+      *(uint4*)(x8 + idx * 8) = *(uint4*)u;
+      *(uint4*)(xh8 + idx * 8) = *(uint4*)w;
+    } else {
+      *(uint4*)(x8 + idx * 8) = *(uint4*)u; *(uint4*)(x8 + idx * 8 + 4) = *(uint4*)(u + 4);
+      *(uint4*)(xh8 + idx * 8) = *(uint4*)w; *(uint4*)(xh8 + idx * 8 + 4) = *(uint4*)(w + 4);
+    }
+  }
+}
+
+extern "C" int sv_scramble_gather_staged(const float* x, const int32_t* perm, float* images6, void* x8, void* xh8, int32_t dtype,
+                                         int32_t B, int32_t H, int32_t W, int32_t patch, void* stream) {
+  if (!x || !perm || !images6 || !x8 || !xh8 || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return SV_E_BADARG;
+  if (dtype != SV_BF16 && dtype != SV_F32) return SV_E_BADARG;
+  if (H != W || H % patch) return SV_E_UNSUPPORTED;
+  const int64_t total = (int64_t)B * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (dtype == SV_BF16)
+    hipLaunchKernelGGL((scramble_staged_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, perm, images6, (bf16_t*)x8,
+                       (bf16_t*)xh8, B, H, W, patch, W / patch);
+  else
+    hipLaunchKernelGGL((scramble_staged_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, perm, images6, (float*)x8,
+                       (float*)xh8, B, H, W, patch, W / patch);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_scramble_gather(const float* x, const int32_t* perm, float* images6, int32_t B,
                                   int32_t H, int32_t W, int32_t patch, void* stream) {
   if (!x || !perm || !images6 || B <= 0 || H <= 0 || W <= 0 || patch <= 0) return SV_E_BADARG;

@@ -58,12 +58,18 @@ def random_perm(B, n_patch, seed, step=0, sample_offset=0, device="cuda"):
     return perm
 
 
-def scramble_gather(x, perm, patch):
+def scramble_gather(x, perm, patch, staged=None):
     """x[B,H,W,3] fp32, perm[B,(H/patch)^2] int32 -> [B,H,W,6] = concat([x, x_aug], axis=-1)."""
     B, H, W, Cc = x.shape
     assert Cc == 3 and x.dtype == torch.float32 and perm.dtype == torch.int32
     assert perm.shape == (B, (H // patch) * (W // patch))
     out = torch.empty((B, H, W, 6), dtype=torch.float32, device=x.device)
+    if staged is not None:                       # (x8, xh8): a plan's in8_x / in8_xh buffers, filled in the same pass
+        x8, xh8 = staged
+        assert x8.shape == (B, H, W, 8) and xh8.shape == (B, H, W, 8) and x8.dtype == xh8.dtype
+        check(_lib.load().sv_scramble_gather_staged(_p(x), _p(perm), _p(out), _p(x8), _p(xh8), sv_dtype(x8.dtype), B, H, W, patch,
+                                                    _stream()), "sv_scramble_gather_staged")
+        return out
     check(_lib.load().sv_scramble_gather(_p(x), _p(perm), _p(out), B, H, W, patch, _stream()), "sv_scramble_gather")
     return out
 

@@ -13,7 +13,7 @@ import torch
 
 from . import dist as svdist
 from ._lib import (PHASE_ADAM, PHASE_ALL, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS,
-                   PHASE_FORWARD, PHASE_LOSS, PHASE_NO_RECON, PHASE_PREP)
+                   PHASE_FORWARD, PHASE_INPUTS_STAGED, PHASE_LOSS, PHASE_NO_RECON, PHASE_PREP)
 from .model import LGVae
 
 METRIC_NAMES = ["x_recon_loss", "x_kl_loss", "x_hat_recon_loss", "x_hat_kl_loss", "total_kl_loss"]
@@ -84,6 +84,9 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
               accumulate_metrics=accumulate_metrics)
     model._calls += 1
     nr = 0 if keep_recon else PHASE_NO_RECON
+    if getattr(images, "_sv_staged_plan", None) is plan:      # Augmentator.scramble(..., plan=plan) filled in8_x / in8_xh already
+        nr |= PHASE_INPUTS_STAGED
+        images._sv_staged_plan = None                         # one step per staging
     if reducer is None or (reducer.world == 1 and not getattr(reducer, "force", False)):
         plan.step(PHASE_ALL | nr, **kw)
         return plan

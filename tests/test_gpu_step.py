@@ -253,3 +253,38 @@ def test_step_without_stored_reconstructions_is_the_same_step(lib_built):
     # (the split-K atomics of the heads / d1 reorder fp32 sums from run to run: equal up to that, not bitwise)
     assert float((g0 - g1).norm() / g0.norm()) < 1e-4 and float((p0 - p1).norm() / p0.norm()) < 1e-3   # (first Adam step = lr * sign-like: near-zero gradients flip)
     assert float(o0.abs().max()) > 0 and float(o1.abs().max()) == 0.0      # stored / never written (the workspace starts zeroed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_staged_augmentation_fills_the_step_inputs(lib_built, dtype):
+    """Augmentator.scramble(x, plan=plan): the scramble kernel also writes the plan's padded input tensors (in8_x / in8_xh) and
+    train_step skips its split / pad pass (SV_PHASE_INPUTS_STAGED).  images6 bit-equal to the plain augmentation, the staged
+    buffers bit-equal to what split_pad derives from it, the step's losses equal."""
+    import torch
+    from split_vae_amd import data, trainer
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+    B, H = 16, 32
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    res = []
+    for staged in (False, True):
+        m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=dtype, device=torch.device("cuda"), seed=3)
+        plan = m.plan(B)
+        aug = Augmentator("scramble", size=4, seed=1)
+        img = aug.augment(x, plan=plan if staged else None)
+        assert (getattr(img, "_sv_staged_plan", None) is plan) == staged
+        if staged:                                       # poison check: the step must not rewrite the buffers from images6
+            in8 = plan.buffer("in8_xh", plan.dtype, (B, H, H, 8)).clone()
+        trainer.train_step(m, img, Adam(learning_rate=1e-4))
+        torch.cuda.synchronize()
+        assert getattr(img, "_sv_staged_plan", None) is None
+        res.append((img.clone(), plan.buffer("in8_x", plan.dtype, (B, H, H, 8)).clone(), plan.buffer("in8_xh", plan.dtype, (B, H, H, 8)).clone(),
+                    trainer.last_losses(plan)))
+        if staged:
+            assert torch.equal(in8, res[-1][2])
+    (i0, a0, b0, l0), (i1, a1, b1, l1) = res
+    assert torch.equal(i0, i1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), k
