@@ -234,6 +234,34 @@ SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyp
                 "wgrad.d5": ["wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
 
 
+def spair_row(dev, B=32, steps=60, warmup=5):
+    """SPLIT-SPAIR (config 5, README.md:93: lg_spair -split_z_l -concat_z_what -dense_local -dense_bg; 48x48 canvases, batch 32 as the
+    reference hard-codes) train step: forward + losses + autograd backward over the split_vae::* operators + clipnorm Adam, captured
+    into one hipGraph and replayed (spair_trainer.GraphedTrainStep); fp32 like the reference and with bf16 convolutions."""
+    import torch
+    from split_vae_amd import spair, spair_main, spair_trainer
+    from split_vae_amd.augmentation import Augmentator
+    out = {"unit": "images/s", "batch": B, "steps": steps, "launch": "hipGraph replay"}
+    for dt_ in ("f32", "bf16"):
+        cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+                                        split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True, dtype=dt_)
+        model = spair.get_model(cfg, device=dev, seed=0)
+        x, _ = spair_main.synthetic_canvases(B, seed=1, device=dev)
+        images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x)
+        step_fn = spair_trainer.GraphedTrainStep(model, spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0), cfg, images)
+        for i in range(warmup):
+            step_fn(images, i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(images, warmup + i)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / steps
+        out[dt_] = {"value": round(B / t, 1), "ms_per_step": round(1e3 * t, 4)}
+        del step_fn, model
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +367,10 @@ def main():
         rows["celeba64_b64"] = row(64, 64, "bf16", 200)        # config 4's per-GPU shard (512 / 8)
         rows["celeba64_b128"] = row(64, 128, "bf16", 200)
         rows["long_run"] = {"steps": 400, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
+        try:
+            rows["lg_spair_b32"] = spair_row(dev)                  # config 5 (SPLIT-SPAIR), the next row of SURVEY 8f
+        except Exception as e:                                    # never at the headline's expense
+            rows["lg_spair_b32"] = {"error": repr(e)[:200]}
 
     if rank != 0:
         if torch.distributed.is_initialized():
