@@ -16,6 +16,7 @@ LAYERS = {  # name: H, Cin, Cout, k, stride, act, y_f32
     "d3": (16, 128, 64, 4, 1, "relu", False),
     "d4": (32, 64, 32, 6, 1, "relu", False),
     "d5": (64, 32, 6, 6, 1, None, True),
+    "e1s2d": (32, 16, 32, 3, 1, "relu", False),      # e1 on the space-to-depth input (2x2 pixels x 3 channels -> 12 of 16): 3x3 stride 1
 }
 
 

@@ -207,3 +207,41 @@ def test_spair_cli_trains_on_synthetic_canvases(lib_built, capsys, extra):
     assert list(hist[-1]["train"]) == spair_trainer.TRAIN_METRIC_NAMES
     assert list(hist[-1]["test0"]) == [n + "0" for n in spair_trainer.TEST_METRIC_NAMES]
     assert all(np.isfinite(v) for v in hist[-1]["train"].values())
+
+
+def test_spair_step_matches_the_golden_fixture(lib_built):
+    """The committed SPLIT-SPAIR vectors (tests/golden/lgspair_b2.npz: README.md:93's model, batch 2, step 41; made from the fp64
+    restatement) against the device step: inputs from the fixture, variables and draws regenerated from their seeds."""
+    import os
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_spair", os.path.join(sys_path, "make_golden_spair.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    G = np.load(os.path.join(sys_path, "lgspair_b2.npz"))
+    cfg = R.default_config(**mk.CONFIG)
+    p = R.init_params(cfg, seed=mk.SEED_W)
+    noise = {k: v.float().cuda() for k, v in R.draw_noise(cfg, mk.B, seed=mk.SEED_N).items()}
+    model = spair.get_model(dotdict(cfg), seed=0)
+    model.set_weights({k: v.numpy() for k, v in p.items()})
+    images = torch.from_numpy(G["images"]).cuda()
+    opt = spair_trainer.ClipnormAdam(learning_rate=1e-4)
+    out = model(images, training=True, noise=noise)
+    total, losses = spair_trainer.compute_losses(dotdict(cfg), images, out, float(mk.STEP), training=True)
+    grads = torch.autograd.grad(total, [v for _, v in model.trainable_variables])
+    o = spair_trainer._unpack(dotdict(cfg), out)
+    assert abs(float(total) - float(G["total_loss"])) <= 2e-4 * abs(float(G["total_loss"]))
+    np.testing.assert_allclose(np.array([float(l) for l in losses]), G["losses"], rtol=2e-4, atol=2e-4)
+    for k in mk.WHOLE:
+        a, b = o[k].detach().double().cpu().numpy(), G["out/" + k]
+        assert np.linalg.norm(a - b) <= 2e-4 * max(np.linalg.norm(b), 1e-12), k
+    for k in mk.SAMPLED:
+        f = o[k].detach().double().cpu().numpy().reshape(-1)
+        assert abs(np.linalg.norm(f) - float(G["norm/" + k])) <= 2e-4 * float(G["norm/" + k]), k
+        s = f[mk.sample_idx(f.size)]
+        assert np.linalg.norm(s - G["sample/" + k]) <= 5e-4 * max(np.linalg.norm(G["sample/" + k]), 1e-12), k
+    gn = np.array([float(g.norm()) for g in grads])
+    np.testing.assert_allclose(gn, G["grad_norms"], rtol=5e-3)

@@ -106,3 +106,19 @@ def test_clipnorm_adam_first_step():
     assert torch.allclose(m[0], 0.1 * torch.tensor([0.6, 0.0, 0.8, 0.0], dtype=torch.float64))      # clipped to unit norm
     assert torch.allclose(m[1], 0.1 * g[1])                                                           # below the threshold: untouched
     assert float(p[0][0]) < 0 and float(p[0][1]) == 0.0
+
+
+def test_oracle_reproduces_the_committed_spair_fixture():
+    """tests/golden/lgspair_b2.npz (made by tests/golden/make_golden_spair.py from this restatement): any change to the oracle's
+    arithmetic shows up here before it silently moves the GPU tests' target."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_spair", os.path.join(here, "golden", "make_golden_spair.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.compute()
+    with np.load(os.path.join(here, "golden", "lgspair_b2.npz")) as G:
+        assert set(G.files) == set(got)
+        for k in G.files:
+            np.testing.assert_allclose(got[k], G[k], rtol=1e-9, atol=1e-12, err_msg=k)
