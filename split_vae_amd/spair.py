@@ -387,10 +387,44 @@ class _Model:
     def get_weights(self):
         return {n: v.detach().cpu().numpy().copy() for (n, _), v in zip(self.store.spec, self.store.vars)}
 
+    def keras_h5_layers(self):
+        """[(top-level layer, [weight names])]: the variables grouped by the Keras sub-model they belong to (spair/spair.py: encoder,
+        decoder, bg_model | bg_encoder, bg_decoder, x_hat_encoder, x_hat_decoder), in variable order."""
+        groups = []
+        for n, _ in self.store.spec:
+            top = n.split("/")[0]
+            wn = (n + ":0") if n.endswith("/bias") else (n + "/kernel:0")
+            if groups and groups[-1][0] == top:
+                groups[-1][1].append(wn)
+            else:
+                groups.append((top, [wn]))
+        return groups
+
     def save_weights(self, path):
+        """spair/trainer.py:424 model.save_weights('models/<run>.h5'): a Keras HDF5 weights file (h5io.py: layer_names / weight_names
+        attribute layout) when the path ends in .h5 / .hdf5 / .keras, else an .npz keyed by the variable names.  Keras layouts either
+        way (conv HWIO, dense [in,out]).  Returns the path written."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5", ".keras")):
+            from . import h5io
+            it = iter(v.detach().cpu().numpy() for v in self.store.vars)
+            return h5io.save_keras_weights(path, [(ln, [(wn, next(it)) for wn in wns]) for ln, wns in self.keras_h5_layers()])
+        path = path if path.endswith(".npz") else path + ".npz"
         np.savez(path, **self.get_weights())
+        return path
 
     def load_weights(self, path):
+        """Inverse of save_weights; HDF5 files are read BY ORDER like Keras' load_weights_from_hdf5_group, shapes checked."""
+        path = str(path)
+        if path.endswith((".h5", ".hdf5", ".keras")):
+            from . import h5io
+            arrs = [a for _, ws in h5io.load_keras_weights(path) for _, a in ws]
+            if [tuple(a.shape) for a in arrs] != [shp for _, shp in self.store.spec]:
+                raise ValueError("weights file does not match this model's variables (count / shapes, by order)")
+            with torch.no_grad():
+                for v, a in zip(self.store.vars, arrs):
+                    v.copy_(torch.from_numpy(a))
+            return
         with np.load(path) as f:
             self.set_weights({k: f[k] for k in f.files})
 

@@ -37,6 +37,7 @@ def build_parser():
     ap.add_argument("--log_every", type=int, default=1000)
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
                     help="bf16: the spatial convolutions on the bf16 MFMA kernels (fp32 accumulation / master weights); f32 = the reference's precision")
+    ap.add_argument("--save_weights", action="store_true", help="write models/<time>.h5 (Keras HDF5 weights) at the end, as spair/trainer.py:424 does")
     ap.add_argument("--graph", action="store_true", help="capture the train step into a hipGraph and replay it (spair_trainer.GraphedTrainStep)")
     return ap
 

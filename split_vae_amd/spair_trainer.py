@@ -283,4 +283,9 @@ def train_spair(model, optimizer, dataset, train_dataset, test_dataset, config, 
         if step >= config.training_steps:
             log('Training done!')
             break
+    if config.save_weights:                                               # spair/trainer.py:424 (the reference always saves; opt-in here)
+        import os
+        from . import h5io
+        os.makedirs('models', exist_ok=True)
+        log('saved', model.save_weights(os.path.join('models', time.strftime("%Y%m%d-%H%M%S") + ('.h5' if h5io.available() else '.npz'))))
     return history
