@@ -84,7 +84,7 @@ int sv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* The same with Keras `clipnorm` (SPLIT-SPAIR: Adam(..., clipnorm=1.0), spair/main.py:109): every gradient tensor is scaled by
  * clipnorm / max(||g * grad_scale||_2, clipnorm) first (tf.clip_by_norm).  tensor_off: DEVICE array of n_tensors+1 element
- * offsets into the flat buffers; norm_ws: DEVICE scratch of 128*n_tensors floats.  Deterministic (fixed-order norms). */
+ * offsets into the flat buffers; norm_ws: DEVICE scratch of 256*n_tensors floats.  Deterministic (fixed-order norms). */
 int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
                           float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
                           float grad_scale, void* stream);

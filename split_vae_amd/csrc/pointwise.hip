@@ -529,17 +529,32 @@ extern "C" int sv_adam_step(float* p, const float* g, float* m, float* v, int64_
 }
 
 // ---- Adam with Keras `clipnorm` (spair/main.py:109: Adam(..., clipnorm=1.0)): every gradient TENSOR is scaled by
-// clipnorm / max(||g||_2, clipnorm) (tf.clip_by_norm) before the update.  Pass 1: 128 partial sums of squares per tensor
+// clipnorm / max(||g||_2, clipnorm) (tf.clip_by_norm) before the update.  Pass 1: 256 partial sums of squares per tensor
 // (fixed strides); pass 2: a workgroup column per tensor adds them in a fixed order and applies the update -- deterministic.
-#define SV_CLIP_PARTS 128
+#define SV_CLIP_PARTS 256
+// element range [lo, hi) of a tensor split into an unaligned head, a float4 body and a tail (the flat buffers are 16-byte aligned, so
+// the split is the same for p, g, m and v)
+__device__ __forceinline__ void clip_split(int64_t lo, int64_t hi, int64_t& a, int64_t& b) {
+  a = min((lo + 3) & ~(int64_t)3, hi);
+  b = max(a, hi & ~(int64_t)3);
+}
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const int64_t* __restrict__ off,
                                                     float* __restrict__ parts, float gscale) {
   const int t = blockIdx.y;
   const int64_t lo = off[t], hi = off[t + 1];
+  int64_t a, b;
+  clip_split(lo, hi, a, b);
   float s = 0.f;
-  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)SV_CLIP_PARTS * 256) {
-    const float v = g[i] * gscale;
-    s += v * v;
+  const float4* g4 = (const float4*)(g + a);
+  const int64_t n4 = (b - a) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)SV_CLIP_PARTS * 256) {
+    const float4 v = g4[i];
+    const float x = v.x * gscale, y = v.y * gscale, z = v.z * gscale, w = v.w * gscale;
+    s += (x * x + y * y) + (z * z + w * w);
+  }
+  if (blockIdx.x == 0) {                                   // head and tail (at most 3 elements each)
+    for (int64_t i = lo + threadIdx.x; i < a; i += 256) { const float v = g[i] * gscale; s += v * v; }
+    for (int64_t i = b + threadIdx.x; i < hi; i += 256) { const float v = g[i] * gscale; s += v * v; }
   }
   __shared__ float red[4];
   s = wave_sum(s);
@@ -554,17 +569,31 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
                                                         const float* __restrict__ alpha_dev) {
   const int t = blockIdx.y;
   if (alpha_dev) alpha = *alpha_dev;                           // hipGraph replay: the bias-corrected step size of iteration t
-  float ss = 0.f;
-  for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];
-  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
   const int64_t lo = off[t], hi = off[t + 1];
-  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) {
-    const float gc = g[i] * sc;
-    float mi = m[i], vi = v[i];
+  if (lo + (int64_t)blockIdx.x * 1024 >= hi && blockIdx.x) return;   // nothing for this workgroup (small tensors): skip the partial sums too
+  float ss = 0.f;
+  for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];   // fixed order: deterministic
+  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
+  int64_t a, b;
+  clip_split(lo, hi, a, b);
+  auto upd = [&](float gi, float& pi, float& mi, float& vi) {
+    const float gc = gi * sc;
     mi = mi + (gc - mi) * omb1;
     vi = vi + (gc * gc - vi) * omb2;
-    p[i] = p[i] - alpha * mi / (sqrtf(vi) + eps);
-    m[i] = mi; v[i] = vi;
+    pi = pi - alpha * mi / (sqrtf(vi) + eps);
+  };
+  const int64_t n4 = (b - a) >> 2;
+  float4* p4 = (float4*)(p + a); float4* m4 = (float4*)(m + a); float4* v4 = (float4*)(v + a);
+  const float4* g4 = (const float4*)(g + a);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
+    upd(gg.x, pp.x, mm.x, vv.x); upd(gg.y, pp.y, mm.y, vv.y); upd(gg.z, pp.z, mm.z, vv.z); upd(gg.w, pp.w, mm.w, vv.w);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = lo + threadIdx.x; i < a; i += 256) { float pi = p[i], mi = m[i], vi = v[i]; upd(g[i], pi, mi, vi); p[i] = pi; m[i] = mi; v[i] = vi; }
+    for (int64_t i = b + threadIdx.x; i < hi; i += 256) { float pi = p[i], mi = m[i], vi = v[i]; upd(g[i], pi, mi, vi); p[i] = pi; m[i] = mi; v[i] = vi; }
   }
 }
 

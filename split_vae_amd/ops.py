@@ -245,7 +245,7 @@ def adam_step_clipnorm(p, g, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2
     """Keras Adam(clipnorm=...) over flat buffers; tensor_off: int64 device tensor of n_tensors+1 offsets.  alpha_dev: a
     1-element device tensor holding adam_alpha(lr, beta1, beta2, t) -- read at run time instead of (lr, t) (hipGraph replay)."""
     nt = tensor_off.numel() - 1
-    ws = torch.empty((128 * nt,), dtype=torch.float32, device=p.device)
+    ws = torch.empty((256 * nt,), dtype=torch.float32, device=p.device)
     check(_lib.load().sv_adam_step_clipnorm_dyn(_p(p), _p(g), _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
                                                 float(beta1), float(beta2), float(eps), int(t), _p(alpha_dev), float(grad_scale),
                                                 _stream()), "sv_adam_step_clipnorm")
