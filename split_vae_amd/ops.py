@@ -324,6 +324,11 @@ class Conv2D:
     def wgrad(self, x, dy, workspace=False, dw=None, db=None):
         """dw / db: zeroed fp32 views to accumulate into (e.g. slices of a flat gradient buffer)."""
         d = self.desc
+        if dw is None and db is None:                    # one zero fill for both accumulators
+            n = d.KH * d.KW * d.Cin * d.Cout
+            n4 = (n + 3) // 4 * 4
+            z = torch.zeros((n4 + d.Cout,), dtype=torch.float32, device=x.device)
+            dw, db = z[:n].view(d.KH, d.KW, d.Cin, d.Cout), z[n4:]
         if dw is None:
             dw = torch.zeros((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=x.device)
         if db is None:
