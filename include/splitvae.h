@@ -95,6 +95,12 @@ int sv_adam_step_clipnorm_dyn(float* p, const float* g, float* m, float* v, cons
                               float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
                               const float* alpha_dev, float grad_scale, void* stream);
 float sv_adam_alpha(float lr, float beta1, float beta2, int64_t t);
+/* The same over SEPARATE gradient tensors: grads = HOST array of n_tensors (<= 128) DEVICE pointers, 16-byte aligned, tensor i
+ * holding tensor_off[i+1] - tensor_off[i] floats.  The addresses are passed to the kernels by value: no flat copy of the
+ * gradients, and a captured hipGraph stays valid while the tensors keep their addresses.  alpha_dev may be NULL. */
+int sv_adam_step_clipnorm_ptrs(float* p, const float* const* grads, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,
+                               float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps, int64_t t,
+                               const float* alpha_dev, float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- K10a: bilinear 2x
  * Replaces tf.image.resize(x,[2H,2W]) (vae/model.py:163,:165,:167; bilinear, half-pixel centres,

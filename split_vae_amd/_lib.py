@@ -88,6 +88,8 @@ SYMBOLS = {
     "sv_spair_zpres_kl_dyn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp, C.c_float, C.c_float, _vp]),
     "sv_adam_step_clipnorm_dyn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                             _i64, _vp, C.c_float, _vp]),
+    "sv_adam_step_clipnorm_ptrs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             _i64, _vp, C.c_float, _vp]),
     "sv_adam_alpha": (C.c_float, [C.c_float, C.c_float, C.c_float, _i64]),
     "sv_spair_loss": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sv_stn_bwd_overwrites": (C.c_int, [_i32, _i32, _i32, _i32]),

@@ -597,6 +597,86 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
   }
 }
 
+// ---- the same over SEPARATE gradient tensors (what an autograd engine hands back): their addresses travel by value in the kernel
+// arguments (<= SV_CLIP_MAX_TENSORS), so no flat copy of the gradients is made (a torch.cat of 31.9 M floats was 98 us of the 3.6 ms
+// SPLIT-SPAIR step) and a captured hipGraph keeps working as long as the tensors keep their addresses.
+#define SV_CLIP_MAX_TENSORS 128
+struct GradPtrs { const float* g[SV_CLIP_MAX_TENSORS]; };
+__global__ __launch_bounds__(256) void sumsq_ptrs_kernel(const GradPtrs P, const int64_t* __restrict__ off, float* __restrict__ parts, float gscale) {
+  const int t = blockIdx.y;
+  const int64_t n = off[t + 1] - off[t];
+  const float* __restrict__ g = P.g[t];                       // 16-byte aligned (its own allocation)
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)SV_CLIP_PARTS * 256) {
+    const float4 v = ((const float4*)g)[i];
+    const float x = v.x * gscale, y = v.y * gscale, z = v.z * gscale, w = v.w * gscale;
+    s += (x * x + y * y) + (z * z + w * w);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) { const float v = g[i] * gscale; s += v * v; }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[(int64_t)t * SV_CLIP_PARTS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void adam_clip_ptrs_kernel(float* __restrict__ p, const GradPtrs P, float* __restrict__ m, float* __restrict__ v,
+                                                             const int64_t* __restrict__ off, const float* __restrict__ parts, float clipnorm,
+                                                             float alpha, float omb1, float omb2, float eps, float gscale,
+                                                             const float* __restrict__ alpha_dev) {
+  const int t = blockIdx.y;
+  if (alpha_dev) alpha = *alpha_dev;
+  const int64_t lo = off[t], hi = off[t + 1];
+  if (lo + (int64_t)blockIdx.x * 1024 >= hi && blockIdx.x) return;
+  float ss = 0.f;
+  for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];
+  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
+  const float* __restrict__ g = P.g[t] - lo;                  // g[i], i in [lo, hi): the flat index of the variable buffers
+  int64_t a, b;
+  clip_split(lo, hi, a, b);
+  auto upd = [&](float gi, float& pi, float& mi, float& vi) {
+    const float gc = gi * sc;
+    mi = mi + (gc - mi) * omb1;
+    vi = vi + (gc * gc - vi) * omb2;
+    pi = pi - alpha * mi / (sqrtf(vi) + eps);
+  };
+  const int64_t n4 = (b - a) >> 2;
+  float4* p4 = (float4*)(p + a); float4* m4 = (float4*)(m + a); float4* v4 = (float4*)(v + a);
+  const bool galigned = ((a - lo) & 3) == 0;                   // the gradient tensor starts at its own 16-byte boundary
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i], gg;
+    const float* gi = g + a + 4 * i;
+    if (galigned) gg = *(const float4*)gi;
+    else gg = make_float4(gi[0], gi[1], gi[2], gi[3]);
+    upd(gg.x, pp.x, mm.x, vv.x); upd(gg.y, pp.y, mm.y, vv.y); upd(gg.z, pp.z, mm.z, vv.z); upd(gg.w, pp.w, mm.w, vv.w);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = lo + threadIdx.x; i < a; i += 256) { float pi = p[i], mi = m[i], vi = v[i]; upd(g[i], pi, mi, vi); p[i] = pi; m[i] = mi; v[i] = vi; }
+    for (int64_t i = b + threadIdx.x; i < hi; i += 256) { float pi = p[i], mi = m[i], vi = v[i]; upd(g[i], pi, mi, vi); p[i] = pi; m[i] = mi; v[i] = vi; }
+  }
+}
+
+extern "C" int sv_adam_step_clipnorm_ptrs(float* p, const float* const* grads, float* m, float* v, const int64_t* tensor_off,
+                                          int32_t n_tensors, float* norm_ws, float clipnorm, float lr, float beta1, float beta2, float eps,
+                                          int64_t t, const float* alpha_dev, float grad_scale, void* stream) {
+  if (!p || !grads || !m || !v || !tensor_off || !norm_ws || n_tensors < 1 || n_tensors > SV_CLIP_MAX_TENSORS || t <= 0 || !(clipnorm > 0.f))
+    return SV_E_BADARG;
+  GradPtrs P;
+  for (int i = 0; i < SV_CLIP_MAX_TENSORS; ++i) P.g[i] = i < n_tensors ? grads[i] : nullptr;
+  for (int i = 0; i < n_tensors; ++i)
+    if (!P.g[i] || ((uintptr_t)P.g[i] & 15)) return SV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const double alpha = svk_adam_alpha(lr, beta1, beta2, t);
+  hipLaunchKernelGGL(sumsq_ptrs_kernel, dim3(SV_CLIP_PARTS, n_tensors), dim3(256), 0, st, P, tensor_off, norm_ws, grad_scale);
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_clip_ptrs_kernel, dim3(256, n_tensors), dim3(256), 0, st, p, P, m, v, tensor_off, norm_ws, clipnorm, (float)alpha,
+                     1.f - beta1, 1.f - beta2, eps, grad_scale, alpha_dev);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" float sv_adam_alpha(float lr, float beta1, float beta2, int64_t t) { return (float)svk_adam_alpha(lr, beta1, beta2, t); }
 
 extern "C" int sv_adam_step_clipnorm(float* p, const float* g, float* m, float* v, const int64_t* tensor_off, int32_t n_tensors,

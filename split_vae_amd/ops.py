@@ -218,6 +218,18 @@ def spair_zpres_kl(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_prob, temper
     return kl, g_pre.reshape(z_pres.shape), g_log.reshape(z_pres.shape)
 
 
+def adam_step_clipnorm_tensors(p, grads, m, v, tensor_off, clipnorm, t, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, alpha_dev=None):
+    """adam_step_clipnorm over a LIST of gradient tensors (one per variable, contiguous fp32, in tensor_off order): their
+    addresses go to the kernels by value -- no flat copy."""
+    nt = tensor_off.numel() - 1
+    assert len(grads) == nt and nt <= 128
+    arr = (C.c_void_p * nt)(*[g.data_ptr() for g in grads])
+    ws = torch.empty((256 * nt,), dtype=torch.float32, device=p.device)
+    check(_lib.load().sv_adam_step_clipnorm_ptrs(_p(p), arr, _p(m), _p(v), _p(tensor_off), nt, _p(ws), float(clipnorm), float(lr),
+                                                 float(beta1), float(beta2), float(eps), int(t), _p(alpha_dev), float(grad_scale),
+                                                 _stream()), "sv_adam_step_clipnorm_ptrs")
+
+
 SPAIR_LOSS_MODES = {"xent": 0, "kl": 1, "kl_prior": 2}
 
 

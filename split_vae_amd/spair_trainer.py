@@ -78,13 +78,17 @@ class ClipnormAdam:
         and the caller advances `iterations` per replay."""
         st = model.store
         if self._slots is None:
-            self._slots = (torch.zeros_like(st.flat), torch.zeros_like(st.flat), torch.empty_like(st.flat))
-        m, v, g = self._slots
-        torch.cat([x.reshape(-1) for x in grads], out=g)
+            self._slots = (torch.zeros_like(st.flat), torch.zeros_like(st.flat))
+        m, v = self._slots
         if alpha_dev is None:
             self.iterations += 1
-        ops.adam_step_clipnorm(st.flat, g, m, v, st.tensor_off, self.clipnorm, max(self.iterations, 1), float(self.learning_rate),
-                               self.beta_1, self.beta_2, self.epsilon, alpha_dev=alpha_dev)
+        gs = [g if (g.is_contiguous() and g.data_ptr() % 16 == 0) else g.contiguous().clone() for g in grads]
+        if len(gs) <= 128:                                # the gradient tensors as they are: their addresses go to the kernels by value
+            ops.adam_step_clipnorm_tensors(st.flat, gs, m, v, st.tensor_off, self.clipnorm, max(self.iterations, 1), float(self.learning_rate),
+                                           self.beta_1, self.beta_2, self.epsilon, alpha_dev=alpha_dev)
+        else:
+            ops.adam_step_clipnorm(st.flat, torch.cat([x.reshape(-1) for x in gs]), m, v, st.tensor_off, self.clipnorm, max(self.iterations, 1),
+                                   float(self.learning_rate), self.beta_1, self.beta_2, self.epsilon, alpha_dev=alpha_dev)
 
 
 def _unpack(config, out):

@@ -299,3 +299,25 @@ def test_loss_reductions_and_their_gradients(ops, mode):
         assert ga is None
     else:
         torch.testing.assert_close(ga.double().cpu() * wv, ar.grad, rtol=2e-5, atol=1e-5 * float(ar.grad.abs().max()))
+
+
+def test_clipnorm_adam_over_separate_gradient_tensors(ops):
+    """sv_adam_step_clipnorm_ptrs (gradient tensors as the autograd engine returns them, addresses by value) == the flat-buffer call,
+    including tensors whose flat offset is not a multiple of 4 (a 1-element bias shifts everything behind it)."""
+    g = torch.Generator().manual_seed(8)
+    shapes = [(37, 64), (64,), (64, 1), (1,), (3, 3, 8, 32), (32,), (4099,), (5,)]
+    grads = [torch.randn(s, generator=g).cuda() * (3.0 if i % 2 else 0.01) for i, s in enumerate(shapes)]
+    offs = np.concatenate([[0], np.cumsum([int(np.prod(s)) for s in shapes])])
+    off = torch.tensor(offs, dtype=torch.int64).cuda()
+    n = int(offs[-1])
+    res = []
+    for mode in ("flat", "ptrs"):
+        p = torch.linspace(-1, 1, n).cuda()
+        m, v = torch.full((n,), 0.01).cuda(), torch.full((n,), 0.02).cuda()
+        if mode == "flat":
+            ops.adam_step_clipnorm(p, torch.cat([x.reshape(-1) for x in grads]), m, v, off, 1.0, 3, 1e-3)
+        else:
+            ops.adam_step_clipnorm_tensors(p, grads, m, v, off, 1.0, 3, 1e-3)
+        res.append((p, m, v))
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)       # the norms' partial sums are taken in a different split
