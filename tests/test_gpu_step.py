@@ -86,8 +86,13 @@ def test_step_fp32_matches_oracle(ops, H, patch, beta, B):
             assert abs(float(losses[i]) - float(loss_ref[k])) <= 1e-4 * abs(float(loss_ref[k])) + 1e-3, k
         for (name, off, shape), gr, gg in zip(plan.param_table, g_ref, unflat(plan, G)):
             tol = 2e-3 * float(gr.abs().max()) + 1e-7
-            err = float((gg.double() - gr).abs().max())
-            assert err <= tol, "grad %s: err %g tol %g" % (name, err, tol)
+            dlt = (gg.double() - gr).abs()
+            err = float(dlt.max())
+            if err > tol:
+                # a ReLU unit within fp32 summation-order noise of zero takes the other gate than the fp64 oracle (analysis in
+                # tests/test_gpu_gm.py::test_gm_step_fp32_matches_oracle): a few elements, small in norm -- nothing else passes here
+                frac, rel = float((dlt > tol).double().mean()), float(dlt.norm() / gr.norm().clamp_min(1e-30))
+                assert frac <= 2e-3 and rel <= 5e-3, "grad %s: err %g tol %g (%.2e of the elements, relative L2 %.2e)" % (name, err, tol, frac, rel)
         P_before = P.clone()
         plan.step(PHASE_ADAM, params=P, grads=G, adam_m=M, adam_v=V, t=t)
         ref_before = [p.detach().clone() for p in ref.params]
