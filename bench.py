@@ -38,12 +38,13 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}
-PROFILE_TAG = "r02"                             # profiles/<tag>_traffic.json: the committed PMC passes `traffic` cites
+PROFILE_TAG = "r03"                             # profiles/<tag>_traffic.json: the committed PMC passes `traffic` cites
 
 
 def _traffic_file():
     import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_*traffic.json")))
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_*traffic.json"))) or \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*traffic.json")))
     return c[-1] if c else os.path.join(ROOT, "profiles", "r01_k_traffic.json")
 
 
@@ -208,6 +209,17 @@ def kernel_table(w, passes=TABLE_PASSES):
     return plan, table
 
 
+def grade(r, dtype):
+    """One row of the per-launch table against the roofline that binds it: the larger of flops / MFMA peak and algorithmic bytes /
+    HBM peak is the launch's floor; `frac` = floor / measured.  Rows with neither (slab reduces, memsets of scratch) are overhead."""
+    avg = r["total_ms"] / max(r["launches"], 1) * 1e-3
+    t_mfma = r["flops"] / (PEAK_TFLOPS[dtype] * 1e12) if r["flops"] else 0.0
+    t_hbm = r["bytes"] / (PEAK_HBM_GBS * 1e9) if r["bytes"] else 0.0
+    bound = "mfma" if t_mfma >= t_hbm and t_mfma > 0 else ("hbm" if t_hbm > 0 else "none")
+    return {"avg_ms": avg * 1e3, "tflops": r["flops"] / avg / 1e12 if r["flops"] else 0.0, "gbs": r["bytes"] / avg / 1e9 if r["bytes"] else 0.0,
+            "bound": bound, "frac": max(t_mfma, t_hbm) / avg if avg else 0.0}
+
+
 DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "upsample_bwd", "upsample_fwd")   # d2..d5 convs + everything that exists only for them
 
 
@@ -262,6 +274,31 @@ def spair_row(dev, B=32, steps=60, warmup=5):
     return out
 
 
+def gm_row(dev, B=64, steps=100, warmup=10):
+    """SPLIT-GMVAE (config 3, README.md:62: --model lggmvae --beta 40 --alpha 40 --y_size 30 --patch_size 4 on SVHN-32, batch 64 =
+    vae/main.py:23's default) train step: scramble + forward + losses + backward + Keras-Adam, bf16 contractions."""
+    import torch
+    from split_vae_amd import data
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae
+    from split_vae_amd.optimizer import Adam
+    x = data.synthetic_images(B, 32, 32, seed=0, device=dev)
+    aug = Augmentator("scramble", size=4, seed=1)
+    m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype="bf16", device=dev, seed=3)
+    m.beta, m.alpha = 40.0, 40.0
+    opt = Adam(learning_rate=1e-4)
+    for _ in range(warmup):
+        train_step_lg_gm_vae(m, aug.augment(x), opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step_lg_gm_vae(m, aug.augment(x), opt)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "steps": steps, "batch": B, "dtype": "bf16",
+            "workload": "SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,15 +347,15 @@ def main():
         tot = sum(r["total_ms"] for r in table)
         sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (args.dtype, H, H, B))
         for r in table:
-            avg = r["total_ms"] / max(r["launches"], 1)
-            tf = r["flops"] / (avg * 1e-3) / 1e12 if r["flops"] else 0.0
-            gb = r["bytes"] / (avg * 1e-3) / 1e9 if r["bytes"] else 0.0
-            frac = tf / PEAK_TFLOPS[args.dtype] if tf else gb / PEAK_HBM_GBS
-            sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of peak\n" %
-                             (r["name"], r["launches"], avg, 100 * r["total_ms"] / tot, tf, gb, 100 * frac))
-    # the launch with the most time among those on the main stream (the weight gradients run beside the input-gradient
-    # chain on a side stream: a bracket around either would time their overlap, not a kernel)
-    dom = next(r for r in table if r["flops"] > 0 and r["name"].startswith("fwd."))
+            g = grade(r, args.dtype)
+            sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline\n" %
+                             (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
+    # the dominant kernel = the top row of the serial table, whatever it is (round 3: it is the weight gradient of d4).  In the timed
+    # region it runs on the weight-gradient side stream beside the input-gradient chain: `achieved` is what the hipEvents around it
+    # on ITS stream give there (co-running launches included), `serial` what it takes alone on the chip.
+    dom = next(r for r in table if r["flops"] > 0)
+    large = [r for r in table if r["total_ms"] / max(r["launches"], 1) >= 0.1 and (r["flops"] or r["bytes"])]
+    worst = min(large, key=lambda r: grade(r, args.dtype)["frac"]) if large else None
 
     plan.profile_filter(dom["name"])
     plan.profile_enable(True)
@@ -363,7 +400,12 @@ def main():
             return r
         rows["fp32"] = row(64, 512, "f32", 40, 5)              # the fp32-parity path (the reference's own precision)
         rows["fp32"]["frac_of_157TF"] = rows["fp32"].pop("frac_of_peak")
+        rows["celeba64_b256"] = row(64, 256, "bf16", 200)      # config 2 (BASELINE.json configs[1]: CelebA-64 bs256 bf16 on one MI355X)
         rows["svhn32_b64"] = row(32, 64, "bf16", 200)          # config C1's shape on the GPU
+        try:
+            rows["lggmvae_svhn32_b64"] = gm_row(dev)             # config 3 (SPLIT-GMVAE)
+        except Exception as e:
+            rows["lggmvae_svhn32_b64"] = {"error": repr(e)[:200]}
         rows["celeba64_b64"] = row(64, 64, "bf16", 200)        # config 4's per-GPU shard (512 / 8)
         rows["celeba64_b128"] = row(64, 128, "bf16", 200)
         rows["long_run"] = {"steps": 400, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
@@ -407,7 +449,20 @@ def main():
                            "hip_kernel": symbol,
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"],
+                           "stream": "weight-gradient side stream (co-runs with the input-gradient chain)" if prof[0]["name"].startswith("wgrad.") and
+                                     not any(x in prof[0]["name"] for x in ("e1", "e2", "d5")) else "main",
                            "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
+        gs = grade(dom, args.dtype)
+        out["roofline"]["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
+                                     "note": "the same launch alone on the chip (per-launch table, side stream off)"}
+        if worst is not None:
+            gw = grade(worst, args.dtype)
+            out["roofline"]["worst_large"] = {"kernel": worst["name"], "bound": gw["bound"], "avg_launch_ms": round(gw["avg_ms"], 4),
+                                              "achieved": round(gw["tflops"] if gw["bound"] == "mfma" else gw["gbs"], 2),
+                                              "unit": "TFLOP/s" if gw["bound"] == "mfma" else "GB/s", "frac": round(gw["frac"], 4),
+                                              "note": "the launch >= 0.1 ms with the lowest fraction of its roofline (serial table)"}
+        out["roofline"]["table"] = [{"kernel": r["name"], "ms": round(grade(r, args.dtype)["avg_ms"], 4), "bound": grade(r, args.dtype)["bound"],
+                                     "frac": round(grade(r, args.dtype)["frac"], 4)} for r in table[:12]]
         # the HBM-bound entry: the ELBO kernel when the step runs it, else (training steps evaluate the loss in the decoder
         # head's epilogue) the Adam update -- 28 algorithmic bytes per parameter
         elbo = next((r for r in table if r["name"].startswith("dlogistic")), None) or \

@@ -399,6 +399,18 @@ static double conv_flops(const sv_conv_desc& d) {
   return 2.0 * d.B * svg_oh(&d) * svg_ow(&d) * (double)d.Cout * d.KH * d.KW * d.Cin;
 }
 
+// algorithmic HBM bytes of one conv-like launch (what a perfect kernel must move once): kind 0 forward (input [low-res when the
+// resize is fused] + output + weights), 1 input gradient (dY + mask + dX), 2 weight gradient (input + dY + fp32 dW)
+static double conv_bytes(const sv_conv_desc& d, int kind, size_t es) {
+  const double in_px = (double)d.B * (d.ups_in ? d.H / 2 : d.H) * (d.ups_in ? d.W / 2 : d.W);
+  const double out_px = (double)d.B * svg_oh(&d) * svg_ow(&d);
+  const double w = (double)d.KH * d.KW * d.Cin * d.Cout;
+  const double x = in_px * d.Cin * es, y = out_px * d.Cout * (d.y_f32 ? 4 : es);
+  if (kind == 0) return x + y + w * es;
+  if (kind == 1) return out_px * d.Cout * es + 2 * x + w * es;
+  return x + out_px * d.Cout * es + w * 4;
+}
+
 #define SV_TRY(x)            \
   do {                       \
     int rc__ = (x);          \
@@ -411,7 +423,7 @@ struct FusedNll { const float* images6; void* grad[2]; float* part[2]; float gsc
 static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const float* params,
                           void* const* y, hipStream_t st, const FusedNll* nll = nullptr) {
   TapGemmArgs a[2];
-  double fl = 0;
+  double fl = 0, by = 0;
   for (int i = 0; i < n; ++i) {
     svg_fwd_args(&L[i]->d, &a[i]);
     a[i].A = x[i];
@@ -423,8 +435,9 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
       a[i].nll_gscale = nll->gscale; a[i].nll_noout = nll->noout;
     }
     fl += conv_flops(L[i]->d);
+    by += conv_bytes(L[i]->d, 0, p->esz());
   }
-  Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, by);
   if (svg_poly(&L[0]->d)) {
     // polyphase head: the out-of-image taps of the border rows / columns go to a workspace first; the conv's epilogue adds them
     const void* wfix[2];
@@ -449,7 +462,8 @@ static int run_fwd_layer(sv_lgvae_plan* p, Layer& L, const void* x, const float*
 static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* dy, const void* const* mask,
                             void* const* dx, bool f32_atomic, hipStream_t st, bool adj = false) {
   TapGemmArgs a[SV_MAX_MULTI];
-  double fl = 0;
+  double fl = 0, by = 0;
+  for (int i = 0; i < n; ++i) by += conv_bytes(L[i]->d, 1, p->esz());
   int m = 0, tap_cfg = svg_pick_cfg(L[0]->d.Cin);
   bool mixed = false;
   const int ncls = svg_dgrad_classes(&L[0]->d);
@@ -461,7 +475,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       fl += conv_flops(L[i]->d);
     }
     if (ok) {
-      Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+      Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, by);
       const int rc = svk_conv_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(a[0].N), st);
       if (rc != SV_E_UNSUPPORTED) return rc;
     }
@@ -489,7 +503,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   if (adj) {                            // no fused kernel for this geometry: nothing was launched, the caller falls back
     if (!svk_row_conv_supported(a, m, L[0]->d.dtype)) return SV_E_UNSUPPORTED;
   }
-  Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, 0);
+  Scope sc(p, st, "dgrad." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, by);
   if (mixed) {   // split-K problems whose widths pick different tiles: one launch each
     for (int i = 0; i < m; ++i) {
       int c2 = svg_pick_cfg(L[0]->d.Cin);
@@ -510,7 +524,8 @@ static int run_dgrad_layer(sv_lgvae_plan* p, Layer& L, const void* dy, const voi
 static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* const* x, const void* const* dy,
                             float* grads, hipStream_t st) {
   WgradArgs a[SV_WGRAD_MAX_MULTI];
-  double fl = 0;
+  double fl = 0, by = 0;
+  for (int i = 0; i < n; ++i) by += conv_bytes(L[i]->d, 2, p->esz());
   const int64_t wsb = p->bbytes("wgrad_ws") / (SV_WGRAD_MAX_MULTI * sv_lgvae_plan::SIDE_MAX);   // one partial-sum slab region per stream and problem
   const std::string ln = L[0]->name.substr(L[0]->name.find('.') + 1), nm = "wgrad." + ln;
   // layers named in SV_WGRAD_MAIN keep their weight gradient on the main stream.  Measured (B = 512, 64x64): the side stream is
@@ -540,7 +555,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       dwv[i] = grads + p->params[L[i]->kparam].off; dbv[i] = grads + p->params[L[i]->bparam].off;
       fl += conv_flops(L[i]->d);
     }
-    Scope sc(p, st, nm, fl, 0);
+    Scope sc(p, st, nm, fl, by);
     SV_TRY(svk_wgrad_tile_multi(a, n, st));
     const sv_conv_desc& d = L[0]->d;
     return svk_poly_wgrad_finish(n, x, dy, pw, dwv, dbv, d.B, d.H / 2, d.W / 2, d.ldx, Cin, d.Cout, SV_POLY_WGRAD_NWG, st);
@@ -553,7 +568,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     a[i].ws = (float*)((char*)p->bp("wgrad_ws") + (p->side_slot * SV_WGRAD_MAX_MULTI + i) * wsb); a[i].ws_bytes = wsb;
     fl += conv_flops(L[i]->d);
   }
-  Scope sc(p, st, nm, fl, 0);
+  Scope sc(p, st, nm, fl, by);
   sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
@@ -603,7 +618,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     const int e0 = d.external_global_encoder ? 1 : 0;
     TapGemmArgs a[2];
     int cfg = 0, cfgs[2] = {0, 0};
-    double fl = 0;
+    double fl = 0, by = 0;
     for (int e = e0; e < 2; ++e) {
       Layer& Lh = p->enc[e][3];
       TapGemmArgs& t = a[e - e0];
@@ -615,8 +630,9 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       t.splitk = svg_choose_splitk(t.M, t.N, (t.P + 7) / 8, &cfg);
       cfgs[e - e0] = cfg;
       fl += conv_flops(Lh.d);
+      by += conv_bytes(Lh.d, 0, p->esz());
     }
-    Scope sc(p, st, "fwd.head", fl, 0);
+    Scope sc(p, st, "fwd.head", fl, by);
     if (e0 || cfgs[0] == cfgs[1]) SV_TRY(svk_tap_gemm_multi(a, 2 - e0, dt, cfgs[0], st));
     else
       for (int e = 0; e < 2; ++e) SV_TRY(svk_tap_gemm(a[e], dt, cfgs[e], st));   // latent sizes with different tiles
@@ -840,7 +856,8 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
     // heads: two Keras kernels/biases per network -> wgrad problems on the column halves of ghead, all in one launch
     WgradArgs a[4];
     int n = 0;
-    double fl = 0;
+    double fl = 0, by = 0;
+    for (int e = e0; e < 2; ++e) by += conv_bytes(p->enc[e][3].d, 2, p->esz());
     for (int e = e0; e < 2; ++e) {
       Layer* L = p->enc[e];
       const int Lh = e == 0 ? Lg : Ll;
@@ -856,7 +873,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
     }
     {
       hipStream_t ws = p->wgrad_stream(st);
-      Scope sc(p, ws, "wgrad.head", fl, 0);
+      Scope sc(p, ws, "wgrad.head", fl, by);
       const int cg = svg_pick_cfg(Lg), cl = svg_pick_cfg(Ll);      // the narrower tile serves both widths
       SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), ws));
     }

@@ -1,8 +1,8 @@
 """Full-size checks (BASELINE.json workload: CelebA-64, per-GPU batch 512, bf16) through the C ABI.
 
-The oracle cannot run 512 x 64 x 64 in seconds, so parity at this size is established through
-size-independent properties of the path (the small-size parity against the oracle is in
-test_gpu_step.py / test_gpu_kernels.py):
+One step of the full batch is compared with the oracle itself (test_b512_step_against_the_oracle: the fp32 torch-CPU
+restatement takes about a second per 512-image step); everything repeated or larger goes through size-independent
+properties of the path (the per-layer parity against the fp64 oracle is in test_gpu_step.py / test_gpu_kernels.py):
 
   * scramble: channels 0-2 bit-identical to the input, channels 3-5 a permutation of its pixels
     (per-image, per-channel multiset = sorted values equal; checksum of checksums);
@@ -14,6 +14,8 @@ test_gpu_step.py / test_gpu_kernels.py):
   * run-to-run reproducibility of everything that is not accumulated with atomics;
   * the optimiser actually descends on a fixed batch.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -197,3 +199,52 @@ def test_bf16_step_tracks_fp32_step_at_full_size(ops, batch):
         nb = float(b.norm())
         assert float((a - b).norm()) <= 8e-2 * nb + 1e-8, name
         assert float((a * b).sum()) >= 0.995 * float(a.norm()) * nb - 1e-12, name
+
+
+@pytest.mark.parametrize("dtype,loss_tol,grad_tol", [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 1e-3, 8e-2)])
+def test_b512_step_against_the_oracle(ops, dtype, loss_tol, grad_tol):
+    """ONE step of the headline workload (CelebA-64, B = 512) against the oracle itself (oracle/torch_ref.RefTrainer: fp32
+    torch-CPU autograd restatement of vae/trainer.py:120-144, about a second per step on the box's host cores), so the
+    kernels that only run at this size are under the oracle, not only under the library's own fp32 path: the polyphase
+    weight gradient of the head (>= 768 images per launch), the fused resize adjoint (>= 256), the 128-column tile rules and
+    the main / side stream placement of the weight gradients.  Tolerances: the 6 loss scalars 1e-4 (fp32) / 1e-3 (bf16)
+    relative; every gradient tensor's relative L2 error 1e-3 (fp32) / 8e-2 (bf16)."""
+    from oracle import np_ref, torch_ref
+    from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM
+    rng = np.random.Generator(np.random.PCG64(11))
+    x = (rng.integers(0, 256, size=(B, H, H, 3)) / 255.0 * 2 - 1).astype(np.float32)
+    G2 = (H // PATCH) ** 2
+    perm = np.stack([rng.permutation(G2) for _ in range(B)]).astype(np.int32)
+    eps = rng.standard_normal((2, B, 128)).astype(np.float32)
+    images = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), PATCH)
+    want_img = np_ref.scramble_batch(x, perm, PATCH).astype(np.float32)
+    assert np.array_equal(images.cpu().numpy(), want_img)
+    params_np = np_ref.glorot_init(H, H, seed=3)
+    for i in range(1, len(params_np), 2):          # non-zero biases so bias paths are exercised
+        params_np[i] = (rng.standard_normal(params_np[i].shape) * 0.05).astype(np.float32)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ref = torch_ref.RefTrainer(params_np, BETA, dtype=torch.float32)
+    _, loss_ref, g_ref = ref.grads(torch.from_numpy(want_img), eps[0], eps[1])
+    plan = ops.LGVaePlan(B, H, H, beta=BETA, dtype=dtype)
+    P = torch.zeros(plan.n_params, dtype=torch.float32)
+    for (name, off, shape), p in zip(plan.param_table, params_np):
+        P[off:off + p.size] = torch.from_numpy(np.ascontiguousarray(p)).flatten()
+    P = P.cuda()
+    G = torch.zeros_like(P)
+    plan.step(PHASE_ALL & ~PHASE_ADAM, params=P, grads=G, images6=images, eps_x=torch.from_numpy(eps[0]).cuda(),
+              eps_x_hat=torch.from_numpy(eps[1]).cuda(), t=1)
+    torch.cuda.synchronize()
+    losses = plan.buffer("losses", torch.float32, (8,)).cpu().double()
+    keys = ["x_recon_loss", "x_kl_loss", "x_hat_recon_loss", "x_hat_kl_loss", "total_kl_loss", "total_loss"]
+    for i, k in enumerate(keys):
+        want = float(loss_ref[k])
+        assert abs(float(losses[i]) - want) <= loss_tol * abs(want) + 1e-3, (k, float(losses[i]), want)
+    Gc = G.cpu()
+    worst = ("", 0.0)
+    for (name, off, shape), gr in zip(plan.param_table, g_ref):
+        gg = Gc[off:off + gr.numel()].reshape(gr.shape).double()
+        rel = float((gg - gr.double()).norm() / gr.double().norm().clamp_min(1e-30))
+        if rel > worst[1]:
+            worst = (name, rel)
+        assert rel <= grad_tol, "grad %s: relative L2 %.3e > %.1e" % (name, rel, grad_tol)
+    print("b512 vs oracle (%s): worst gradient %s relative L2 %.3e" % (dtype, worst[0], worst[1]))
