@@ -640,6 +640,7 @@ extern "C" int sv_conv2d_nhwc_wgrad_poly(const sv_conv_desc* d, const void* x_lo
   if (!x_lo || !dy || !dw || !workspace || workspace_bytes < sv_conv2d_wgrad_poly_workspace_bytes(d)) return SV_E_BADARG;
   float* pw = (float*)((char*)workspace + SV_WGRAD_WS_BYTES);
   const int Cin = svg_cin_pad(d);
+  if (!svk_poly_wgrad_supported(d->H / 2, d->W / 2, Cin, d->Cout)) return SV_E_UNSUPPORTED;   // before anything is enqueued
   WgradArgs a;
   svg_poly_wgrad_args(d, &a);
   a.A = x_lo; a.dY = dy; a.dW = pw; a.dbias = pw + 25 * Cin * 32; a.ws = (float*)workspace; a.ws_bytes = SV_WGRAD_WS_BYTES;

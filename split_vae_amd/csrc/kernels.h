@@ -195,6 +195,7 @@ int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, 
 
 // polyphase weight gradient of the decoder head, the small terms (poly_wgrad.hip)
 int64_t svk_poly_wgrad_ws_floats(int Cin, int nwg);
+bool svk_poly_wgrad_supported(int h_lo, int w_lo, int Cin, int Cout);   // checked before the main term is launched
 int svk_poly_wgrad_finish(int n, const void* const* x_lo, const void* const* dy, float* const* ws, float* const* dW, float* const* dbias,
                           int B, int h, int w, int lda, int Cin, int Cout, int nwg, hipStream_t st);
 

@@ -542,7 +542,8 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // kernels cost more than they save below that: 16 images 42 vs 20 us; 1024 images 132 vs 184 us)
   static const bool no_pw = getenv("SV_NO_POLY_WGRAD") != nullptr;
   static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 768;   // (512 images per launch: +0.4 %; 1024: -1.0 %)
-  if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2) {
+  if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2 &&
+      svk_poly_wgrad_supported(L[0]->d.H / 2, L[0]->d.W / 2, svg_cin_pad(&L[0]->d), L[0]->d.Cout)) {   // else: the direct form below
     static const char* pw_name[2] = {"polyw_x", "polyw_xh"};
     float* pw[2];
     float *dwv[2], *dbv[2];

@@ -210,10 +210,19 @@ __global__ __launch_bounds__(256) void poly_wgrad_project_kernel(const PolyWgrad
 static inline int poly_wgrad_per(int Cin) { return 6 * 6 * (Cin / 16) * 256; }
 int64_t svk_poly_wgrad_ws_floats(int Cin, int nwg) { return (int64_t)25 * Cin * 32 + 32 + poly_wgrad_per(Cin) * (1 + (int64_t)nwg); }
 
+static inline size_t poly_wgrad_frame_lds(int h, int w, int Cin) {
+  const int L = 2 * (h > w ? h : w), LW = L + 5, PSL = Cin * 2 + 32;
+  return (size_t)4 * LW * PSL + (size_t)6 * L * 32;
+}
+// the frame kernel's line buffers must fit the CU's LDS (160 KB on gfx950): low-res extents up to 128 at Cin = 32
+bool svk_poly_wgrad_supported(int h, int w, int Cin, int Cout) {
+  return (Cin == 32 || Cin == 64) && Cout <= 8 && poly_wgrad_frame_lds(h, w, Cin) <= 160 * 1024;
+}
+
 // frame term + reduce + projection for n <= 2 twin problems.  ws[i] (floats, zero on first use): [dWp 25*Cin*32][dbp 32][gsum][slabs nwg]
 int svk_poly_wgrad_finish(int n, const void* const* x_lo, const void* const* dy, float* const* ws, float* const* dW, float* const* dbias,
                           int B, int h, int w, int lda, int Cin, int Cout, int nwg, hipStream_t st) {
-  if (n < 1 || n > 2 || (Cin != 32 && Cin != 64) || Cout > 8 || nwg < 1) return SV_E_UNSUPPORTED;
+  if (n < 1 || n > 2 || nwg < 1) return SV_E_UNSUPPORTED;
   const int per = poly_wgrad_per(Cin);
   PolyWgradMulti m;
   PolyWgradFin f;
@@ -225,11 +234,16 @@ int svk_poly_wgrad_finish(int n, const void* const* x_lo, const void* const* dy,
     m.x[i] = (const bf16_t*)x_lo[k]; m.dy[i] = (const bf16_t*)dy[k]; m.slab[i] = slab;
     f.slab[i] = slab; f.dW[i] = dW[k]; f.dbias[i] = dbias ? dbias[k] : nullptr;
   }
-  const int L = 2 * (h > w ? h : w), LW = L + 5, PSL = Cin * 2 + 32;
-  const size_t lds = (size_t)4 * LW * PSL + (size_t)6 * L * 32;
-  if (lds > 64 * 1024) return SV_E_UNSUPPORTED;
-  if (Cin == 32) hipLaunchKernelGGL((poly_wgrad_frame_kernel<2>), dim3(nwg, n), dim3(384), lds, st, m, B, h, w, lda);
-  else hipLaunchKernelGGL((poly_wgrad_frame_kernel<4>), dim3(nwg, n), dim3(384), lds, st, m, B, h, w, lda);
+  const size_t lds = poly_wgrad_frame_lds(h, w, Cin);
+  if (!svk_poly_wgrad_supported(h, w, Cin, Cout)) return SV_E_UNSUPPORTED;   // (callers check BEFORE they launch the main term)
+  // 128x128 images: 75.6 KB of line buffers -- above the 64 KB a kernel gets without the attribute, well inside gfx950's 160 KB
+  if (Cin == 32) {
+    sv_ensure_dynamic_lds((const void*)poly_wgrad_frame_kernel<2>, lds);
+    hipLaunchKernelGGL((poly_wgrad_frame_kernel<2>), dim3(nwg, n), dim3(384), lds, st, m, B, h, w, lda);
+  } else {
+    sv_ensure_dynamic_lds((const void*)poly_wgrad_frame_kernel<4>, lds);
+    hipLaunchKernelGGL((poly_wgrad_frame_kernel<4>), dim3(nwg, n), dim3(384), lds, st, m, B, h, w, lda);
+  }
   SV_LAUNCH_CHECK();
   hipLaunchKernelGGL(poly_wgrad_reduce_kernel, dim3((per + 127) / 128, n), dim3(256), 0, st, f, nwg, per);
   SV_LAUNCH_CHECK();

@@ -248,3 +248,32 @@ def test_b512_step_against_the_oracle(ops, dtype, loss_tol, grad_tol):
             worst = (name, rel)
         assert rel <= grad_tol, "grad %s: relative L2 %.3e > %.1e" % (name, rel, grad_tol)
     print("b512 vs oracle (%s): worst gradient %s relative L2 %.3e" % (dtype, worst[0], worst[1]))
+
+
+def test_celeba128_step_at_a_polyphase_sized_launch(ops):
+    """celeba128 (vae/data.py:18) at 384 images per network = 768 per launch, the size from which the plan takes the polyphase
+    weight gradient of the head: at 128 x 128 its frame kernel needs 75.6 KB of LDS (it returned SV_E_UNSUPPORTED after half the
+    step had been enqueued; now the cap is raised, and the plan checks feasibility before it launches anything).  The bf16 step
+    against the exact-fp32 step of the same library, as in test_bf16_step_tracks_fp32_step_at_full_size."""
+    from split_vae_amd import data
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    Hh, Bb = 128, 384
+    model = LGVae(128, 128, image_shape=[-1, Hh, Hh, 3], dtype="f32", device=torch.device("cuda"), seed=3)
+    P = model.flat
+    x = data.synthetic_images(Bb, Hh, Hh, seed=0, device="cuda")
+    img = Augmentator("scramble", size=PATCH, seed=1).augment(x)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        plan = ops.LGVaePlan(Bb, Hh, Hh, beta=BETA, dtype=dt)
+        _, G, L = _run(ops, plan, P, img, 0)
+        res[dt] = (G.clone(), L.clone(), plan.param_table)
+        del plan
+    (G32, L32, table), (G16, L16, _) = res[torch.float32], res[torch.bfloat16]
+    for i in (0, 1, 2, 3, 5):
+        assert abs(float(L16[i]) - float(L32[i])) <= 1e-3 * abs(float(L32[i])) + 1e-3, (i, float(L16[i]), float(L32[i]))
+    for name, off, shape in table:
+        n = int(np.prod(shape))
+        a, b = G16[off:off + n].double(), G32[off:off + n].double()
+        nb = float(b.norm())
+        assert float((a - b).norm()) <= 8e-2 * nb + 1e-8, name

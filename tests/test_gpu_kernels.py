@@ -577,8 +577,7 @@ def test_d5_input_gradient_ignores_stale_lds(ops):
         assert torch.equal(again, first)
 
 
-@pytest.mark.parametrize("B", [2, 9])
-@pytest.mark.parametrize("H", [32, 64])
+@pytest.mark.parametrize("H,B", [(32, 2), (32, 9), (64, 2), (64, 9), (128, 2)])   # 128: the frame kernel's 75.6 KB of line buffers (> the 64 KB default cap)
 def test_polyphase_weight_gradient_of_the_head(ops, H, B):
     """Conv2DBackpropFilter + BiasAddGrad of the decoder head in polyphase form (poly_wgrad.hip; the algebra is pinned on CPU
     by tests/test_polyphase_math.py) against autograd of the fp64 resize -> conv on the same bf16 operands, and against the
