@@ -32,8 +32,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")     # before any HIP call: see split_vae_amd/__init__.py (a 4th hardware queue slows the DP step)
 sys.path.insert(0, ROOT)
+import split_vae_amd  # noqa: E402
+split_vae_amd.configure_hw_queues()                 # before any HIP call (a 4th hardware queue slows the DP step: split_vae_amd/__init__.py)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)

@@ -347,9 +347,14 @@ def losses(cfg, images, o, step):
     return total, lst
 
 
-def clipnorm_adam_(params, grads, m, v, t, lr=1e-4, clipnorm=1.0, beta1=0.9, beta2=0.999, eps=1e-7):
-    """tf.keras.optimizers.Adam(lr, clipnorm=1.0) (spair/main.py:109): tf.clip_by_norm per gradient tensor, then the Keras Adam of
-    torch_ref.keras_adam_."""
+def clipnorm_adam_(params, grads, m, v, t, lr=1e-4, clipnorm=1.0, beta1=0.9, beta2=0.999, eps=1e-7, clip_in_apply=False):
+    """tf.keras.optimizers.Adam(lr, clipnorm=1.0) (spair/main.py:109) as the reference's loop uses it: tape.gradient ->
+    apply_gradients (spair/trainer.py:226-227).  [TF-2.0 semantics] the pinned tensorflow_gpu==2.0.0 clips only in
+    get_gradients / _compute_gradients, not in apply_gradients (TF >= 2.4 does): clip_in_apply=False (default, pinned version) is
+    the plain Keras Adam of torch_ref.keras_adam_; True = tf.clip_by_norm per gradient tensor first."""
+    if not clip_in_apply:
+        torch_ref.keras_adam_(params, list(grads), m, v, t, lr, beta1, beta2, eps)
+        return
     clipped = []
     for g in grads:
         n = torch.sqrt((g * g).sum())

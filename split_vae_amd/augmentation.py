@@ -46,7 +46,11 @@ class Augmentator(object):
             staged = (plan.buffer("in8_x", plan.dtype, (B, H, W, 8)), plan.buffer("in8_xh", plan.dtype, (B, H, W, 8)))
         out = ops.scramble_gather(x.contiguous(), perm.to(torch.int32).contiguous(), self.size, staged=staged)
         if staged is not None:
-            out._sv_staged_plan = plan
+            # valid for ONE train_step on this plan, and only while nothing else has written the plan's input buffers since
+            # (another staged batch, a test_step / encode / visualizer call of the same batch size) and `out` is not edited in place:
+            # trainer.train_step checks the generation and the tensor's version counter and falls back to its own split / pad pass
+            plan.in8_gen += 1
+            out._sv_staged_plan, out._sv_staged_gen, out._sv_staged_version = plan, plan.in8_gen, out._version
         return out[0] if single else out
 
     def no_op(self, x):

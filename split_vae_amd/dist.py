@@ -17,6 +17,8 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from torch.distributed.run."""
+    from . import configure_hw_queues
+    configure_hw_queues()                            # main / weight-gradient / communication queue (split_vae_amd/__init__.py)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

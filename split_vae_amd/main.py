@@ -40,6 +40,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from . import configure_hw_queues
+    configure_hw_queues()                            # before the first HIP call (split_vae_amd/__init__.py)
     config = dotdict(vars(args))
     config.label = not config.no_label
     print('Config:', config)

@@ -394,6 +394,9 @@ class LGVaePlan:
         nbytes = lib.sv_lgvae_workspace_bytes(h)
         self.workspace = torch.zeros((nbytes,), dtype=torch.uint8, device=self.device)
         check(lib.sv_lgvae_plan_bind(h, _p(self.workspace), nbytes, _stream()), "sv_lgvae_plan_bind")
+        # generation of the shared input buffers in8_x / in8_xh: bumped by every writer (a staged augmentation, the split / pad
+        # pass of any step that runs the encoders' forward); a staged batch is only valid while its generation is the current one
+        self.in8_gen = 0
 
     def __del__(self):
         try:
@@ -418,6 +421,8 @@ class LGVaePlan:
         a.seed, a.step, a.sample_offset = seed, step, sample_offset
         a.lr, a.beta1, a.beta2, a.adam_eps, a.t = lr, beta1, beta2, adam_eps, t
         a.grad_scale, a.phases, a.accumulate_metrics = grad_scale, phases, 1 if accumulate_metrics else 0
+        if (phases & _lib.PHASE_FWD_ENCODERS) and not (phases & _lib.PHASE_INPUTS_STAGED):
+            self.in8_gen += 1                                  # this step's split / pad pass overwrites in8_x / in8_xh
         check(self.lib.sv_lgvae_step(self.handle, C.byref(a), _stream()), "sv_lgvae_step")
 
     def graph_enable(self, on=True):

@@ -38,6 +38,9 @@ def build_parser():
     ap.add_argument("--dtype", type=str, default="f32", choices=["f32", "bf16"],
                     help="bf16: the spatial convolutions on the bf16 MFMA kernels (fp32 accumulation / master weights); f32 = the reference's precision")
     ap.add_argument("--save_weights", action="store_true", help="write models/<time>.h5 (Keras HDF5 weights) at the end, as spair/trainer.py:424 does")
+    ap.add_argument("--clipnorm_semantics", type=str, default="tf2.0", choices=["tf2.0", "tf2.4"],
+                    help="Adam(clipnorm=1.0) in a tape.gradient -> apply_gradients loop (spair/main.py:109, spair/trainer.py:226-227): the pinned "
+                         "tensorflow_gpu==2.0.0 does not clip in apply_gradients (default); TF >= 2.4 clips every gradient tensor with tf.clip_by_norm")
     ap.add_argument("--graph", action="store_true", help="capture the train step into a hipGraph and replay it (spair_trainer.GraphedTrainStep)")
     return ap
 
@@ -70,6 +73,8 @@ def synthetic_canvases(B, seed=0, device="cuda", size=48):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from . import configure_hw_queues
+    configure_hw_queues()                            # before the first HIP call (split_vae_amd/__init__.py)
     config = dotdict(vars(args))
     config.label = not config.no_label
     print('Config:', config)
@@ -96,7 +101,8 @@ def main(argv=None):
         model = spair.get_model(config, seed=config.seed)
         print(type(model))
         model.summary()
-        optimizer = spair_trainer.ClipnormAdam(config.learning_rate, clipnorm=1.0)          # spair/main.py:109
+        optimizer = spair_trainer.ClipnormAdam(config.learning_rate, clipnorm=1.0,         # spair/main.py:109
+                                               clip_in_apply=(config.clipnorm_semantics == "tf2.4"))
         print('Training SPAIR')
         history = spair_trainer.train_spair(model, optimizer, config.dataset, batches(), test_batches, config)
     return history

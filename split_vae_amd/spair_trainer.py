@@ -62,10 +62,20 @@ def compute_z_pres_kl_yolo_air(z_pres, z_pres_logits, z_pres_pre_sigmoid, prior_
 
 
 class ClipnormAdam:
-    """tf.keras.optimizers.Adam(learning_rate, clipnorm=...) (spair/main.py:109) over a model's flat variable buffer."""
+    """tf.keras.optimizers.Adam(learning_rate, clipnorm=...) (spair/main.py:109) over a model's flat variable buffer.
 
-    def __init__(self, learning_rate=1e-4, clipnorm=1.0, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
-        self.learning_rate, self.clipnorm = learning_rate, clipnorm
+    [TF-2.0 semantics] The reference's step is tape.gradient -> optimizer.apply_gradients (spair/trainer.py:226-227).  Under the
+    pinned tensorflow_gpu==2.0.0 (requirements.txt:7) OptimizerV2 applies `clipnorm` only inside get_gradients /
+    _compute_gradients (the minimize / fit paths); apply_gradients does not clip (it does from TF 2.4 on).  So with the pinned
+    version Adam(lr, clipnorm=1.0) is a plain Keras Adam in this training loop: `clip_in_apply=False`, the default, like
+    --gm_dropout's default follows the pinned version; `clip_in_apply=True` (--clipnorm_semantics tf2.4) clips each gradient
+    tensor with tf.clip_by_norm before the update.  Not executable here (no TensorFlow): documented switch, both tested."""
+
+    def __init__(self, learning_rate=1e-4, clipnorm=1.0, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_in_apply=False):
+        self.learning_rate = learning_rate
+        self.clip_in_apply = bool(clip_in_apply)
+        # the kernels scale by clipnorm / max(||g||, clipnorm): a norm bound no fp32 gradient reaches makes that exactly 1
+        self.clipnorm = clipnorm if self.clip_in_apply else 3.0e38
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.iterations = 0
         self._slots = None

@@ -85,7 +85,9 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
     model._calls += 1
     nr = 0 if keep_recon else PHASE_NO_RECON
     if getattr(images, "_sv_staged_plan", None) is plan:      # Augmentator.scramble(..., plan=plan) filled in8_x / in8_xh already
-        nr |= PHASE_INPUTS_STAGED
+        # ... and nothing has overwritten them since (generation), nor was `images` edited in place (version counter)
+        if images._sv_staged_gen == plan.in8_gen and images._sv_staged_version == images._version:
+            nr |= PHASE_INPUTS_STAGED
         images._sv_staged_plan = None                         # one step per staging
     if reducer is None or (reducer.world == 1 and not getattr(reducer, "force", False)):
         plan.step(PHASE_ALL | nr, **kw)

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import split_vae_amd
+    split_vae_amd.configure_hw_queues()          # what the entry points do, before any test touches the GPU
 
 
 @pytest.fixture(scope="session")

@@ -61,8 +61,9 @@ def test_two_ranks_over_rccl_equal_one(lib_built, tmp_path, backend):
     one = _run(1, str(tmp_path / "one.npz"))
     two = _run(2, str(tmp_path / "two.npz"), backend=backend)
     g1, g2 = one["grads"], two["grads"] / 2.0
-    assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
-    assert np.linalg.norm(one["params"] - two["params"]) <= 1e-1 * np.linalg.norm(one["params"] - _init_params())
+    # the original bounds: never observed to flake on a multi-GPU box (none was ever available), so not loosened on a guess
+    assert np.linalg.norm(g1 - g2) <= 2e-3 * np.linalg.norm(g1)
+    assert np.linalg.norm(one["params"] - two["params"]) <= 5e-2 * np.linalg.norm(one["params"] - _init_params())
 
 
 @pytest.mark.parametrize("backend", ["nccl", "sv_comm"])

@@ -261,6 +261,47 @@ def test_step_without_stored_reconstructions_is_the_same_step(lib_built):
 
 
 @pytest.mark.gpu
+def test_stale_staged_inputs_are_not_trusted(lib_built):
+    """The staged inputs live in the plan's shared in8_x / in8_xh: a test_step / second staged batch on the same plan, or an in-place
+    edit of the batch, between augment(plan=) and train_step must make train_step fall back to its own split / pad pass."""
+    import torch
+    from split_vae_amd import data, trainer
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+    B, H = 16, 32
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    other = data.synthetic_images(B, H, H, seed=9, device="cuda")
+
+    def run(disturb):
+        m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="bf16", device=torch.device("cuda"), seed=3)
+        plan = m.plan(B)
+        img = Augmentator("scramble", size=4, seed=1).augment(x, plan=plan if disturb else None)
+        want = img.clone()
+        if disturb == "test_step":
+            trainer.test_step(m, Augmentator("scramble", size=4, seed=2).augment(other))     # overwrites in8_* with another batch
+        elif disturb == "second_staging":
+            Augmentator("scramble", size=4, seed=2).augment(other, plan=plan)                # a prefetched batch
+        elif disturb == "in_place":
+            img.mul_(0.5)
+            want = img.clone()
+        m._calls = 7                                                                         # same Philox step for every variant
+        trainer.train_step(m, img, Adam(learning_rate=1e-4))
+        torch.cuda.synchronize()
+        return want, trainer.last_losses(plan)
+
+    for disturb in ("test_step", "second_staging", "in_place"):
+        img_d, got = run(disturb)
+        m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="bf16", device=torch.device("cuda"), seed=3)
+        m._calls = 7
+        trainer.train_step(m, img_d, Adam(learning_rate=1e-4))
+        torch.cuda.synchronize()
+        ref = trainer.last_losses(m.plan(B))
+        for k in ref:
+            assert abs(ref[k] - got[k]) <= 1e-5 * max(1.0, abs(ref[k])), (disturb, k, ref[k], got[k])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_staged_augmentation_fills_the_step_inputs(lib_built, dtype):
     """Augmentator.scramble(x, plan=plan): the scramble kernel also writes the plan's padded input tensors (in8_x / in8_xh) and

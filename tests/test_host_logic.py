@@ -282,5 +282,6 @@ def test_spair_cli_flags_match_reference():
                                   "--local_latent_size 4 --model lg_spair -split_z_l -concat_z_what -dense_local -dense_bg "
                                   "--training_steps 200000".split())
     assert (b.model, b.split_z_l, b.concat_z_what, b.dense_local, b.dense_bg, b.local_latent_size) == ("lg_spair", True, True, True, True, 4)
+    assert a.clipnorm_semantics == "tf2.0"            # not a reference flag: which TF version's Adam(clipnorm=...) semantics
     c = default_config(model="lg_spair")
     assert c.concat_z_bg is None and c.bg_model is None and c.image_size == [48, 48, 3]     # keys no flag defines read as None

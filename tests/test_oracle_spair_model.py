@@ -102,10 +102,16 @@ def test_clipnorm_adam_first_step():
     g = [torch.tensor([3.0, 0.0, 4.0, 0.0], dtype=torch.float64), torch.tensor([0.3, 0.4], dtype=torch.float64)]    # norms 5 and 0.5
     m = [torch.zeros_like(x) for x in p]
     v = [torch.zeros_like(x) for x in p]
-    R.clipnorm_adam_(p, g, m, v, 1, lr=0.1, clipnorm=1.0)
+    R.clipnorm_adam_(p, g, m, v, 1, lr=0.1, clipnorm=1.0, clip_in_apply=True)                        # TF >= 2.4: apply_gradients clips
     assert torch.allclose(m[0], 0.1 * torch.tensor([0.6, 0.0, 0.8, 0.0], dtype=torch.float64))      # clipped to unit norm
     assert torch.allclose(m[1], 0.1 * g[1])                                                           # below the threshold: untouched
     assert float(p[0][0]) < 0 and float(p[0][1]) == 0.0
+    # [TF-2.0 semantics] the pinned tensorflow_gpu==2.0.0: apply_gradients does not clip -> the plain Keras Adam (the default)
+    p2 = [torch.zeros(4, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)]
+    m2 = [torch.zeros_like(x) for x in p2]
+    v2 = [torch.zeros_like(x) for x in p2]
+    R.clipnorm_adam_(p2, g, m2, v2, 1, lr=0.1, clipnorm=1.0)
+    assert torch.allclose(m2[0], 0.1 * g[0]) and torch.allclose(m2[1], 0.1 * g[1])
 
 
 def test_oracle_reproduces_the_committed_spair_fixture():
