@@ -254,14 +254,19 @@ def spair_row(dev, B=32, steps=60, warmup=5):
     import torch
     from split_vae_amd import spair, spair_main, spair_trainer
     from split_vae_amd.augmentation import Augmentator
-    out = {"unit": "images/s", "batch": B, "steps": steps, "launch": "hipGraph replay"}
+    out = {"unit": "images/s", "batch": B, "steps": steps,
+           "launch": "f32: one native launch sequence per step (sv_tape_run, eager); bf16 convolutions: torch-autograd graph as a hipGraph replay"}
     for dt_ in ("f32", "bf16"):
         cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
                                         split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True, dtype=dt_)
         model = spair.get_model(cfg, device=dev, seed=0)
         x, _ = spair_main.synthetic_canvases(B, seed=1, device=dev)
         images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x)
-        step_fn = spair_trainer.GraphedTrainStep(model, spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0), cfg, images)
+        if dt_ == "f32":
+            opt = spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0)
+            step_fn = lambda im, i: spair_trainer.train_step(model, im, opt, i, cfg)          # noqa: E731 (native: spair_native.NativeStep)
+        else:
+            step_fn = spair_trainer.GraphedTrainStep(model, spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0), cfg, images)
         for i in range(warmup):
             step_fn(images, i)
         torch.cuda.synchronize()
@@ -271,6 +276,14 @@ def spair_row(dev, B=32, steps=60, warmup=5):
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / steps
         out[dt_] = {"value": round(B / t, 1), "ms_per_step": round(1e3 * t, 4)}
+        if dt_ == "f32":
+            ns = model.native(B, cfg)
+            # algorithmic HBM bytes of the step: the variables once per pass (forward, input gradients, weight gradients written) + Adam's
+            # 28 B per variable; achieved = that / the step time (the step is HBM- and launch-latency-bound: 31.9 M variables, 32 images)
+            nv = model.count_params()
+            by = nv * (4 * 3 + 28)
+            out[dt_]["roofline"] = {"bound": "hbm", "algorithmic_bytes": by, "achieved": round(by / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": round(by / t / 1e9 / PEAK_HBM_GBS, 4), "tape_nodes": ns.n_nodes}
         del step_fn, model
     return out
 

@@ -419,6 +419,84 @@ int sv_lgvae_profile_read(sv_lgvae_plan* plan, int32_t max_entries, char names[]
                           double* total_ms, int32_t* launches, double* flops_per_launch,
                           double* bytes_per_launch);
 
+/* ---------------------------------------------------------------- SPLIT-SPAIR: Dense layers, exact fp32 on the matrix cores
+ * tf.keras.layers.Dense (spair/spair.py:135-154, :185-202, :246-273, :341-366, :424-467) for ANY fan-in / fan-out, reading the Keras
+ * [in, out] kernel as it lies in the variable buffer (dense_f32.hip).  x [M, ldx], y / dy [M, ldy], w [K, N] row-major.
+ *   fwd:   y = act(x . w + bias)                       act: SV_ACT_NONE | SV_ACT_RELU
+ *   dgrad: dx = dy . w^T (accumulate != 0: added to dx with atomics, K may be split over workgroups)
+ *   wgrad: dw += x^T . dy, dbias += column sums of dy (atomics onto the zeroed gradients; dbias may be NULL) */
+int sv_dense_f32_fwd(const float* x, int32_t ldx, const float* w, const float* bias, float* y, int32_t ldy, int32_t M, int32_t K,
+                     int32_t N, int32_t act, void* stream);
+int sv_dense_f32_dgrad(const float* dy, int32_t ldy, const float* w, float* dx, int32_t ldx, int32_t M, int32_t K, int32_t N,
+                       int32_t accumulate, void* stream);
+int sv_dense_f32_wgrad(const float* x, int32_t ldx, const float* dy, int32_t ldy, float* dw, float* dbias, int32_t M, int32_t K,
+                       int32_t N, void* stream);
+
+/* ---------------------------------------------------------------- SPLIT-SPAIR: the train step as one native launch sequence
+ * Replaces, for spair/: SPAIR.call / LGSPAIR.call (spair/spair.py:35-49, :84-106), the loss assembly and tape.gradient of train_step
+ * (spair/trainer.py:136-228) and optimizer.apply_gradients (:226-227, spair/main.py:109).  The host records the model ONCE as a list
+ * of nodes over fp32 2-D tensors [rows, cols | row pitch ld floats] (split_vae_amd/spair_native.py mirrors the reference's classes);
+ * sv_tape_run walks it forwards and backwards natively: no Python, autograd engine or library GEMM between the launches (tape.hip).
+ * Tensor ids index the tape's tensors; *_off are float offsets into the flat variable / gradient buffers (-1: none). */
+typedef struct sv_tape sv_tape;
+enum { SV_TAPE_DENSE = 0, SV_TAPE_CONV, SV_TAPE_UNARY, SV_TAPE_SAMPLE, SV_TAPE_LOGITNOISE, SV_TAPE_UPSAMPLE, SV_TAPE_STN, SV_TAPE_RENDER,
+       SV_TAPE_ZPRES, SV_TAPE_LOSS, SV_TAPE_NOISE };
+enum { SV_TAPE_COPY = 0, SV_TAPE_RELU, SV_TAPE_SIGMOID, SV_TAPE_SOFTPLUS /* softplus(x + p0) */, SV_TAPE_CLAMP /* [p0, p1] */,
+       SV_TAPE_SCALE /* p0 * x */ };
+enum { SV_TAPE_PHASE_FORWARD = 1, SV_TAPE_PHASE_BACKWARD = 2, SV_TAPE_PHASE_ADAM = 4 };
+typedef struct {
+  int32_t kind;                 /* SV_TAPE_* node kind */
+  int32_t x, y, t2, t3, t4, t5, t6;   /* tensors: main input, output, extra inputs (-1: none); per kind:
+      DENSE       y[M,N] = act(x[M,K] . W + b)                         (Dense; also the backbone's 1x1 convolutions)
+      CONV        y = act(conv2d_same(x, W) + b); B,H,W,C = input extent, Cout, k, stride       (spair/spair.py Conv2D layers)
+      UNARY       y[:, yo:yo+n] = op(x[:, xo:xo+n]), `rep` output rows per input row (tf.tile / concat / slice / activations)
+      SAMPLE      y[:, yo:] = x[:, xo:] + t2[:, o2:] * t3[:, o3:]      (Sampling, spair/utils.py:19-24: mean, sig, eps)
+      LOGITNOISE  y = (x + log(t2 + 1e-8) - log(1 - t2 + 1e-8)) / p0   (concrete_binary_pre_sigmoid_sample, spair/utils.py:14-17)
+      UPSAMPLE    y = tf.image.resize(x, 2x) on [B,H,W,C=ld]           (spair/spair.py:175-180, :360-364)
+      STN         y (, t3 = obj_bbox_mask) = STN(x = images, t2 = z_where [B*Hc*Wc,4]); B,H,W,C input, Ho,Wo output, Hc,Wc cells, inverse
+      RENDER      y = Renderer(x = objects, t2 = bg, t3 = z_depth, t4 = z_pres, t5 = z_pres_logits, t6 = GaussianNoise draw (-1)); R cells
+      ZPRES       loss[loss_idx] = compute_z_pres_kl_yolo_air(x = z_pres, t2 = logits, t3 = pre_sigmoid); prior_prob = dyn[dyn_idx], p0 = tau
+      LOSS        loss[loss_idx] = per-image sums of mode 0 xent(x = label, t2 = pred) | 1 kl(x = mean, t2 = sig) | 2 kl vs N(dyn[dyn_idx] | p0, p1)
+                  over rows [b*R, (b+1)*R) x columns [xo | o2, +n)
+      NOISE       y <- Philox draws, op 0: normal * p0, 1: uniform (skipped when the run pins the noise tensors) */
+  int32_t xo, yo, o2, o3;       /* column offsets */
+  int32_t n, rep, op, act;
+  float p0, p1;
+  int64_t w_off, b_off;
+  int32_t B, H, W, C, Cout, k, stride, Ho, Wo, Hc, Wc, inverse, training;
+  int32_t loss_idx, dyn_idx, mode, R, stream_id;
+  int32_t group;                /* UNARY: consecutive nodes with the same non-zero group are independent of each other and run as ONE launch */
+} sv_tape_node;
+typedef struct {
+  float* params;                /* flat fp32 variables (updated by the ADAM phase) */
+  float* grads;                 /* flat fp32 gradients, same layout (zeroed and filled by the BACKWARD phase) */
+  const float* loss_weights;    /* HOST array [n_weights]: total = sum_i loss_weights[i] * mean_b loss_i (spair/trainer.py:165-207) */
+  int32_t n_weights;
+  float dyn[8];                 /* step-dependent scalars the nodes reference (prior_z_pres_prob, the zoom prior's mean: :153, :156) */
+  uint64_t seed, step;          /* Philox key of the NOISE nodes */
+  int32_t pinned_noise;         /* != 0: the caller filled the noise tensors (tests) */
+  int32_t phases;               /* SV_TAPE_PHASE_* */
+  int32_t accumulate_metrics;
+  float* adam_m; float* adam_v; int64_t n_params;
+  float lr, beta1, beta2, adam_eps; int64_t t;
+  float clipnorm;               /* > 0: tf.clip_by_norm per variable before the update (TF >= 2.4 apply_gradients); 0: plain Keras Adam */
+  const int64_t* tensor_off; int32_t n_tensors; float* norm_ws;   /* clipnorm only: device [n_tensors + 1] offsets, [n_tensors * 256] floats */
+} sv_tape_run_args;
+int sv_tape_create(sv_tape** out, int32_t batch, int32_t conv_dtype);
+void sv_tape_destroy(sv_tape* t);
+int32_t sv_tape_tensor(sv_tape* t, int64_t rows, int32_t cols, int32_t ld, int32_t need_grad);       /* -> tensor id (>= 0) or SV_E_* */
+int32_t sv_tape_view(sv_tape* t, int32_t src, int64_t rows, int32_t cols, int32_t ld);               /* same storage, other 2-D shape */
+int sv_tape_add(sv_tape* t, const sv_tape_node* node);
+/* reported[j] = sum_i matrix[j * 16 + i] * mean_b loss_i: the `losses` list of train_step (spair/trainer.py:158-160, :208-216) */
+int sv_tape_set_report(sv_tape* t, const float* matrix, int32_t n_report);
+int sv_tape_finalize(sv_tape* t);
+int64_t sv_tape_workspace_bytes(const sv_tape* t);
+int sv_tape_bind(sv_tape* t, void* workspace, int64_t bytes, void* stream);                           /* zero-fills the workspace */
+int sv_tape_tensor_info(const sv_tape* t, int32_t id, int64_t* offset, int64_t* grad_offset);        /* byte offsets (-1: no gradient) */
+/* out block (floats): [total, reported x 16, mean loss_i x 16]; metric block: running sums of [total, reported x 16], then the count */
+int sv_tape_loss_info(const sv_tape* t, int64_t* out_offset, int64_t* metric_offset, int32_t* n_loss);
+int sv_tape_run(sv_tape* t, const sv_tape_run_args* args, void* stream);
+
 /* ---- K16 data-parallel gradient exchange: absent in the reference (single device) -----------
  * One process per GPU; gradients of the batch-mean loss (vae/trainer.py:13,:127-128,:137) are averaged over equal
  * shards by an in-place all-reduce(sum) of the flat fp32 gradient buffer; 1/world is sv_adam_step's grad_scale.

@@ -46,6 +46,29 @@ class StepArgs(C.Structure):
                 ("accumulate_metrics", C.c_int32)]
 
 
+class TapeNode(C.Structure):
+    """sv_tape_node (include/splitvae.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ("kind", "x", "y", "t2", "t3", "t4", "t5", "t6", "xo", "yo", "o2", "o3", "n", "rep", "op", "act")] +
+                [("p0", C.c_float), ("p1", C.c_float), ("w_off", C.c_int64), ("b_off", C.c_int64)] +
+                [(n, C.c_int32) for n in ("B", "H", "W", "C", "Cout", "k", "stride", "Ho", "Wo", "Hc", "Wc", "inverse", "training",
+                                          "loss_idx", "dyn_idx", "mode", "R", "stream_id", "group")])
+
+
+class TapeRunArgs(C.Structure):
+    """sv_tape_run_args (include/splitvae.h)."""
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("loss_weights", C.POINTER(C.c_float)), ("n_weights", C.c_int32),
+                ("dyn", C.c_float * 8), ("seed", C.c_uint64), ("step", C.c_uint64), ("pinned_noise", C.c_int32), ("phases", C.c_int32),
+                ("accumulate_metrics", C.c_int32), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("n_params", C.c_int64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("t", C.c_int64),
+                ("clipnorm", C.c_float), ("tensor_off", C.c_void_p), ("n_tensors", C.c_int32), ("norm_ws", C.c_void_p)]
+
+
+TAPE_DENSE, TAPE_CONV, TAPE_UNARY, TAPE_SAMPLE, TAPE_LOGITNOISE, TAPE_UPSAMPLE, TAPE_STN, TAPE_RENDER, TAPE_ZPRES, TAPE_LOSS, TAPE_NOISE = range(11)
+TAPE_COPY, TAPE_RELU, TAPE_SIGMOID, TAPE_SOFTPLUS, TAPE_CLAMP, TAPE_SCALE = range(6)
+TAPE_PHASE_FORWARD, TAPE_PHASE_BACKWARD, TAPE_PHASE_ADAM = 1, 2, 4
+TAPE_MAX_LOSS = 16
+
+
 class GmDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("latent", C.c_int32), ("y_size", C.c_int32),
                 ("tau", C.c_float), ("dtype", C.c_int32)]
@@ -125,6 +148,21 @@ SYMBOLS = {
     "sv_gm_encoder_forward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
     "sv_gm_encoder_backward": (C.c_int, [_vp, C.POINTER(GmArgs), _vp]),
     "sv_gm_encoder_y_kl": (C.c_int, [_vp, _vp]),
+    "sv_dense_f32_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_dense_f32_dgrad": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sv_dense_f32_wgrad": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "sv_tape_create": (C.c_int, [C.POINTER(_vp), _i32, _i32]),
+    "sv_tape_destroy": (None, [_vp]),
+    "sv_tape_tensor": (_i32, [_vp, _i64, _i32, _i32, _i32]),
+    "sv_tape_view": (_i32, [_vp, _i32, _i64, _i32, _i32]),
+    "sv_tape_add": (C.c_int, [_vp, C.POINTER(TapeNode)]),
+    "sv_tape_set_report": (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
+    "sv_tape_finalize": (C.c_int, [_vp]),
+    "sv_tape_workspace_bytes": (_i64, [_vp]),
+    "sv_tape_bind": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sv_tape_tensor_info": (C.c_int, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "sv_tape_loss_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "sv_tape_run": (C.c_int, [_vp, C.POINTER(TapeRunArgs), _vp]),
     "sv_comm_unique_id": (C.c_int, [_vp]),
     "sv_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "sv_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -521,3 +521,40 @@ def gm_head_bwd(dz, zm, zs, pm, ps, eps, kl_scale, g_am, g_as, g_apm, g_aps):
     B, L = zm.shape
     check(_lib.load().sv_gm_head_bwd(_p(dz), dz.shape[1], _p(zm), _p(zs), _p(pm), _p(ps), _p(eps), float(kl_scale), _p(g_am),
                                      _p(g_as), _p(g_apm), _p(g_aps), sv_dtype(g_am.dtype), B, L, _stream()), "sv_gm_head_bwd")
+
+
+# ---------------------------------------------------------------- SPLIT-SPAIR Dense layers (dense_f32.hip)
+def _pr(t):
+    """Pointer of a 2-D tensor whose rows are contiguous (any row pitch)."""
+    assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+    return C.c_void_p(t.data_ptr())
+
+
+def dense_f32_fwd(x, w, bias=None, act=None):
+    """y = act(x . w + bias) for x [M, K] fp32 (row pitch = x.stride(0)), w [K, N] (Keras Dense kernel): exact-fp32 MFMA."""
+    M, K = x.shape
+    N = w.shape[1]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib.load().sv_dense_f32_fwd(_pr(x), x.stride(0), _p(w), _p(bias), _p(y), N, M, K, N, 1 if act == "relu" else 0, _stream()),
+          "sv_dense_f32_fwd")
+    return y
+
+
+def dense_f32_dgrad(dy, w, out=None):
+    """dx = dy . w^T; out: an fp32 [M, K] tensor the product is ADDED to (atomics, K split over workgroups)."""
+    M, N = dy.shape
+    K = w.shape[0]
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    check(_lib.load().sv_dense_f32_dgrad(_pr(dy), dy.stride(0), _p(w), _pr(dx), dx.stride(0), M, K, N, 1 if out is not None else 0, _stream()),
+          "sv_dense_f32_dgrad")
+    return dx
+
+
+def dense_f32_wgrad(x, dy):
+    """(dw [K, N], dbias [N]) = (x^T . dy, column sums of dy)."""
+    M, K = x.shape
+    N = dy.shape[1]
+    dw = torch.zeros((K, N), dtype=torch.float32, device=x.device)
+    db = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    check(_lib.load().sv_dense_f32_wgrad(_pr(x), x.stride(0), _pr(dy), dy.stride(0), _p(dw), _p(db), M, K, N, _stream()), "sv_dense_f32_wgrad")
+    return dw, db

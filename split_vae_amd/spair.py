@@ -52,13 +52,17 @@ class VarStore:
                 lim = math.sqrt(6.0 / (rf * shp[-2] + rf * shp[-1]))
                 chunks.append(rng.uniform(-lim, lim, size=n).astype(np.float32))
             offs.append(o)
-            o += n
+            pad = (-n) % 4                                           # every variable starts 16-B aligned (the kernels read 16-B pieces)
+            if pad:
+                chunks.append(np.zeros((pad,), np.float32))          # the gaps stay zero: zero gradient, zero Adam moments, no update
+            o += n + pad
         offs.append(o)
         self.offsets = offs
+        self.n_params = sum(int(np.prod(shp)) for _, shp in self.spec)
         self.flat = torch.from_numpy(np.concatenate(chunks)).to(device)
         self.tensor_off = torch.tensor(offs, dtype=torch.int64, device=device)
         # leaves sharing the flat storage: autograd returns one gradient per variable, the optimizer updates the flat buffer in place
-        self.vars = [self.flat[offs[i]:offs[i + 1]].view(shp).detach().requires_grad_(True) for i, (_, shp) in enumerate(self.spec)]
+        self.vars = [self.flat[offs[i]:offs[i] + int(np.prod(shp))].view(shp).detach().requires_grad_(True) for i, (_, shp) in enumerate(self.spec)]
 
 
 class _Layer:
@@ -368,14 +372,24 @@ class _Model:
         for c in store.convs:
             c.compute_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.device = torch.device(device)
+        self.seed = seed
         self.generator = torch.Generator(device=device).manual_seed(seed + 1)
+        self._native = {}                        # (batch, training) -> spair_native.NativeStep
+
+    def native(self, B, config, training=True):
+        """The model recorded as a native launch sequence for batch B (spair_native.NativeStep), built once."""
+        key = (B, bool(training))
+        if key not in self._native:
+            from .spair_native import NativeStep
+            self._native[key] = NativeStep(self, config, B, training)
+        return self._native[key]
 
     @property
     def trainable_variables(self):
         return [(n, v) for (n, _), v in zip(self.store.spec, self.store.vars)]
 
     def count_params(self):
-        return int(self.store.flat.numel())
+        return int(self.store.n_params)
 
     def set_weights(self, weights):
         """{name: array-like} (any subset), e.g. another implementation's variables by name."""

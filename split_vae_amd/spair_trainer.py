@@ -83,6 +83,12 @@ class ClipnormAdam:
     def alpha(self, t):
         return ops.adam_alpha(self.learning_rate, self.beta_1, self.beta_2, t)
 
+    def slots(self, flat):
+        """Adam's m / v for the model's flat variable buffer."""
+        if self._slots is None:
+            self._slots = (torch.zeros_like(flat), torch.zeros_like(flat))
+        return self._slots
+
     def apply_gradients(self, model, grads, alpha_dev=None):
         """alpha_dev: 1-element device tensor with alpha(iterations + 1) -- the captured (hipGraph) step reads the step size from it
         and the caller advances `iterations` per replay."""
@@ -93,6 +99,8 @@ class ClipnormAdam:
         if alpha_dev is None:
             self.iterations += 1
         gs = [g if (g.is_contiguous() and g.data_ptr() % 16 == 0) else g.contiguous().clone() for g in grads]
+        # variables start 16-B aligned in the flat buffer: a gradient whose size is not a multiple of 4 is zero-padded to its slot
+        gs = [g if g.numel() % 4 == 0 else torch.nn.functional.pad(g.reshape(-1), (0, (-g.numel()) % 4)) for g in gs]
         if len(gs) <= 128:                                # the gradient tensors as they are: their addresses go to the kernels by value
             ops.adam_step_clipnorm_tensors(st.flat, gs, m, v, st.tensor_off, self.clipnorm, max(self.iterations, 1), float(self.learning_rate),
                                            self.beta_1, self.beta_2, self.epsilon, alpha_dev=alpha_dev)
@@ -174,8 +182,40 @@ def compute_losses(config, images, out, step, training=True, dyn=None):
     return total, losses
 
 
+_TAPE_MAX = 16          # sv_tape_loss_info: [total, reported x 16, mean loss_i x 16]
+
+RETURN_NAMES = ["x_recon", "z_what", "z_what_mean", "z_what_sigma", "z_where", "z_where_mean", "z_where_sigma", "z_depth", "z_depth_mean",
+                "z_depth_sigma", "z_pres", "z_pres_logits", "z_pres_pre_sigmoid", "all_glimpses", "obj_recon_unnorm", "obj_recon_alpha",
+                "obj_full_recon_unnorm"]
+
+
+def _native_ok(model):
+    """The native launch sequence (spair_native.NativeStep) runs the fp32 model; SV_SPAIR_AUTOGRAD=1 keeps the torch-autograd graph over the
+    split_vae::* operators (the bf16-convolution mode still takes that path)."""
+    import os
+    return (getattr(model, "dtype", "f32") or "f32") == "f32" and not os.environ.get("SV_SPAIR_AUTOGRAD")
+
+
+def _return_names(config):
+    extra = ["z_bg", "z_bg_mean", "z_bg_sig", "x_hat_recon", "z_l", "z_l_mean", "z_l_sig"] if config.model == "lg_spair" else \
+        (["z_bg", "z_bg_mean", "z_bg_sig"] if config.model == "bg_spair" else [])
+    return RETURN_NAMES + extra                                          # the step's return drops obj_bbox_mask (:230-232)
+
+
+def train_step_native(model, images, optimizer, step, config, noise=None, return_grads=False, accumulate_metrics=False):
+    """train_step as ONE native call (sv_tape_run): forward, loss assembly, adjoint, Adam -- no autograd engine, no ATen kernels."""
+    ns = model.native(images.shape[0], config, training=True)
+    lo = ns.run(images, step_scalars(config, float(step), True), optimizer=optimizer, noise=noise, backward=True,
+                accumulate_metrics=accumulate_metrics)
+    res = ns.outputs(_return_names(config))
+    losses = ns._loss_list                                                # views of the tape's loss block (overwritten by the next step)
+    return (res, losses, lo[0], ns.grad_views()) if return_grads else (res, losses)
+
+
 def train_step(model, images, optimizer, step, config, noise=None, return_grads=False):
     """spair/trainer.py:136-234.  `noise`: pinned random draws by name (tests); default = the model's device generator."""
+    if _native_ok(model):
+        return train_step_native(model, images, optimizer, step, config, noise, return_grads)
     out = model(images, training=True, noise=noise)
     total_loss, losses = compute_losses(config, images, out, float(step), training=True)
     variables = [v for _, v in model.trainable_variables]
@@ -245,6 +285,19 @@ class GraphedTrainStep:
 @torch.no_grad()
 def test_step(model, images, config, labels=None, noise=None):
     """spair/trainer.py:236-308 (the reference evaluates with model(images, training=True) too)."""
+    if _native_ok(model) and labels is None:
+        ns = model.native(images.shape[0], config, training=True)
+        lo = ns.run(images, step_scalars(config, 0.0, False), noise=noise, backward=False)
+        names = _return_names(config)
+        # mean loss_i of the tape: [x_recon, zoom, what, where, depth, z_pres, (bg, l, x_hat)]
+        means = [lo[1 + _TAPE_MAX + i] for i in range(ns.n_loss)]
+        losses = means[:6]
+        if config.model == "lg_spair":                                  # test_step :262-285
+            losses = losses + [means[6] + means[7], means[7], means[8]]
+        elif config.model == "bg_spair":
+            z = torch.zeros((), device=images.device)
+            losses = losses + [means[6], z, z]
+        return ns.outputs(names), losses
     out = model(images, training=True, noise=noise)
     _, losses = compute_losses(config, images, out, 0.0, training=False)
     if labels is not None:

@@ -85,7 +85,9 @@ def test_spair_step_matches_oracle(lib_built, name):
     R.clipnorm_adam_(pl, [gb if gb is not None else torch.zeros_like(v) for gb, v in zip(grads_ref, pl)], m, vv, 1, lr=1e-3, clipnorm=1.0,
                      clip_in_apply=clip)
     upd_ref = torch.cat([(a - b.detach()).reshape(-1) for a, b in zip(pl, p.values())])
-    upd = (model.store.flat - before).double().cpu()
+    d = (model.store.flat - before).double().cpu()                                # variables start 16-B aligned in the flat buffer
+    offs = model.store.offsets
+    upd = torch.cat([d[offs[i]:offs[i] + int(np.prod(shp))] for i, (_, shp) in enumerate(model.store.spec)])
     assert float((upd - upd_ref).norm() / upd_ref.norm()) < 2e-2          # first Adam step = lr * sign-like: tiny gradients flip easily
     assert float(upd.abs().max()) <= 1e-3 * 1.0001
 
@@ -130,9 +132,11 @@ def test_spair_training_reduces_the_loss(lib_built):
 
 
 @pytest.mark.parametrize("name", ["spair", "lg_spair_readme"])
-def test_graphed_step_equals_eager_steps(lib_built, name):
-    """GraphedTrainStep (one hipGraph replay per step, step-dependent scalars in device memory) against the eager train_step: same
+def test_graphed_step_equals_eager_steps(lib_built, name, monkeypatch):
+    """GraphedTrainStep (one hipGraph replay per step, step-dependent scalars in device memory) against the eager train_step of the SAME
+    engine (the torch-autograd graph over the split_vae::* operators, SV_SPAIR_AUTOGRAD=1: what the bf16-convolution mode still runs): same
     pinned draws, steps 7..10 of the annealing schedule -> the same losses and variables (up to the order of fp32 atomics)."""
+    monkeypatch.setenv("SV_SPAIR_AUTOGRAD", "1")
     from oracle import spair_model_ref as R
     from split_vae_amd import spair, spair_trainer
     from split_vae_amd.utils import dotdict
@@ -248,6 +252,59 @@ def test_spair_step_matches_the_golden_fixture(lib_built):
         assert np.linalg.norm(s - G["sample/" + k]) <= 5e-4 * max(np.linalg.norm(G["sample/" + k]), 1e-12), k
     gn = np.array([float(g.norm()) for g in grads])
     np.testing.assert_allclose(gn, G["grad_norms"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("name", ["spair", "lg_spair_readme"])
+def test_native_step_tracks_the_autograd_step(lib_built, name, monkeypatch):
+    """The native launch sequence (spair_native.NativeStep: one sv_tape_run per step) against the torch-autograd graph over the same
+    kernels' operators, four Adam steps from the same variables and pinned draws: same losses (2e-4), variables within 1e-3 of the
+    distance travelled per unit... (Adam turns rounding-level gradient differences of near-zero entries into full-lr moves)."""
+    from oracle import spair_model_ref as R
+    from split_vae_amd import spair, spair_trainer
+    from split_vae_amd.utils import dotdict
+    cfg = dotdict(R.default_config(**CONFIGS[name]))
+    cfg.z_pres_anneal_step, cfg.anneal_until = 20.0, 15.0
+    B = 4
+    images = torch.rand(B, 48, 48, 6 if cfg.model == "lg_spair" else 3, generator=torch.Generator().manual_seed(3)).cuda()
+    noise = {k: v.float().cuda() for k, v in R.draw_noise(cfg, B, seed=9).items()}
+    runs = []
+    for native in (True, False):
+        if not native:
+            monkeypatch.setenv("SV_SPAIR_AUTOGRAD", "1")
+        model = spair.get_model(cfg, seed=2)
+        start = model.store.flat.clone()
+        opt = spair_trainer.ClipnormAdam(learning_rate=1e-3, clipnorm=1.0)
+        hist = []
+        for step in range(7, 11):
+            _, losses = spair_trainer.train_step(model, images, opt, step, cfg, noise=noise)
+            hist.append([float(l) for l in losses])
+        assert opt.iterations == 4
+        runs.append((hist, model.store.flat.clone(), start))
+    (h0, p0, s0), (h1, p1, _) = runs
+    for a, b in zip(h0, h1):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (a, b)
+    assert float((p0 - p1).norm()) < 2e-2 * float((p0 - s0).norm())          # 2 % of the distance the four steps moved the variables
+
+
+def test_native_step_launch_count_and_metrics(lib_built):
+    """README.md:93's SPLIT-SPAIR model at the reference's batch 32: the whole train step is one sv_tape_run; the recorded node count bounds
+    its launches; the metric accumulators sum the reported losses natively."""
+    from split_vae_amd import spair, spair_main, spair_trainer
+    cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+                                    split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True)
+    model = spair.get_model(cfg, seed=0)
+    images = torch.rand(32, 48, 48, 6, generator=torch.Generator().manual_seed(5)).cuda()
+    opt = spair_trainer.ClipnormAdam(cfg.learning_rate)
+    tot = []
+    for step in range(12):
+        _, losses, total, _ = spair_trainer.train_step_native(model, images, opt, step, cfg, return_grads=True, accumulate_metrics=True)
+        tot.append(float(total))
+    ns = model.native(32, cfg)
+    assert ns.n_nodes <= 130, ns.n_nodes
+    torch.cuda.synchronize()
+    assert abs(float(ns.metric[0]) - sum(tot)) <= 1e-4 * abs(sum(tot)) and float(ns.metric[17]) == 12.0
+    assert np.isfinite(tot).all() and tot[-1] < tot[0]
 
 
 @pytest.mark.parametrize("ext", [".h5", ".npz"])
