@@ -139,6 +139,16 @@ inline void sv_ensure_dynamic_lds(const void* kernel, size_t bytes) {
   }
 }
 
+// SV_DETERMINISTIC=1: every reduction runs in a fixed order -- no split-K / m-split fp32 atomics (one workgroup owns an output tile, or
+// partial sums go through slabs summed in index order), bias gradients through per-workgroup partials.  Same inputs twice -> identical
+// bits (SURVEY section 5's determinism test; tests/test_gpu_determinism.py).  Off by default: the split-K dense layers are faster with
+// atomics.  Read once per process.
+#include <stdlib.h>
+inline bool sv_deterministic() {
+  static const bool d = getenv("SV_DETERMINISTIC") != nullptr && atoi(getenv("SV_DETERMINISTIC")) != 0;
+  return d;
+}
+
 // Timing-ablation bits (skip staging / the MFMA loop / stores: WRONG results, for profiling only) exist only in builds
 // with -DSV_DEBUG_KNOBS (SV_EXTRA_FLAGS=-DSV_DEBUG_KNOBS python split_vae_amd/build.py); the shipped library has none.
 #ifdef SV_DEBUG_KNOBS

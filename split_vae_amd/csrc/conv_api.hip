@@ -387,7 +387,7 @@ void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs) {
   const int tiles = ((a->Nrows + BRt[cfg] - 1) / BRt[cfg]) * ((a->N + BNt[cfg] - 1) / BNt[cfg]);
   int z = target_wgs / (tiles > 0 ? tiles : 1);
   const int maxz = (a->M + ms - 1) / ms;
-  if (z < 1) z = 1;
+  if (z < 1 || sv_deterministic()) z = 1;      // deterministic: no m-split, the kernel's plain (non-atomic) epilogue
   if (z > maxz) z = maxz;
   a->msplit = round_up((a->M + z - 1) / z, ms);
 }

@@ -4,6 +4,7 @@
 #include <string.h>
 #include "../../include/splitvae.h"
 #include "kernels.h"
+#include "common.hip.h"
 
 static inline int svg_epp(const sv_conv_desc* d) { return d->dtype == SV_BF16 ? 8 : 4; }
 static inline int svg_r8(int v) { return (v + 7) / 8 * 8; }
@@ -69,6 +70,7 @@ static inline int svg_choose_splitk(int M, int N, int nk, int* cfg_io = nullptr)
   int cfg = svg_pick_cfg(N);
   int tiles = ((M + BMt[cfg] - 1) / BMt[cfg]) * ((N + BNt[cfg] - 1) / BNt[cfg]);
   if (tiles >= 128) return 1;
+  if (sv_deterministic()) return 1;        // one workgroup per output tile: a single add per element, whatever the launch order
   static const bool small = getenv("SV_SPLITK_NO_SMALL") == nullptr;   // 64 x 32 tiles (tap-GEMM cfg 4): +0.8 % on the step; knob restores 128 x 64
   if (small && cfg_io && (N % 32) == 0) {
     static const int tgt_small = getenv("SV_SPLITK_WGS") ? atoi(getenv("SV_SPLITK_WGS")) : 512;

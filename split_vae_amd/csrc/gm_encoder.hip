@@ -202,6 +202,10 @@ extern "C" int sv_gm_encoder_create(const sv_gm_desc* d, sv_gm_encoder** out) {
   e->add("g_hh", (int64_t)B * 512 * 4); e->add("g_h5", BF * 4); e->add("g_y", (int64_t)B * Kp * 4);
   e->add("g_yh2", (int64_t)B * 128 * 4); e->add("g_yh1", (int64_t)B * 1024 * 4); e->add("g_h1", BF * 4);
   e->add("acc_end", 0);
+  // partial-sum slabs of the tile weight gradients (two-stage flush: faster than fp32 atomics and run-to-run identical)
+  int64_t wsb = 0;
+  for (int l = 0; l < NLAYER; ++l) { const int64_t b = sv_conv2d_wgrad_workspace_bytes(&e->conv[l]); wsb = b > wsb ? b : wsb; }
+  e->add("wgrad_ws", wsb);
   *out = e;
   return SV_OK;
 }
@@ -297,7 +301,8 @@ extern "C" int sv_gm_encoder_backward(sv_gm_encoder* e, const sv_gm_args* a, voi
     if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
   }
   auto wg = [&](int l, const void* x, const void* dy) {
-    return sv_conv2d_nhwc_wgrad(&e->conv[l], x, dy, a->grads + e->params[2 * l].off, a->grads + e->params[2 * l + 1].off, stream);
+    return sv_conv2d_nhwc_wgrad_ws(&e->conv[l], x, dy, a->grads + e->params[2 * l].off, a->grads + e->params[2 * l + 1].off, e->bp("wgrad_ws"),
+                                   e->bufs.at("wgrad_ws").bytes, stream);
   };
   auto dg_acc = [&](int l, const void* dy, const char* acc) {   // split-K input gradient added into an fp32 buffer
     return sv_conv2d_nhwc_dgrad(&e->conv[l], dy, e->wdgrad(l), nullptr, e->bp(acc), 1, stream);

@@ -139,6 +139,7 @@ int svk_wgrad_multi(const WgradArgs* a, int n, int dtype, int cfg, hipStream_t s
 struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
+  float* bslab;                               // with slab: [msplit][128] bias partials behind the dW slabs (summed by the reduce kernel)
   int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
   int layer_id;             // instantiation id (tuning table of svk_wgrad_tile_multi)
   int contig;               // tiles of a workgroup: contiguous run (1) or strided by the grid (0)
@@ -158,13 +159,13 @@ struct WgradTileArgs {
 };
 #define SV_WGRAD_MAX_MULTI 2
 struct WgradTileMulti { WgradTileArgs a[SV_WGRAD_MAX_MULTI]; };     // blockIdx.z selects the problem
-struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; };
+struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; const float* bslab[SV_WGRAD_MAX_MULTI]; float* dbias[SV_WGRAD_MAX_MULTI]; };
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
 int svk_wgrad_tile_multi(const WgradArgs* w, int n, hipStream_t st);   // n twin layers, one launch (own ws each)
 int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st);
 // tile kernel when the layer has an instantiation (bf16), im2col kernel otherwise
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st);
-#define SV_WGRAD_WS_BYTES (512LL * 36 * 4 * 256 * 4)   // 512 workgroups x 36 fragments x 4 waves x 256 floats
+#define SV_WGRAD_WS_BYTES (512LL * 36 * 4 * 256 * 4 + 512LL * 128 * 4)   // 512 workgroups x 36 fragments x 4 waves x 256 floats + their bias partials
 
 // ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
 struct PrepJob {

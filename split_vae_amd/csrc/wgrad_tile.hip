@@ -251,7 +251,9 @@ bias_part:
     if (grp == 0 && tid < ycols && tid < g.N && (!g.fold_kw || (tid & 7) < g.fold_c)) {
       float s = 0.f;
       for (int k = 0; k < nbg * NG; ++k) s += red[k * ycols + tid];
-      atomicAdd(g.dbias + (g.fold_kw ? (tid & 7) : tid), s);
+      // slab path: one partial per workgroup behind the dW slabs, summed in workgroup order by the reduce kernel (deterministic)
+      if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + tid] = s;
+      else atomicAdd(g.dbias + (g.fold_kw ? (tid & 7) : tid), s);
     }
   }
 }
@@ -266,8 +268,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
                                                            int fold_c, int pairx, int assign) {
   const float* __restrict__ slab = m.slab[blockIdx.z];
   float* __restrict__ dW = m.dW[blockIdx.z];
-  constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
   __shared__ float4 part[8][32];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && m.bslab[blockIdx.z]) {
+    // bias gradient: the workgroups' partial column sums, always in the same order (x-packed head: both pixel parities of a channel).
+    // Two interleaved halves of the workgroup rows per column, many loads in flight, combined through LDS.
+    const float* __restrict__ bs = m.bslab[blockIdx.z];
+    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
+    float s = 0.f;
+    if (c < N && (!fold_kw || c < fold_c)) {
+#pragma unroll 8
+      for (int x = h; x < msplit; x += 2) s += bs[x * 128 + c] + (fold_kw ? bs[x * 128 + c + 8] : 0.f);
+    }
+    float* bred = (float*)&part[0][0];
+    if (h) bred[c] = s;
+    __syncthreads();
+    if (!h && c < N && (!fold_kw || c < fold_c)) m.dbias[blockIdx.z][c] += s + bred[c];
+    __syncthreads();
+  }
+  constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)
   const int y = blockIdx.y, col = threadIdx.x & 31, row = threadIdx.x >> 5;
   const int e = (blockIdx.x * 32 + col) * 4;                     // first of this thread's 4 floats (PER % 128 == 0)
   const float* p = slab + (int64_t)y * PER + e;
@@ -339,7 +357,7 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   }
   dim3 grid(msplit, groups, n), block(256 * NG);
   constexpr int PER = 4 * TPW * CIF * COF * 256;
-  const int64_t need = (int64_t)msplit * groups * PER * 4;
+  const int64_t need = (int64_t)msplit * groups * PER * 4 + (int64_t)msplit * 128 * 4;      // + one (<= 128-column) bias partial per workgroup row
   static const bool no_slab = getenv("SV_WT_ATOMICS") != nullptr;
   WgradTileMulti m;
   WgradReduceMulti r;
@@ -349,7 +367,8 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
     m.a[i] = a[i];
     m.a[i].dbg = dbg;
     m.a[i].slab = slab ? a[i].ws : nullptr;
-    r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW;
+    m.a[i].bslab = (slab && a[i].dbias && a[i].ldy <= 128) ? a[i].ws + (int64_t)msplit * groups * PER : nullptr;
+    r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW; r.bslab[i] = m.a[i].bslab; r.dbias[i] = a[i].dbias;
   }
   hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();

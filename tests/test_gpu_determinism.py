@@ -1,0 +1,89 @@
+"""GPU: SV_DETERMINISTIC=1 (SURVEY section 5 "determinism test": same inputs twice -> identical bits).
+
+The switch is read once per process by the library, so every test here runs a child process with it set:
+  * the whole training step (CelebA-64, 64 images: config 4's shard; bf16 and fp32; SPLIT-GMVAE too) twice from the same state:
+    losses, all gradients and the updated weights bit for bit;
+  * the fp32 oracle comparison of tests/test_gpu_step.py and the one-rank RCCL test at their ORIGINAL bounds
+    (SV_TEST_STRICT=1 removes the "a ReLU gate within summation-order noise of zero fell the other way" allowance that the default,
+    atomics-ordered path needs).
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent('''
+    import hashlib, sys
+    sys.path.insert(0, %r)
+    import torch
+    from split_vae_amd import data, trainer
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+
+    def run(dtype, H, B, patch):
+        x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+        img = Augmentator("scramble", size=patch, seed=1).augment(x)
+        m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=dtype, device=torch.device("cuda"), seed=3)
+        m.beta = 120.0
+        opt = Adam(learning_rate=1e-4)
+        h = hashlib.sha256()
+        for _ in range(3):
+            plan = trainer.train_step(m, img, opt)
+            torch.cuda.synchronize()
+            for t in (plan.buffer("losses", torch.float32, (8,)), m.grad_flat, m.flat):
+                h.update(t.detach().cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    def run_gm(dtype):
+        from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae
+        x = data.synthetic_images(64, 32, 32, seed=0, device="cuda")
+        img = Augmentator("scramble", size=4, seed=1).augment(x)
+        m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype=dtype, device="cuda", seed=3)
+        m.beta, m.alpha = 40.0, 40.0
+        opt = Adam(learning_rate=1e-4)
+        h = hashlib.sha256()
+        for _ in range(3):
+            train_step_lg_gm_vae(m, img, opt)
+            torch.cuda.synchronize()
+            for g in m.gradients:
+                h.update(g.detach().cpu().numpy().tobytes())
+            for v in m.trainable_variables:
+                h.update(v.detach().cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    for name, fn in (("lgvae bf16 64x64 B=64", lambda: run("bf16", 64, 64, 8)), ("lgvae f32 32x32 B=16", lambda: run("f32", 32, 16, 1)),
+                     ("lgvae bf16 64x64 B=512", lambda: run("bf16", 64, 512, 8)), ("lggmvae bf16", lambda: run_gm("bf16")),
+                     ("lggmvae f32", lambda: run_gm("f32"))):
+        a, b = fn(), fn()
+        print(name, "OK" if a == b else "DIFFERENT", a[:16], b[:16])
+''') % ROOT
+
+
+def _env():
+    return dict(os.environ, SV_DETERMINISTIC="1", SV_TEST_STRICT="1")
+
+
+def test_training_steps_are_bitwise_reproducible(lib_built):
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if " OK " in l or " DIFFERENT " in l]
+    assert len(lines) == 5, r.stdout
+    assert all(" OK " in l for l in lines), "\n".join(lines)
+
+
+def test_oracle_bounds_hold_without_the_gate_flip_allowance(lib_built):
+    """The fp32 oracle comparisons at their original bounds, three consecutive runs each (deterministic: one outcome every time)."""
+    # (the SPLIT-GMVAE fp32 test keeps its allowance: with a fixed summation order its one ReLU unit whose pre-activation is within fp32
+    #  rounding of zero ALWAYS takes the gate opposite to the fp64 oracle's -- reproducibly, which the bitwise test above shows -- so the
+    #  allowance there is about fp32 vs fp64, not about run-to-run order)
+    tests = ["tests/test_gpu_step.py::test_step_fp32_matches_oracle",
+             "tests/test_gpu_dist.py::test_one_rank_through_the_rccl_path_equals_the_plain_step"]
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q"] + tests, capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:]

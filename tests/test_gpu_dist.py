@@ -78,8 +78,9 @@ def test_one_rank_through_the_rccl_path_equals_the_plain_step(lib_built, tmp_pat
     # twenty) puts a ReLU unit's pre-activation within that noise of zero, and its gate -- with that unit's share of the
     # gradients -- falls differently in the two runs: a few thousandths of the gradient's norm (tests/test_gpu_gm.py has the
     # analysis).  The bounds leave room for that, not for a missing bucket.
-    assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
-    assert np.linalg.norm(one["params"] - dp["params"]) <= 1e-1 * np.linalg.norm(one["params"] - _init_params())
+    strict = bool(os.environ.get("SV_TEST_STRICT"))           # under SV_DETERMINISTIC=1 (tests/test_gpu_determinism.py): the original bounds
+    assert np.linalg.norm(g1 - g2) <= (1e-3 if strict else 1e-2) * np.linalg.norm(g1)
+    assert np.linalg.norm(one["params"] - dp["params"]) <= (1e-2 if strict else 1e-1) * np.linalg.norm(one["params"] - _init_params())
     assert np.allclose(one["losses"], dp["losses"], rtol=1e-3, atol=1e-3)
 
 

@@ -1,6 +1,8 @@
 """GPU parity of the SPLIT-GMVAE step (LGGMVae.call + train_step_lg_gm_vae + Keras-Adam; SURVEY 8a row A9,
 config 3: SVHN-32, y_size 30, tau 0.4, beta 40, alpha 40, patch 4) against the oracle restatement
 (oracle/gm_ref.py) on identical inputs, weights and random draws (eps, Gumbel uniforms, dropout masks)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,6 +104,8 @@ def test_gm_step_fp32_matches_oracle(ops, dropout):
                 torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * scale + 1e-9,
                                            msg=lambda m: "step %d grad %s: %s" % (t, name, m))
             except AssertionError:
+                if os.environ.get("SV_TEST_STRICT"):     # SV_DETERMINISTIC=1 runs (tests/test_gpu_determinism.py): the plain bound, no second outcome
+                    raise
                 # About one run in twenty a ReLU unit of decoder_x (one channel of h4 at one pixel, for these inputs) has a
                 # pre-activation within fp32 summation-order noise (split-K atomics upstream) of ZERO after the first update,
                 # and its gate falls on the other side than in the fp64 oracle.  The forward value hardly moves (the unit is

@@ -1,5 +1,7 @@
 """GPU parity of the whole SPLIT-VAE step (LGVae.call + train_step_lg_vae + Keras-Adam) through
 the C ABI plan, against the oracle restatement on identical inputs / eps / perm / weights."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -89,6 +91,7 @@ def test_step_fp32_matches_oracle(ops, H, patch, beta, B):
             dlt = (gg.double() - gr).abs()
             err = float(dlt.max())
             if err > tol:
+                assert not os.environ.get("SV_TEST_STRICT"), "grad %s: err %g tol %g (strict: SV_DETERMINISTIC run)" % (name, err, tol)
                 # a ReLU unit within fp32 summation-order noise of zero takes the other gate than the fp64 oracle (analysis in
                 # tests/test_gpu_gm.py::test_gm_step_fp32_matches_oracle): a few elements, small in norm -- nothing else passes here
                 frac, rel = float((dlt > tol).double().mean()), float(dlt.norm() / gr.norm().clamp_min(1e-30))
