@@ -175,6 +175,25 @@ struct sv_lgvae_plan {
 
 namespace {
 
+// SV_ROCTX=1: every plan scope ("fwd.d4", "wgrad.d4", "adam_step" ...) is also a roctx range, so a `rocprofv3 --marker-trace
+// --kernel-trace` timeline names the layers directly.  libroctx64 is bound at run time (no link dependency); off by default.
+#include <dlfcn.h>
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("SV_ROCTX");
+    if (!e || !atoi(e)) return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static const Roctx& roctx() { static const Roctx r; return r; }
+
 struct Scope {   // hipEvent bracket around one launch when profiling is on
   sv_lgvae_plan* p; hipStream_t st; int entry = -1, entry2 = -1; hipEvent_t a = nullptr, b = nullptr, m1 = nullptr, m2 = nullptr;
   bool on, on2 = false;
@@ -192,7 +211,9 @@ struct Scope {   // hipEvent bracket around one launch when profiling is on
     p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0});
     return e;
   }
+  bool marked = false;
   Scope(sv_lgvae_plan* p_, hipStream_t st_, const std::string& name, double flops, double bytes) : p(p_), st(st_), on(p_->prof_on) {
+    if (roctx().push) { roctx().push(name.c_str()); marked = true; }
     if (on && !p->prof_filter.empty() && p->prof_filter != name) on = false;
     if (!on) return;
     entry = find(name, flops, bytes);
@@ -211,6 +232,7 @@ struct Scope {   // hipEvent bracket around one launch when profiling is on
     if (!b) b = get();
   }
   ~Scope() {
+    if (marked) roctx().pop();
     if (!b) return;
     (void)hipEventRecord(b, st);
     if (!m1) { p->pending.push_back(ProfPending{entry, a, b}); return; }

@@ -3,8 +3,8 @@
 LGGMVae = LGVae whose global encoder is Encoder(type='gmvae') (vae/model.py:48-79, call_gmvae :116-135).
 encoder_x_hat, both decoders, the two reconstruction terms and the N(0,1) KL of the local latent are the
 LGVae step plan, built with `external_global_encoder` (the plan then skips its own encoder_x).  The GMVAE
-global encoder is orchestrated here, layer by layer, on the same HIP kernels: its convs and dense layers
-are sv_conv2d_* calls (dense = 1x1 conv on a 1x1 grid), the glue between them is gm_pointwise.hip.
+global encoder runs on the same HIP kernels -- its convs and dense layers are sv_conv2d_* calls (dense = 1x1 conv on a 1x1 grid),
+the glue between them is gm_pointwise.hip -- sequenced natively by csrc/gm_encoder.hip (sv_gm_encoder_*: one C call per phase).
 torch only owns the buffers.
 
 Trainable variables, in the reference's layer-tracking order: the 24 arrays of the gmvae encoder
@@ -44,160 +44,53 @@ class _Dense:
         self.conv = ops.Conv2D(B, 1, 1, cin, cout, 1, 1, act=None, dtype=dtype, y_f32=True)
 
 
-class GMEncoder:
-    """Encoder(latent_dims, type='gmvae', y_size, tau) for one batch size."""
+GM_LAYER_NAMES = ["encoder_x/h_block/conv2d", "encoder_x/h_block/conv2d_1", "encoder_x/h_block/conv2d_2",
+                  "encoder_x/y_block/dense", "encoder_x/y_block/dense_1", "encoder_x/y_dense", "encoder_x/h_top_dense",
+                  "encoder_x/z_prior_mean", "encoder_x/z_prior_sig", "encoder_x/e1", "encoder_x/z_mean", "encoder_x/z_sig"]
+GM_LAYERS = ["c1", "c2", "c3", "d1", "d2", "yd", "ht", "pm", "ps", "e1", "zm", "zs"]   # variable order (kernel, bias each)
 
-    LAYERS = ["c1", "c2", "c3", "d1", "d2", "yd", "ht", "pm", "ps", "e1", "zm", "zs"]   # variable order (kernel, bias each)
 
-    def __init__(self, B, H, W, latent, y_size, tau, dtype, device):
-        self.B, self.H, self.W, self.L, self.K, self.tau, self.dtype, self.device = B, H, W, latent, y_size, tau, dtype, device
-        self.F = (H // 8) * (W // 8) * 128
-        F_, K, L = self.F, y_size, latent
-        self.shapes = [(6, 6, 3, 128), (128,), (6, 6, 128, 128), (128,), (4, 4, 128, 128), (128,),
-                       (F_, 1024), (1024,), (1024, 128), (128,), (128, K), (K,), (K, 512), (512,),
-                       (K, L), (L,), (K, L), (L,), (F_, 512), (512,), (512, L), (L,), (512, L), (L,)]
-        self.names = ["encoder_x/h_block/conv2d", "encoder_x/h_block/conv2d_1", "encoder_x/h_block/conv2d_2",
-                      "encoder_x/y_block/dense", "encoder_x/y_block/dense_1", "encoder_x/y_dense", "encoder_x/h_top_dense",
-                      "encoder_x/z_prior_mean", "encoder_x/z_prior_sig", "encoder_x/e1", "encoder_x/z_mean", "encoder_x/z_sig"]
-        self.table, off = [], 0
-        for i, shp in enumerate(self.shapes):
-            self.table.append((self.names[i // 2] + ("/kernel" if i % 2 == 0 else "/bias"), off, shp))
-            off += (int(np.prod(shp)) + 3) // 4 * 4
-        self.n_params = off
-        cv = lambda h, cin, cout, k: ops.Conv2D(B, h, h, cin, cout, k, 2, act=None, dtype=dtype)
-        self.conv = {"c1": cv(H, 3, 128, 6), "c2": cv(H // 2, 128, 128, 6), "c3": cv(H // 4, 128, 128, 4)}
-        dn = lambda cin, cout: _Dense(B, cin, cout, dtype).conv
-        self.conv.update({"d1": dn(F_, 1024), "d2": dn(1024, 128), "yd": dn(128, K), "ht": dn(K, 512), "pm": dn(K, L),
-                          "ps": dn(K, L), "e1": dn(F_, 512), "zm": dn(512, L), "zs": dn(512, L)})
-        T, f32 = dtype, torch.float32
-        z = lambda *s, dt=T: torch.zeros(s, dtype=dt, device=device)
-        Kp = _r8(K)
-        self.buf = dict(
-            h1=z(B, H // 2, H // 2, 128), h2=z(B, H // 4, H // 4, 128), h3=z(B, self.F),
-            a1=z(B, 1024, dt=f32), yh1a=z(B, 1024), yh1=z(B, 1024), keep1=z(B, 1024, dt=f32),
-            a2=z(B, 128, dt=f32), yh2=z(B, 128), logits=z(B, K, dt=f32), y=z(B, K, dt=f32), y_lp=z(B, Kp), u=z(B, K, dt=f32),
-            a_pm=z(B, L, dt=f32), a_ps=z(B, L, dt=f32), a_t=z(B, 512, dt=f32), h_top=z(B, 512),
-            h5=z(B, self.F), keep5=z(B, self.F, dt=f32), a_e=z(B, 512, dt=f32), he=z(B, 512), hh=z(B, 512),
-            a_m=z(B, L, dt=f32), a_s=z(B, L, dt=f32), zm=z(B, L, dt=f32), zs=z(B, L, dt=f32), z=z(B, L, dt=f32),
-            pm=z(B, L, dt=f32), ps=z(B, L, dt=f32), eps=z(B, L, dt=f32), kl2=z(B, dt=f32), ykl=z(B, dt=f32),
-            # backward
-            g_am=z(B, L), g_as=z(B, L), g_apm=z(B, L), g_aps=z(B, L), g_hh=z(B, 512, dt=f32), g_ae=z(B, 512), g_at=z(B, 512),
-            g_h5=z(B, self.F, dt=f32), g_y=z(B, Kp, dt=f32), g_logits=z(B, Kp), g_yh2=z(B, 128, dt=f32), g_a2=z(B, 128),
-            g_yh1=z(B, 1024, dt=f32), g_a1=z(B, 1024), g_h1=z(B, self.F, dt=f32), g_c3=z(B, self.F),
-            g_c2=z(B, H // 4, H // 4, 128), g_c1=z(B, H // 2, H // 2, 128))
+def gm_param_table(H, W, latent, y_size):
+    """(name, offset, shape) of the 24 variables of Encoder(type='gmvae') (vae/model.py:48-79) in the reference's layer-tracking
+    order, each 16-B aligned in the flat buffer (the layout csrc/gm_encoder.hip's build_params uses)."""
+    F_, K, L = (H // 8) * (W // 8) * 128, y_size, latent
+    shapes = [(6, 6, 3, 128), (128,), (6, 6, 128, 128), (128,), (4, 4, 128, 128), (128,),
+              (F_, 1024), (1024,), (1024, 128), (128,), (128, K), (K,), (K, 512), (512,),
+              (K, L), (L,), (K, L), (L,), (F_, 512), (512,), (512, L), (L,), (512, L), (L,)]
+    table, off = [], 0
+    for i, shp in enumerate(shapes):
+        table.append((GM_LAYER_NAMES[i // 2] + ("/kernel" if i % 2 == 0 else "/bias"), off, shp))
+        off += (int(np.prod(shp)) + 3) // 4 * 4
+    return table
 
-    def views(self, flat):
-        # cached per buffer: this runs ~25 times per step (it was over half of the step's host time)
-        key = (flat.data_ptr(), flat.numel())
-        cache = self.__dict__.setdefault("_view_cache", {})
-        if key not in cache:
-            if len(cache) > 8:
-                cache.clear()
-            cache[key] = [flat[off:off + int(np.prod(shp))].view(*shp) for (_, off, shp) in self.table]
-        return cache[key]
+
+class PriorHead:
+    """The two Dense layers encode_y needs (z_prior_mean / z_prior_sig of a GIVEN y, vae/model.py:137-140) for n rows: inference only.
+    (The training sequence of the whole encoder is native: NativeGMEncoder / csrc/gm_encoder.hip.)"""
+
+    def __init__(self, n, H, W, latent, y_size, dtype, device):
+        self.table = gm_param_table(H, W, latent, y_size)
+        self.conv = {k: _Dense(n, y_size, latent, dtype).conv for k in ("pm", "ps")}
+        f32, Kp = torch.float32, _r8(y_size)
+        z = lambda *s, dt=dtype: torch.zeros(s, dtype=dt, device=device)
+        self.buf = dict(y_lp=z(n, Kp), a_pm=z(n, latent, dt=f32), a_ps=z(n, latent, dt=f32), zm=z(n, latent, dt=f32), zs=z(n, latent, dt=f32),
+                        z=z(n, latent, dt=f32), pm=z(n, latent, dt=f32), ps=z(n, latent, dt=f32), kl2=z(n, dt=f32))
 
     def _kb(self, flat, name):
-        i = self.LAYERS.index(name)
-        v = self.views(flat)
-        k, b = v[2 * i], v[2 * i + 1]
-        if k.dim() == 2:
-            k = k.view(1, 1, *k.shape)                  # dense kernel [in,out] == HWIO with H=W=1
-        return k, b
+        i = GM_LAYERS.index(name)
+        (_, ko, ks), (_, bo, bs) = self.table[2 * i], self.table[2 * i + 1]
+        k = flat[ko:ko + int(np.prod(ks))].view(1, 1, *ks)       # dense kernel [in,out] == HWIO with H=W=1
+        return k, flat[bo:bo + int(np.prod(bs))]
 
     def prep(self, flat):
-        for n in self.LAYERS:
-            self.conv[n].prep(self._kb(flat, n)[0])
-
-    # ------------------------------------------------------------------ call_gmvae (vae/model.py:116-135)
-    def forward(self, flat, in8_x, zcat, training, eps=None, u=None, keep1=None, keep5=None, seed=0, step=0, sample_offset=0):
-        b, c, B, K = self.buf, self.conv, self.B, self.K
-        rate = GM_RATE if training else 0.0
-        bias = lambda n: self._kb(flat, n)[1]
-        rows = lambda t: t.view(-1, 128)
-        # h_block: three stride-2 convs with ELU (:50-52)
-        c["c1"].fwd(in8_x, bias("c1"), out=b["h1"]); ops.act_fwd(rows(b["h1"]), 128, rows(b["h1"]), "elu")
-        c["c2"].fwd(b["h1"], bias("c2"), out=b["h2"]); ops.act_fwd(rows(b["h2"]), 128, rows(b["h2"]), "elu")
-        h3 = b["h3"].view(B, self.H // 8, self.W // 8, 128)
-        c["c3"].fwd(b["h2"], bias("c3"), out=h3); ops.act_fwd(rows(h3), 128, rows(h3), "elu")
-        # y_block (:54-58) -> y_dense (:60) -> Gumbel-softmax (:121-122)
-        c["d1"].fwd(b["h3"], bias("d1"), out=b["a1"])
-        ops.act_fwd(b["a1"], 1024, b["yh1"], "elu", y_act=b["yh1a"], rate=rate, keep_in=keep1, keep_out=b["keep1"], seed=seed,
-                    step=step, stream_id=11, sample_offset=sample_offset)
-        c["d2"].fwd(b["yh1"], bias("d2"), out=b["a2"]); ops.act_fwd(b["a2"], 128, b["yh2"], "elu")
-        c["yd"].fwd(b["yh2"], bias("yd"), out=b["logits"])
-        ops.gumbel_softmax_fwd(b["logits"], K, self.tau, b["y"], b["y_lp"], u=u, u_out=b["u"], seed=seed, step=step,
-                               sample_offset=sample_offset)
-        # prior (:124-125), h_top (:127), encoder block (:128-133)
-        c["pm"].fwd(b["y_lp"], bias("pm"), out=b["a_pm"])
-        c["ps"].fwd(b["y_lp"], bias("ps"), out=b["a_ps"])
-        c["ht"].fwd(b["y_lp"], bias("ht"), out=b["a_t"]); ops.act_fwd(b["a_t"], 512, b["h_top"], "elu")
-        ops.act_fwd(b["h3"], self.F, b["h5"], None, rate=rate, keep_in=keep5, keep_out=b["keep5"], seed=seed, step=step,
-                    stream_id=15, sample_offset=sample_offset)
-        c["e1"].fwd(b["h5"], bias("e1"), out=b["a_e"]); ops.act_fwd(b["a_e"], 512, b["he"], "elu")
-        ops.add(b["he"], b["h_top"], b["hh"])
-        c["zm"].fwd(b["hh"], bias("zm"), out=b["a_m"])
-        c["zs"].fwd(b["hh"], bias("zs"), out=b["a_s"])
-        ops.gm_head_fwd(b["a_m"], b["a_s"], b["a_pm"], b["a_ps"], b["zm"], b["zs"], b["z"], b["pm"], b["ps"], zcat, 0, b["kl2"],
-                        eps=eps, eps_out=b["eps"], seed=seed, step=step, sample_offset=sample_offset)
-        self._rate = rate
-
-    # ------------------------------------------------------------------ adjoint (tape.gradient, vae/trainer.py:167)
-    def backward(self, flat, grad_flat, in8_x, gz, beta, alpha):
-        """gz [B, >=L] fp32: dL/dz_x from the decoder (columns [0, L)).  Accumulates the 24 gradients into grad_flat
-        (zeroed by the caller) and fills ykl."""
-        b, c, B, K, L, F_ = self.buf, self.conv, self.B, self.K, self.L, self.F
-        rate = self._rate
-        gv = self.views(grad_flat)
-        for t in ("g_hh", "g_h5", "g_y", "g_yh2", "g_yh1", "g_h1"):
-            b[t].zero_()                                # fp32 accumulation targets of the split-K dgrads
-
-        def wg(name, x, dy):
-            i = self.LAYERS.index(name)
-            dw = gv[2 * i] if gv[2 * i].dim() == 4 else gv[2 * i].view(1, 1, *gv[2 * i].shape)
-            c[name].wgrad(x, dy, dw=dw, db=gv[2 * i + 1])
-
-        ops.gm_head_bwd(gz, b["zm"], b["zs"], b["pm"], b["ps"], b["eps"], beta / B, b["g_am"], b["g_as"], b["g_apm"], b["g_aps"])
-        wg("zm", b["hh"], b["g_am"]); wg("zs", b["hh"], b["g_as"])
-        c["zm"].dgrad(b["g_am"], f32_atomic=True, out=b["g_hh"].view(B, 1, 1, 512))
-        c["zs"].dgrad(b["g_as"], f32_atomic=True, out=b["g_hh"].view(B, 1, 1, 512))
-        ops.act_bwd(b["g_hh"], 512, b["g_ae"], y_act=b["he"], act="elu")
-        ops.act_bwd(b["g_hh"], 512, b["g_at"], y_act=b["h_top"], act="elu")
-        wg("e1", b["h5"], b["g_ae"])
-        c["e1"].dgrad(b["g_ae"], f32_atomic=True, out=b["g_h5"].view(B, 1, 1, F_))
-        Kp = b["y_lp"].shape[1]
-        for n, g in (("ht", "g_at"), ("pm", "g_apm"), ("ps", "g_aps")):
-            wg(n, b["y_lp"], b[g])
-            c[n].dgrad(b[g], f32_atomic=True, out=b["g_y"].view(B, 1, 1, Kp))
-        ops.gumbel_softmax_bwd(b["g_y"], b["y"], b["logits"], K, self.tau, alpha / B, b["g_logits"], b["ykl"])
-        wg("yd", b["yh2"], b["g_logits"])
-        c["yd"].dgrad(b["g_logits"], f32_atomic=True, out=b["g_yh2"].view(B, 1, 1, 128))
-        ops.act_bwd(b["g_yh2"], 128, b["g_a2"], y_act=b["yh2"], act="elu")
-        wg("d2", b["yh1"], b["g_a2"])
-        c["d2"].dgrad(b["g_a2"], f32_atomic=True, out=b["g_yh1"].view(B, 1, 1, 1024))
-        ops.act_bwd(b["g_yh1"], 1024, b["g_a1"], y_act=b["yh1a"], act="elu", rate=rate, keep=b["keep1"])
-        wg("d1", b["h3"], b["g_a1"])
-        c["d1"].dgrad(b["g_a1"], f32_atomic=True, out=b["g_h1"].view(B, 1, 1, F_))
-        # h feeds y_block (g_h1) and, through do5, e1 (g_h5): combine, then ELU' of conv3
-        ops.act_bwd(b["g_h5"], F_, b["g_c3"], y_act=b["h3"], act="elu", rate=rate, keep=b["keep5"], gx2=b["g_h1"])
-        rows = lambda t: t.view(-1, 128)
-        g_c3 = b["g_c3"].view(B, self.H // 8, self.W // 8, 128)
-        wg("c3", b["h2"], g_c3)
-        g_h2 = c["c3"].dgrad(g_c3)
-        ops.act_bwd(rows(g_h2), 128, rows(b["g_c2"]), y_act=rows(b["h2"]), act="elu")
-        wg("c2", b["h1"], b["g_c2"])
-        g_h1 = c["c2"].dgrad(b["g_c2"])
-        ops.act_bwd(rows(g_h1), 128, rows(b["g_c1"]), y_act=rows(b["h1"]), act="elu")
-        wg("c1", in8_x, b["g_c1"])
-
-    def y_kl_only(self):
-        b = self.buf
-        ops.gumbel_softmax_bwd(None, b["y"], b["logits"], self.K, self.tau, 0.0, None, b["ykl"])
+        for n in ("pm", "ps"):
+            self.conv[n].prep(self._kb(flat, n)[0], dgrad=False)
 
 
 class NativeGMEncoder:
     """The same encoder sequenced natively (csrc/gm_encoder.hip, include/splitvae.h `sv_gm_encoder_*`): one C call each
     for weight preparation, forward and backward instead of ~110 ctypes calls per step.  `buf[name]` are views of
-    its workspace (same names as GMEncoder.buf)."""
+    its workspace."""
 
     def __init__(self, B, H, W, latent, y_size, tau, dtype, device):
         self.B, self.H, self.W, self.L, self.K, self.tau, self.dtype, self.device = B, H, W, latent, y_size, tau, dtype, device
@@ -268,7 +161,7 @@ class LGGMVae(LGVae):
         self.dropout_in_training = bool(dropout_in_training)
         self.alpha = 40.0                                  # vae/main.py:29 (--alpha)
         self._enc, self._enc_py = {}, {}
-        self.gm_table = GMEncoder(1, self.H, self.W, global_latent_dims, y_size, tau, self.dtype, self.device).table
+        self.gm_table = gm_param_table(self.H, self.W, global_latent_dims, y_size)
         self.gm_n_params = self.gm_table[-1][1] + (int(np.prod(self.gm_table[-1][2])) + 3) // 4 * 4
         self.gm_flat = torch.zeros(self.gm_n_params, dtype=torch.float32, device=self.device)
         self.gm_grad_flat = torch.zeros_like(self.gm_flat)
@@ -349,16 +242,14 @@ class LGGMVae(LGVae):
         return self._plans[key]
 
     def encoder(self, B):
-        """The natively sequenced encoder (SV_GM_PYTHON=1: the per-layer Python sequence, kept as the readable restatement
-        of the launch order and for A/B)."""
+        """The natively sequenced encoder (csrc/gm_encoder.hip) for batch B."""
         if B not in self._enc:
-            cls = GMEncoder if os.environ.get("SV_GM_PYTHON") == "1" else NativeGMEncoder
-            self._enc[B] = cls(B, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
+            self._enc[B] = NativeGMEncoder(B, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
         return self._enc[B]
 
     def _py_encoder(self, n):
         if n not in self._enc_py:
-            self._enc_py[n] = GMEncoder(n, self.H, self.W, self.global_latent_dims, self.y_size, self.tau, self.dtype, self.device)
+            self._enc_py[n] = PriorHead(n, self.H, self.W, self.global_latent_dims, self.y_size, self.dtype, self.device)
         return self._enc_py[n]
 
     def _forward(self, inputs, training, eps, noise, want_loss, plan_kw):

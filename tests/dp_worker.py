@@ -1,5 +1,7 @@
 """Worker of tests/test_gpu_dist.py: one data-parallel rank of the SPLIT-VAE step on the (shared) GPU.
-usage: python tests/dp_worker.py <out.npz> <global_batch> <steps>   (RANK / WORLD_SIZE / MASTER_* in the env)"""
+usage: python tests/dp_worker.py <out.npz> <global_batch> <steps> [config]   (RANK / WORLD_SIZE / MASTER_* in the env)
+config: "svhn32_f32" (default: SVHN-32 fp32, the oracle's precision) | "celeba64_bf16" (config 4's shape: CelebA-64, bf16 contractions,
+beta 120, patch 8 -- at 64 images per rank the shard takes its own small-launch tile rules and stream placement)"""
 import os
 import sys
 
@@ -16,12 +18,13 @@ from split_vae_amd.optimizer import Adam                    # noqa: E402
 
 def main():
     out, GB, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    cfg = sys.argv[4] if len(sys.argv) > 4 else "svhn32_f32"
     rank, local_rank, world = svdist.init_from_env()
     torch.cuda.set_device(local_rank % torch.cuda.device_count())      # nccl: one device per rank; gloo: the ranks share device 0
-    H, patch = 32, 4
+    H, patch, dtype, beta = (64, 8, "bf16", 120.0) if cfg == "celeba64_bf16" else (32, 4, "f32", 40.0)
     lo, hi = svdist.shard_bounds(GB, rank, world)
-    model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="f32", device="cuda", seed=3)
-    model.beta = 40.0
+    model = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype=dtype, device="cuda", seed=3)
+    model.beta = beta
     opt = Adam(learning_rate=1e-3)
     aug = Augmentator("scramble", size=patch, seed=1)
     x = data.synthetic_images(hi - lo, H, H, seed=0, device="cuda", sample_offset=lo)

@@ -106,3 +106,55 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.SplitVaeError):
         _lib.load()
+
+
+def test_tape_host_logic_without_gpu(lib_built):
+    """sv_tape_*: recording, argument checks, workspace layout -- pure host code (also what scripts/asan_host.sh runs under ASan + UBSan)."""
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.sv_tape_create(C.byref(h), 0, _lib.SV_F32) == _lib.STATUS_BADARG
+    assert lib.sv_tape_create(C.byref(h), 4, _lib.SV_BF16) == _lib.STATUS_UNSUPPORTED
+    assert lib.sv_tape_create(C.byref(h), 4, _lib.SV_F32) == 0
+    x = lib.sv_tape_tensor(h, 64, 177, 180, 0)
+    y = lib.sv_tape_tensor(h, 64, 64, 64, 1)
+    z = lib.sv_tape_tensor(h, 64, 10, 12, 1)
+    assert (x, y, z) == (0, 1, 2)
+    assert lib.sv_tape_tensor(h, 64, 10, 8, 1) == _lib.STATUS_BADARG            # pitch below the width
+    v = lib.sv_tape_view(h, y, 4, 1024, 1024)
+    assert v == 3 and lib.sv_tape_view(h, y, 4, 2048, 2048) == _lib.STATUS_BADARG  # a view cannot outgrow its storage
+
+    def node(kind, **kw):
+        n = _lib.TapeNode()
+        for f in ("x", "y", "t2", "t3", "t4", "t5", "t6"):
+            setattr(n, f, -1)
+        n.w_off = n.b_off = -1
+        n.dyn_idx = n.loss_idx = -1
+        n.rep, n.kind = 1, kind
+        for k, val in kw.items():
+            setattr(n, k, val)
+        return lib.sv_tape_add(h, C.byref(n))
+
+    assert node(_lib.TAPE_DENSE, x=x, y=y, w_off=0, b_off=177 * 64, act=_lib.SV_ACT_RELU) == 0
+    assert node(_lib.TAPE_DENSE, x=x, y=y, w_off=-1) == _lib.STATUS_BADARG        # a Dense layer without a kernel
+    assert node(_lib.TAPE_DENSE, x=y, y=z, w_off=12000, b_off=12640) == 0
+    assert node(_lib.TAPE_UNARY, op=_lib.TAPE_SOFTPLUS, x=z, y=z, xo=1, yo=1, n=1) == 0
+    assert node(_lib.TAPE_UNARY, op=_lib.TAPE_COPY, x=z, y=y, xo=0, yo=60, n=10) == _lib.STATUS_BADARG     # columns 60..69 of a 64-wide tensor
+    assert node(_lib.TAPE_UNARY, op=99, x=z, y=z, n=1) == _lib.STATUS_BADARG
+    assert node(_lib.TAPE_LOSS, loss_idx=0, mode=1, x=z, xo=0, t2=z, o2=1, R=16, n=1) == 0
+    assert node(_lib.TAPE_LOSS, loss_idx=16, mode=1, x=z, t2=z, R=16, n=1) == _lib.STATUS_BADARG          # 16 loss slots
+    assert node(_lib.TAPE_CONV, x=x, y=y, w_off=0, b_off=0, B=1, H=8, W=8, C=177, Cout=64, k=3, stride=1) != 0   # 177 channels: no conv geometry
+    assert node(99) == _lib.STATUS_BADARG
+    assert lib.sv_tape_workspace_bytes(h) == -1                                  # not finalized yet
+    rep = (C.c_float * 16)(*([1.0] + [0.0] * 15))
+    assert lib.sv_tape_set_report(h, rep, 1) == 0 and lib.sv_tape_set_report(h, rep, 17) == _lib.STATUS_BADARG
+    assert lib.sv_tape_finalize(h) == 0 and lib.sv_tape_finalize(h) == _lib.STATUS_BADARG
+    ws = lib.sv_tape_workspace_bytes(h)
+    assert ws > 64 * (180 + 64 + 12) * 4 and ws % 256 == 0
+    off, goff = C.c_int64(), C.c_int64()
+    assert lib.sv_tape_tensor_info(h, x, C.byref(off), C.byref(goff)) == 0 and goff.value == -1 and off.value % 256 == 0
+    assert lib.sv_tape_tensor_info(h, v, C.byref(off), C.byref(goff)) == 0 and goff.value >= 0
+    assert lib.sv_tape_tensor_info(h, 9, None, None) == _lib.STATUS_BADARG
+    assert lib.sv_tape_bind(h, None, ws, None) == _lib.STATUS_BADARG
+    assert lib.sv_tape_run(h, None, None) == _lib.STATUS_BADARG
+    lib.sv_tape_destroy(h)

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, out, gb=32, steps=3, backend="gloo", force=False):
+def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32_f32"):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -31,7 +31,7 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SV_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         if force:
             env["SV_DIST_FORCE"] = "1"
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps), config],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=600)
@@ -48,6 +48,18 @@ def test_two_ranks_equal_one(lib_built, tmp_path):
     p1, p2 = one["params"], two["params"]
     # Adam turns rounding-level differences of near-zero gradients into full-lr moves: compare to the 3-step movement
     assert np.linalg.norm(p1 - p2) <= 1e-1 * np.linalg.norm(p1 - _init_params())
+    assert np.all(np.isfinite(two["losses"]))
+
+
+def test_two_ranks_equal_one_at_config_4s_shard(lib_built, tmp_path):
+    """Config 4's per-GPU shape (BASELINE.json configs[3]: CelebA-64, bf16, global batch 512 = 64 images per GPU at N = 8): two ranks of
+    64 images against one process with 128.  At 64 images the plan takes its small-launch tile rules, the banded input gradients
+    and the shard-size-dependent stream placement, none of which the SVHN-32 fp32 case above reaches.  bf16: the two halves round
+    their activations exactly as the whole batch does (per-image arithmetic), only the batch reductions reorder."""
+    one = _run(1, str(tmp_path / "one.npz"), gb=128, steps=1, config="celeba64_bf16")
+    two = _run(2, str(tmp_path / "two.npz"), gb=128, steps=1, config="celeba64_bf16")
+    g1, g2 = one["grads"], two["grads"] / 2.0
+    assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
     assert np.all(np.isfinite(two["losses"]))
 
 
