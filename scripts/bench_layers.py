@@ -69,7 +69,8 @@ def main():
         if "wgrad" in which:
             n = lib.sv_conv2d_wgrad_workspace_bytes(C.byref(conv.desc))
             ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
-            t = timeit(lambda: lib.sv_conv2d_nhwc_wgrad_ws(C.byref(conv.desc), P(x), P(dy), P(dw), P(db), P(ws), C.c_int64(n), st()))
+            pdb = None if os.environ.get("SV_BENCH_NOBIAS") else P(db)        # A/B: the bias gradient's share of the launch
+            t = timeit(lambda: lib.sv_conv2d_nhwc_wgrad_ws(C.byref(conv.desc), P(x), P(dy), P(dw), pdb, P(ws), C.c_int64(n), st()))
             res.append("wgrad %7.1f us %6.0f TF/s" % (t, flops / t / 1e6))
         print("%-3s B=%d  %s" % (name, B, "  |  ".join(res)), flush=True)
 

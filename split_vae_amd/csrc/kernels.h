@@ -167,6 +167,24 @@ int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipS
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st);
 #define SV_WGRAD_WS_BYTES (512LL * 36 * 4 * 256 * 4 + 512LL * 128 * 4)   // 512 workgroups x 36 fragments x 4 waves x 256 floats + their bias partials
 
+// ---- the latent block's GEMMs (latent_gemm.hip): out [M, N] = A [M, K] . W^T, A and the prepared image W [N, K] K-contiguous
+struct NtGemmProb {
+  const void* A; int lda;         // bf16 [M][lda]
+  const void* W; int ldw;         // bf16 [N][ldw] (a prepared forward / input-gradient image)
+  void* out; int ldo;             // bf16 [M][ldo], or (out_f32) the fp32 slabs [splitk][M][ldo] of the K slices
+  const float* bias;              // [N] or null (bf16 output only)
+  const void* mask;               // bf16 [M][ldo] or null: out = mask > 0 ? out : 0
+  int M, N, K, act, splitk, out_f32;
+  int64_t slab_stride;            // floats between K slices
+  int zbase;                      // first blockIdx.z of this problem (filled by svk_nt_gemm_multi)
+};
+struct NtGemmMulti { NtGemmProb p[2]; int n; };
+struct NtReduceMulti { const float* slab[2]; float* out[2]; int S[2]; int64_t stride[2]; int64_t count[2]; };
+bool svk_nt_gemm_supported(const NtGemmProb& p);
+int svk_nt_gemm_pick_splitk(int M, int N, int K, int nprob);
+int svk_nt_gemm_multi(NtGemmProb* p, int n, int bm, hipStream_t st);
+int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_t st);
+
 // ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
 struct PrepJob {
   int64_t src_off;     // element offset into the flat fp32 parameter buffer

@@ -1,0 +1,206 @@
+// The latent block's GEMMs (bf16, fp32 accumulate): the encoder heads e4_mean | e4_sd (vae/model.py:41-42, :111-112), the decoders'
+// d1 Dense (:152, :160) and their input gradients (tape.gradient, vae/trainer.py:137).  Plain row-major products
+//     out [M, N] = A [M, K] . W^T,   A and the prepared weight image W [N, K] both K-contiguous
+// with M = the batch (64 ... 512 rows) and K, N in {128, 256, 2048, 8192, ...}: 0.8 % of the step's FLOPs but, as eight dependent
+// launches of the im2col kernel (two-deep register staging, 64 x 32 tiles, split-K fp32 atomics onto memset buffers), 10 % of its
+// time.  Here a workgroup moves a whole 128-deep K phase of its tile -- A [BM x 128] and W [128 x 128] -- into LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, every load of the phase in flight at once), waits once, and runs the phase's
+// MFMAs (16x16x32 bf16, operands swapped so a lane ends up with 4 consecutive output channels of one row); two or three such
+// workgroups per CU overlap each other's phases.  LDS rows are 256 B (one bank row), so the 16-B piece p of row r lives in slot
+// p ^ (r & 15): the DMA writes linearly and each lane FETCHES the piece that belongs in its slot; fragment reads un-swizzle.
+// Big-K layers (heads forward, d1 input gradient: K = H/8 * W/8 * 128) split K over blockIdx.z into fp32 slabs [S][M][N] that
+// nt_slab_reduce_kernel sums in slice order -- no atomics, no zero fill, run-to-run identical.
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BN = 128, BK = 128, RB = 256;        // tile columns, K per phase, bytes per LDS row
+
+template <int BM>
+__global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int inst = (mg.n > 1 && (int)blockIdx.z >= mg.p[1].zbase) ? 1 : 0;
+  const NtGemmProb& g = mg.p[inst];
+  const int zi = (int)blockIdx.z - g.zbase;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= g.M || n0 >= g.N || zi >= g.splitk) return;
+  char* sA = smem;
+  char* sW = smem + BM * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BK;
+  const int lr = lane & 15, lg = lane >> 4;
+  constexpr int FM = BM / 32;                      // 16-row fragments per wave along M (waves 2 x 2: (BM / 2) x 64 each)
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
+  f32x4 acc[FM][4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* __restrict__ Ab = (const bf16_t*)g.A;
+  const bf16_t* __restrict__ Wb = (const bf16_t*)g.W;
+  auto issue = [&](int ph) {
+    const int kk = kbeg + ph * BK;
+    // one wave-instruction = 64 x 16 B = 4 LDS rows; lane -> (row 4q + lane / 16, slot lane % 16) fetches piece slot ^ (row & 15)
+#pragma unroll
+    for (int q = wave; q < BM / 4; q += 4) {
+      const int r = 4 * q + lg, gm = min(m0 + r, g.M - 1);           // rows past M re-read the last row (discarded in the epilogue)
+      const bf16_t* src = Ab + (int64_t)gm * g.lda + kk + ((lr ^ (r & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sA + q * (4 * RB)),
+                                       16, 0, 0);
+    }
+#pragma unroll
+    for (int q = wave; q < BN / 4; q += 4) {
+      const int r = 4 * q + lg;
+      const bf16_t* src = Wb + (int64_t)(n0 + r) * g.ldw + kk + ((lr ^ (r & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sW + q * (4 * RB)),
+                                       16, 0, 0);
+    }
+  };
+  issue(0);
+  for (int ph = 0; ph < nph; ++ph) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMAs have landed ...
+    __syncthreads();                                        // ... and everybody else's
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int p = ks * 4 + lg;
+      uint4 af[FM], wf[4];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm + i * 16 + lr;
+        af[i] = *(const uint4*)(sA + r * RB + ((p ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn + j * 16 + lr;
+        wf[j] = *(const uint4*)(sW + r * RB + ((p ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+    }
+    if (ph + 1 < nph) {
+      __syncthreads();                                      // the tile is consumed: the next phase may overwrite it
+      issue(ph + 1);
+    }
+  }
+  // D rows = channels, columns = GEMM rows: lane holds channels n0 + wn + 16 j + 4 lg + {0..3} of row m0 + wm + 16 i + lr
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm + i * 16 + lr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn + j * 16 + lg * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+      if (g.out_f32) {                                      // K slice -> its slab (bias and activation belong to the consumer)
+        *(float4*)((float*)g.out + (int64_t)zi * g.slab_stride + (int64_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        continue;
+      }
+      if (g.bias) {
+        const float4 b = *(const float4*)(g.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (g.act == SV_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      const int64_t o = (int64_t)m * g.ldo + n;
+      if (g.mask) {                                         // ReLU gate of the tensor this gradient lands on
+        bf16_t mk[4];
+        *(uint2*)mk = *(const uint2*)((const bf16_t*)g.mask + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = (float)mk[e] > 0.f ? pk[e] : (bf16_t)0.f;
+      }
+      *(uint2*)((bf16_t*)g.out + o) = *(uint2*)pk;
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i] in slice order (i over M * ldo floats), both problems of a launch (blockIdx.y)
+__global__ __launch_bounds__(256) void nt_slab_reduce_kernel(const NtReduceMulti r) {
+  const int z = blockIdx.y;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= r.count[z]) return;
+  const float* __restrict__ s = r.slab[z] + i;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int k = 0; k < r.S[z]; ++k) {
+    const float4 v = *(const float4*)(s + (int64_t)k * r.stride[z]);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  *(float4*)(r.out[z] + i) = a;
+}
+
+template <int BM>
+int launch_nt(const NtGemmMulti& m, hipStream_t st) {
+  int gx = 0, gy = 0;
+  for (int i = 0; i < m.n; ++i) {
+    gx = max(gx, (m.p[i].M + BM - 1) / BM);
+    gy = max(gy, m.p[i].N / BN);
+  }
+  const int gz = m.p[m.n - 1].zbase + m.p[m.n - 1].splitk;
+  const size_t lds = (size_t)(BM + BN) * RB;
+  sv_ensure_dynamic_lds((const void*)nt_gemm_kernel<BM>, lds);
+  hipLaunchKernelGGL((nt_gemm_kernel<BM>), dim3(gx, gy, gz), dim3(256), lds, st, m);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+}  // namespace
+
+bool svk_nt_gemm_supported(const NtGemmProb& p) {
+  if (p.M < 1 || p.N < BN || (p.N % BN) || p.K < BK || (p.K % BK) || p.splitk < 1 || (p.K % p.splitk) || ((p.K / p.splitk) % BK)) return false;
+  if ((p.lda & 7) || (p.ldw & 7) || (p.ldo & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.out & 15)) return false;
+  if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+  return true;
+}
+
+// K slices for a big-K layer: enough workgroups to fill the chip (>= ~256 per launch of `nprob` problems), whole 128-deep phases
+int svk_nt_gemm_pick_splitk(int M, int N, int K, int nprob) {
+  if (N < BN || K < BK) return 1;                           // (not a shape this kernel takes: svk_nt_gemm_supported refuses it)
+  const int bm = 64;
+  const int tiles = ((M + bm - 1) / bm) * (N / BN) * (nprob < 1 ? 1 : nprob);
+  int s = (256 + tiles - 1) / tiles;
+  const int maxs = K / BK;
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  while (s > 1 && ((K % s) || ((K / s) % BK))) --s;       // slices of whole phases
+  return s;
+}
+
+// n <= 2 problems per launch (the x / x-hat twins); zbase is filled here.  bm: 64 | 128 rows per tile.
+int svk_nt_gemm_multi(NtGemmProb* p, int n, int bm, hipStream_t st) {
+  if (n < 1 || n > 2 || (bm != 64 && bm != 128)) return SV_E_BADARG;
+  NtGemmMulti m;
+  m.n = n;
+  int z = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!svk_nt_gemm_supported(p[i])) return SV_E_UNSUPPORTED;
+    p[i].zbase = z;
+    z += p[i].splitk;
+    m.p[i] = p[i];
+  }
+  if (n == 1) m.p[1] = m.p[0];
+  return bm == 64 ? launch_nt<64>(m, st) : launch_nt<128>(m, st);
+}
+
+int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_t st) {
+  NtReduceMulti r;
+  int64_t mx = 0;
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    r.slab[i] = (const float*)p[k].out; r.out[i] = out[k]; r.S[i] = p[k].splitk; r.stride[i] = p[k].slab_stride;
+    r.count[i] = (int64_t)p[k].M * p[k].ldo;
+    mx = r.count[i] > mx ? r.count[i] : mx;
+  }
+  hipLaunchKernelGGL(nt_slab_reduce_kernel, dim3((unsigned)((mx / 4 + 255) / 256), n), dim3(256), 0, st, r);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

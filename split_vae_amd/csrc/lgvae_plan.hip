@@ -369,6 +369,13 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("polyfix_xh", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));
   p->add_buf("polyw_x", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);        // polyphase weight gradient of the head: dW', dbias', frame slabs
   p->add_buf("polyw_xh", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);
+  {   // K-slice slabs of the heads' forward and d1's input gradient (latent_gemm.hip): [S][B][N] fp32 per network
+    const int64_t Fd = (H / 8) * (W / 8) * 128;
+    const int s1 = svk_nt_gemm_pick_splitk((int)B, 2 * Lg, (int)Fd, 2), s2 = svk_nt_gemm_pick_splitk((int)B, Lg + Ll, (int)Fd, 2);
+    const int64_t a = (int64_t)s1 * B * 2 * (Lg > Ll ? Lg : Ll) * 4, b = (int64_t)s2 * B * (Lg + Ll) * 4;
+    p->add_buf("lat_ws_x", a > b ? a : b);
+    p->add_buf("lat_ws_xh", a > b ? a : b);
+  }
   p->add_buf("dyn", sizeof(SvDynArgs));
   p->add_buf("losses", 8 * 4);
   p->add_buf("metric_acc", 8 * 4);
@@ -417,6 +424,13 @@ static void build_buffers(sv_lgvae_plan* p) {
   same("g1_", B * F * es);
 }
 
+// the latent block's GEMMs on latent_gemm.hip (LDS-DMA phases, split-K through fp32 slabs summed in slice order) instead of the im2col
+// kernel's split-K atomics; SV_NO_LATENT_GEMM restores the old launches (A/B)
+static bool latent_gemm_on(const sv_lgvae_plan* p) {
+  static const bool off = getenv("SV_NO_LATENT_GEMM") != nullptr;
+  return !off && p->d.dtype == SV_BF16;
+}
+
 static double conv_flops(const sv_conv_desc& d) {
   return 2.0 * d.B * svg_oh(&d) * svg_ow(&d) * (double)d.Cout * d.KH * d.KW * d.Cin;
 }
@@ -460,6 +474,21 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     by += conv_bytes(L[i]->d, 0, p->esz());
   }
   Scope sc(p, st, "fwd." + L[0]->name.substr(L[0]->name.find('.') + 1), fl, by);
+  if (latent_gemm_on(p) && !nll && L[0]->d.H == 1 && L[0]->d.W == 1 && L[0]->d.KH == 1 && !L[0]->d.y_f32) {   // Dense (d1): latent_gemm.hip
+    NtGemmProb q[2];
+    for (int i = 0; i < n; ++i) {
+      const sv_conv_desc& d = L[i]->d;
+      NtGemmProb& g = q[i];
+      memset(&g, 0, sizeof(g));
+      g.A = x[i]; g.lda = d.ldx;
+      g.W = a[i].Wt; g.ldw = svg_cin_pad(&d);
+      g.out = y[i]; g.ldo = d.ldy;
+      g.bias = a[i].bias; g.act = d.act;
+      g.M = d.B; g.N = d.Cout; g.K = d.Cin; g.splitk = 1;
+    }
+    const int rc = svk_nt_gemm_multi(q, n, L[0]->d.B >= 256 ? 128 : 64, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
   if (svg_poly(&L[0]->d)) {
     // polyphase head: the out-of-image taps of the border rows / columns go to a workspace first; the conv's epilogue adds them
     const void* wfix[2];
@@ -656,7 +685,29 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       by += conv_bytes(Lh.d, 0, p->esz());
     }
     Scope sc(p, st, "fwd.head", fl, by);
-    if (e0 || cfgs[0] == cfgs[1]) SV_TRY(svk_tap_gemm_multi(a, 2 - e0, dt, cfgs[0], st));
+    bool done = false;
+    if (latent_gemm_on(p)) {
+      NtGemmProb q[2];
+      float* outs[2];
+      int nq = 0;
+      for (int e = e0; e < 2; ++e, ++nq) {
+        Layer& Lh = p->enc[e][3];
+        NtGemmProb& g = q[nq];
+        memset(&g, 0, sizeof(g));
+        g.A = p->bp(std::string("a3_") + en[e]); g.lda = Lh.d.Cin;
+        g.W = (char*)p->bp("warena") + Lh.wf_off * p->esz(); g.ldw = Lh.d.Cin;
+        g.out = p->bp(std::string("lat_ws_") + en[e]); g.ldo = Lh.d.Cout;
+        g.M = B; g.N = Lh.d.Cout; g.K = Lh.d.Cin; g.out_f32 = 1;
+        g.splitk = svk_nt_gemm_pick_splitk(B, g.N, g.K, 2);     // (as the slab buffers were sized)
+        g.slab_stride = (int64_t)B * g.ldo;
+        outs[nq] = (float*)p->bp(std::string("pre_") + en[e]);
+      }
+      const int rc = svk_nt_gemm_multi(q, nq, 64, st);
+      if (rc == SV_OK) { SV_TRY(svk_nt_slab_reduce(q, outs, nq, st)); done = true; }
+      else if (rc != SV_E_UNSUPPORTED) return rc;
+    }
+    if (done) {}
+    else if (e0 || cfgs[0] == cfgs[1]) SV_TRY(svk_tap_gemm_multi(a, 2 - e0, dt, cfgs[0], st));
     else
       for (int e = 0; e < 2; ++e) SV_TRY(svk_tap_gemm(a[e], dt, cfgs[e], st));   // latent sizes with different tiles
   }
@@ -841,7 +892,30 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     both("g1_", g1);
     SV_TRY(run_wgrad_layers(p, 2, Ls, zin, g1, s->grads, st));
     for (int k = 0; k < 2; ++k) Ld[k].d.ldx = Ld[k].d.Cin;   // dz has its own row pitch (Lz), not the zcat pitch
-    SV_TRY(run_dgrad_layers(p, 2, Lds, g1, none2, gz, true, st));
+    bool done = false;
+    if (latent_gemm_on(p)) {
+      NtGemmProb q[2];
+      float* outs[2];
+      double fl = 0, by = 0;
+      for (int k = 0; k < 2; ++k) {
+        const sv_conv_desc& dd = Ld[k].d;
+        NtGemmProb& g = q[k];
+        memset(&g, 0, sizeof(g));
+        g.A = g1[k]; g.lda = dd.ldy;
+        g.W = (char*)p->bp("warena") + Ld[k].wd_off[0] * p->esz(); g.ldw = svg_gdy(&dd);
+        g.out = p->bp(k == 0 ? "lat_ws_x" : "lat_ws_xh"); g.ldo = dd.Cin;
+        g.M = B; g.N = dd.Cin; g.K = dd.Cout; g.out_f32 = 1;
+        g.splitk = svk_nt_gemm_pick_splitk(B, g.N, g.K, 2);
+        g.slab_stride = (int64_t)B * g.ldo;
+        outs[k] = (float*)gz[k];
+        fl += conv_flops(dd); by += conv_bytes(dd, 1, p->esz());
+      }
+      Scope sc(p, st, "dgrad.d1", fl, by);
+      const int rc = svk_nt_gemm_multi(q, 2, 64, st);
+      if (rc == SV_OK) { SV_TRY(svk_nt_slab_reduce(q, outs, 2, st)); done = true; }
+      else if (rc != SV_E_UNSUPPORTED) return rc;
+    }
+    if (!done) SV_TRY(run_dgrad_layers(p, 2, Lds, g1, none2, gz, true, st));
   }
   return SV_OK;
 }
@@ -903,7 +977,27 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
     Layer* Ls[2] = {&p->enc[0][3], &p->enc[1][3]};
     const void *gh[2] = {p->bp("ghead_x"), p->bp("ghead_xh")}, *a3[2] = {p->bp("a3_x"), p->bp("a3_xh")};
     void* ga3[2] = {p->bp("ga3_x"), p->bp("ga3_xh")};
-    SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gh + e0, a3 + e0, ga3 + e0, false, st));
+    bool done = false;
+    if (latent_gemm_on(p)) {
+      NtGemmProb q[2];
+      int nq = 0;
+      double fl = 0, by = 0;
+      for (int e = e0; e < 2; ++e, ++nq) {
+        Layer& Lh = p->enc[e][3];
+        NtGemmProb& g = q[nq];
+        memset(&g, 0, sizeof(g));
+        g.A = gh[e]; g.lda = Lh.d.Cout;
+        g.W = (char*)p->bp("warena") + Lh.wd_off[0] * p->esz(); g.ldw = Lh.d.Cout;
+        g.out = ga3[e]; g.ldo = Lh.d.Cin; g.mask = a3[e];
+        g.M = B; g.N = Lh.d.Cin; g.K = Lh.d.Cout; g.splitk = 1;
+        fl += conv_flops(Lh.d); by += conv_bytes(Lh.d, 1, p->esz());
+      }
+      Scope sc(p, st, "dgrad.head", fl, by);
+      const int rc = svk_nt_gemm_multi(q, nq, B >= 256 ? 128 : 64, st);
+      if (rc == SV_OK) done = true;
+      else if (rc != SV_E_UNSUPPORTED) return rc;
+    }
+    if (!done) SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gh + e0, a3 + e0, ga3 + e0, false, st));
   }
   if (do_convs) {
     auto both = [&](const char* n, const void** out) { out[0] = p->bp(std::string(n) + "x"); out[1] = p->bp(std::string(n) + "xh"); };

@@ -90,10 +90,24 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
     for (int i = 0; i < CIF; ++i)
 #pragma unroll
       for (int j = 0; j < COF; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY = ones^T . dY: one more "tap" whose A operand is all ones, on the dY fragments the loop
+  // already holds (wave w takes the output-channel fragments j = w, w + 4, ...: KC * ceil(COF / 4) extra MFMAs per wave and tile and at
+  // most two more accumulators -- a full set of COF per wave cost the 8-fragment layers their occupancy --; every row of the result
+  // is the column sum).
+  // (The first version summed the columns with scalar LDS reads: 5-30 us of the launch -- e1 91 -> 61 us without it -- and only on the
+  // channel-slice-0 workgroups, i.e. on the launch's critical path.)
+  // Measured per layer (B = 512, serial table): d4 0.180 -> 0.172 ms, d5 0.143 -> 0.136, d3 0.098 -> 0.087 with the MFMA form; e2 0.076 ->
+  // 0.106, e1 0.076 -> 0.084, d2 0.079 -> 0.083 (their register budgets are the tight ones): those keep the scalar column sums.
+  constexpr bool BIASM = NG == 1 && (OCC == 3 || (TPW == 4 && CIF == 2));       // the d4 / d5 instantiations (three workgroups per CU) and d3's
+  constexpr int BJ = (COF + 3) / 4;
+  f32x4 bacc[BJ];
   float bsum = 0.f;
+  const int bcol = tid & (g.ldy - 1), bgrp = tid / g.ldy, nbg = 256 / g.ldy;
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) bacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool do_bias = g.dbias != nullptr && blockIdx.y == 0;
   const int ycols = g.ldy;                          // dY channels per pixel (power of two >= 8)
-  const int bcol = tid & (ycols - 1), bgrp = tid / ycols, nbg = 256 / ycols;
+  const short8_t ones = (short8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
 
   const bf16_t* __restrict__ Ab = (const bf16_t*)g.A + ci0;
   const bf16_t* __restrict__ Yb = (const bf16_t*)g.dY;
@@ -148,6 +162,12 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
         const short4_t lo = tr16(sDy + dy_lane + dy_chunk(kc, 0) + j * 32), hi = tr16(sDy + dy_lane + dy_chunk(kc, 1) + j * 32);
         bfr[j] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+      if (BIASM && do_bias) {
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+          if ((j & 3) == wave)          // wave-uniform
+            bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bfr[j]), bacc[j >> 2], 0, 0, 0);
+      }
       // A fragments of the (tap, ci-fragment) sequence u = t2*CIF + i, prefetched PF deep so the
       // LDS round trip (~100+ cycles) hides under the MFMAs of earlier fragments
       constexpr int U = TPW * CIF, PF = U < SV_WT_PF ? U : SV_WT_PF;
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? OCC : 1) void wgrad_tile_kernel
               __builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[j]), acc[u / CIF][u % CIF][j], 0, 0, 0);
       }
     }
-    if (do_bias && has) {
+    if (!BIASM && do_bias && has) {
       for (int r = bgrp; r < 32 * KC; r += nbg) bsum += (float)*(const bf16_t*)(sDy + r * g.YS + bcol * 2);
     }
   }
@@ -246,11 +266,22 @@ bias_part:
   if (do_bias) {
     __syncthreads();
     float* red = (float*)smem;
-    red[(grp * nbg + bgrp) * ycols + bcol] = bsum;
+    int nred;
+    if constexpr (BIASM) {                          // [NG][ycols]: row 0 of the column-sum fragments (fragment j lives in wave j & 3)
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+          if ((j & 3) == wave && j * 16 + lane < ycols) red[grp * ycols + j * 16 + lane] = bacc[j >> 2][0];
+      }
+      nred = NG;
+    } else {
+      red[(grp * nbg + bgrp) * ycols + bcol] = bsum;
+      nred = nbg * NG;
+    }
     __syncthreads();
     if (grp == 0 && tid < ycols && tid < g.N && (!g.fold_kw || (tid & 7) < g.fold_c)) {
       float s = 0.f;
-      for (int k = 0; k < nbg * NG; ++k) s += red[k * ycols + tid];
+      for (int k = 0; k < nred; ++k) s += red[k * ycols + tid];
       // slab path: one partial per workgroup behind the dW slabs, summed in workgroup order by the reduce kernel (deterministic)
       if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + tid] = s;
       else atomicAdd(g.dbias + (g.fold_kw ? (tid & 7) : tid), s);
