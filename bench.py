@@ -255,18 +255,16 @@ def spair_row(dev, B=32, steps=60, warmup=5):
     from split_vae_amd import spair, spair_main, spair_trainer
     from split_vae_amd.augmentation import Augmentator
     out = {"unit": "images/s", "batch": B, "steps": steps,
-           "launch": "f32: one native launch sequence per step (sv_tape_run, eager); bf16 convolutions: torch-autograd graph as a hipGraph replay"}
+           "launch": "one native launch sequence per step (sv_tape_run: forward, losses, adjoint, Adam; eager launches); f32 = the reference's "
+                     "precision, bf16 = bf16 operands in the spatial convolutions only"}
     for dt_ in ("f32", "bf16"):
         cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
                                         split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True, dtype=dt_)
         model = spair.get_model(cfg, device=dev, seed=0)
         x, _ = spair_main.synthetic_canvases(B, seed=1, device=dev)
         images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x)
-        if dt_ == "f32":
-            opt = spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0)
-            step_fn = lambda im, i: spair_trainer.train_step(model, im, opt, i, cfg)          # noqa: E731 (native: spair_native.NativeStep)
-        else:
-            step_fn = spair_trainer.GraphedTrainStep(model, spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0), cfg, images)
+        opt = spair_trainer.ClipnormAdam(cfg.learning_rate, clipnorm=1.0)
+        step_fn = lambda im, i: spair_trainer.train_step(model, im, opt, i, cfg)          # noqa: E731 (native: spair_native.NativeStep)
         for i in range(warmup):
             step_fn(images, i)
         torch.cuda.synchronize()

@@ -11,7 +11,8 @@ from split_vae_amd import spair, spair_main, spair_trainer
 from split_vae_amd.augmentation import Augmentator
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
+cfg = spair_main.default_config(dtype=DT, model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
                                 split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True)
 model = spair.get_model(cfg, seed=0)
 x, _ = spair_main.synthetic_canvases(B, seed=1)
@@ -27,5 +28,5 @@ for i in range(steps):
 t_host = (time.perf_counter() - t0) / steps
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / steps
-print({"batch": B, "ms_per_step": round(1e3 * t, 4), "host_ms_per_step": round(1e3 * t_host, 4), "images_per_s": round(B / t, 1),
+print({"batch": B, "dtype": DT, "ms_per_step": round(1e3 * t, 4), "host_ms_per_step": round(1e3 * t_host, 4), "images_per_s": round(B / t, 1),
        "tape_nodes": model.native(B, cfg).n_nodes})

@@ -161,6 +161,14 @@ __global__ __launch_bounds__(256) void acc_kernel(float* __restrict__ dst, int l
   const int j = (int)(i - r * n);
   dst[r * ld + o + j] += scale * src[i];
 }
+// fp32 -> bf16 (conv_dtype bf16: the spatial convolutions' operands; round to nearest even), 4 elements per thread
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = *(const float4*)(x + i * 4);
+  bf16_t o[4] = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+  *(uint2*)(y + i * 4) = *(uint2*)o;
+}
 // Philox draws: kind 0 normal(0, std) (Box-Muller), 1 uniform (0, 1]
 __global__ __launch_bounds__(256) void noise_kernel(float* __restrict__ y, int ld, int64_t total, int n, int kind, float std, uint64_t seed, uint64_t step,
                                                     uint32_t stream_id) {
@@ -290,7 +298,6 @@ struct sv_tape {
 
 extern "C" int sv_tape_create(sv_tape** out, int32_t batch, int32_t conv_dtype) {
   if (!out || batch < 1 || (conv_dtype != SV_F32 && conv_dtype != SV_BF16)) return SV_E_BADARG;
-  if (conv_dtype != SV_F32) return SV_E_UNSUPPORTED;      // (bf16 convolutions: not sequenced natively yet)
   sv_tape* t = new sv_tape();
   t->B = batch; t->dtype = conv_dtype;
   memset(t->report, 0, sizeof(t->report));
@@ -341,10 +348,11 @@ extern "C" int sv_tape_add(sv_tape* t, const sv_tape_node* nd) {
       memset(&c, 0, sizeof(c));
       c.B = n.B; c.H = n.H; c.W = n.W; c.Cin = n.C; c.Cout = n.Cout; c.KH = c.KW = n.k; c.stride = n.stride;
       c.act = n.act; c.dtype = t->dtype; c.ldx = T(n.x).ld; c.ldy = T(n.y).ld;
+      c.y_f32 = t->dtype == SV_BF16 ? 1 : 0;        // bf16 operands, fp32 activations between the layers
       const int rc = svg_check(&c);
       if (rc) return rc;
       if (T(n.x).rows != (int64_t)n.B * n.H * n.W || T(n.y).rows != (int64_t)n.B * svg_oh(&c) * svg_ow(&c)) return SV_E_BADARG;
-      if (c.ldy != svg_gdy(&c) || ilog2_exact(c.ldy) < 0) return SV_E_BADARG;    // the input-gradient kernels index dY by r8(Cout), a power of two
+      if (c.ldy != svg_gdy(&c) || ilog2_exact(c.ldy) < 0 || (c.ldx & 3)) return SV_E_BADARG;    // the input-gradient kernels index dY by r8(Cout), a power of two
       e.has_conv = true;
       break;
     }
@@ -441,6 +449,10 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
       }
     }
     auto scratch = [&](int64_t floats) { const int64_t o = t->scratch_floats; t->scratch_floats += (floats + 63) / 64 * 64; return o; };
+    if (n.kind == SV_TAPE_CONV && t->dtype == SV_BF16) {                                    // bf16 copies of x and of dY
+      e.scratch = scratch((t->tens[n.x].rows * t->tens[n.x].ld + 1) / 2);
+      e.scratch2 = scratch((t->tens[n.y].rows * t->tens[n.y].ld + 1) / 2);
+    }
     if (n.kind == SV_TAPE_STN) e.scratch = scratch(t->tens[n.t2].rows * 4);
     if (n.kind == SV_TAPE_ZPRES) { e.scratch = scratch(t->tens[n.t2].rows); e.scratch2 = scratch(t->tens[n.t3].rows); }
     if (n.kind == SV_TAPE_RENDER) {
@@ -522,7 +534,15 @@ int node_forward(sv_tape* t, size_t i, const sv_tape_run_args* a, bool with_grad
     }
     case SV_TAPE_CONV: {
       const size_t es = t->dtype == SV_BF16 ? 2 : 4;
-      return sv_conv2d_nhwc_fwd(&e.cd, t->act(n.x), t->ws + t->off_arena + e.wf_off * es, a->params + n.b_off, t->act(n.y), st);
+      const void* xin = t->act(n.x);
+      if (t->dtype == SV_BF16) {
+        const TT& x = T(n.x);
+        const int64_t n4 = x.rows * x.ld / 4;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n4)), dim3(256), 0, st, t->act(n.x), (bf16_t*)t->scr(e.scratch), n4);
+        SV_LAUNCH_CHECK();
+        xin = t->scr(e.scratch);
+      }
+      return sv_conv2d_nhwc_fwd(&e.cd, xin, t->ws + t->off_arena + e.wf_off * es, a->params + n.b_off, t->act(n.y), st);
     }
     case SV_TAPE_UNARY: {
       const TT &x = T(n.x), &y = T(n.y);
@@ -615,6 +635,14 @@ int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t s
         return SV_OK;
       }
       const size_t es = t->dtype == SV_BF16 ? 2 : 4;
+      if (t->dtype == SV_BF16) {               // bf16 operands (x was cast in the forward pass), fp32 gradients: dx is ADDED to the zeroed buffer
+        const int64_t n4 = y.rows * y.ld / 4;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n4)), dim3(256), 0, st, gy, (bf16_t*)t->scr(e.scratch2), n4);
+        SV_LAUNCH_CHECK();
+        SV_TRY(sv_conv2d_nhwc_wgrad(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, st));
+        if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, t->scr(e.scratch2), t->ws + t->off_arena + e.wd_off * es, nullptr, gx, 1, st));
+        return SV_OK;
+      }
       SV_TRY(sv_conv2d_nhwc_wgrad(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, st));
       if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, gy, t->ws + t->off_arena + e.wd_off * es, nullptr, gx, multi(n.x) ? 1 : 0, st));
       return SV_OK;

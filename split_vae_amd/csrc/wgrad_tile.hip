@@ -301,19 +301,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   float* __restrict__ dW = m.dW[blockIdx.z];
   __shared__ float4 part[8][32];
   if (blockIdx.x == 0 && blockIdx.y == 0 && m.bslab[blockIdx.z]) {
-    // bias gradient: the workgroups' partial column sums, always in the same order (x-packed head: both pixel parities of a channel).
-    // Two interleaved halves of the workgroup rows per column, many loads in flight, combined through LDS.
+    // bias gradient: the workgroups' partial column sums [msplit][128], always in the same order: like the dW slabs below, eight thread
+    // rows take the splits x = row, row + 8, ... with 16-B loads and are combined through LDS in row order
     const float* __restrict__ bs = m.bslab[blockIdx.z];
-    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
-    float s = 0.f;
-    if (c < N && (!fold_kw || c < fold_c)) {
+    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-      for (int x = h; x < msplit; x += 2) s += bs[x * 128 + c] + (fold_kw ? bs[x * 128 + c + 8] : 0.f);
+    for (int x = row; x < msplit; x += 8) {
+      const float4 v = *(const float4*)(bs + x * 128 + col * 4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
     }
-    float* bred = (float*)&part[0][0];
-    if (h) bred[c] = s;
+    part[row][col] = s4;
     __syncthreads();
-    if (!h && c < N && (!fold_kw || c < fold_c)) m.dbias[blockIdx.z][c] += s + bred[c];
+    if (!row) {
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { const float4 v = part[r][col]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+      part[0][col] = s4;
+    }
+    __syncthreads();
+    const float* tot = (const float*)&part[0][0];             // [128] column sums
+    const int c = threadIdx.x;
+    if (c < N && c < 128 && (!fold_kw || c < fold_c)) m.dbias[blockIdx.z][c] += tot[c] + (fold_kw ? tot[c + 8] : 0.f);
     __syncthreads();
   }
   constexpr int NFR = TPW * CIF * COF, PER = 4 * NFR * 256;      // floats per (split, group)

@@ -41,10 +41,11 @@ class NativeStep:
     def __init__(self, model, config, B, training=True):
         self.lib = _lib.load()
         self.model, self.cfg, self.B, self.training = model, config, B, training
-        if (getattr(model, "dtype", "f32") or "f32") != "f32":
-            raise NotImplementedError("the native SPLIT-SPAIR step sequences the fp32 model (config.dtype == 'f32')")
+        # config.dtype 'bf16': the spatial convolutions take bf16 operands (fp32 accumulation, master weights and activations); Dense
+        # layers, STN, Renderer and losses are fp32 either way
+        bf16 = (getattr(model, "dtype", "f32") or "f32") == "bf16"
         h = C.c_void_p()
-        check(self.lib.sv_tape_create(C.byref(h), B, _lib.SV_F32), "sv_tape_create")
+        check(self.lib.sv_tape_create(C.byref(h), B, _lib.SV_BF16 if bf16 else _lib.SV_F32), "sv_tape_create")
         self.h = h
         self.store = model.store
         self.device = model.store.flat.device

@@ -190,10 +190,10 @@ RETURN_NAMES = ["x_recon", "z_what", "z_what_mean", "z_what_sigma", "z_where", "
 
 
 def _native_ok(model):
-    """The native launch sequence (spair_native.NativeStep) runs the fp32 model; SV_SPAIR_AUTOGRAD=1 keeps the torch-autograd graph over the
-    split_vae::* operators (the bf16-convolution mode still takes that path)."""
+    """The native launch sequence (spair_native.NativeStep) is the step; SV_SPAIR_AUTOGRAD=1 keeps the torch-autograd graph over the
+    split_vae::* operators (round 2's form: A/B and the operator-level tests)."""
     import os
-    return (getattr(model, "dtype", "f32") or "f32") == "f32" and not os.environ.get("SV_SPAIR_AUTOGRAD")
+    return not os.environ.get("SV_SPAIR_AUTOGRAD")
 
 
 def _return_names(config):
