@@ -185,6 +185,12 @@ int svk_nt_gemm_pick_splitk(int M, int N, int K, int nprob);
 int svk_nt_gemm_multi(NtGemmProb* p, int n, int bm, hipStream_t st);
 int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_t st);
 
+// dW [Kw, N] = X^T . dY, dbias [N] = colsum(dY): X [M, ldx] (columns [0, Kw) used; Kw_real <= Kw rows of dW are stored), dY [M, ldy]
+struct TnWgradProb { const void* X; int ldx; const void* dY; int ldy; float* dW; float* dbias; int M, Kw, Kw_real, N; };
+struct TnWgradMulti { TnWgradProb p[4]; };
+bool svk_tn_wgrad_supported(const TnWgradProb& p);
+int svk_tn_wgrad_multi(const TnWgradProb* p, int n, hipStream_t st);
+
 // ---- batched weight preparation (fp32 HWIO master -> MFMA-ready images), job table in device memory
 struct PrepJob {
   int64_t src_off;     // element offset into the flat fp32 parameter buffer

@@ -204,3 +204,134 @@ int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradients of the latent block's Dense layers (Conv2DBackpropFilter + BiasAddGrad of tape.gradient for e4_mean / e4_sd / d1):
+//     dW [Kw, N] = X^T . dY,   dbias [N] = column sums of dY,   X [M, Kw] and dY [M, N] both row-major (the contraction runs over
+// their ROWS, M = the batch).  Same LDS-DMA phases as above (128 batch rows of X [.. x 128] and dY [.. x 128] per phase), the MFMA
+// operands read k-major with ds_read_b64_tr_b16 (the lane map of wgrad.hip: K index 8g + 4h + q <-> row 16h + 4g + q on both
+// operands).  A 16-B piece p of LDS row r sits in slot p ^ 2 (r & 7): the eight rows one lane-half of a transposed read touches land
+// on eight different 32-B bank groups.  One workgroup owns a 128 x 128 tile of dW over the WHOLE batch: plain stores, no m-split,
+// no atomics; the workgroups of the first Kw tile also produce dbias (an all-ones MFMA tap on the dY fragments).
+namespace {
+
+__device__ __forceinline__ short4_t tn_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
+}
+
+__global__ __launch_bounds__(256) void tn_wgrad_kernel(const TnWgradMulti mg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TnWgradProb& g = mg.p[blockIdx.z];
+  const int w0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  if (w0 >= g.Kw || n0 >= g.N) return;
+  char* sA = smem;                    // X tile  [128 rows][256 B]
+  char* sB = smem + 128 * 256;        // dY tile [128 rows][256 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = g.dbias != nullptr && blockIdx.x == 0 && wm == 0;
+  const short8_t ones = (short8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16_t* __restrict__ Xb = (const bf16_t*)g.X;
+  const bf16_t* __restrict__ Yb = (const bf16_t*)g.dY;
+  const int nph = (g.M + 127) / 128;
+  auto issue = [&](int ph) {
+    const int m_base = ph * 128;
+#pragma unroll
+    for (int q = wave; q < 32; q += 4) {            // 4 LDS rows per wave-instruction, 32 instructions per operand tile
+      const int r = 4 * q + lg, gm = min(m_base + r, g.M - 1);
+      const int piece = lr ^ (2 * (r & 7));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + (int64_t)gm * g.ldx + w0 + piece * 8),
+                                       (__attribute__((address_space(3))) void*)(sA + q * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Yb + (int64_t)gm * g.ldy + n0 + piece * 8),
+                                       (__attribute__((address_space(3))) void*)(sB + q * 1024), 16, 0, 0);
+    }
+  };
+  issue(0);
+  for (int ph = 0; ph < nph; ++ph) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int valid = min(128, g.M - ph * 128);      // M is a multiple of 32: whole 32-row chunks
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk * 32 >= valid) break;
+      const int mrow = kk * 32 + 4 * lg + lq;        // (+16 for the high half: same row & 7)
+      const int sw = 2 * (mrow & 7);
+      short8_t af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = wm + i * 16 + 4 * lp;
+        const char* p = sA + mrow * 256 + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2;
+        const short4_t lo = tn_tr16(p), hi = tn_tr16(p + 16 * 256);
+        af[i] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn + j * 16 + 4 * lp;
+        const char* p = sB + mrow * 256 + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2;
+        const short4_t lo = tn_tr16(p), hi = tn_tr16(p + 16 * 256);
+        bf[j] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bf[j]), bacc[j], 0, 0, 0);
+      }
+    }
+    if (ph + 1 < nph) {
+      __syncthreads();
+      issue(ph + 1);
+    }
+  }
+  // D row = (lane >> 4) * 4 + reg -> Kw index, column = lane & 15 -> output channel
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = w0 + wm + i * 16 + lg * 4 + r;
+      if (w >= g.Kw_real) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g.dW[(int64_t)w * g.N + n0 + wn + j * 16 + lr] = acc[i][j][r];
+    }
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.dbias[n0 + wn + j * 16 + lane] = bacc[j][0];
+  }
+}
+
+}  // namespace
+
+bool svk_tn_wgrad_supported(const TnWgradProb& p) {
+  return p.M >= 32 && !(p.M & 31) && p.Kw >= 128 && !(p.Kw & 127) && p.N >= 128 && !(p.N & 127) && !(p.ldx & 7) && !(p.ldy & 7) &&
+         !((uintptr_t)p.X & 15) && !((uintptr_t)p.dY & 15) && p.Kw_real <= p.Kw && p.Kw_real > 0;
+}
+
+// n <= 4 problems per launch (both networks' d1, or the four head kernels); dW / dbias are ASSIGNED
+int svk_tn_wgrad_multi(const TnWgradProb* p, int n, hipStream_t st) {
+  if (n < 1 || n > 4) return SV_E_BADARG;
+  TnWgradMulti m;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!svk_tn_wgrad_supported(p[i])) return SV_E_UNSUPPORTED;
+    m.p[i] = p[i];
+    gx = max(gx, p[i].Kw / 128);
+    gy = max(gy, p[i].N / 128);
+  }
+  for (int i = n; i < 4; ++i) m.p[i] = p[0];
+  const size_t lds = 2 * 128 * 256;
+  sv_ensure_dynamic_lds((const void*)tn_wgrad_kernel, lds);
+  hipLaunchKernelGGL(tn_wgrad_kernel, dim3(gx, gy, n), dim3(256), lds, st, m);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

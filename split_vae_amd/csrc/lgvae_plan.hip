@@ -589,6 +589,22 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   const char* on_main = on_main_env ? on_main_env : (n * L[0]->d.B >= 768 ? "e1,e2,d5" : "e1,e2");
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
+  if (latent_gemm_on(p) && L[0]->d.H == 1 && L[0]->d.W == 1 && L[0]->d.KH == 1 && n <= 4) {     // Dense (d1): latent_gemm.hip, whole batch per tile
+    TnWgradProb q[4];
+    for (int i = 0; i < n; ++i) {
+      const sv_conv_desc& d = L[i]->d;
+      q[i] = TnWgradProb{x[i], d.ldx, dy[i], d.ldy, grads + p->params[L[i]->kparam].off, grads + p->params[L[i]->bparam].off, d.B, svg_cin_pad(&d),
+                         d.Cin, d.Cout};
+      fl += conv_flops(d);
+    }
+    bool ok = true;
+    for (int i = 0; i < n; ++i) ok = ok && svk_tn_wgrad_supported(q[i]);
+    if (ok) {
+      Scope sc(p, st, nm, fl, by);
+      return svk_tn_wgrad_multi(q, n, st);
+    }
+    fl = 0;
+  }
   // the decoder head's weight gradient in polyphase form (poly_wgrad.hip) from ~768 images per launch (its three small
   // kernels cost more than they save below that: 16 images 42 vs 20 us; 1024 images 132 vs 184 us)
   static const bool no_pw = getenv("SV_NO_POLY_WGRAD") != nullptr;
@@ -971,8 +987,18 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
     {
       hipStream_t ws = p->wgrad_stream(st);
       Scope sc(p, ws, "wgrad.head", fl, by);
+      bool done = false;
+      if (latent_gemm_on(p) && n <= 4) {
+        TnWgradProb q[4];
+        bool ok = true;
+        for (int i = 0; i < n; ++i) {
+          q[i] = TnWgradProb{a[i].A, a[i].lda, a[i].dY, a[i].ldy, a[i].dW, a[i].dbias, B, a[i].Cin_pad, a[i].Cin_real, a[i].N};
+          ok = ok && svk_tn_wgrad_supported(q[i]);
+        }
+        if (ok) { SV_TRY(svk_tn_wgrad_multi(q, n, ws)); done = true; }
+      }
       const int cg = svg_pick_cfg(Lg), cl = svg_pick_cfg(Ll);      // the narrower tile serves both widths
-      SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), ws));
+      if (!done) SV_TRY(svk_wgrad_dispatch_multi(a, n, dt, e0 ? cl : (cg > cl ? cg : cl), ws));
     }
     Layer* Ls[2] = {&p->enc[0][3], &p->enc[1][3]};
     const void *gh[2] = {p->bp("ghead_x"), p->bp("ghead_xh")}, *a3[2] = {p->bp("a3_x"), p->bp("a3_xh")};
