@@ -221,7 +221,7 @@ def grade(r, dtype):
             "bound": bound, "frac": max(t_mfma, t_hbm) / avg if avg else 0.0}
 
 
-DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "upsample_bwd", "upsample_fwd")   # d2..d5 convs + everything that exists only for them
+DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "wgrad.all.reduce", "upsample_bwd", "upsample_fwd")   # (the one slab reduce of ALL layers is booked here whole: conservative)   # d2..d5 convs + everything that exists only for them
 
 
 def decoder_stack(table, dtype, passes):

@@ -120,6 +120,8 @@ struct WgradArgs {
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
   hipEvent_t ev_mid[2];   // profiling: when set, both are recorded after the main kernel, before the slab reduce
+  struct WgradReduceDesc* defer; int* n_defer;   // slab path: do NOT launch the reduce, append its descriptor here (svk_wgrad_reduce_all later;
+                                                 // the slab workspace must stay untouched until then)
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
@@ -140,6 +142,7 @@ struct WgradTileArgs {
   const void* A; const void* dY; float* dW; float* dbias;
   float* slab; float* ws; int64_t ws_bytes;   // slab = ws when the two-stage flush is used
   float* bslab;                               // with slab: [msplit][128] bias partials behind the dW slabs (summed by the reduce kernel)
+  struct WgradReduceDesc* defer; int* n_defer;   // see WgradArgs
   int B, IH, IW, lda, cl2, S, SX, fold_kw, fold_c;
   int layer_id;             // instantiation id (tuning table of svk_wgrad_tile_multi)
   int contig;               // tiles of a workgroup: contiguous run (1) or strided by the grid (0)
@@ -157,6 +160,14 @@ struct WgradTileArgs {
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
 };
+// one deferred slab reduce (one problem of one layer): everything wgrad_reduce_kernel needs, as run-time values
+struct WgradReduceDesc {
+  const float* slab; float* dW; const float* bslab; float* dbias;
+  int msplit, groups, ncg, CW, Cin_real, N, ntaps, fold_kw, fold_c, pairx, assign, TPW, CIF, COF;
+};
+#define SV_WGRAD_DEFER_MAX 16
+struct WgradReduceAll { WgradReduceDesc d[SV_WGRAD_DEFER_MAX]; int first[SV_WGRAD_DEFER_MAX + 1]; int n; };   // first: block ranges of the flat grid
+int svk_wgrad_reduce_all(const WgradReduceDesc* d, int n, hipStream_t st);   // every pending reduce in ONE launch (blockIdx.z = descriptor)
 #define SV_WGRAD_MAX_MULTI 2
 struct WgradTileMulti { WgradTileArgs a[SV_WGRAD_MAX_MULTI]; };     // blockIdx.z selects the problem
 struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; const float* bslab[SV_WGRAD_MAX_MULTI]; float* dbias[SV_WGRAD_MAX_MULTI]; };

@@ -100,6 +100,10 @@ struct sv_lgvae_plan {
   std::vector<PrepJob> jobs;
   int prep_blocks;
   int64_t arena_elems;
+  // slab reduces of the tile weight gradients, deferred: every layer keeps its partial sums in its own workspace region and ONE launch
+  // sums them all after the backward pass (after the side stream has joined).  Opt-in (SV_DEFER_REDUCE=1): see run_wgrad_layers for the measurement
+  WgradReduceDesc red_pending[64];
+  int n_pending = 0;
   bool nll_fused = false;  // the last decoder forward evaluated the loss in the head's epilogue (nllpart_*, g5_* are valid)
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
   // weight gradients on a second stream (they feed only Adam / the all-reduce; the input-gradient chain is the critical
@@ -365,6 +369,7 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("jobs", (int64_t)p->jobs.size() * sizeof(PrepJob));
   p->add_buf("warena", p->arena_elems * es);
   p->add_buf("wgrad_ws", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI * sv_lgvae_plan::SIDE_MAX);   // per side stream, per problem
+  if (getenv("SV_DEFER_REDUCE")) p->add_buf("wslab", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI * 7);    // per tile-wgrad layer (e1 e2 e3 d2 d3 d4 d5) and problem: deferred reduces
   p->add_buf("polyfix_x", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));   // border terms of the polyphase head (poly_fix.hip)
   p->add_buf("polyfix_xh", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));
   p->add_buf("polyw_x", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);        // polyphase weight gradient of the head: dW', dbias', frame slabs
@@ -628,16 +633,27 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     const sv_conv_desc& d = L[0]->d;
     return svk_poly_wgrad_finish(n, x, dy, pw, dwv, dbv, d.B, d.H / 2, d.W / 2, d.ldx, Cin, d.Cout, SV_POLY_WGRAD_NWG, st);
   }
+  // measured (profiles/r03_f_defer.txt): one launch instead of seven saves 20-26 us of SERIAL time, but the slabs (~250 MB a step) are then read
+  // cold from HBM on the critical path after the join instead of warm from L2 / MALL on the side stream: B = 512 -0.5..1 %, B = 64 +5 %.  Opt-in.
+  static const bool no_defer = getenv("SV_DEFER_REDUCE") == nullptr;
+  static const char* slots[7] = {"e1", "e2", "e3", "d2", "d3", "d4", "d5"};
+  int slot = -1;
+  for (int k = 0; k < 7; ++k) if (ln == slots[k]) slot = k;
+  const bool defer = !no_defer && slot >= 0 && L[0]->d.dtype == SV_BF16 && n <= SV_WGRAD_MAX_MULTI;
   for (int i = 0; i < n; ++i) {
     svg_wgrad_args(&L[i]->d, &a[i]);
     a[i].A = x[i]; a[i].dY = dy[i];
     a[i].dW = grads + p->params[L[i]->kparam].off;
     a[i].dbias = grads + p->params[L[i]->bparam].off;
     a[i].ws = (float*)((char*)p->bp("wgrad_ws") + (p->side_slot * SV_WGRAD_MAX_MULTI + i) * wsb); a[i].ws_bytes = wsb;
+    if (defer) {                        // its own slab region, reduced with every other layer's after the backward pass
+      a[i].ws = (float*)((char*)p->bp("wslab") + (int64_t)(slot * SV_WGRAD_MAX_MULTI + i) * SV_WGRAD_WS_BYTES); a[i].ws_bytes = SV_WGRAD_WS_BYTES;
+      a[i].defer = p->red_pending; a[i].n_defer = &p->n_pending;
+    }
     fl += conv_flops(L[i]->d);
   }
   Scope sc(p, st, nm, fl, by);
-  sc.split(nm + ".reduce", 0, a[0].ev_mid);
+  if (!defer) sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
 static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void* dy, float* grads, hipStream_t st) {
@@ -1152,6 +1168,12 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
   if (ph & (SV_PHASE_BWD_ENC_HEADS | SV_PHASE_BWD_ENC_CONVS))
     SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st));
   SV_TRY(p->join_side(st));
+  if (p->n_pending) {                    // every layer's partial sums -> dW / dbias, one launch (fixed order: deterministic)
+    Scope sc(p, st, "wgrad.all.reduce", 0, 0);
+    const int np = p->n_pending;
+    p->n_pending = 0;
+    SV_TRY(svk_wgrad_reduce_all(p->red_pending, np, st));
+  }
   if (ph & SV_PHASE_ADAM) {
     Scope sc(p, st, "adam_step", 0, (double)p->nparams * 28);
     SV_TRY(svk_adam_step(s->params, s->grads, s->adam_m, s->adam_v, p->nparams, s->lr, s->beta1, s->beta2,

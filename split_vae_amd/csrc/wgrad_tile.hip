@@ -363,6 +363,91 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceMult
   }
 }
 
+// The same reduce for ANY layer with its fragment counts as run-time values: all the pending reduces of a backward pass in one launch
+// (blockIdx.z = descriptor).  At 64 images per GPU the seven per-layer reduce launches were ~11 us each for a few hundred KB.
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradReduceAll m) {
+  int z = 0;                               // flat grid: descriptor z owns blocks [first[z], first[z+1]) (no empty workgroups: a padded 3-D grid of
+  while (z + 1 < m.n && (int)blockIdx.x >= m.first[z + 1]) ++z;      // 60 k early-exit workgroups cost 60 us by itself)
+  const WgradReduceDesc& g = m.d[z];
+  const int NFR = g.TPW * g.CIF * g.COF, PER = 4 * NFR * 256;
+  const int lb = blockIdx.x - m.first[z], bpg = PER / 128;
+  const int by = lb / bpg, bx = lb - by * bpg;
+  __shared__ float4 part[8][32];
+  const int msplit = g.msplit, fold_kw = g.fold_kw, N = g.N;
+  if (bx == 0 && by == 0 && g.bslab) {
+    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int x = row; x < msplit; x += 8) {
+      const float4 v = *(const float4*)(g.bslab + x * 128 + col * 4);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    part[row][col] = s4;
+    __syncthreads();
+    if (!row) {
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { const float4 v = part[r][col]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+      part[0][col] = s4;
+    }
+    __syncthreads();
+    const float* tot = (const float*)&part[0][0];
+    const int c = threadIdx.x;
+    if (c < N && c < 128 && (!fold_kw || c < g.fold_c)) g.dbias[c] += tot[c] + (fold_kw ? tot[c + 8] : 0.f);
+    __syncthreads();
+  }
+  const int y = by, col = threadIdx.x & 31, row = threadIdx.x >> 5;
+  const int e = (bx * 32 + col) * 4;
+  const float* p = g.slab + (int64_t)y * PER + e;
+  const int64_t xs = (int64_t)g.groups * PER;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int x = row; x < msplit; x += 8) {
+    const float4 v = *(const float4*)(p + x * xs);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[row][col] = s;
+  __syncthreads();
+  if (row) return;
+#pragma unroll
+  for (int r = 1; r < 8; ++r) {
+    const float4 v = part[r][col];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int wave = e / (NFR * 256), rem = e - wave * (NFR * 256), f = rem >> 8, r4 = (rem >> 6) & 3, lane = rem & 63;
+  const int t2 = f / (g.CIF * g.COF), i = (f / g.COF) % g.CIF, j = f % g.COF;
+  const int tg = y / g.ncg, cg = y - tg * g.ncg;
+  const int tap = tg * 4 * g.TPW + wave * g.TPW + t2;
+  const int cl = i * 16 + (lane >> 4) * 4 + r4, ci = g.pairx ? (cl & 7) : cg * g.CW + cl, co = j * 16 + (lane & 15);
+  if (tap >= g.ntaps || (!g.pairx && cl >= g.CW) || ci >= g.Cin_real) return;
+  const int otap = g.pairx ? 2 * tap + (cl >> 3) : tap;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (co + k >= N) continue;
+    const int64_t di = dw_index(otap, ci, co + k, g.Cin_real, N, fold_kw, g.fold_c);
+    if (di < 0) continue;
+    if (fold_kw) atomicAdd(g.dW + di, sv[k]); else if (g.assign) g.dW[di] = sv[k]; else g.dW[di] += sv[k];
+  }
+}
+
+int svk_wgrad_reduce_all(const WgradReduceDesc* d, int n, hipStream_t st) {
+  for (int b = 0; b < n; b += SV_WGRAD_DEFER_MAX) {
+    WgradReduceAll m;
+    m.n = n - b < SV_WGRAD_DEFER_MAX ? n - b : SV_WGRAD_DEFER_MAX;
+    int total = 0;
+    for (int i = 0; i < m.n; ++i) {
+      m.d[i] = d[b + i];
+      const int per = 4 * d[b + i].TPW * d[b + i].CIF * d[b + i].COF * 256;
+      m.first[i] = total;
+      total += (per / 128) * d[b + i].groups;
+    }
+    m.first[m.n] = total;
+    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(total), dim3(256), 0, st, m);
+    SV_LAUNCH_CHECK();
+  }
+  return SV_OK;
+}
+
 template <int TPW, int CIF, int COF, int KC, int NG, int OCC = 2>
 static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t st, const hipEvent_t* ev_mid) {
   constexpr int HFB = ((TPW * CIF * COF + 1) / 2) * 4 * 1024;     // bytes of the cross-group exchange (NG = 2)
@@ -412,6 +497,12 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
   hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
+  if (slab && !(dbg & 1) && a[0].defer && a[0].n_defer && *a[0].n_defer + n <= 64) {      // the caller reduces every layer's slabs in one launch later
+    for (int i = 0; i < n; ++i)
+      a[0].defer[(*a[0].n_defer)++] = WgradReduceDesc{m.a[i].slab, a[i].dW, m.a[i].bslab, a[i].dbias, msplit, groups, a[0].ncg, a[0].CW, a[0].Cin_real,
+                                                      a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c, a[0].pairx, a[0].assign, TPW, CIF, COF};
+    return SV_OK;
+  }
   if (slab && !(dbg & 1)) {
     hipLaunchKernelGGL((wgrad_reduce_kernel<TPW, CIF, COF>), dim3(PER / 128, groups, n), dim3(256), 0, st, r, msplit, groups,
                        a[0].ncg, a[0].CW, a[0].Cin_real, a[0].N, a[0].ntaps, a[0].fold_kw, a[0].fold_c, a[0].pairx, a[0].assign);
@@ -534,6 +625,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
     av[i] = a;
     av[i].A = wv[i].A; av[i].dY = wv[i].dY; av[i].dW = wv[i].dW; av[i].dbias = wv[i].dbias;
     av[i].ws = allow_slab ? wv[i].ws : nullptr; av[i].ws_bytes = allow_slab ? wv[i].ws_bytes : 0;
+    av[i].defer = wv[i].defer; av[i].n_defer = wv[i].n_defer;
   }
   // <TPW, CIF, COF, KC>
   switch (id) {
