@@ -244,7 +244,8 @@ def decoder_stack(table, dtype, passes):
 SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyphase head; the symbol also serves e1's forward (traffic = their mean)
                 "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
                 "fwd.d3": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi4E"], "fwd.e2": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi0E"],
-                "wgrad.d5": ["wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_tile_kernel<9, 1, 2, 8, "]}
+                "wgrad.d5": ["wgrad_tile_kernel<7, 1, 2, 8, ", "wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_roll_kernel", "wgrad_tile_kernel<9, 1, 2, 8, "],
+                "dgrad.d4": ["RowCfg<6, 6, 32, 64, 32, "], "dgrad.d5": ["RowCfg<6, 6, 8, 32, 64, "], "dgrad.d3": ["RowCfg<4, 4, 64, 128, "]}
 
 
 def spair_row(dev, B=32, steps=60, warmup=5):
