@@ -248,6 +248,16 @@ SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyp
                 "dgrad.d4": ["RowCfg<6, 6, 32, 64, 32, "], "dgrad.d5": ["RowCfg<6, 6, 8, 32, 64, "], "dgrad.d3": ["RowCfg<4, 4, 64, 128, "]}
 
 
+def wgrad_main_layers(images_per_launch, dtype):
+    """The layers whose weight gradient the plan keeps on the main stream (csrc/lgvae_plan.hip: run_wgrad_layers; the rest go to the side stream)."""
+    env = os.environ.get("SV_WGRAD_MAIN")
+    if env is not None:
+        return env.split(",")
+    if images_per_launch < 768:
+        return ["e1", "e2"]
+    return ["e1", "e2", "d4"] if dtype == "bf16" and os.environ.get("SV_NO_WGRAD_ROLL") is None else ["e1", "e2", "d5"]
+
+
 def spair_row(dev, B=32, steps=60, warmup=5):
     """SPLIT-SPAIR (config 5, README.md:93: lg_spair -split_z_l -concat_z_what -dense_local -dense_bg; 48x48 canvases, batch 32 as the
     reference hard-codes) train step: forward + losses + autograd backward over the split_vae::* operators + clipnorm Adam, captured
@@ -363,9 +373,10 @@ def main():
             g = grade(r, args.dtype)
             sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline\n" %
                              (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
-    # the dominant kernel = the top row of the serial table, whatever it is (round 3: it is the weight gradient of d4).  In the timed
-    # region it runs on the weight-gradient side stream beside the input-gradient chain: `achieved` is what the hipEvents around it
-    # on ITS stream give there (co-running launches included), `serial` what it takes alone on the chip.
+    # the dominant kernel = the top row of the serial table, whatever it is (round 3: the weight gradient of d4, or d4's input gradient /
+    # forward: the three are within 2 %).  In the timed region the two streams of the backward pass overlap: `achieved` is what the hipEvents
+    # around the launch on ITS stream give there (co-running launches of the other stream included; `stream` names it), `serial` what the
+    # launch takes alone on the chip.
     dom = next(r for r in table if r["flops"] > 0)
     large = [r for r in table if r["total_ms"] / max(r["launches"], 1) >= 0.1 and (r["flops"] or r["bytes"])]
     worst = min(large, key=lambda r: grade(r, args.dtype)["frac"]) if large else None
@@ -463,7 +474,8 @@ def main():
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"],
                            "stream": "weight-gradient side stream (co-runs with the input-gradient chain)" if prof[0]["name"].startswith("wgrad.") and
-                                     not any(x in prof[0]["name"] for x in ("e1", "e2", "d5")) else "main",
+                                     prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, args.dtype) else
+                                     "main (the weight-gradient side stream runs other layers' launches beside it)",
                            "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
         gs = grade(dom, args.dtype)
         out["roofline"]["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),

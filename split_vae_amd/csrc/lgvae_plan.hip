@@ -590,8 +590,14 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // ("" = everything on the side stream)
   // Batch dependence (re-measured per shard size): d5 on the main stream pays from ~768 images per launch (B = 512: -0.4 %)
   // and costs below that (B = 256: +0.6 %, 128: +4 %, 64: +2 %); e1 / e2 on the main stream pay at every size.
+  // Round 3: d4's weight gradient on the rolling-window kernel (wgrad_roll.hip) is one persistent 8-wave workgroup per CU with the whole
+  // register file: nothing co-resides with it, so beside the input-gradient chain it only gets the CUs that chain leaves (0.147 ms alone,
+  // 0.27 live).  From 768 images per launch it stays on the main stream instead of d5's (re-measured, B = 512: "e1,e2,d5" 2.073 / 2.078 ms,
+  // "e1,e2,d4" 2.056 / 2.063, "e1,e2,d5,d4" 2.072, "e1,e2,d4,d3" 2.076; B = 256 +-0, B = 128 / 64: +2.5 %, so not below the threshold)
   static const char* on_main_env = getenv("SV_WGRAD_MAIN");
-  const char* on_main = on_main_env ? on_main_env : (n * L[0]->d.B >= 768 ? "e1,e2,d5" : "e1,e2");
+  static const bool roll_off = getenv("SV_NO_WGRAD_ROLL") != nullptr;
+  const bool big = n * L[0]->d.B >= 768;
+  const char* on_main = on_main_env ? on_main_env : !big ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" : "e1,e2,d5";
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
   if (latent_gemm_on(p) && L[0]->d.H == 1 && L[0]->d.W == 1 && L[0]->d.KH == 1 && n <= 4) {     // Dense (d1): latent_gemm.hip, whole batch per tile
