@@ -248,13 +248,15 @@ SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyp
                 "dgrad.d4": ["RowCfg<6, 6, 32, 64, 32, "], "dgrad.d5": ["RowCfg<6, 6, 8, 32, 64, "], "dgrad.d3": ["RowCfg<4, 4, 64, 128, "]}
 
 
-def wgrad_main_layers(images_per_launch, dtype):
+def wgrad_main_layers(images_per_launch, dtype, world=1):
     """The layers whose weight gradient the plan keeps on the main stream (csrc/lgvae_plan.hip: run_wgrad_layers; the rest go to the side stream)."""
     env = os.environ.get("SV_WGRAD_MAIN")
     if env is not None:
         return env.split(",")
     if images_per_launch < 768:
         return ["e1", "e2"]
+    if dtype == "bf16" and world == 1 and int(os.environ.get("SV_SIDE_STREAMS", "2")) >= 2:
+        return ["e1", "e2"]                      # whole steps: two side streams take everything else
     return ["e1", "e2", "d4"] if dtype == "bf16" and os.environ.get("SV_NO_WGRAD_ROLL") is None else ["e1", "e2", "d5"]
 
 
@@ -473,8 +475,8 @@ def main():
                            "hip_kernel": symbol,
                            "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
                            "flops_per_launch": prof[0]["flops"],
-                           "stream": "weight-gradient side stream (co-runs with the input-gradient chain)" if prof[0]["name"].startswith("wgrad.") and
-                                     prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, args.dtype) else
+                           "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
+                                     prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, args.dtype, world) else
                                      "main (the weight-gradient side stream runs other layers' launches beside it)",
                            "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
         gs = grade(dom, args.dtype)

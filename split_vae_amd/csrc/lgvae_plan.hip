@@ -112,6 +112,7 @@ struct sv_lgvae_plan {
   enum { SIDE_MAX = 4 };
   hipStream_t side[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // SV_SIDE_STREAMS of them, taken round-robin: the weight
   hipEvent_t ev_fork = nullptr, ev_join[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // gradients of different layers are independent
+  int side_use = 1;        // streams the current call hands layers to (run_phases)
   int nside = 0, side_next = 0, side_slot = 0;   // side_slot: which stream (and which slab workspace) the last wgrad_stream() gave out
   bool side_pending = false;
   hipStream_t wgrad_stream(hipStream_t st) {
@@ -123,7 +124,7 @@ struct sv_lgvae_plan {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
-      static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 1;
+      static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 2;      // created; `side_use` of them are used per call
       const int k = want < 1 ? 1 : want > SIDE_MAX - 1 ? SIDE_MAX - 1 : want;   // the last workspace slot belongs to the main stream
       if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return st;
       for (int i = 0; i < k; ++i) {
@@ -133,7 +134,8 @@ struct sv_lgvae_plan {
       }
       if (!nside) return st;
     }
-    const int slot = side_next % nside;
+    const int use = side_use < nside ? side_use : nside;
+    const int slot = side_next % use;
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
     side_next = slot + 1;
     side_slot = slot;
@@ -597,7 +599,9 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   static const char* on_main_env = getenv("SV_WGRAD_MAIN");
   static const bool roll_off = getenv("SV_NO_WGRAD_ROLL") != nullptr;
   const bool big = n * L[0]->d.B >= 768;
-  const char* on_main = on_main_env ? on_main_env : !big ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" : "e1,e2,d5";
+  // With TWO side streams (whole bf16 steps at this size, see run_phases) only the two tail layers stay: "e1,e2" 2.004 / 2.006 ms,
+  // "e1,e2,d1" 2.008, "e1" / "e2" 2.03, "" 2.039, "e1,e2,d4" 2.061, "e1,e2,d5" 2.119.
+  const char* on_main = on_main_env ? on_main_env : (!big || p->side_use >= 2) ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" : "e1,e2,d5";
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
   if (latent_gemm_on(p) && L[0]->d.H == 1 && L[0]->d.W == 1 && L[0]->d.KH == 1 && n <= 4) {     // Dense (d1): latent_gemm.hip, whole batch per tile
@@ -1157,6 +1161,16 @@ extern "C" int sv_lgvae_buffer(const sv_lgvae_plan* p, const char* name, int64_t
 
 static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
   const int ph = s->phases;
+  {
+    // Two weight-gradient side streams for a whole step at >= 768 images per launch, one otherwise.  Re-measured in round 3 (round 2: +-0):
+    // B = 512 2.056 -> 2.005 ms (three launches in flight fill the CUs the rolling-window d4 kernel and the row-ring input gradients leave);
+    // B = 256 +1.8 %, 128 +6 %, 64 +3 % (launches too small to share the chip three ways); a data-parallel step (phase-split calls: the
+    // communication stream is a further active queue) 2.14 -> 2.15 ms over torch's nccl, 2.12 -> 3.31 ms over sv_comm (four active streams
+    // on GPU_MAX_HW_QUEUES = 3): one.  SV_SIDE_STREAMS forces a count.
+    static const int forced = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 0;
+    const bool whole = (ph & SV_PHASE_ALL) == SV_PHASE_ALL;
+    p->side_use = forced > 0 ? forced : (whole && p->d.dtype == SV_BF16 && 2 * p->d.B >= 768) ? 2 : 1;
+  }
   if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
   static const bool no_fused_nll = getenv("SV_NO_FUSED_NLL") != nullptr;    // A/B: dlogistic_kernel after the forward
   const bool want_nll = !no_fused_nll && (ph & SV_PHASE_FWD_DECODERS) && (ph & SV_PHASE_LOSS) && s->grads && s->images6 &&
