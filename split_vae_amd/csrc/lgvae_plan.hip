@@ -113,6 +113,7 @@ struct sv_lgvae_plan {
   hipStream_t side[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // SV_SIDE_STREAMS of them, taken round-robin: the weight
   hipEvent_t ev_fork = nullptr, ev_join[SIDE_MAX] = {nullptr, nullptr, nullptr, nullptr};   // gradients of different layers are independent
   int side_use = 1;        // streams the current call hands layers to (run_phases)
+  int side_count = 0;      // layers forked since the last join
   int nside = 0, side_next = 0, side_slot = 0;   // side_slot: which stream (and which slab workspace) the last wgrad_stream() gave out
   bool side_pending = false;
   hipStream_t wgrad_stream(hipStream_t st) {
@@ -135,7 +136,10 @@ struct sv_lgvae_plan {
       if (!nside) return st;
     }
     const int use = side_use < nside ? side_use : nside;
-    const int slot = side_next % use;
+    static const char* order = getenv("SV_SIDE_ORDER");        // experiment: stream per forked layer in launch order, e.g. "0110" (repeats)
+    int slot = side_next % use;
+    if (order && order[0]) { const int c = order[side_count % (int)strlen(order)] - '0'; if (c >= 0 && c < use) slot = c; }
+    ++side_count;
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
     side_next = slot + 1;
     side_slot = slot;
@@ -146,6 +150,7 @@ struct sv_lgvae_plan {
     if (!side_pending) return SV_OK;
     side_pending = false;
     side_next = 0;                     // every step hands the layers to the same streams
+    side_count = 0;
     for (int i = 0; i < nside; ++i)
       if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return (int)hipGetLastError();
     return SV_OK;
