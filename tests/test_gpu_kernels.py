@@ -250,6 +250,7 @@ LAYERS = [  # name, H, Cin, Cout, k, stride, act, y_f32
     ("e1_64", 64, 3, 32, 6, 2, "relu", False),
     ("d5_64", 64, 32, 6, 6, 1, None, True),
     ("d4_64", 32, 64, 32, 6, 1, "relu", False),      # two 16-pixel column strips per image (wgrad_roll.hip)
+    ("d4_128", 64, 64, 32, 6, 1, "relu", False),     # four strips: first / inner / last strip variants of the rolling-window kernel
 ]
 
 
@@ -308,7 +309,7 @@ def test_conv_fwd_dgrad_wgrad(ops, layer, dtype):
     torch.testing.assert_close(dx2[..., :Cin].double().cpu(), xr.grad, rtol=rtol, atol=atol * float(xr.grad.abs().max()))
 
 
-@pytest.mark.parametrize("layer", [l for l in LAYERS if l[0] in ("d3", "d4", "d4_64", "d5", "d5_64")], ids=lambda l: l[0])
+@pytest.mark.parametrize("layer", [l for l in LAYERS if l[0] in ("d3", "d4", "d4_64", "d4_128", "d5", "d5_64")], ids=lambda l: l[0])
 def test_conv_fused_upsample_equals_materialised(ops, layer):
     """ups_in: the tile staging interpolates from the low-res tensor.  Same blend order as the
     stand-alone resize kernel -> the forward output is BITWISE the unfused result; the weight
@@ -338,8 +339,8 @@ def test_conv_fused_upsample_equals_materialised(ops, layer):
         ring[3:H - 3, 3:H - 3] = False
         assert float((a - r)[:, ring].norm() / r[:, ring].norm()) < 4e-3
         assert float((a - r).abs().max()) < 2e-2 * float(r.abs().max())
-    elif name == "d4_64":
-        # 32 x 32 grid: the fused form runs on the row-ring kernel, the materialised one on the tile kernel (other summation order)
+    elif name in ("d4_64", "d4_128"):
+        # 32 x 32 grid (and larger): the fused form runs on the row-ring kernel, the materialised one on the tile kernel (other summation order)
         torch.testing.assert_close(y1.float(), y0.float(), rtol=2e-2, atol=2e-2 * float(y0.float().abs().max()))
     else:
         assert torch.equal(y0, y1)
