@@ -51,11 +51,12 @@ struct RowConvArgs {
   int y_lo, x_lo;       // tap (ky, kx) reads input pixel (y + ky + y_lo, x + kx + x_lo)
   int bands, band_rows; // an image is cut into `bands` row bands of band_rows rows (a unit of work = one band)
   const void* mask;     // ADJ configs: the low-res activation whose ReLU mask (> 0) gates the low-res gradient (or null);
-                        // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo]
+                        // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo].
+                        // CLS configs: the layer input [B, 2H, 2W, ldo] whose ReLU mask gates the gradient `out` of the same shape (or null)
 };
 struct RowConvMulti { RowConvArgs a[2]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -65,6 +66,12 @@ struct RowCfg {
   // stay in an LDS ring and leave as the LOW-RES gradient through the adjoint of the resize (+ ReLU mask) -- the hi-res
   // tensor and the stand-alone upsample2x_bwd pass never exist (vae/model.py:163-167 backwards).
   static constexpr bool ADJ = ADJ_;
+  // CLS: the MERGED PARITY CLASSES of a stride-2 layer's input gradient (TapGemmArgs::cls_n; conv_api.hip: svg_dgrad_merged_args): a
+  // stride-1 KH x KW conv over the dY grid whose N = 4 * (N / 4) columns are (class, channel); class (ph, pw) lands on pixel
+  // (2y + ph, 2x + pw) of the [B, 2H, 2W, ldo] gradient, gated by the ReLU mask of the layer input.  Its weight image keeps the
+  // class order of the taps (y-major, offsets descending): only the one-time weight load indexes differently.
+  static constexpr bool CLS = CLS_;
+  static_assert(!CLS_ || (!UPS_ && !ADJ_ && KS_ == 1 && (N_ / 4) % 16 == 0), "merged parity classes");
   // TP: 8-channel pixels (the 6-channel head's gradient): one 16-B piece per pixel, so an MFMA K step (32) packs FOUR
   // taps -- the four lane quarters read four consecutive input ROWS (ky = 4g + kq; KH = 6 -> two groups, 2 of 8 dummies)
   static constexpr bool TP = CIN == 8;
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 Wr[nb][cc][kx][ky] = kyy < KH ? *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + kyy) * 8) : z;
               } else
-                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
+                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (C::CLS ? (KH - 1 - ky) * KW + (KW - 1 - kx) : kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
             }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[nb][e] = g.bias ? g.bias[(nbg * NBW + nb) * 16 + kq * 4 + e] : 0.f;
@@ -479,6 +486,31 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
               bf16_t pk[4] = {(bf16_t)acc[nb][j][0], (bf16_t)acc[nb][j][1], (bf16_t)acc[nb][j][2], (bf16_t)acc[nb][j][3]};
               *(uint2*)(sOut + ((obase + yw + j) % C::ORR) * C::OROWB + (x0 + m) * (C::N * 2) + ((nbg * NBW + nb) * 16 + kq * 4) * 2) = *(const uint2*)pk;
             }
+        } else if constexpr (C::CLS) {
+          if (!(dbg & 4)) {
+            // a 16-column block = 16 channels of ONE parity class: pixel (2 (yw + j) + ph, 2 (x0 + m) + pw), channels chb + 4 kq ..
+            constexpr int CN = C::N / 4;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+              const int col = (nbg * NBW + nb) * 16, cls = col / CN, chb = col - cls * CN;
+              const int64_t pix0 = ((int64_t)b * 2 * g.H + 2 * yw + (cls >> 1)) * (2 * g.W) + 2 * (x0 + m) + (cls & 1);
+#pragma unroll
+              for (int j = 0; j < MF; ++j) {
+                const int64_t o = (pix0 + (int64_t)j * 4 * g.W) * g.ldo + chb + kq * 4;
+                bf16_t pk[4] = {(bf16_t)acc[nb][j][0], (bf16_t)acc[nb][j][1], (bf16_t)acc[nb][j][2], (bf16_t)acc[nb][j][3]};
+                if (g.mask) {
+                  const uint2 mv = *(const uint2*)((const bf16_t*)g.mask + o);
+                  const uint32_t mw[2] = {mv.x, mv.y};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits: > 0 <=> sign clear and not zero
+                    if ((h & 0x8000u) || !(h & 0x7fffu)) pk[e] = (bf16_t)0.f;
+                  }
+                }
+                *(uint2*)((bf16_t*)g.out + o) = *(const uint2*)pk;
+              }
+            }
+          }
         } else
         if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
           // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m
@@ -594,6 +626,9 @@ using RC_d3g  = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;           // d3
 using RC_d3ga = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true>;
 using RC_d5g  = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4>;          // d5 input gradient (8-channel pixels: four taps per K step)
 using RC_d5ga = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4, true>;
+// e2 input gradient, merged parity classes (K 576, 4 x 32 columns): 4-wave workgroups, a wave = the two column blocks of one class.
+// Measured in the step (2 x 512 images): tile kernel 0.103 ms; 8 waves x one block 0.082; this 0.075; this with 8 rows per step 0.098
+using RC_e2g  = RowCfg<3, 3, 64, 128, 16, 4, 2, 1, 1, 1, false, 4, false, true>;
 
 }  // namespace
 
@@ -606,19 +641,31 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
   for (int i = 0; i < n; ++i) {
     const TapGemmArgs& p = t[i];
     if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
-    if (p.S != 1 || p.SX != 1 || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
-    if (p.mask && !p.adj) return SV_E_UNSUPPORTED;                     // a ReLU mask on the output itself: tile kernel
+    static const bool no_cls = getenv("SV_RC_NO_CLS") != nullptr;     // A/B: merged parity classes on the tile kernel
+    const bool cls = p.cls_n > 0;
+    if (cls && (no_cls || p.adj)) return SV_E_UNSUPPORTED;
+    if (p.S != 1 || p.SX != 1 || p.OS != (cls ? 2 : 1) || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
+    if (p.mask && !p.adj && !cls) return SV_E_UNSUPPORTED;             // a ReLU mask on the output itself: tile kernel
     const int OY = 1 << p.lOY, OX = 1 << p.lOX;
-    if (OY != p.IH || OX != p.IW || p.OHF != OY || p.OWF != OX) return SV_E_UNSUPPORTED;
+    if (OY != p.IH || OX != p.IW || p.OHF != OY * p.OS || p.OWF != OX * p.OS) return SV_E_UNSUPPORTED;
     const int cin = (1 << p.cl2) * 8;
     if (p.lda != cin || p.Ktot != p.ntaps * cin) return SV_E_UNSUPPORTED;
-    int kh = 1;
-    while (kh < p.ntaps && p.dx[kh] == p.dx[0]) ++kh;
-    if (p.ntaps % kh) return SV_E_UNSUPPORTED;
-    const int kw = p.ntaps / kh;
-    for (int q = 0; q < p.ntaps; ++q)                                  // x-major, y-minor full grid
-      if (p.dy[q] != p.dy[0] + q % kh || p.dx[q] != p.dx[0] + q / kh) return SV_E_UNSUPPORTED;
+    int kh = 1, kw = 1;
+    if (cls) {                                                         // the classes' own order: y-major, offsets descending from +1
+      kh = kw = 3;
+      if (p.ntaps != 9 || p.bias) return SV_E_UNSUPPORTED;
+      for (int q = 0; q < 9; ++q)
+        if (p.dy[q] != 1 - q / 3 || p.dx[q] != 1 - q % 3) return SV_E_UNSUPPORTED;
+    } else {
+      while (kh < p.ntaps && p.dx[kh] == p.dx[0]) ++kh;
+      if (p.ntaps % kh) return SV_E_UNSUPPORTED;
+      kw = p.ntaps / kh;
+      for (int q = 0; q < p.ntaps; ++q)                                // x-major, y-minor full grid
+        if (p.dy[q] != p.dy[0] + q % kh || p.dx[q] != p.dx[0] + q / kh) return SV_E_UNSUPPORTED;
+    }
     int c = -1;
+    if (cls) { if (cin == 64 && p.N == 128 && p.cls_n == 32 && OX == 16) c = 8; }
+    else
     if (kh == 6 && kw == 6 && cin == 64 && p.N == 32 && OX == 32 && p.ups && !p.adj) c = 0;
     else if (kh == 6 && kw == 6 && cin == 32 && p.N == 64 && OX == 32 && !p.ups) c = p.adj ? 4 : 1;
     else if (kh == 4 && kw == 4 && cin == 128 && p.N == 64 && OX == 16 && p.ups && !p.adj) c = 2;
@@ -627,15 +674,15 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
     if (c < 0 || (i && c != cfg)) return SV_E_UNSUPPORTED;
     cfg = c;
     const int step = 4;
-    if (OY % step || p.ldo < p.N) return SV_E_UNSUPPORTED;
+    if (OY % step || p.ldo < (cls ? p.cls_n : p.N)) return SV_E_UNSUPPORTED;
     RowConvArgs& r = a[i];
-    r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out; r.mask = p.adj ? p.mask : nullptr;
+    r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out; r.mask = (p.adj || cls) ? p.mask : nullptr;
     r.B = p.M >> (p.lOY + p.lOX); r.H = OY; r.W = OX;
     r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
-    r.y_lo = p.dy[0]; r.x_lo = p.dx[0];
+    r.y_lo = cls ? -1 : p.dy[0]; r.x_lo = cls ? -1 : p.dx[0];
     // small batches: cut the images into row bands until there is a unit of work for every workgroup slot (not with the
     // fused adjoint: its low-res rows straddle band edges)
-    const bool four = c == 0 || c == 1 || c == 4 || c == 6 || c == 7;
+    const bool four = c == 0 || c == 1 || c == 4 || c == 6 || c == 7 || c == 8;
     int bands = 1;
     while (!p.adj && n * r.B * bands < (four ? 512 : 256) && OY / (bands * 2) >= step && (OY / (bands * 2)) % step == 0) bands *= 2;
     r.bands = bands; r.band_rows = OY / bands;
@@ -666,6 +713,7 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 5: return launch_row<RC_d3ga>(a, n, st);
     case 6: return launch_row<RC_d5g>(a, n, st);
     case 7: return launch_row<RC_d5ga>(a, n, st);
+    case 8: return launch_row<RC_e2g>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }

@@ -251,6 +251,7 @@ LAYERS = [  # name, H, Cin, Cout, k, stride, act, y_f32
     ("d5_64", 64, 32, 6, 6, 1, None, True),
     ("d4_64", 32, 64, 32, 6, 1, "relu", False),      # two 16-pixel column strips per image (wgrad_roll.hip)
     ("d4_128", 64, 64, 32, 6, 1, "relu", False),     # four strips: first / inner / last strip variants of the rolling-window kernel
+    ("e2_64", 32, 32, 64, 6, 2, "relu", False),      # 16 x 16 class grid: the merged parity classes of its input gradient on the row-ring kernel
 ]
 
 
@@ -499,6 +500,39 @@ def test_merged_parity_classes_match_one_problem_per_class(lib_built, tmp_path):
     for key in res[0].files:
         assert np.array_equal(res[0][key], res[1][key]), key
         assert np.count_nonzero(res[0][key]) > res[0][key].size // 4
+
+
+def test_merged_parity_classes_on_the_row_ring_kernel(lib_built, tmp_path):
+    """The same input gradient at CelebA-64's size (32 x 32 input, 16 x 16 class grid), where the merged problem runs on the weight-stationary
+    row-ring kernel (row_conv.hip, RC_e2g: class -> sub-pixel store + ReLU mask in its epilogue), against the tile kernel (SV_RC_NO_CLS=1): other
+    K order, so bf16 roundings of differently ordered fp32 sums (4e-3 of the norm); masked zeros in the same places."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(12)\n"
+        "outs = []\n"
+        "for B in (1, 5, 64):\n"
+        "    w = (torch.randn(6, 6, 32, 64, generator=g) * 0.03).cuda()\n"
+        "    dy = torch.randn(B, 16, 16, 64, generator=g).bfloat16().cuda()\n"
+        "    mask = torch.randn(B, 32, 32, 32, generator=g).bfloat16().cuda()\n"
+        "    c = ops.Conv2D(B, 32, 32, 32, 64, 6, 2, act='relu', dtype=torch.bfloat16); c.prep(w)\n"
+        "    outs += [c.dgrad(dy).float().cpu().numpy(), c.dgrad(dy, relu_mask=mask).float().cpu().numpy(), (mask > 0).cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env in (("row", {}), ("tile", {"SV_RC_NO_CLS": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    keys = res[0].files
+    for i in range(0, len(keys), 3):
+        for k in keys[i:i + 2]:
+            a, b = res[0][k].astype(np.float64), res[1][k].astype(np.float64)
+            assert np.linalg.norm(a - b) <= 4e-3 * np.linalg.norm(b), k
+        gate = res[0][keys[i + 2]]
+        assert not np.any(res[0][keys[i + 1]][~gate]) and np.count_nonzero(res[0][keys[i + 1]]) > gate.sum() // 2
 
 
 ADJ_LAYERS = [  # name, H (hi-res conv input = output size), Cin, Cout, k, y_f32
