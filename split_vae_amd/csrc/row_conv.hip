@@ -56,7 +56,7 @@ struct RowConvArgs {
 };
 struct RowConvMulti { RowConvArgs a[2]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -71,6 +71,13 @@ struct RowCfg {
   // (2y + ph, 2x + pw) of the [B, 2H, 2W, ldo] gradient, gated by the ReLU mask of the layer input.  Its weight image keeps the
   // class order of the taps (y-major, offsets descending): only the one-time weight load indexes differently.
   static constexpr bool CLS = CLS_;
+  // S2D: a STRIDE-2 forward layer (k = 2 KH, pad KH - 1) as the stride-1 KH x KW conv over the space-to-depth view of its input: a
+  // "pixel" of the class grid is the 2 x 2 block of input pixels, CIN = 4 x the layer's channels, the 32-channel K chunk cc = (py, px)
+  // of s2d tap (ky, kx) is tap (2 ky + py, 2 kx + px) of the layer's own (y-major) weight image -- nothing is re-prepared, only the DMA
+  // source address and the one-time weight load index differently.  `A` is the layer's input [B, 2H, 2W, lda], lda = CIN / 4.
+  static constexpr bool S2D = S2D_;
+  // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
+  static_assert(!S2D_ || (!UPS_ && !ADJ_ && !CLS_ && (CIN_ == 128 || CIN_ == 32)), "space-to-depth form");
   static_assert(!CLS_ || (!UPS_ && !ADJ_ && KS_ == 1 && (N_ / 4) % 16 == 0), "merged parity classes");
   // TP: 8-channel pixels (the 6-channel head's gradient): one 16-B piece per pixel, so an MFMA K step (32) packs FOUR
   // taps -- the four lane quarters read four consecutive input ROWS (ky = 4g + kq; KH = 6 -> two groups, 2 of 8 dummies)
@@ -199,7 +206,7 @@ template <typename C>
 __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int Ya, int nrows, int qa, char* sRing, int w, int nw, int lane) {
   constexpr int LPR = C::TP ? C::WIDTH : C::WIDTH * 2;      // lanes per (row, plane): one 16-B piece each
   static_assert(LPR <= 64, "one DMA instruction per (row, plane)");
-  const bf16_t* img = (const bf16_t*)g.A + (int64_t)b * g.H * g.W * g.lda;
+  const bf16_t* img = (const bf16_t*)g.A + (int64_t)b * g.H * g.W * g.lda * (C::S2D ? 4 : 1);
   const int PL = -g.x_lo;
   const bool on = lane < LPR;
   for (int idx = w; idx < nrows * C::NPL; idx += nw) {
@@ -207,7 +214,10 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
     const int Y = Ya + d;
     int slot = qa + d;
     if (slot >= C::R) slot -= C::R;
+    // S2D, 32-channel sub-pixels: plane p = sub-pixel (py, px) = (p >> 2, (p >> 1) & 1), channel half p & 1 of the input pixel (2Y + py, 2X + px)
     const bf16_t* src = C::TP ? img + ((int64_t)Y * g.W + lane) * g.lda
+                      : (C::S2D && C::CIN == 128) ? img + ((int64_t)(2 * Y + (p >> 2)) * (2 * g.W) + 2 * (lane >> 1) + ((p >> 1) & 1)) * g.lda + (2 * (p & 1) + (lane & 1)) * 8
+                      : C::S2D ? img + ((int64_t)(2 * Y + p) * (2 * g.W) + lane) * g.lda          // 8-channel sub-pixels: plane p = input row parity, the row is linear
                               : img + ((int64_t)Y * g.W + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
     const bool inside = (unsigned)Y < (unsigned)g.H;
 #pragma unroll
@@ -351,6 +361,12 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 Wr[nb][cc][kx][ky] = kyy < KH ? *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + kyy) * 8) : z;
               } else
+                if constexpr (C::S2D && C::CIN == 128) {
+                  const int c4 = ks * CPW + cc, py = c4 >> 1, px = c4 & 1;
+                  Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + py) * (2 * KW) + 2 * kx + px) * 32 + kq * 8);
+                } else if constexpr (C::S2D) {
+                  Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + (kq >> 1)) * (2 * KW) + 2 * kx + (kq & 1)) * 8);
+                } else
                 Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (C::CLS ? (KH - 1 - ky) * KW + (KW - 1 - kx) : kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
             }
 #pragma unroll
@@ -629,6 +645,10 @@ using RC_d5ga = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4, true>;
 // e2 input gradient, merged parity classes (K 576, 4 x 32 columns): 4-wave workgroups, a wave = the two column blocks of one class.
 // Measured in the step (2 x 512 images): tile kernel 0.103 ms; 8 waves x one block 0.082; this 0.075; this with 8 rows per step 0.098
 using RC_e2g  = RowCfg<3, 3, 64, 128, 16, 4, 2, 1, 1, 1, false, 4, false, true>;
+// e2 forward (k 6, stride 2, 32 -> 64 channels) as a 3 x 3 stride-1 conv over the space-to-depth input (K 1152)
+using RC_e2f  = RowCfg<3, 3, 128, 64, 16, 4, 1, 1, 1, 1, false, 4, false, false, true>;
+// e1 forward (k 6, stride 2, 8-channel padded RGB -> 32 channels) the same way: 32 s2d channels = ONE K chunk per tap (K 288)
+using RC_e1f  = RowCfg<3, 3, 32, 32, 32, 4, 1, 1, 2, 1, false, 4, false, false, true>;
 
 }  // namespace
 
@@ -642,7 +662,31 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
     const TapGemmArgs& p = t[i];
     if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
     static const bool no_cls = getenv("SV_RC_NO_CLS") != nullptr;     // A/B: merged parity classes on the tile kernel
+    static const bool no_s2d = getenv("SV_RC_NO_S2D") != nullptr;     // A/B: the stride-2 forward on the tile kernel
     const bool cls = p.cls_n > 0;
+    if (p.S == 2 && p.SX == 2 && !cls) {                               // stride-2 forward: the space-to-depth form
+      if (no_s2d || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox || p.mask || p.adj || p.ups) return SV_E_UNSUPPORTED;
+      const int OY = 1 << p.lOY, OX = 1 << p.lOX, cin = (1 << p.cl2) * 8;
+      if (p.IH != 2 * OY || p.IW != 2 * OX || p.OHF != OY || p.OWF != OX || OY % 4) return SV_E_UNSUPPORTED;
+      int c = -1;
+      if (cin == 32 && p.N == 64 && OX == 16) c = 9;                   // e2
+      else if (cin == 8 && p.N == 32 && OX == 32) c = 10;              // e1
+      if (c < 0 || p.lda != cin || p.ntaps != 36 || p.Ktot != 36 * cin || p.ldo < p.N) return SV_E_UNSUPPORTED;
+      for (int q = 0; q < 36; ++q)                                     // the layer's own order: y-major, pad 2
+        if (p.dy[q] != q / 6 - 2 || p.dx[q] != q % 6 - 2) return SV_E_UNSUPPORTED;
+      if (i && cfg != c) return SV_E_UNSUPPORTED;
+      cfg = c;
+      RowConvArgs& r = a[i];
+      r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out; r.mask = nullptr;
+      r.B = p.M >> (p.lOY + p.lOX); r.H = OY; r.W = OX;
+      r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
+      r.y_lo = -1; r.x_lo = -1;
+      int bands = 1;
+      while (n * r.B * bands < 512 && OY / (bands * 2) >= 4 && (OY / (bands * 2)) % 4 == 0) bands *= 2;
+      r.bands = bands; r.band_rows = OY / bands;
+      if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
+      continue;
+    }
     if (cls && (no_cls || p.adj)) return SV_E_UNSUPPORTED;
     if (p.S != 1 || p.SX != 1 || p.OS != (cls ? 2 : 1) || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox) return SV_E_UNSUPPORTED;
     if (p.mask && !p.adj && !cls) return SV_E_UNSUPPORTED;             // a ReLU mask on the output itself: tile kernel
@@ -692,7 +736,8 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
   // fwd.d3 0.077 vs 0.081: their blend staging costs this kernel what the weight streaming costs that one); at small
   // batches this kernel wins clearly (128 images: d3 18 vs 33 us).  SV_RC_FWD=1 / 0 forces it on / off.
   static const int fwd_mode = getenv("SV_RC_FWD") ? atoi(getenv("SV_RC_FWD")) : -1;
-  if ((cfg == 0 || cfg == 2) && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512))) return SV_E_UNSUPPORTED;
+  // (Round 3, re-measured under the two-side-stream schedule: d4 forward 0.137 ms here against 0.146 on the tile kernel, d3 still equal: d4 always here.)
+  if ((cfg == 0 && fwd_mode == 0) || (cfg == 2 && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512)))) return SV_E_UNSUPPORTED;
   return cfg;
 }
 
@@ -714,6 +759,8 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 6: return launch_row<RC_d5g>(a, n, st);
     case 7: return launch_row<RC_d5ga>(a, n, st);
     case 8: return launch_row<RC_e2g>(a, n, st);
+    case 9: return launch_row<RC_e2f>(a, n, st);
+    case 10: return launch_row<RC_e1f>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }
