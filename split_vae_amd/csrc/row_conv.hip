@@ -54,9 +54,9 @@ struct RowConvArgs {
                         // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo].
                         // CLS configs: the layer input [B, 2H, 2W, ldo] whose ReLU mask gates the gradient `out` of the same shape (or null)
 };
-struct RowConvMulti { RowConvArgs a[2]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
+struct RowConvMulti { RowConvArgs a[4]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -76,6 +76,11 @@ struct RowCfg {
   // of s2d tap (ky, kx) is tap (2 ky + py, 2 kx + px) of the layer's own (y-major) weight image -- nothing is re-prepared, only the DMA
   // source address and the one-time weight load index differently.  `A` is the layer's input [B, 2H, 2W, lda], lda = CIN / 4.
   static constexpr bool S2D = S2D_;
+  // PAIR: 8-pixel-wide images (d2's 8 x 8 grid): the 16-pixel strip of an MFMA is the same row of TWO images, laid side by side in the ring
+  // with a zero gap of KW - 1 pixels (each half sees its own SAME padding); a unit of work is a pair of images.  Only the lane's ring
+  // offset, the DMA (one instruction per image) and the store address know.  g.W = 8, g.B = images (the last pair may be half).
+  static constexpr bool PAIR = PAIR_;
+  static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && !S2D_ && CIN_ != 8), "image pairs");
   // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
   static_assert(!S2D_ || (!UPS_ && !ADJ_ && !CLS_ && (CIN_ == 128 || CIN_ == 32)), "space-to-depth form");
   static_assert(!CLS_ || (!UPS_ && !ADJ_ && KS_ == 1 && (N_ / 4) % 16 == 0), "merged parity classes");
@@ -88,7 +93,7 @@ struct RowCfg {
   static constexpr int KHG = TP ? 2 : KH;                     // weight fragments per (chunk, filter column)
   static_assert(NBG * KS * XG * RG == WAVES, "one role per wave");
   static_assert((TP || CIN % 32 == 0) && NCH % KS == 0 && N % (16 * NBW) == 0 && WIDTH % (16 * XG) == 0, "shape");
-  static constexpr int TIW = WIDTH + KW - 1, STEP = RG * MF, WIN = TP ? MF + 4 : MF + KH - 1;
+  static constexpr int TIW = PAIR ? 2 * (8 + KW - 1) : WIDTH + KW - 1, STEP = RG * MF, WIN = TP ? MF + 4 : MF + KH - 1;
   // ring rows.  8 waves: two windows (the current one + the next step's STEP new rows, or the whole first window of the
   // workgroup's NEXT unit, staged during the last step).  4 waves: one window + one step (the next unit's first window
   // is staged between units; the other workgroup of the CU computes meanwhile)
@@ -209,6 +214,26 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
   const bf16_t* img = (const bf16_t*)g.A + (int64_t)b * g.H * g.W * g.lda * (C::S2D ? 4 : 1);
   const int PL = -g.x_lo;
   const bool on = lane < LPR;
+  if constexpr (C::PAIR) {                                   // b = pair index: images 2b, 2b + 1, each row half its own 16-lane DMA
+    for (int idx = w; idx < nrows * C::NPL; idx += nw) {
+      const int d = idx / C::NPL, p = idx - d * C::NPL;
+      const int Y = Ya + d;
+      int slot = qa + d;
+      if (slot >= C::R) slot -= C::R;
+      const bool inside = (unsigned)Y < (unsigned)g.H;
+#pragma unroll
+      for (int im = 0; im < 2; ++im) {
+        const int bi = 2 * b + im;
+        char* dst = sRing + p * C::PLB + slot * C::ROWB + (PL + im * (8 + C::KW - 1)) * 32;
+        const bf16_t* src = (const bf16_t*)g.A + (((int64_t)bi * g.H + Y) * 8 + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
+        if (lane < 16) {
+          if (inside && bi < g.B) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+    return;
+  }
   for (int idx = w; idx < nrows * C::NPL; idx += nw) {
     const int d = idx / C::NPL, p = idx - d * C::NPL;
     const int Y = Ya + d;
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   constexpr int NT = C::NT;
   const int dbg0 = SV_DBG(mg.dbg);
   const int m = lane & 15, kq = lane >> 4;
-  const int lane_off = C::TP ? m * 16 + kq * C::ROWB : m * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
+  const int lane_off = C::TP ? m * 16 + kq * C::ROWB : (m + (C::PAIR ? (m >> 3) * (KW - 1) : 0)) * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
   if (tid < 16) sFlag[tid] = 0;
   const int dbg = SV_DBG(mg.dbg);                           // 1 skip staging, 2 skip the MFMA loop, 4 skip the stores, 8 skip the K-half exchange
 
@@ -318,7 +343,10 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   // first window of the workgroup's NEXT unit, which lands right behind the current window (R = two windows).
   constexpr int NST = C::SPW * NBW * MF;                      // global stores a storing wave issues per step (behind its DMAs)
   if (!(dbg & 1)) {
-    const int prob = blockIdx.x / mg.units_per_prob, r0 = blockIdx.x - prob * mg.units_per_prob;
+    // PAIR (four problems: twins x output-channel halves): unit u = (r0, prob) with prob fastest, so a workgroup (grid % problems == 0)
+    // stays on one problem and loads its weights once
+    const int np = mg.units / mg.units_per_prob;
+    const int prob = C::PAIR ? (int)blockIdx.x % np : (int)blockIdx.x / mg.units_per_prob, r0 = C::PAIR ? (int)blockIdx.x / np : (int)blockIdx.x - prob * mg.units_per_prob;
     const RowConvArgs& g = mg.a[prob];
     if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
     else {
@@ -334,16 +362,17 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   }
   int q0 = 0;                                                // ring slot of input row y0 + y_lo of the current step
   for (int u = blockIdx.x; u < mg.units; u += gridDim.x) {
-    const int prob = u / mg.units_per_prob;
+    const int np = mg.units / mg.units_per_prob;
+    const int prob = C::PAIR ? u % np : u / mg.units_per_prob;
     const RowConvArgs& g = mg.a[prob];
-    const int r0 = u - prob * mg.units_per_prob;
+    const int r0 = C::PAIR ? u / np : u - prob * mg.units_per_prob;
     const int band = r0 % g.bands, b = r0 / g.bands;
     const int yb = band * g.band_rows;
     const int un = u + gridDim.x;                            // the next unit of this workgroup
     const bool has_next = un < mg.units;
-    const int nprob = has_next ? un / mg.units_per_prob : prob;
+    const int nprob = has_next ? (C::PAIR ? un % np : un / mg.units_per_prob) : prob;
     const RowConvArgs& gn = mg.a[nprob];
-    const int rn = un - nprob * mg.units_per_prob;
+    const int rn = C::PAIR ? un / np : un - nprob * mg.units_per_prob;
     if (prob != cur_prob) {
       cur_prob = prob;
       const bf16_t* Wt = (const bf16_t*)g.Wt;
@@ -529,8 +558,11 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
           }
         } else
         if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
-          // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m
-          bf16_t* ob = (bf16_t*)g.out + (((int64_t)b * g.H + yw) * g.W + x0 + m) * g.ldo + kq * 4;
+          // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m (PAIR: pixel m & 7 of image 2b + (m >> 3))
+          const int bi = C::PAIR ? 2 * b + (m >> 3) : b;
+          const int64_t o0 = (((int64_t)bi * g.H + yw) * g.W + (C::PAIR ? (m & 7) : x0 + m)) * g.ldo + kq * 4;
+          bf16_t* ob = (bf16_t*)g.out + o0;
+          const bool st_on = !C::PAIR || bi < g.B;
 #pragma unroll
           for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -542,7 +574,17 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 if (g.act == SV_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
               }
               bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-              *(uint2*)(ob + (int64_t)j * g.W * g.ldo + (nbg * NBW + nb) * 16) = *(const uint2*)pk;
+              const int64_t oo = (int64_t)j * g.W * g.ldo + (nbg * NBW + nb) * 16;
+              if (C::PAIR && g.mask && st_on) {                 // a ReLU mask on the output itself (d2's input gradient)
+                const uint2 mv = *(const uint2*)((const bf16_t*)g.mask + o0 + oo);
+                const uint32_t mw[2] = {mv.x, mv.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                  if ((h & 0x8000u) || !(h & 0x7fffu)) pk[e] = (bf16_t)0.f;
+                }
+              }
+              if (st_on) *(uint2*)(ob + oo) = *(const uint2*)pk;
             }
         }
         SV_STAMP(t_epi);
@@ -590,9 +632,8 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 template <typename C>
 static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
   RowConvMulti m;
-  for (int i = 0; i < n; ++i) m.a[i] = a[i];
-  if (n == 1) m.a[1] = a[0];
-  m.units_per_prob = a[0].B * a[0].bands;
+  for (int i = 0; i < 4; ++i) m.a[i] = a[i < n ? i : 0];
+  m.units_per_prob = (C::PAIR ? (a[0].B + 1) / 2 : a[0].B) * a[0].bands;
   m.units = n * m.units_per_prob;
   m.dbg = 0;
   m.stamps = nullptr;
@@ -606,7 +647,8 @@ static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
 #endif
   static const int wgs_env = getenv("SV_RC_WGS") ? atoi(getenv("SV_RC_WGS")) : 0;
   const int wgs_max = wgs_env ? wgs_env : 256 * (8 / C::WAVES);                          // one 8-wave or two 4-wave workgroups per CU
-  const int grid = m.units < wgs_max ? m.units : wgs_max;
+  int grid = m.units < wgs_max ? m.units : wgs_max;
+  if (C::PAIR) grid = grid / n * n;                          // a workgroup stays on one problem (see the kernel's unit decode)
   sv_ensure_dynamic_lds((const void*)row_conv_kernel<C>, C::LDS);
   hipLaunchKernelGGL((row_conv_kernel<C>), dim3(grid), dim3(C::NT), C::LDS, st, m);
   SV_LAUNCH_CHECK();
@@ -645,6 +687,9 @@ using RC_d5ga = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4, true>;
 // e2 input gradient, merged parity classes (K 576, 4 x 32 columns): 4-wave workgroups, a wave = the two column blocks of one class.
 // Measured in the step (2 x 512 images): tile kernel 0.103 ms; 8 waves x one block 0.082; this 0.075; this with 8 rows per step 0.098
 using RC_e2g  = RowCfg<3, 3, 64, 128, 16, 4, 2, 1, 1, 1, false, 4, false, true>;
+// d2 forward / input gradient (k 4, 128 -> 128 channels on the 8 x 8 grid, K 2048): image PAIRS per strip; its 512 KB of weights do not fit one CU's
+// registers, so every problem runs as two output-channel halves (N 64: the d3-forward register budget) -- four problems per launch
+using RC_d2   = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, false, 8, false, false, false, true>;
 // e2 forward (k 6, stride 2, 32 -> 64 channels) as a 3 x 3 stride-1 conv over the space-to-depth input (K 1152)
 using RC_e2f  = RowCfg<3, 3, 128, 64, 16, 4, 1, 1, 1, 1, false, 4, false, false, true>;
 // e1 forward (k 6, stride 2, 8-channel padded RGB -> 32 channels) the same way: 32 s2d channels = ONE K chunk per tap (K 288)
@@ -654,10 +699,11 @@ using RC_e1f  = RowCfg<3, 3, 32, 32, 32, 4, 1, 1, 2, 1, false, 4, false, false, 
 
 // n (1 or 2: the x / x-hat twins) tap-GEMM problems of identical geometry on the row-ring kernel; SV_E_UNSUPPORTED when
 // the shape has no instantiation (the caller falls back to the tile kernel)
-static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {      // -> instantiation id, or SV_E_UNSUPPORTED
+static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int* nprob = nullptr) {      // a[4]; -> instantiation id (and the number of kernel problems), or SV_E_UNSUPPORTED
   static const bool off = getenv("SV_NO_ROWCONV") != nullptr;          // A/B: the tile kernel for every layer
   if (off || dtype != SV_BF16 || n < 1 || n > 2) return SV_E_UNSUPPORTED;
   int cfg = -1;
+  if (nprob) *nprob = n;
   for (int i = 0; i < n; ++i) {
     const TapGemmArgs& p = t[i];
     if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
@@ -685,6 +731,31 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
       while (n * r.B * bands < 512 && OY / (bands * 2) >= 4 && (OY / (bands * 2)) % 4 == 0) bands *= 2;
       r.bands = bands; r.band_rows = OY / bands;
       if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
+      continue;
+    }
+    static const bool no_pair = getenv("SV_RC_NO_PAIR") != nullptr;   // A/B: the 8 x 8-grid layer d2 on the tile kernel
+    // (measured, 2 x 512 images: forward 0.053 -> 0.048 ms; the input gradient 0.056 -> 0.058, so only SV_RC_PAIR_DGRAD=1 sends it here)
+    static const bool pair_dgrad = getenv("SV_RC_PAIR_DGRAD") != nullptr;
+    if (!no_pair && !cls && p.S == 1 && p.SX == 1 && p.OS == 1 && p.lOX == 3 && p.lOY == 3 && p.ntaps == 16 && p.N == 128 && !p.ups && !p.adj && (!p.mask || pair_dgrad)) {
+      // d2 forward / input gradient: image pairs per strip, two output-channel halves per problem (RC_d2)
+      const int cin = (1 << p.cl2) * 8;
+      if (p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox || cin != 128 || p.lda != 128 || p.Ktot != 16 * 128 || p.ldo < 128) return SV_E_UNSUPPORTED;
+      if (p.IH != 8 || p.IW != 8 || p.OHF != 8 || p.OWF != 8) return SV_E_UNSUPPORTED;
+      for (int q = 0; q < 16; ++q)                                     // x-major, y-minor full grid
+        if (p.dy[q] != p.dy[0] + q % 4 || p.dx[q] != p.dx[0] + q / 4) return SV_E_UNSUPPORTED;
+      if (i && cfg != 11) return SV_E_UNSUPPORTED;
+      cfg = 11;
+      for (int h = 0; h < 2; ++h) {
+        RowConvArgs& r = a[2 * i + h];
+        r.A = p.A; r.Wt = (const bf16_t*)p.Wt + (int64_t)h * 64 * p.Ktot; r.bias = p.bias ? p.bias + 64 * h : nullptr;
+        r.out = (bf16_t*)p.out + 64 * h; r.mask = p.mask ? (const bf16_t*)p.mask + 64 * h : nullptr;
+        r.B = p.M >> 6; r.H = 8; r.W = 8;
+        r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
+        r.y_lo = p.dy[0]; r.x_lo = p.dx[0];
+        r.bands = 1; r.band_rows = 8;
+      }
+      if (i && a[2 * i].B != a[0].B) return SV_E_UNSUPPORTED;
+      if (nprob) *nprob = 2 * n;
       continue;
     }
     if (cls && (no_cls || p.adj)) return SV_E_UNSUPPORTED;
@@ -742,13 +813,13 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a) {   
 }
 
 bool svk_row_conv_supported(const TapGemmArgs* t, int n, int dtype) {
-  RowConvArgs a[2];
+  RowConvArgs a[4];
   return row_plan(t, n, dtype, a) >= 0;
 }
 
 int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
-  RowConvArgs a[2];
-  const int cfg = row_plan(t, n, dtype, a);
+  RowConvArgs a[4];
+  const int cfg = row_plan(t, n, dtype, a, &n);
   switch (cfg) {
     case 0: return launch_row<RC_d4f>(a, n, st);
     case 1: return launch_row<RC_d4g>(a, n, st);
@@ -761,6 +832,7 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 8: return launch_row<RC_e2g>(a, n, st);
     case 9: return launch_row<RC_e2f>(a, n, st);
     case 10: return launch_row<RC_e1f>(a, n, st);
+    case 11: return launch_row<RC_d2>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }
