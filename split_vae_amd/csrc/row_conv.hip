@@ -1,4 +1,6 @@
-// Weight-stationary stride-1 NHWC convolution for the decoder stack (d3/d4 forward and input gradients), gfx950.
+// Weight-stationary stride-1 NHWC convolution, gfx950: the decoder stack (d3 / d4 / d5 forward and input gradients, d2 forward) and -- as
+// stride-1 problems in disguise -- the encoder's stride-2 layers e1 / e2 forward (space-to-depth view, RowCfg::S2D) and e2's input gradient
+// (merged parity classes, RowCfg::CLS); 8-pixel-wide images go two to a strip (RowCfg::PAIR).  DESIGN.md 4h.
 //
 // tile_conv.hip re-streams the weight tile of every K step through LDS for every 256-pixel tile and runs its phases
 // (stage -> K loop -> store) one after the other inside a workgroup.  Here the roles are turned around:

@@ -358,6 +358,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_roll_kernel(const RollMulti mg) 
 
 }  // namespace
 
+// workgroups per problem: one per CU over the launch, and at least `SV_ROLL_MIN_STRIPS` strips each (every workgroup flushes a 295-KB slab
+// whatever it computed: at 64 images per network 128 one-strip workgroups wrote and re-read 75 MB for 19 steps of work each)
+static int roll_wgs(int n, int nstrips) {
+  static const int min_strips = getenv("SV_ROLL_MIN_STRIPS") ? atoi(getenv("SV_ROLL_MIN_STRIPS")) : 1;
+  int X = 256 / n;
+  const int cap = (nstrips + min_strips - 1) / min_strips;
+  if (X > cap) X = cap;
+  return X < 1 ? 1 : X;
+}
+
 bool svk_wgrad_roll_supported(const WgradArgs* wv, int n) {
   static const bool off = getenv("SV_NO_WGRAD_ROLL") != nullptr;
   if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) return false;
@@ -369,8 +379,7 @@ bool svk_wgrad_roll_supported(const WgradArgs* wv, int n) {
     if (w.dy[t] != t / KS - PAD || w.dx[t] != t % KS - PAD) return false;
   const int B = w.M >> (w.lOY + w.lOX);
   const int nstrips = B * (w.OX / 16);
-  int X = 256 / n;
-  if (X > nstrips) X = nstrips;
+  const int X = roll_wgs(n, nstrips);
   const int64_t need = (int64_t)X * 4 * 72 * 256 * 4 + (int64_t)X * 128 * 4;
   for (int i = 0; i < n; ++i)
     if (!wv[i].ws || wv[i].ws_bytes < need) return false;
@@ -383,8 +392,7 @@ int svk_wgrad_roll_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const int B = w.M >> (w.lOY + w.lOX);
   RollMulti m;
   const int nxs = w.OX / 16, nstrips = B * nxs;
-  int X = 256 / n;                                  // one workgroup per CU over the whole launch
-  if (X > nstrips) X = nstrips;
+  const int X = roll_wgs(n, nstrips);
   WgradReduceDesc rd[SV_WGRAD_MAX_MULTI];
   for (int i = 0; i < n; ++i) {
     RollArgs& a = m.a[i];
