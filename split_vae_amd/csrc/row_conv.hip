@@ -82,9 +82,12 @@ struct RowCfg {
   // with a zero gap of KW - 1 pixels (each half sees its own SAME padding); a unit of work is a pair of images.  Only the lane's ring
   // offset, the DMA (one instruction per image) and the store address know.  g.W = 8, g.B = images (the last pair may be half).
   static constexpr bool PAIR = PAIR_;
-  static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && !S2D_ && CIN_ != 8), "image pairs");
+  static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && CIN_ != 8 && (!S2D_ || CIN_ == 256)), "image pairs");
   // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
-  static_assert(!S2D_ || (!UPS_ && !ADJ_ && !CLS_ && (CIN_ == 128 || CIN_ == 32)), "space-to-depth form");
+  // CIN 256 (e3: k 4, pad 1, 64-channel sub-pixels, with PAIR): the 2 x 2 blocks are aligned one pixel EARLIER -- block (Y, X) = input rows
+  // 2Y - 1, 2Y x columns 2X - 1, 2X -- so that the four taps of a row are exactly two blocks (KH = KW = 2, y_lo = x_lo = 0): block row / column 8
+  // of the 9 x 9 block grid holds real data in its first sub-row / sub-column (the kernel stages it as its halo row / pixel).
+  static_assert(!S2D_ || (!UPS_ && !ADJ_ && !CLS_ && (CIN_ == 128 || CIN_ == 32 || (CIN_ == 256 && PAIR_))), "space-to-depth form");
   static_assert(!CLS_ || (!UPS_ && !ADJ_ && KS_ == 1 && (N_ / 4) % 16 == 0), "merged parity classes");
   // TP: 8-channel pixels (the 6-channel head's gradient): one 16-B piece per pixel, so an MFMA K step (32) packs FOUR
   // taps -- the four lane quarters read four consecutive input ROWS (ky = 4g + kq; KH = 6 -> two groups, 2 of 8 dummies)
@@ -227,6 +230,18 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
       for (int im = 0; im < 2; ++im) {
         const int bi = 2 * b + im;
         char* dst = sRing + p * C::PLB + slot * C::ROWB + (PL + im * (8 + C::KW - 1)) * 32;
+        if constexpr (C::S2D) {
+          // plane p = sub-pixel (py, px) = (p >> 3, (p >> 2) & 1), 16-channel quarter p & 3 of input pixel (2Y + py - 1, 2X + px - 1), X = 0..8;
+          // a sub-row / sub-column outside the 16 x 16 input is never written by a DMA: zero-filled row, or the ring's initial zeros
+          const int py = p >> 3, px = (p >> 2) & 1, iy = 2 * Y + py - 1, ix = 2 * (lane >> 1) + px - 1;
+          const bf16_t* src = (const bf16_t*)g.A + (((int64_t)bi * 16 + iy) * 16 + ix) * g.lda + (p & 3) * 16 + (lane & 1) * 8;
+          if (lane < 18) {
+            if ((unsigned)iy < 16u && bi < g.B) {
+              if ((unsigned)ix < 16u) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else *(uint4*)(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+          }
+          continue;
+        }
         const bf16_t* src = (const bf16_t*)g.A + (((int64_t)bi * g.H + Y) * 8 + (lane >> 1)) * g.lda + (2 * p + (lane & 1)) * 8;
         if (lane < 16) {
           if (inside && bi < g.B) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -395,6 +410,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 if constexpr (C::S2D && C::CIN == 128) {
                   const int c4 = ks * CPW + cc, py = c4 >> 1, px = c4 & 1;
                   Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + py) * (2 * KW) + 2 * kx + px) * 32 + kq * 8);
+                } else if constexpr (C::S2D && C::CIN == 256) {
+                  const int c8 = ks * CPW + cc, py = c8 >> 2, px = (c8 >> 1) & 1;
+                  Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + py) * (2 * KW) + 2 * kx + px) * 64 + (c8 & 1) * 32 + kq * 8);
                 } else if constexpr (C::S2D) {
                   Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + (kq >> 1)) * (2 * KW) + 2 * kx + (kq & 1)) * 8);
                 } else
@@ -692,6 +710,8 @@ using RC_e2g  = RowCfg<3, 3, 64, 128, 16, 4, 2, 1, 1, 1, false, 4, false, true>;
 // d2 forward / input gradient (k 4, 128 -> 128 channels on the 8 x 8 grid, K 2048): image PAIRS per strip; its 512 KB of weights do not fit one CU's
 // registers, so every problem runs as two output-channel halves (N 64: the d3-forward register budget) -- four problems per launch
 using RC_d2   = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, false, 8, false, false, false, true>;
+// e3 forward (k 4, stride 2, 64 -> 128 channels, 16 x 16 -> 8 x 8): space-to-depth with shifted blocks (K 1024) on image pairs
+using RC_e3f  = RowCfg<2, 2, 256, 128, 16, 4, 1, 1, 1, 1, false, 8, false, false, true, true>;
 // e2 forward (k 6, stride 2, 32 -> 64 channels) as a 3 x 3 stride-1 conv over the space-to-depth input (K 1152)
 using RC_e2f  = RowCfg<3, 3, 128, 64, 16, 4, 1, 1, 1, 1, false, 4, false, false, true>;
 // e1 forward (k 6, stride 2, 8-channel padded RGB -> 32 channels) the same way: 32 s2d channels = ONE K chunk per tap (K 288)
@@ -711,6 +731,7 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
     if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
     static const bool no_cls = getenv("SV_RC_NO_CLS") != nullptr;     // A/B: merged parity classes on the tile kernel
     static const bool no_s2d = getenv("SV_RC_NO_S2D") != nullptr;     // A/B: the stride-2 forward on the tile kernel
+    static const bool no_pair_s2d = getenv("SV_RC_NO_E3") != nullptr; // A/B: e3's forward on the tile kernel
     const bool cls = p.cls_n > 0;
     if (p.S == 2 && p.SX == 2 && !cls) {                               // stride-2 forward: the space-to-depth form
       if (no_s2d || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox || p.mask || p.adj || p.ups) return SV_E_UNSUPPORTED;
@@ -719,16 +740,19 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
       int c = -1;
       if (cin == 32 && p.N == 64 && OX == 16) c = 9;                   // e2
       else if (cin == 8 && p.N == 32 && OX == 32) c = 10;              // e1
-      if (c < 0 || p.lda != cin || p.ntaps != 36 || p.Ktot != 36 * cin || p.ldo < p.N) return SV_E_UNSUPPORTED;
-      for (int q = 0; q < 36; ++q)                                     // the layer's own order: y-major, pad 2
-        if (p.dy[q] != q / 6 - 2 || p.dx[q] != q % 6 - 2) return SV_E_UNSUPPORTED;
+      else if (cin == 64 && p.N == 128 && OX == 8 && OY == 8 && !no_pair_s2d) c = 12;    // e3 (k 4)
+      const int kk = c == 12 ? 4 : 6, pad = c == 12 ? 1 : 2;
+      if (c < 0 || p.lda != cin || p.ntaps != kk * kk || p.Ktot != kk * kk * cin || p.ldo < p.N) return SV_E_UNSUPPORTED;
+      for (int q = 0; q < kk * kk; ++q)                                // the layer's own order: y-major
+        if (p.dy[q] != q / kk - pad || p.dx[q] != q % kk - pad) return SV_E_UNSUPPORTED;
       if (i && cfg != c) return SV_E_UNSUPPORTED;
       cfg = c;
       RowConvArgs& r = a[i];
       r.A = p.A; r.Wt = p.Wt; r.bias = p.bias; r.out = p.out; r.mask = nullptr;
       r.B = p.M >> (p.lOY + p.lOX); r.H = OY; r.W = OX;
       r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
-      r.y_lo = -1; r.x_lo = -1;
+      r.y_lo = c == 12 ? 0 : -1; r.x_lo = c == 12 ? 0 : -1;
+      if (c == 12) { r.W = 8; r.bands = 1; r.band_rows = 8; if (i && r.B != a[0].B) return SV_E_UNSUPPORTED; continue; }
       int bands = 1;
       while (n * r.B * bands < 512 && OY / (bands * 2) >= 4 && (OY / (bands * 2)) % 4 == 0) bands *= 2;
       r.bands = bands; r.band_rows = OY / bands;
@@ -835,6 +859,7 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 9: return launch_row<RC_e2f>(a, n, st);
     case 10: return launch_row<RC_e1f>(a, n, st);
     case 11: return launch_row<RC_d2>(a, n, st);
+    case 12: return launch_row<RC_e3f>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }

@@ -253,6 +253,7 @@ LAYERS = [  # name, H, Cin, Cout, k, stride, act, y_f32
     ("d4_128", 64, 64, 32, 6, 1, "relu", False),     # four strips: first / inner / last strip variants of the rolling-window kernel
     ("e2_64", 32, 32, 64, 6, 2, "relu", False),      # 16 x 16 class grid: the merged parity classes of its input gradient on the row-ring kernel
     ("d2_64", 8, 128, 128, 4, 1, "relu", False),     # 8 x 8 grid: image pairs per strip on the row-ring kernel (B = 3: a half pair)
+    ("e3_64", 16, 64, 128, 4, 2, "relu", False),     # k 4 stride 2 onto the 8 x 8 grid: shifted space-to-depth blocks on image pairs
 ]
 
 
