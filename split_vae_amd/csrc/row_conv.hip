@@ -52,13 +52,15 @@ struct RowConvArgs {
   int lda, ldo, Ktot, act;
   int y_lo, x_lo;       // tap (ky, kx) reads input pixel (y + ky + y_lo, x + kx + x_lo)
   int bands, band_rows; // an image is cut into `bands` row bands of band_rows rows (a unit of work = one band)
+  int os, ooy, oox;     // output pixel of grid pixel (y, x): (os * y + ooy, os * x + oox) of a [B, os * H, os * W, ldo] tensor (os = 2: one parity
+                        // class of a stride-2 layer's input gradient; 1, 0, 0 otherwise)
   const void* mask;     // ADJ configs: the low-res activation whose ReLU mask (> 0) gates the low-res gradient (or null);
                         // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo].
                         // CLS configs: the layer input [B, 2H, 2W, ldo] whose ReLU mask gates the gradient `out` of the same shape (or null)
 };
-struct RowConvMulti { RowConvArgs a[4]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
+struct RowConvMulti { RowConvArgs a[8]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -82,6 +84,7 @@ struct RowCfg {
   // with a zero gap of KW - 1 pixels (each half sees its own SAME padding); a unit of work is a pair of images.  Only the lane's ring
   // offset, the DMA (one instruction per image) and the store address know.  g.W = 8, g.B = images (the last pair may be half).
   static constexpr bool PAIR = PAIR_;
+  static constexpr bool REV = REV_ || CLS_;                   // the weight image holds the taps y-major with DESCENDING offsets (the parity classes' order)
   static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && CIN_ != 8 && (!S2D_ || CIN_ == 256)), "image pairs");
   // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
   // CIN 256 (e3: k 4, pad 1, 64-channel sub-pixels, with PAIR): the 2 x 2 blocks are aligned one pixel EARLIER -- block (Y, X) = input rows
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 } else if constexpr (C::S2D) {
                   Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * ky + (kq >> 1)) * (2 * KW) + 2 * kx + (kq & 1)) * 8);
                 } else
-                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (C::CLS ? (KH - 1 - ky) * KW + (KW - 1 - kx) : kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
+                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (C::REV ? (KH - 1 - ky) * KW + (KW - 1 - kx) : kx * KH + ky) * C::CIN + (ks * CPW + cc) * 32 + kq * 8);
             }
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[nb][e] = g.bias ? g.bias[(nbg * NBW + nb) * 16 + kq * 4 + e] : 0.f;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
         if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
           // D rows = channels: a lane holds 4 consecutive channels of pixel x0 + m (PAIR: pixel m & 7 of image 2b + (m >> 3))
           const int bi = C::PAIR ? 2 * b + (m >> 3) : b;
-          const int64_t o0 = (((int64_t)bi * g.H + yw) * g.W + (C::PAIR ? (m & 7) : x0 + m)) * g.ldo + kq * 4;
+          const int64_t o0 = (((int64_t)bi * (g.os * g.H) + g.os * yw + g.ooy) * (g.os * g.W) + g.os * (C::PAIR ? (m & 7) : x0 + m) + g.oox) * g.ldo + kq * 4;
           bf16_t* ob = (bf16_t*)g.out + o0;
           const bool st_on = !C::PAIR || bi < g.B;
 #pragma unroll
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
                 if (g.act == SV_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
               }
               bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-              const int64_t oo = (int64_t)j * g.W * g.ldo + (nbg * NBW + nb) * 16;
+              const int64_t oo = (int64_t)j * g.os * (g.os * g.W) * g.ldo + (nbg * NBW + nb) * 16;
               if (C::PAIR && g.mask && st_on) {                 // a ReLU mask on the output itself (d2's input gradient)
                 const uint2 mv = *(const uint2*)((const bf16_t*)g.mask + o0 + oo);
                 const uint32_t mw[2] = {mv.x, mv.y};
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 template <typename C>
 static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
   RowConvMulti m;
-  for (int i = 0; i < 4; ++i) m.a[i] = a[i < n ? i : 0];
+  for (int i = 0; i < 8; ++i) m.a[i] = a[i < n ? i : 0];
   m.units_per_prob = (C::PAIR ? (a[0].B + 1) / 2 : a[0].B) * a[0].bands;
   m.units = n * m.units_per_prob;
   m.dbg = 0;
@@ -712,6 +715,9 @@ using RC_e2g  = RowCfg<3, 3, 64, 128, 16, 4, 2, 1, 1, 1, false, 4, false, true>;
 using RC_d2   = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, false, 8, false, false, false, true>;
 // e3 forward (k 4, stride 2, 64 -> 128 channels, 16 x 16 -> 8 x 8): space-to-depth with shifted blocks (K 1024) on image pairs
 using RC_e3f  = RowCfg<2, 2, 256, 128, 16, 4, 1, 1, 1, 1, false, 8, false, false, true, true>;
+// e3 input gradient (k 4, stride 2): its four parity classes are four 2 x 2 stride-1 problems over the 8 x 8 dY grid with their own windows
+// (K 512, 64 columns each, class -> sub-pixel store with the ReLU mask): eight problems per launch (classes x networks) on image pairs
+using RC_e3g  = RowCfg<2, 2, 128, 64, 16, 4, 1, 1, 1, 1, false, 4, false, false, false, true, true>;
 // e2 forward (k 6, stride 2, 32 -> 64 channels) as a 3 x 3 stride-1 conv over the space-to-depth input (K 1152)
 using RC_e2f  = RowCfg<3, 3, 128, 64, 16, 4, 1, 1, 1, 1, false, 4, false, false, true>;
 // e1 forward (k 6, stride 2, 8-channel padded RGB -> 32 channels) the same way: 32 s2d channels = ONE K chunk per tap (K 288)
@@ -723,12 +729,14 @@ using RC_e1f  = RowCfg<3, 3, 32, 32, 32, 4, 1, 1, 2, 1, false, 4, false, false, 
 // the shape has no instantiation (the caller falls back to the tile kernel)
 static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int* nprob = nullptr) {      // a[4]; -> instantiation id (and the number of kernel problems), or SV_E_UNSUPPORTED
   static const bool off = getenv("SV_NO_ROWCONV") != nullptr;          // A/B: the tile kernel for every layer
-  if (off || dtype != SV_BF16 || n < 1 || n > 2) return SV_E_UNSUPPORTED;
+  if (off || dtype != SV_BF16 || n < 1 || n > 8) return SV_E_UNSUPPORTED;
   int cfg = -1;
   if (nprob) *nprob = n;
+  for (int k = 0; k < 8; ++k) { a[k].os = 1; a[k].ooy = 0; a[k].oox = 0; }
   for (int i = 0; i < n; ++i) {
     const TapGemmArgs& p = t[i];
     if (p.lOY < 0 || p.lOX < 0) return SV_E_UNSUPPORTED;
+    if (n > 2 && !(getenv("SV_RC_E3G") && p.S == 1 && p.OS == 2 && p.ntaps == 4 && !p.cls_n)) return SV_E_UNSUPPORTED;   // more than the twins: only e3's class problems
     static const bool no_cls = getenv("SV_RC_NO_CLS") != nullptr;     // A/B: merged parity classes on the tile kernel
     static const bool no_s2d = getenv("SV_RC_NO_S2D") != nullptr;     // A/B: the stride-2 forward on the tile kernel
     static const bool no_pair_s2d = getenv("SV_RC_NO_E3") != nullptr; // A/B: e3's forward on the tile kernel
@@ -759,6 +767,28 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
       if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
       continue;
     }
+    // (measured, 2 x 512 images: 0.050 ms here against 0.044 on the tile kernel -- eight problems of two 4-row steps per image pair are all
+    // prologue --, so only SV_RC_E3G=1 sends it here)
+    static const bool e3g = getenv("SV_RC_E3G") != nullptr;
+    if (e3g && !cls && p.S == 1 && p.SX == 1 && p.OS == 2 && p.ntaps == 4 && p.N == 64 && p.lOX == 3 && p.lOY == 3 && !p.ups && !p.adj) {
+      const int cin = (1 << p.cl2) * 8;
+      if (p.splitk != 1 || p.d2s || p.out_f32 || p.bias || cin != 128 || p.lda != 128 || p.Ktot != 4 * 128 || p.ldo < 64) return SV_E_UNSUPPORTED;
+      if (p.IH != 8 || p.IW != 8 || p.OHF != 16 || p.OWF != 16 || (unsigned)p.ooy > 1u || (unsigned)p.oox > 1u) return SV_E_UNSUPPORTED;
+      for (int q = 0; q < 4; ++q)                                      // the class's own order: y-major, offsets descending
+        if (p.dy[q] != p.dy[0] - q / 2 || p.dx[q] != p.dx[0] - q % 2) return SV_E_UNSUPPORTED;
+      if (i && cfg != 13) return SV_E_UNSUPPORTED;
+      cfg = 13;
+      RowConvArgs& r = a[i];
+      r.A = p.A; r.Wt = p.Wt; r.bias = nullptr; r.out = p.out; r.mask = p.mask;
+      r.B = p.M >> 6; r.H = 8; r.W = 8;
+      r.lda = p.lda; r.ldo = p.ldo; r.Ktot = p.Ktot; r.act = p.act;
+      r.y_lo = p.dy[0] - 1; r.x_lo = p.dx[0] - 1;
+      r.bands = 1; r.band_rows = 8;
+      r.os = 2; r.ooy = p.ooy; r.oox = p.oox;
+      if (i && r.B != a[0].B) return SV_E_UNSUPPORTED;
+      continue;
+    }
+    if (n > 2) return SV_E_UNSUPPORTED;                               // every other form: one problem or the x / x-hat twins
     static const bool no_pair = getenv("SV_RC_NO_PAIR") != nullptr;   // A/B: the 8 x 8-grid layer d2 on the tile kernel
     // (measured, 2 x 512 images: forward 0.053 -> 0.048 ms; the input gradient 0.056 -> 0.058, so only SV_RC_PAIR_DGRAD=1 sends it here)
     static const bool pair_dgrad = getenv("SV_RC_PAIR_DGRAD") != nullptr;
@@ -839,12 +869,12 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
 }
 
 bool svk_row_conv_supported(const TapGemmArgs* t, int n, int dtype) {
-  RowConvArgs a[4];
+  RowConvArgs a[8];
   return row_plan(t, n, dtype, a) >= 0;
 }
 
 int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
-  RowConvArgs a[4];
+  RowConvArgs a[8];
   const int cfg = row_plan(t, n, dtype, a, &n);
   switch (cfg) {
     case 0: return launch_row<RC_d4f>(a, n, st);
@@ -860,6 +890,7 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 10: return launch_row<RC_e1f>(a, n, st);
     case 11: return launch_row<RC_d2>(a, n, st);
     case 12: return launch_row<RC_e3f>(a, n, st);
+    case 13: return launch_row<RC_e3g>(a, n, st);
   }
   return SV_E_UNSUPPORTED;
 }

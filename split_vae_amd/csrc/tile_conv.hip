@@ -673,7 +673,8 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   static const bool no_multi = getenv("SV_NO_MULTI") != nullptr;        // A/B: one launch per problem
   static const int dbg = SV_DBG(getenv("SV_TC_DBG") ? atoi(getenv("SV_TC_DBG")) : 0);
   if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
-  if (!force_tap && n <= 2) {                          // the decoder's wide stride-1 layers: weights in registers, rows rolling through LDS
+  if (!force_tap && n <= 8) {                          // weights in registers, rows rolling through LDS (row_conv.hip takes one problem, the x / x-hat
+                                                       // twins, or the up to eight class problems of a stride-2 layer's input gradient)
     const int rc = svk_row_conv_try(t, n, dtype, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
