@@ -478,6 +478,9 @@ def main():
                            "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
                                      prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, args.dtype, world) else
                                      "main (the weight-gradient side stream runs other layers' launches beside it)",
+                           "live_note": "achieved / frac are LIVE: hipEvents around the launch on its stream inside the timed region, where up to three "
+                                        "launches share the chip (two weight-gradient side streams beside the input-gradient chain from 768 images per "
+                                        "launch: DESIGN.md 4g); `serial` is the same launch alone on the chip",
                            "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
         gs = grade(dom, args.dtype)
         out["roofline"]["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
