@@ -537,6 +537,48 @@ def test_merged_parity_classes_on_the_row_ring_kernel(lib_built, tmp_path):
         assert not np.any(res[0][keys[i + 1]][~gate]) and np.count_nonzero(res[0][keys[i + 1]]) > gate.sum() // 2
 
 
+def test_e1_weight_gradient_wave_pipeline(lib_built, tmp_path):
+    """e1's weight gradient at a batch where the per-wave pipeline runs (wgrad_e1.hip: from 512 strips per launch) against the fp64 gradient
+    of the same bf16 operands (conv2d_same + autograd on the CPU) and against the tile kernel (SV_NO_WGRAD_E1=1): dW, dbias; an odd batch
+    (257: ragged last workgroup) and the two-network launch shape are covered by the step tests."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(21)\n"
+        "outs = []\n"
+        "for B in (256, 257):\n"
+        "    x = torch.randn(B, 64, 64, 3, generator=g).bfloat16()\n"
+        "    dy = torch.randn(B, 32, 32, 32, generator=g).bfloat16()\n"
+        "    c = ops.Conv2D(B, 64, 64, 3, 32, 6, 2, act='relu', dtype=torch.bfloat16); c.prep((torch.randn(6, 6, 3, 32, generator=g) * 0.05).cuda())\n"
+        "    xp = torch.zeros(B, 64, 64, c.desc.ldx, dtype=torch.bfloat16); xp[..., :3] = x\n"
+        "    dw, db = c.wgrad(xp.cuda(), dy.cuda(), workspace=True)\n"
+        "    outs += [dw.float().cpu().numpy(), db.float().cpu().numpy()]\n"
+        "    if len(sys.argv) > 2:\n"
+        "        import torch.nn.functional as F\n"
+        "        w = torch.zeros(32, 3, 6, 6, dtype=torch.float64, requires_grad=True)\n"
+        "        xr = F.pad(x.double().permute(0, 3, 1, 2), (2, 2, 2, 2))\n"
+        "        y = F.conv2d(xr, w, stride=2)\n"
+        "        y.backward(dy.double().permute(0, 3, 1, 2))\n"
+        "        outs += [w.grad.permute(2, 3, 1, 0).numpy(), dy.double().sum((0, 1, 2)).numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env, extra in (("wave", {}, ["ref"]), ("tile", {"SV_NO_WGRAD_E1": "1"}, [])):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out] + extra, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    wave, tile = res
+    wk, tk = wave.files, tile.files
+    for i in range(2):                       # per batch: wave = [dw, db, ref_dw, ref_db], tile = [dw, db]
+        dw, db, rdw, rdb = (wave[wk[4 * i + k]].astype(np.float64) for k in range(4))
+        tdw, tdb = (tile[tk[2 * i + k]].astype(np.float64) for k in range(2))
+        assert np.linalg.norm(dw - rdw) <= 2e-3 * np.linalg.norm(rdw) and np.abs(dw - rdw).max() <= 1e-2 * np.abs(rdw).max()
+        assert np.linalg.norm(db - rdb) <= 2e-3 * np.linalg.norm(rdb)
+        assert np.linalg.norm(dw - tdw) <= 2e-3 * np.linalg.norm(tdw) and np.linalg.norm(db - tdb) <= 2e-3 * np.linalg.norm(tdb)
+
+
 ADJ_LAYERS = [  # name, H (hi-res conv input = output size), Cin, Cout, k, y_f32
     ("d3_64", 16, 128, 64, 4, False),
     ("d4_64", 32, 64, 32, 6, False),
