@@ -210,7 +210,8 @@ bool svk_wgrad_e1_supported(const WgradArgs* wv, int n) {
   for (int t = 0; t < 36; ++t)
     if (w.dy[t] != t / 6 - 2 || w.dx[t] != t % 6 - 2) return false;
   const int B = w.M / (OH * OW);
-  if (n * 2 * B < 512) return false;           // small launches: too few strips for the waves of the chip (the tile kernel cuts 2-D tiles)
+  static const int min_tasks = getenv("SV_WGRAD_E1_MIN") ? atoi(getenv("SV_WGRAD_E1_MIN")) : 512;
+  if (n * 2 * B < min_tasks) return false;     // small launches: too few strips for the waves of the chip (the tile kernel cuts 2-D tiles)
   const int X = e1_wgs(n, 2 * B);
   const int64_t need = (int64_t)X * 4 * 10 * 256 * 4 + (int64_t)X * 128 * 4;
   for (int i = 0; i < n; ++i)
