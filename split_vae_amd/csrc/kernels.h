@@ -175,6 +175,9 @@ int svk_wgrad_roll_multi(const WgradArgs* w, int n, hipStream_t st);
 // e1's weight gradient, one pipeline per wave (wgrad_e1.hip): needs the slab workspace
 bool svk_wgrad_e1_supported(const WgradArgs* w, int n);
 int svk_wgrad_e1_multi(const WgradArgs* w, int n, hipStream_t st);
+// e2's weight gradient, rolling window over the space-to-depth input (wgrad_e2.hip): needs the slab workspace
+bool svk_wgrad_e2_supported(const WgradArgs* w, int n);
+int svk_wgrad_e2_multi(const WgradArgs* w, int n, hipStream_t st);
 struct WgradTileMulti { WgradTileArgs a[SV_WGRAD_MAX_MULTI]; };     // blockIdx.z selects the problem
 struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; const float* bslab[SV_WGRAD_MAX_MULTI]; float* dbias[SV_WGRAD_MAX_MULTI]; };
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad

@@ -579,6 +579,46 @@ def test_e1_weight_gradient_wave_pipeline(lib_built, tmp_path):
         assert np.linalg.norm(dw - tdw) <= 2e-3 * np.linalg.norm(tdw) and np.linalg.norm(db - tdb) <= 2e-3 * np.linalg.norm(tdb)
 
 
+def test_e2_weight_gradient_rolling_window(lib_built, tmp_path):
+    """e2's weight gradient on wgrad_e2.hip (forced on at small batches with SV_WGRAD_E2_MIN=1; in the step it runs from 512 images per
+    launch) against the fp64 gradient of the same bf16 operands and against the tile kernel (SV_NO_WGRAD_E2=1): B = 5 (one image per
+    workgroup) and B = 300 (two per workgroup, a ragged last one)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "import torch.nn.functional as F\n"
+        "g = torch.Generator().manual_seed(22)\n"
+        "outs = []\n"
+        "for B in (5, 300):\n"
+        "    x = torch.randn(B, 32, 32, 32, generator=g).bfloat16()\n"
+        "    dy = torch.randn(B, 16, 16, 64, generator=g).bfloat16()\n"
+        "    c = ops.Conv2D(B, 32, 32, 32, 64, 6, 2, act='relu', dtype=torch.bfloat16); c.prep((torch.randn(6, 6, 32, 64, generator=g) * 0.05).cuda())\n"
+        "    dw, db = c.wgrad(x.cuda(), dy.cuda(), workspace=True)\n"
+        "    outs += [dw.float().cpu().numpy(), db.float().cpu().numpy()]\n"
+        "    if len(sys.argv) > 2:\n"
+        "        w = torch.zeros(64, 32, 6, 6, dtype=torch.float64, requires_grad=True)\n"
+        "        y = F.conv2d(F.pad(x.double().permute(0, 3, 1, 2), (2, 2, 2, 2)), w, stride=2)\n"
+        "        y.backward(dy.double().permute(0, 3, 1, 2))\n"
+        "        outs += [w.grad.permute(2, 3, 1, 0).numpy(), dy.double().sum((0, 1, 2)).numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env, extra in (("roll", {"SV_WGRAD_E2_MIN": "1"}, ["ref"]), ("tile", {"SV_NO_WGRAD_E2": "1"}, [])):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out] + extra, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    roll, tile = res
+    rk, tk = roll.files, tile.files
+    for i in range(2):
+        dw, db, rdw, rdb = (roll[rk[4 * i + k]].astype(np.float64) for k in range(4))
+        tdw, tdb = (tile[tk[2 * i + k]].astype(np.float64) for k in range(2))
+        assert np.linalg.norm(dw - rdw) <= 2e-3 * np.linalg.norm(rdw) and np.abs(dw - rdw).max() <= 1e-2 * np.abs(rdw).max()
+        assert np.linalg.norm(db - rdb) <= 2e-3 * np.linalg.norm(rdb)
+        assert np.linalg.norm(dw - tdw) <= 2e-3 * np.linalg.norm(tdw) and np.linalg.norm(db - tdb) <= 2e-3 * np.linalg.norm(tdb)
+
+
 ADJ_LAYERS = [  # name, H (hi-res conv input = output size), Cin, Cout, k, y_f32
     ("d3_64", 16, 128, 64, 4, False),
     ("d4_64", 32, 64, 32, 6, False),
