@@ -557,27 +557,33 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
         } else if constexpr (C::CLS) {
           if (!(dbg & 4)) {
             // a 16-column block = 16 channels of ONE parity class: pixel (2 (yw + j) + ph, 2 (x0 + m) + pw), channels chb + 4 kq ..
+            // All NBW * MF mask loads go out before the first is used (one after the other they were 47 % of the launch: in-kernel stamps).
             constexpr int CN = C::N / 4;
+            int64_t o[NBW][MF];
+            uint2 mv[NBW][MF];
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
               const int col = (nbg * NBW + nb) * 16, cls = col / CN, chb = col - cls * CN;
               const int64_t pix0 = ((int64_t)b * 2 * g.H + 2 * yw + (cls >> 1)) * (2 * g.W) + 2 * (x0 + m) + (cls & 1);
 #pragma unroll
               for (int j = 0; j < MF; ++j) {
-                const int64_t o = (pix0 + (int64_t)j * 4 * g.W) * g.ldo + chb + kq * 4;
-                bf16_t pk[4] = {(bf16_t)acc[nb][j][0], (bf16_t)acc[nb][j][1], (bf16_t)acc[nb][j][2], (bf16_t)acc[nb][j][3]};
-                if (g.mask) {
-                  const uint2 mv = *(const uint2*)((const bf16_t*)g.mask + o);
-                  const uint32_t mw[2] = {mv.x, mv.y};
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits: > 0 <=> sign clear and not zero
-                    if ((h & 0x8000u) || !(h & 0x7fffu)) pk[e] = (bf16_t)0.f;
-                  }
-                }
-                *(uint2*)((bf16_t*)g.out + o) = *(const uint2*)pk;
+                o[nb][j] = (pix0 + (int64_t)j * 4 * g.W) * g.ldo + chb + kq * 4;
+                mv[nb][j] = g.mask ? *(const uint2*)((const bf16_t*)g.mask + o[nb][j]) : make_uint2(0x3f803f80u, 0x3f803f80u);
               }
             }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+              for (int j = 0; j < MF; ++j) {
+                bf16_t pk[4] = {(bf16_t)acc[nb][j][0], (bf16_t)acc[nb][j][1], (bf16_t)acc[nb][j][2], (bf16_t)acc[nb][j][3]};
+                const uint32_t mw[2] = {mv[nb][j].x, mv[nb][j].y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits: > 0 <=> sign clear and not zero
+                  if ((h & 0x8000u) || !(h & 0x7fffu)) pk[e] = (bf16_t)0.f;
+                }
+                *(uint2*)((bf16_t*)g.out + o[nb][j]) = *(const uint2*)pk;
+              }
           }
         } else
         if ((C::KS == 1 || ks == 0) && !(dbg & 4)) {
