@@ -1,5 +1,6 @@
+"""e2's input gradient (merged parity classes, masked) alone: time per launch; with a -DSV_DEBUG_KNOBS build and SV_RC_STAMP=1 the row-ring kernel prints its phase shares."""
 import os, sys
-sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/split_vae_amd") else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from split_vae_amd import ops
 B = 1024
