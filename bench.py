@@ -230,7 +230,7 @@ def decoder_stack(table, dtype, passes):
     fl = ms = 0.0
     for r in table:
         n = r["name"]
-        if not n.startswith(DECODER_STACK) or n.split(".")[1].startswith("d1"):
+        if not n.startswith(DECODER_STACK) or any(p.startswith("d1") for p in n.split(".")[1:]):
             continue
         ms += r["total_ms"] / passes
         fl += r["flops"] * r["launches"] / passes
