@@ -2,11 +2,12 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
+# a step = from one random_perm_kernel (the augmentation's first launch) to the next (the early optimizer tail launches Adam several times)
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("random_perm_kernel")]
 a, b = idx[-3], idx[-2]
-t0 = int(rows[a]["End_Timestamp"])
+t0 = int(rows[a]["Start_Timestamp"])
 qs = {}
-for r in rows[a + 1:b + 1]:
+for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
     n = re.sub(r"\(.*", "", n)[:64]

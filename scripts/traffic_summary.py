@@ -25,8 +25,15 @@ for k in sorted(set(rd) | set(wr)):
     out[k[:120]] = {"launches_sampled": len(r), "read_bytes_per_launch": round(2 * 1024 * sum(r) / len(r)),
                     "write_bytes_per_launch": round(1024 * sum(w) / len(w)),
                     "hbm_bytes_per_launch": round(2 * 1024 * sum(r) / len(r) + 1024 * sum(w) / len(w))}
-# bytes per training step: every launch of every kernel, divided by the number of steps run (= launches of the Adam kernel)
+# bytes per training step: every launch of every kernel that runs at least once per step, divided by the number of steps run (= launches
+# of the Adam kernel).  Kernels launched fewer times than there are steps are the process's SET-UP (torch zero-filling the 1.6 GB
+# workspace and the parameter / moment buffers once): they are listed, not charged to the step (rounds 1-3 charged them: +0.21 GB per
+# step at 12 profiled steps, `setup_bytes_per_step_if_charged`).
 steps = max([len(v) for k, v in wr.items() if "adam_kernel" in k] + [1])
-total = sum(2 * 1024 * sum(v) for v in rd.values()) + sum(1024 * sum(v) for v in wr.values())
-print(json.dumps({"unit": "bytes per launch", "steps_profiled": steps, "total_bytes_per_step": round(total / steps), "correction": "FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE KiB x1",
+setup = sorted(k for k in set(rd) | set(wr) if max(len(rd.get(k, [])), len(wr.get(k, []))) < steps)
+total = sum(2 * 1024 * sum(v) for k, v in rd.items() if k not in setup) + sum(1024 * sum(v) for k, v in wr.items() if k not in setup)
+setup_total = sum(2 * 1024 * sum(v) for k, v in rd.items() if k in setup) + sum(1024 * sum(v) for k, v in wr.items() if k in setup)
+print(json.dumps({"unit": "bytes per launch", "steps_profiled": steps, "total_bytes_per_step": round(total / steps),
+                  "setup_kernels_not_charged": [k[:80] for k in setup], "setup_bytes_per_step_if_charged": round(setup_total / steps),
+                  "correction": "FETCH_SIZE KiB x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE KiB x1",
                   "kernels": out}, indent=1))

@@ -262,10 +262,11 @@ int svk_reparam_kl_fwd_twin(const float* const* pre, const float* const* bias_me
                             const float* const* eps, float* const* eps_out, float* const* z_mean, float* const* z_sig,
                             float* const* z, void* z_lp, int z_dtype, int ldz, const int* z_col, float* const* kl, int B,
                             const int* L, uint64_t seed, uint64_t step, int64_t sample_offset, hipStream_t st,
-                            const SvDynArgs* dyn = nullptr);
+                            const SvDynArgs* dyn = nullptr, const int* S = nullptr, const int64_t* slab_stride = nullptr);   // S: `pre` = K-slice slabs, summed in the kernel
 int svk_reparam_kl_bwd_twin(const float* const* dz, const int* ld_dz, const float* const* dz2, const int* ld_dz2,
                             const float* const* z_mean, const float* const* z_sig, const float* const* eps, float kl_scale,
-                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st);
+                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st,
+                            const int* S = nullptr, const int64_t* stride = nullptr, const int* S2 = nullptr, const int64_t* stride2 = nullptr);   // S: dz / dz2 = K-slice slabs
 int svk_set_dyn(SvDynArgs* dyn, uint64_t seed, uint64_t step, int64_t sample_offset, float adam_alpha, hipStream_t st);
 double svk_adam_alpha(float lr, float beta1, float beta2, int64_t t);
 int svk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

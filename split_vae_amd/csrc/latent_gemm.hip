@@ -123,6 +123,110 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
   }
 }
 
+// The same tile with a RING of NS phase slots (big-K slices: several phases per workgroup, one workgroup per CU, so nothing else hides a
+// phase's transfer time): phase ph + NS - 1 is issued right after the barrier that retires phase ph - 1, i.e. NS - 1 phases are in flight
+// beside the MFMAs of phase ph.  The transfers are inline assembly with counted waits (the compiler would order every LDS read behind a
+// DMA builtin's vmcnt(0): wgrad_roll.hip); every wave issues the same PER instructions per phase, so "all but the youngest PER * n"
+// is exactly "phase ph has landed".  K-slice slabs only (bias / activation belong to the consumer).
+__device__ __forceinline__ void nt_dma16(const void* base, uint32_t off, const char* lds) {     // base: wave-uniform; off: this lane's byte offset
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+
+template <int BM, int NS>
+__global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int inst = (mg.n > 1 && (int)blockIdx.z >= mg.p[1].zbase) ? 1 : 0;
+  const NtGemmProb g = mg.p[inst];                  // (a copy: by reference the fields are re-read from the argument segment in the loop)
+  const int zi = (int)blockIdx.z - g.zbase;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= g.M || n0 >= g.N || zi >= g.splitk) return;
+  constexpr int SLOTB = (BM + BN) * RB;
+  constexpr int PER = (BM + BN) / 16;               // DMA instructions per wave and phase
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BK;
+  const int lr = lane & 15, lg = lane >> 4;
+  constexpr int FM = BM / 32;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
+  f32x4 acc[FM][4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this lane's source offsets (bytes, phase 0 of the slice): row part + swizzled piece; a phase adds 2 BK bytes
+  uint32_t offA[BM / 16], offW[BN / 16];
+#pragma unroll
+  for (int i = 0; i < BM / 16; ++i) {
+    const int r = 4 * (wave + 4 * i) + lg, gm = min(m0 + r, g.M - 1);
+    offA[i] = (uint32_t)(((int64_t)gm * g.lda + kbeg + ((lr ^ (r & 15)) << 3)) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 16; ++i) {
+    const int r = 4 * (wave + 4 * i) + lg;
+    offW[i] = (uint32_t)(((int64_t)(n0 + r) * g.ldw + kbeg + ((lr ^ (r & 15)) << 3)) * 2);
+  }
+  auto issue = [&](int ph, int slot) {
+    char* sA = smem + slot * SLOTB;
+    char* sW = sA + BM * RB;
+    const uint32_t kb = (uint32_t)ph * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) nt_dma16(g.A, offA[i] + kb, sA + (wave + 4 * i) * (4 * RB));
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i) nt_dma16(g.W, offW[i] + kb, sW + (wave + 4 * i) * (4 * RB));
+  };
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nph) issue(i, i);
+  int slot = 0;
+  for (int ph = 0; ph < nph; ++ph) {
+    // phases issued beyond ph: min(NS - 2, nph - 1 - ph)
+    const int ahead = min(NS - 2, nph - 1 - ph);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // phase ph is complete; phase ph - 1 is consumed by every wave
+    if (ph + NS - 1 < nph) {
+      int ns = slot + NS - 1;
+      if (ns >= NS) ns -= NS;
+      issue(ph + NS - 1, ns);
+    }
+    const char* sA = smem + slot * SLOTB;
+    const char* sW = sA + BM * RB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int p = ks * 4 + lg;
+      uint4 af[FM], wf[4];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm + i * 16 + lr;
+        af[i] = *(const uint4*)(sA + r * RB + ((p ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn + j * 16 + lr;
+        wf[j] = *(const uint4*)(sW + r * RB + ((p ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+    }
+    if (++slot == NS) slot = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm + i * 16 + lr;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn + j * 16 + lg * 4;
+      *(float4*)((float*)g.out + (int64_t)zi * g.slab_stride + (int64_t)m * g.ldo + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
 // out[i] = sum_s slab[s][i] in slice order (i over M * ldo floats), both problems of a launch (blockIdx.y)
 __global__ __launch_bounds__(256) void nt_slab_reduce_kernel(const NtReduceMulti r) {
   const int z = blockIdx.y;
@@ -141,11 +245,24 @@ __global__ __launch_bounds__(256) void nt_slab_reduce_kernel(const NtReduceMulti
 template <int BM>
 int launch_nt(const NtGemmMulti& m, hipStream_t st) {
   int gx = 0, gy = 0;
+  bool ring = BM == 64;                 // slab launches whose slices span several phases: the ring form
+  static const bool no_ring = getenv("SV_NO_NT_RING") != nullptr;
   for (int i = 0; i < m.n; ++i) {
     gx = max(gx, (m.p[i].M + BM - 1) / BM);
     gy = max(gy, m.p[i].N / BN);
+    ring = ring && m.p[i].out_f32 && m.p[i].K / m.p[i].splitk >= 2 * BK;
   }
   const int gz = m.p[m.n - 1].zbase + m.p[m.n - 1].splitk;
+  if constexpr (BM == 64) {
+    if (ring && !no_ring) {
+      constexpr int NS = 3;
+      const size_t lds = (size_t)NS * (BM + BN) * RB;
+      sv_ensure_dynamic_lds((const void*)nt_gemm_ring_kernel<BM, NS>, lds);
+      hipLaunchKernelGGL((nt_gemm_ring_kernel<BM, NS>), dim3(gx, gy, gz), dim3(256), lds, st, m);
+      SV_LAUNCH_CHECK();
+      return SV_OK;
+    }
+  }
   const size_t lds = (size_t)(BM + BN) * RB;
   sv_ensure_dynamic_lds((const void*)nt_gemm_kernel<BM>, lds);
   hipLaunchKernelGGL((nt_gemm_kernel<BM>), dim3(gx, gy, gz), dim3(256), lds, st, m);

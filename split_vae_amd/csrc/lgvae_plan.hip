@@ -106,6 +106,11 @@ struct sv_lgvae_plan {
   int n_pending = 0;
   bool nll_fused = false;  // the last decoder forward evaluated the loss in the head's epilogue (nllpart_*, g5_* are valid)
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
+  // the K-slice slabs of d1's input gradient are still unsummed in lat_ws_x / lat_ws_xh: reparam_kl_bwd sums them itself (one launch less)
+  bool dz_slabs = false;
+  bool lat_head_ok = false, lat_d1_ok = false;     // the heads' forward / d1's input gradient of this plan run on latent_gemm.hip (shapes are fixed per plan)
+  int dz_S[2] = {0, 0};
+  int64_t dz_stride[2] = {0, 0};
   // weight gradients on a second stream (they feed only Adam / the all-reduce; the input-gradient chain is the critical
   // path): fork = the side stream waits for the event recorded on the main stream when dY is ready, join before Adam and
   // at the end of every sv_lgvae_step call
@@ -438,6 +443,11 @@ static void build_buffers(sv_lgvae_plan* p) {
 
 // the latent block's GEMMs on latent_gemm.hip (LDS-DMA phases, split-K through fp32 slabs summed in slice order) instead of the im2col
 // kernel's split-K atomics; SV_NO_LATENT_GEMM restores the old launches (A/B)
+// the slab sums of the two split-K launches live in their consumers (Sampling + KL forward / backward) instead of nt_slab_reduce_kernel
+static bool latent_fuse_on() {
+  static const bool off = getenv("SV_NO_LATENT_FUSE") != nullptr;
+  return !off;
+}
 static bool latent_gemm_on(const sv_lgvae_plan* p) {
   static const bool off = getenv("SV_NO_LATENT_GEMM") != nullptr;
   return !off && p->d.dtype == SV_BF16;
@@ -689,7 +699,12 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
   const int B = d.B, H = d.H, W = d.W, dt = d.dtype;
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
   const char* en[2] = {"x", "xh"};
-  if (do_enc) {
+  static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;   // A/B: one launch per network for the small pointwise kernels
+  bool pre_slabs = false;
+  int pre_S[2] = {0, 0};
+  int64_t pre_stride[2] = {0, 0};
+  // (not needed once both split-K launches of this plan have gone through latent_gemm.hip's slabs: nothing accumulates into these buffers)
+  if (do_enc && !(latent_gemm_on(p) && p->lat_head_ok && p->lat_d1_ok && !d.external_global_encoder)) {
     // the head pre-activations (split-K partial sums) and dz (split-K dgrad of d1) accumulate with atomics
     char* z0 = (char*)p->bp("pre_x");
     char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
@@ -750,15 +765,20 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
         outs[nq] = (float*)p->bp(std::string("pre_") + en[e]);
       }
       const int rc = svk_nt_gemm_multi(q, nq, 64, st);
-      if (rc == SV_OK) { SV_TRY(svk_nt_slab_reduce(q, outs, nq, st)); done = true; }
-      else if (rc != SV_E_UNSUPPORTED) return rc;
+      if (rc == SV_OK) {
+        done = true;
+        p->lat_head_ok = true;
+        if (latent_fuse_on() && !e0 && !no_twin && q[0].splitk <= 16 && q[1].splitk <= 16) {   // (more slices: one wave per row reads them too slowly, B = 64: +4 %)            // Sampling + KL sum the slabs themselves (in slice order: the same bits)
+          pre_slabs = true;
+          for (int e = 0; e < 2; ++e) { pre_S[e] = q[e].splitk; pre_stride[e] = q[e].slab_stride; }
+        } else SV_TRY(svk_nt_slab_reduce(q, outs, nq, st));
+      } else if (rc != SV_E_UNSUPPORTED) return rc;
     }
     if (done) {}
     else if (e0 || cfgs[0] == cfgs[1]) SV_TRY(svk_tap_gemm_multi(a, 2 - e0, dt, cfgs[0], st));
     else
       for (int e = 0; e < 2; ++e) SV_TRY(svk_tap_gemm(a[e], dt, cfgs[e], st));   // latent sizes with different tiles
   }
-  static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;   // A/B: one launch per network for the small pointwise kernels
   if (do_enc && !d.external_global_encoder && !no_twin) {
     // both networks' Sampling + KL in one launch
     Scope sc(p, st, "reparam_kl_fwd", 0, (double)B * (Lg + Ll) * 16);
@@ -768,14 +788,14 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     for (int e = 0; e < 2; ++e) {
       const std::string sfx = en[e];
       const Layer& Lh = p->enc[e][3];
-      pre[e] = (const float*)p->bp("pre_" + sfx);
+      pre[e] = (const float*)p->bp((pre_slabs ? "lat_ws_" : "pre_") + sfx);
       bm[e] = s->params + p->params[Lh.kparam + 1].off; bs[e] = s->params + p->params[Lh.kparam + 3].off;
       eps[e] = e == 0 ? s->eps_x : s->eps_x_hat;
       eo[e] = (float*)p->bp("eps_" + sfx); zm[e] = (float*)p->bp("z_mean_" + sfx); zs[e] = (float*)p->bp("z_sig_" + sfx);
       zz[e] = (float*)p->bp("z_" + sfx); kl[e] = (float*)p->bp("kl_" + sfx);
     }
     SV_TRY(svk_reparam_kl_fwd_twin(pre, bm, bs, eps, eo, zm, zs, zz, p->bp("zcat"), dt, Lc, zc, kl, B, LL, s->seed, s->step,
-                                   s->sample_offset, st, p->dyn));
+                                   s->sample_offset, st, p->dyn, pre_slabs ? pre_S : nullptr, pre_stride));
   } else
   for (int e = d.external_global_encoder ? 1 : 0; e < 2 && do_enc; ++e) {
     const std::string sfx = en[e];
@@ -940,6 +960,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     SV_TRY(run_wgrad_layers(p, 2, Ls, zin, g1, s->grads, st));
     for (int k = 0; k < 2; ++k) Ld[k].d.ldx = Ld[k].d.Cin;   // dz has its own row pitch (Lz), not the zcat pitch
     bool done = false;
+    p->dz_slabs = false;
     if (latent_gemm_on(p)) {
       NtGemmProb q[2];
       float* outs[2];
@@ -959,8 +980,15 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
       }
       Scope sc(p, st, "dgrad.d1", fl, by);
       const int rc = svk_nt_gemm_multi(q, 2, 64, st);
-      if (rc == SV_OK) { SV_TRY(svk_nt_slab_reduce(q, outs, 2, st)); done = true; }
-      else if (rc != SV_E_UNSUPPORTED) return rc;
+      if (rc == SV_OK) {
+        done = true;
+        p->lat_d1_ok = true;
+        static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;
+        if (latent_fuse_on() && !d.external_global_encoder && !no_twin && q[0].splitk <= 16 && q[1].splitk <= 16) {     // reparam_kl_bwd sums the slabs (SPLIT-GMVAE reads gz_x: summed here)
+          p->dz_slabs = true;
+          for (int k = 0; k < 2; ++k) { p->dz_S[k] = q[k].splitk; p->dz_stride[k] = q[k].slab_stride; }
+        } else SV_TRY(svk_nt_slab_reduce(q, outs, 2, st));
+      } else if (rc != SV_E_UNSUPPORTED) return rc;
     }
     if (!done) SV_TRY(run_dgrad_layers(p, 2, Lds, g1, none2, gz, true, st));
   }
@@ -985,6 +1013,14 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       const float* zs[2] = {(const float*)p->bp("z_sig_x"), (const float*)p->bp("z_sig_xh")};
       const float* ep[2] = {(const float*)p->bp("eps_x"), (const float*)p->bp("eps_xh")};
       void* gp[2] = {p->bp("ghead_x"), p->bp("ghead_xh")};
+      if (p->dz_slabs) {
+        const float *sx = (const float*)p->bp("lat_ws_x"), *sxh = (const float*)p->bp("lat_ws_xh");
+        const float* dzs[2] = {sx, sx + Lg};
+        const float* dz2s[2] = {nullptr, sxh};
+        const int S[2] = {p->dz_S[0], p->dz_S[0]}, S2[2] = {0, p->dz_S[1]};
+        const int64_t sd[2] = {p->dz_stride[0], p->dz_stride[0]}, sd2[2] = {0, p->dz_stride[1]};
+        SV_TRY(svk_reparam_kl_bwd_twin(dzs, ld, dz2s, ld2, zm, zs, ep, kl_scale, gp, dt, B, LL, st, S, sd, S2, sd2));
+      } else
       SV_TRY(svk_reparam_kl_bwd_twin(dz, ld, dz2, ld2, zm, zs, ep, kl_scale, gp, dt, B, LL, st));
     } else {
     if (!e0)

@@ -290,6 +290,7 @@ struct ReparamFwdArgs {
   void* z_lp;
   float* kl;
   int ldz, z_col, L, stream_id;
+  int S; int64_t slab_stride;      // S > 0: `pre` is the first of S K-slice slabs of the heads' GEMM (latent_gemm.hip), summed here in slice order
 };
 template <typename TZ>
 __device__ __forceinline__ void reparam_kl_fwd_body(const ReparamFwdArgs& g, int B, uint64_t seed, uint64_t step, int64_t sample_offset) {
@@ -305,8 +306,17 @@ __device__ __forceinline__ void reparam_kl_fwd_body(const ReparamFwdArgs& g, int
   const uint64_t gs = (uint64_t)(sample_offset + b);
   float acc = 0.f;
   for (int j = lane; j < L; j += 64) {
-    const float mu = pre[(int64_t)b * 2 * L + j] + bias_mean[j];
-    const float sg = softplus_f(pre[(int64_t)b * 2 * L + L + j] + bias_sd[j]);
+    float pm, ps;
+    if (g.S > 0) {                                         // as nt_slab_reduce_kernel: 0 + slab 0 + slab 1 + ... (bitwise the two-launch result)
+      pm = 0.f; ps = 0.f;
+      const float* __restrict__ q = pre + (int64_t)b * 2 * L + j;
+#pragma unroll 8
+      for (int k = 0; k < g.S; ++k) { pm += q[(int64_t)k * g.slab_stride]; ps += q[(int64_t)k * g.slab_stride + L]; }
+    } else {
+      pm = pre[(int64_t)b * 2 * L + j]; ps = pre[(int64_t)b * 2 * L + L + j];
+    }
+    const float mu = pm + bias_mean[j];
+    const float sg = softplus_f(ps + bias_sd[j]);
     float e;
     if (eps) {
       e = eps[(int64_t)b * L + j];
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
     float* __restrict__ z, TZ* __restrict__ z_lp, int ldz, int z_col, float* __restrict__ kl, int B,
     int L, uint64_t seed, uint64_t step, int stream_id, int64_t sample_offset, const SvDynArgs* __restrict__ dyn) {
   if (dyn) { seed = dyn->seed; step = dyn->step; sample_offset = dyn->sample_offset; }   // captured step (graph replay)
-  const ReparamFwdArgs g = {pre, bias_mean, bias_sd, eps, eps_out, z_mean, z_sig, z, (void*)z_lp, kl, ldz, z_col, L, stream_id};
+  const ReparamFwdArgs g = {pre, bias_mean, bias_sd, eps, eps_out, z_mean, z_sig, z, (void*)z_lp, kl, ldz, z_col, L, stream_id, 0, 0};
   reparam_kl_fwd_body<TZ>(g, B, seed, step, sample_offset);
 }
 
@@ -353,10 +363,12 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_twin_kernel(const ReparamF
 int svk_reparam_kl_fwd_twin(const float* const* pre, const float* const* bias_mean, const float* const* bias_sd,
                             const float* const* eps, float* const* eps_out, float* const* z_mean, float* const* z_sig,
                             float* const* z, void* z_lp, int z_dtype, int ldz, const int* z_col, float* const* kl, int B,
-                            const int* L, uint64_t seed, uint64_t step, int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn) {
+                            const int* L, uint64_t seed, uint64_t step, int64_t sample_offset, hipStream_t st, const SvDynArgs* dyn,
+                            const int* S, const int64_t* slab_stride) {
   ReparamFwdTwin t;
   for (int e = 0; e < 2; ++e)
-    t.a[e] = {pre[e], bias_mean[e], bias_sd[e], eps[e], eps_out[e], z_mean[e], z_sig[e], z[e], z_lp, kl[e], ldz, z_col[e], L[e], e};
+    t.a[e] = {pre[e], bias_mean[e], bias_sd[e], eps[e], eps_out[e], z_mean[e], z_sig[e], z[e], z_lp, kl[e], ldz, z_col[e], L[e], e,
+              S ? S[e] : 0, S ? slab_stride[e] : 0};
   dim3 grid((B + 3) / 4, 2), block(256);
   if (z_dtype == SV_BF16) hipLaunchKernelGGL((reparam_kl_fwd_twin_kernel<bf16_t>), grid, block, 0, st, t, B, seed, step, sample_offset, dyn);
   else if (z_dtype == SV_F32) hipLaunchKernelGGL((reparam_kl_fwd_twin_kernel<float>), grid, block, 0, st, t, B, seed, step, sample_offset, dyn);
@@ -413,7 +425,10 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
   }
 }
 
-struct ReparamBwdArgs { const float *dz, *dz2, *z_mean, *z_sig, *eps; void* g_pre; int ld_dz, ld_dz2, L; };
+struct ReparamBwdArgs {
+  const float *dz, *dz2, *z_mean, *z_sig, *eps; void* g_pre; int ld_dz, ld_dz2, L;
+  int S, S2; int64_t stride, stride2;      // S > 0: dz / dz2 are the first of S / S2 K-slice slabs of d1's input gradient, summed here in slice order
+};
 struct ReparamBwdTwin { ReparamBwdArgs a[2]; };
 template <typename TG>
 __global__ __launch_bounds__(256) void reparam_kl_bwd_twin_kernel(const ReparamBwdTwin t, float kl_scale, int B) {
@@ -423,8 +438,23 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_twin_kernel(const ReparamB
   TG* __restrict__ g_pre = (TG*)g.g_pre;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / L), j = (int)(i - (int64_t)b * L);
-    float gg = g.dz[(int64_t)b * g.ld_dz + j];
-    if (g.dz2) gg += g.dz2[(int64_t)b * g.ld_dz2 + j];
+    float gg;
+    if (g.S > 0) {                                         // as nt_slab_reduce_kernel (bitwise the two-launch result)
+      gg = 0.f;
+      const float* __restrict__ q = g.dz + (int64_t)b * g.ld_dz + j;
+#pragma unroll 8
+      for (int k = 0; k < g.S; ++k) gg += q[(int64_t)k * g.stride];
+      if (g.dz2) {
+        float g2 = 0.f;
+        const float* __restrict__ q2 = g.dz2 + (int64_t)b * g.ld_dz2 + j;
+#pragma unroll 8
+        for (int k = 0; k < g.S2; ++k) g2 += q2[(int64_t)k * g.stride2];
+        gg += g2;
+      }
+    } else {
+      gg = g.dz[(int64_t)b * g.ld_dz + j];
+      if (g.dz2) gg += g.dz2[(int64_t)b * g.ld_dz2 + j];
+    }
     const float mu = g.z_mean[i], sg = g.z_sig[i], e = g.eps[i];
     const float dmu = gg + kl_scale * mu;
     const float dsg = gg * e + kl_scale * (sg - 1.f / sg);
@@ -435,11 +465,13 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_twin_kernel(const ReparamB
 }
 int svk_reparam_kl_bwd_twin(const float* const* dz, const int* ld_dz, const float* const* dz2, const int* ld_dz2,
                             const float* const* z_mean, const float* const* z_sig, const float* const* eps, float kl_scale,
-                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st) {
+                            void* const* g_pre, int g_dtype, int B, const int* L, hipStream_t st,
+                            const int* S, const int64_t* stride, const int* S2, const int64_t* stride2) {
   ReparamBwdTwin t;
   int Lmax = 0;
   for (int e = 0; e < 2; ++e) {
-    t.a[e] = {dz[e], dz2[e], z_mean[e], z_sig[e], eps[e], g_pre[e], ld_dz[e], ld_dz2[e], L[e]};
+    t.a[e] = {dz[e], dz2[e], z_mean[e], z_sig[e], eps[e], g_pre[e], ld_dz[e], ld_dz2[e], L[e],
+              S ? S[e] : 0, S ? S2[e] : 0, S ? stride[e] : 0, S ? stride2[e] : 0};
     Lmax = L[e] > Lmax ? L[e] : Lmax;
   }
   dim3 grid((unsigned)(((int64_t)B * Lmax + 255) / 256), 2), block(256);

@@ -87,3 +87,21 @@ def test_oracle_bounds_hold_without_the_gate_flip_allowance(lib_built):
     for _ in range(3):
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q"] + tests, capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=1500)
         assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_latent_block_fused_slab_sums_and_ring_kernel_keep_the_bits(lib_built):
+    """latent_gemm.hip's ring form of the split-K launches (heads forward, d1 input gradient) and the slab sums fused into Sampling + KL
+    forward / backward (vae/model.py:9-13, :110-113, :160; vae/trainer.py:137) against the two-launch forms they replace: five training
+    steps (B = 64 / 512 / 70, bf16 and fp32; the weights edited in place and an evaluation call in between) hash identically, because
+    the slices are summed in the same order wherever the sum runs."""
+    out = {}
+    for knobs in ({}, {"SV_NO_LATENT_FUSE": "1"}, {"SV_NO_NT_RING": "1"}, {"SV_NO_LATENT_FUSE": "1", "SV_NO_NT_RING": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r03_step_hash.py")], capture_output=True, text=True,
+                           env=dict(_env(), **knobs), cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if " B=" in l]
+        assert len(lines) == 4, r.stdout
+        out[tuple(sorted(knobs))] = lines
+    ref = out[()]
+    for k, v in out.items():
+        assert v == ref, (k, v, ref)
