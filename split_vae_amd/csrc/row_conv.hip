@@ -93,26 +93,28 @@ struct RowCfg {
   static_assert(!S2D_ || (!UPS_ && !ADJ_ && !CLS_ && (CIN_ == 128 || CIN_ == 32 || (CIN_ == 256 && PAIR_))), "space-to-depth form");
   static_assert(!CLS_ || (!UPS_ && !ADJ_ && KS_ == 1 && (N_ / 4) % 16 == 0), "merged parity classes");
   // TP: 8-channel pixels (the 6-channel head's gradient): one 16-B piece per pixel, so an MFMA K step (32) packs FOUR
-  // taps -- the four lane quarters read four consecutive input ROWS (ky = 4g + kq; KH = 6 -> two groups, 2 of 8 dummies)
+  // taps -- the lane quarter kq reads pixel (row + (kq >> 1), column + (kq & 1)): a fragment is a 2 x 2 block of taps, the 6 x 6 filter is
+  // exactly 3 x 3 such blocks (K = 288 = 9 steps, none padded).  (Until round 3's end the quarters read four consecutive ROWS of one
+  // filter column: 6 x 2 row groups with 2 of 8 rows dummies = 12 steps; 25 % fewer MFMAs and half the fragment reads now.)
   static constexpr bool TP = CIN == 8;
-  static_assert(!TP || (KH == 6 && !UPS_ && KS == 1), "tap-packed form");
+  static_assert(!TP || (KH == 6 && KW == 6 && !UPS_ && KS == 1), "tap-packed form");
   static_assert(!ADJ_ || (!UPS_ && KS_ == 1), "the adjoint epilogue belongs to plain input-gradient layers");
   static constexpr int NCH = TP ? 1 : CIN / 32, CPW = NCH / KS, NBG = N / 16 / NBW;
-  static constexpr int KHG = TP ? 2 : KH;                     // weight fragments per (chunk, filter column)
+  static constexpr int KHG = TP ? KH / 2 : KH, KWG = TP ? KW / 2 : KW;   // weight fragments per chunk: KWG x KHG (TP: 2 x 2 tap blocks)
   static_assert(NBG * KS * XG * RG == WAVES, "one role per wave");
   static_assert((TP || CIN % 32 == 0) && NCH % KS == 0 && N % (16 * NBW) == 0 && WIDTH % (16 * XG) == 0, "shape");
-  static constexpr int TIW = PAIR ? 2 * (8 + KW - 1) : WIDTH + KW - 1, STEP = RG * MF, WIN = TP ? MF + 4 : MF + KH - 1;
+  static constexpr int TIW = PAIR ? 2 * (8 + KW - 1) : WIDTH + KW - 1, STEP = RG * MF, WIN = TP ? MF + 4 : MF + KH - 1;   // (TP: fragment w = rows w, w + 1)
   // ring rows.  8 waves: two windows (the current one + the next step's STEP new rows, or the whole first window of the
   // workgroup's NEXT unit, staged during the last step).  4 waves: one window + one step (the next unit's first window
   // is staged between units; the other workgroup of the CU computes meanwhile)
   static constexpr bool PRE = WAVES == 8;
   static constexpr int R = PRE ? 2 * (STEP + KH - 1) : 2 * STEP + KH - 1;
   static constexpr int PIXB = TP ? 16 : 32;                   // bytes per pixel in a plane
-  // TP: a fragment's four lane quarters read four consecutive rows: the row pitch is a multiple of 256 B (then the 16-lane
-  // groups of ds_read_b128 cover each bank row exactly once) and the ring's first three rows are kept twice, behind its
-  // end, so that rows slot .. slot+3 are always linear
+  // TP: a fragment's lane quarters read two consecutive rows (16 pixels each, the odd quarters one pixel to the right: every 16-lane
+  // group of the ds_read_b128 covers 256 contiguous bytes = each bank once); the row pitch is a multiple of 256 B and the ring's first
+  // row is kept twice, behind its end, so that rows slot, slot + 1 are always linear
   static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : TIW * 32;
-  static constexpr int RDUP = TP ? 3 : 0;
+  static constexpr int RDUP = TP ? 1 : 0;
   static constexpr int NPL = TP ? 1 : CIN / 16, PLB = (R + RDUP) * ROWB;    // planes (two 16-B pieces each; TP: one piece), bytes per plane
   static constexpr int RING = NPL * PLB;
   static constexpr int EXS = 2;                               // exchange slots per wave pair
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   constexpr int NT = C::NT;
   const int dbg0 = SV_DBG(mg.dbg);
   const int m = lane & 15, kq = lane >> 4;
-  const int lane_off = C::TP ? m * 16 + kq * C::ROWB : (m + (C::PAIR ? (m >> 3) * (KW - 1) : 0)) * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
+  const int lane_off = C::TP ? (m + (kq & 1)) * 16 + (kq >> 1) * C::ROWB : (m + (C::PAIR ? (m >> 3) * (KW - 1) : 0)) * 32 + (kq & 1) * 16 + ((kq >> 1) + ks * CPW * 2) * C::PLB;
   if (tid < 16) sFlag[tid] = 0;
   const int dbg = SV_DBG(mg.dbg);                           // 1 skip staging, 2 skip the MFMA loop, 4 skip the stores, 8 skip the K-half exchange
 
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #ifdef SV_DEBUG_KNOBS
   if (mg.stamps) tlast = __builtin_amdgcn_s_memtime();
 #endif
-  bf16x8 Wr[NBW][CPW][KW][C::KHG];
+  bf16x8 Wr[NBW][CPW][C::KWG][C::KHG];
   float bv[NBW][4];
   int obase = 0;                                             // ADJ: out-ring slot of hi-res row 0 of the current unit
   int cur_prob = -1;
@@ -402,13 +404,11 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc)
 #pragma unroll
-          for (int kx = 0; kx < KW; ++kx)
+          for (int kx = 0; kx < C::KWG; ++kx)
 #pragma unroll
             for (int ky = 0; ky < C::KHG; ++ky) {
-              if constexpr (C::TP) {                         // fragment (kx, group ky): lane quarter kq carries tap (4*ky + kq, kx), zero past KH
-                const int kyy = 4 * ky + kq;
-                bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                Wr[nb][cc][kx][ky] = kyy < KH ? *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + (kx * KH + kyy) * 8) : z;
+              if constexpr (C::TP) {                         // fragment (kx, ky) = tap block: lane quarter kq carries tap (2 ky + (kq >> 1), 2 kx + (kq & 1))
+                Wr[nb][cc][kx][ky] = *(const bf16x8*)(Wt + (int64_t)n * g.Ktot + ((2 * kx + (kq & 1)) * KH + 2 * ky + (kq >> 1)) * 8);
               } else
                 if constexpr (C::S2D && C::CIN == 128) {
                   const int c4 = ks * CPW + cc, py = c4 >> 1, px = c4 & 1;
@@ -482,20 +482,20 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #pragma unroll
           for (int j = 0; j < WIN; ++j) win[j] = *(const bf16x8*)(sRing + abase[j]);
           if constexpr (C::TP) {
-            // fragment w = input rows qw+w .. qw+w+3 (one per lane quarter) at filter column kx: it is tap group g of output row w - 4g
+            // fragment w = input rows qw+w, qw+w+1 x filter columns 2kx, 2kx+1 (one tap per lane quarter): it is tap-row pair gq of output row w - 2 gq
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
+            for (int kx = 0; kx < C::KWG; ++kx) {
 #pragma unroll
               for (int w = 0; w < WIN; ++w) {
 #pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {
-                  const int j = w - 4 * gq;
+                for (int gq = 0; gq < C::KHG; ++gq) {
+                  const int j = w - 2 * gq;
                   if (j < 0 || j >= MF) continue;
 #pragma unroll
                   for (int nb = 0; nb < NBW; ++nb)
                     acc[nb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[nb][0][kx][gq], win[w], acc[nb][j], 0, 0, 0);
                 }
-                if (kx + 1 < KW) win[w] = *(const bf16x8*)(sRing + abase[w] + (kx + 1) * 16);
+                if (kx + 1 < C::KWG) win[w] = *(const bf16x8*)(sRing + abase[w] + (kx + 1) * 32);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
