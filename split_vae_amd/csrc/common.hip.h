@@ -60,6 +60,28 @@ __device__ __forceinline__ f32x2 lerp2(f32x2 a, f32x2 b, float w) {
   return __builtin_elementwise_fma(b - a, (f32x2){w, w}, a);
 }
 
+// One hi-res row's share of the 2x bilinear resize adjoint (ResizeBilinearGrad, vae/model.py:163-167 backwards) for 8 bf16 channels:
+//   acc[e] += wy * (.25 v0[e] + .75 v1[e] + .75 v2[e] + .25 v3[e]),   v0..v3 = the pixels at columns 2j-1 .. 2j+2 (clamped), wy = .25 | .75
+// as v_dot2c_f32_bf16 on (column, column + 1) pairs: the products wy * wx (1/16, 3/16, 9/16) are exact in bf16, every product is exact in
+// fp32, accumulation in fp32.  Half the VALU instructions of convert + fma per element (v_perm_b32 pairs the two columns' halves).
+// upsample2x_bwd_kernel (pointwise.hip) and the row-ring kernel's fused epilogue (row_conv.hip) both go through here, rows a = -1..2 in
+// that order: bitwise the same gradient either way.
+__device__ __forceinline__ void adj2x_row_bf16(float acc[8], const uint4 v0, const uint4 v1, const uint4 v2, const uint4 v3, const bool outer) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  // (w(2j-1), w(2j)) and (w(2j+1), w(2j+2)) times wy, as packed bf16: 1/16 = 0x3D80, 3/16 = 0x3E40, 9/16 = 0x3F10
+  const uint32_t w01 = outer ? 0x3E403D80u : 0x3F103E40u, w23 = outer ? 0x3D803E40u : 0x3E403F10u;
+  const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w}, a3[4] = {v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(a1[k], a0[k], 0x05040100u), hi01 = __builtin_amdgcn_perm(a1[k], a0[k], 0x07060302u);
+    const uint32_t lo23 = __builtin_amdgcn_perm(a3[k], a2[k], 0x05040100u), hi23 = __builtin_amdgcn_perm(a3[k], a2[k], 0x07060302u);
+    acc[2 * k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, lo01), __builtin_bit_cast(bf2_t, w01), acc[2 * k], false);
+    acc[2 * k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, lo23), __builtin_bit_cast(bf2_t, w23), acc[2 * k], false);
+    acc[2 * k + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, hi01), __builtin_bit_cast(bf2_t, w01), acc[2 * k + 1], false);
+    acc[2 * k + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, hi23), __builtin_bit_cast(bf2_t, w23), acc[2 * k + 1], false);
+  }
+}
+
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }

@@ -794,6 +794,16 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < EPP; ++e) acc[e] = 0.f;
     const T* base = g_hi + (int64_t)b * 4 * H * W * C + c * EPP;
+    if constexpr (sizeof(T) == 2) {                          // bf16: column pairs through v_dot2c_f32_bf16 (adj2x_row_bf16, common.hip.h)
+      const int64_t xo[4] = {(int64_t)max(2 * j - 1, 0) * C, (int64_t)2 * j * C, (int64_t)(2 * j + 1) * C, (int64_t)min(2 * j + 2, 2 * W - 1) * C};
+#pragma unroll
+      for (int a = -1; a <= 2; ++a) {
+        const int oy = min(max(2 * i + a, 0), 2 * H - 1);
+        const T* row = base + (int64_t)oy * 2 * W * C;
+        adj2x_row_bf16(acc, *(const uint4*)(row + xo[0]), *(const uint4*)(row + xo[1]), *(const uint4*)(row + xo[2]), *(const uint4*)(row + xo[3]),
+                       a == -1 || a == 2);
+      }
+    } else {
 #pragma unroll
     for (int a = -1; a <= 2; ++a) {
       const int oy = min(max(2 * i + a, 0), 2 * H - 1);
@@ -807,6 +817,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int e = 0; e < EPP; ++e) acc[e] += w * to_f32(v[e]);
       }
+    }
     }
     const int64_t o = (((int64_t)b * H + i) * W + j) * C + c * EPP;
     T r[EPP];

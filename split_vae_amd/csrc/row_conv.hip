@@ -283,7 +283,7 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
 // ADJ: low-res gradient rows [e_lo, e_hi] of image b from the hi-res gradient rows in the out ring:
 //   g_lo[i, j] = sum_{a, d in -1..2} wy[a] wx[d] g_hi[clamp(2i + a), clamp(2j + d)],  w = (.25, .75, .75, .25)
 // then the ReLU mask of the low-res activation -- the arithmetic (and summation order) of upsample2x_bwd_kernel
-// (pointwise.hip), on the same bf16-rounded hi-res values: bitwise the unfused result.
+// (pointwise.hip: both call adj2x_row_bf16, common.hip.h), on the same bf16-rounded hi-res values: bitwise the unfused result.
 template <typename C>
 __device__ __forceinline__ void adjoint_rows(const RowConvArgs& g, int b, int e_lo, int e_hi, int obase, const char* sOut, int t, int nt) {
   constexpr int NP8 = C::N / 8, LW = C::WIDTH / 2, IPR = LW * NP8;
@@ -298,20 +298,12 @@ __device__ __forceinline__ void adjoint_rows(const RowConvArgs& g, int b, int e_
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int xo[4] = {max(2 * j - 1, 0) * (C::N * 2), 2 * j * (C::N * 2), (2 * j + 1) * (C::N * 2), min(2 * j + 2, C::WIDTH - 1) * (C::N * 2)};
 #pragma unroll
     for (int a = -1; a <= 2; ++a) {
       const int oy = min(max(2 * i + a, 0), g.H - 1);
-      const float wy = (a == -1 || a == 2) ? 0.25f : 0.75f;
       const char* row = sOut + ((obase + oy) % C::ORR) * C::OROWB + c * 16;
-#pragma unroll
-      for (int d = -1; d <= 2; ++d) {
-        const int ox = min(max(2 * j + d, 0), C::WIDTH - 1);
-        const float wgt = wy * ((d == -1 || d == 2) ? 0.25f : 0.75f);
-        bf16_t v[8];
-        *(uint4*)v = *(const uint4*)(row + ox * (C::N * 2));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
-      }
+      adj2x_row_bf16(acc, *(const uint4*)(row + xo[0]), *(const uint4*)(row + xo[1]), *(const uint4*)(row + xo[2]), *(const uint4*)(row + xo[3]), a == -1 || a == 2);
     }
     bf16_t res[8], m8[8];
     *(uint4*)m8 = mv;
