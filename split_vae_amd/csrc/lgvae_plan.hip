@@ -710,7 +710,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
     if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
     p->gz_clean = true;
-  }
+  } else if (do_enc) p->gz_clean = true;       // (nothing accumulates into dz either: the backward must not re-zero it)
   if (do_enc && !(s->phases & SV_PHASE_INPUTS_STAGED)) {      // (staged: sv_scramble_gather_staged filled in8_x / in8_xh for this images6)
     Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
     SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
