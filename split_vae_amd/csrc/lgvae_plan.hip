@@ -108,6 +108,8 @@ struct sv_lgvae_plan {
   bool gz_clean = false;   // dz accumulators zeroed by the last encoder-forward phase and not yet used
   // the K-slice slabs of d1's input gradient are still unsummed in lat_ws_x / lat_ws_xh: reparam_kl_bwd sums them itself (one launch less)
   bool dz_slabs = false;
+  bool dz_valid = false;        // the decoders' backward has run since the last encoder forward (dz is what reparam_kl_bwd may read)
+  bool gz_zero_skipped = false; // that forward did not zero dz (slab path): an encoder backward WITHOUT the decoders' (KL terms only) zeroes it first
   bool lat_head_ok = false, lat_d1_ok = false;     // the heads' forward / d1's input gradient of this plan run on latent_gemm.hip (shapes are fixed per plan)
   int dz_S[2] = {0, 0};
   int64_t dz_stride[2] = {0, 0};
@@ -710,7 +712,12 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
     if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
     p->gz_clean = true;
-  } else if (do_enc) p->gz_clean = true;       // (nothing accumulates into dz either: the backward must not re-zero it)
+    p->gz_zero_skipped = false;
+  } else if (do_enc) {
+    p->gz_clean = true;                        // (nothing accumulates into dz either: the backward must not re-zero it)
+    p->gz_zero_skipped = true;
+  }
+  if (do_enc) { p->dz_slabs = false; p->dz_valid = false; }
   if (do_enc && !(s->phases & SV_PHASE_INPUTS_STAGED)) {      // (staged: sv_scramble_gather_staged filled in8_x / in8_xh for this images6)
     Scope sc(p, st, "split_pad", 0, (double)B * H * W * (24 + 16.0 * p->esz()));
     SV_TRY(svk_split_pad(s->images6, p->bp("in8_x"), p->bp("in8_xh"), dt, (int64_t)B * H * W, st));
@@ -768,7 +775,8 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
       if (rc == SV_OK) {
         done = true;
         p->lat_head_ok = true;
-        if (latent_fuse_on() && !e0 && !no_twin && q[0].splitk <= 16 && q[1].splitk <= 16) {   // (more slices: one wave per row reads them too slowly, B = 64: +4 %)            // Sampling + KL sum the slabs themselves (in slice order: the same bits)
+        // Sampling + KL sum the slabs themselves, in slice order: the same bits (more than 16 slices: one wave per row reads them too slowly, B = 64: +4 %)
+        if (latent_fuse_on() && !e0 && !no_twin && q[0].splitk <= 16 && q[1].splitk <= 16) {
           pre_slabs = true;
           for (int e = 0; e < 2; ++e) { pre_S[e] = q[e].splitk; pre_stride[e] = q[e].slab_stride; }
         } else SV_TRY(svk_nt_slab_reduce(q, outs, nq, st));
@@ -961,6 +969,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     for (int k = 0; k < 2; ++k) Ld[k].d.ldx = Ld[k].d.Cin;   // dz has its own row pitch (Lz), not the zcat pitch
     bool done = false;
     p->dz_slabs = false;
+    p->dz_valid = true;
     if (latent_gemm_on(p)) {
       NtGemmProb q[2];
       float* outs[2];
@@ -1002,6 +1011,12 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
   const char* en[2] = {"x", "xh"};
   const float kl_scale = d.beta / (float)B;
   const int e0 = d.external_global_encoder ? 1 : 0;
+  if (do_heads && !p->dz_valid && p->gz_zero_skipped) {       // KL terms only (no decoder backward since the forward): dz = 0
+    char* z0 = (char*)p->bp("gz_x");
+    char* z1 = (char*)p->bp("gz_xh") + p->bbytes("gz_xh");
+    if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
+    p->gz_zero_skipped = false;
+  }
   if (do_heads) {
     Scope sc(p, st, "reparam_kl_bwd", 0, 0);
     static const bool no_twin = getenv("SV_NO_TWIN_POINTWISE") != nullptr;
@@ -1291,8 +1306,8 @@ extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void
     if (hi != hipSuccess) { e.exec = nullptr; return (int)hi; }
   } else {
     // the host-side state the phases would have left behind
-    if (ph & SV_PHASE_FWD_ENCODERS) p->gz_clean = true;
-    if (ph & SV_PHASE_BWD_DECODERS) p->gz_clean = false;
+    if (ph & SV_PHASE_FWD_ENCODERS) { p->gz_clean = true; p->dz_valid = false; }
+    if (ph & SV_PHASE_BWD_DECODERS) { p->gz_clean = false; p->dz_valid = true; }
   }
   if (hipGraphLaunch(e.exec, st) != hipSuccess) return (int)hipGetLastError();
   return SV_OK;

@@ -337,3 +337,36 @@ def test_staged_augmentation_fills_the_step_inputs(lib_built, dtype):
     assert torch.equal(i0, i1) and torch.equal(a0, a1) and torch.equal(b0, b1)
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), k
+
+
+def test_encoder_backward_without_the_decoders_sees_zero_dz(lib_built):
+    """PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS right after a forward (no decoder backward: the KL terms' gradient only, vae/trainer.py:12-13)
+    must not pick up the previous step's dz -- the slab path no longer zeroes those buffers every forward.  The head-bias
+    gradient of encoder_x_hat is then d(beta * KL) / d(pre) summed over the batch, which has a closed form in z_mean / z_sig."""
+    import torch
+    from split_vae_amd import data, trainer
+    from split_vae_amd._lib import PHASE_PREP, PHASE_FORWARD, PHASE_LOSS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    from split_vae_amd.optimizer import Adam
+    B, H = 256, 64
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    img = Augmentator("scramble", size=8, seed=1).augment(x)
+    m = LGVae(128, 128, image_shape=[-1, H, H, 3], dtype="bf16", device=torch.device("cuda"), seed=3)
+    m.beta = 120.0
+    opt = Adam(learning_rate=1e-4)
+    for _ in range(2):                                          # whole steps first: the slab path is active, dz slabs hold a real gradient
+        plan = trainer.train_step(m, img, opt)
+    plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS, params=m.flat, grads=m.grad_flat, images6=img, seed=m.seed, step=7)
+    plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, params=m.flat, grads=m.grad_flat, images6=img, seed=m.seed, step=7)
+    torch.cuda.synchronize()
+    zm = plan.buffer("z_mean_xh", torch.float32, (B, 128)).double()
+    zs = plan.buffer("z_sig_xh", torch.float32, (B, 128)).double()
+    ks = m.beta / B
+    want_mean = (ks * zm).sum(0)                                # d KL / d mu = mu
+    want_sd = (ks * (zs - 1.0 / zs) * (1.0 - torch.exp(-zs))).sum(0)     # d KL / d sigma * softplus'
+    names = [n for n, _, _ in m.param_table]
+    g = {n: t for n, t in zip(names, m.gradients)}
+    gm, gs = g["encoder_x_hat/e4_mean/bias"].double(), g["encoder_x_hat/e4_sd/bias"].double()
+    assert float((gm - want_mean).abs().max()) <= 2e-2 * float(want_mean.abs().max()) + 1e-6
+    assert float((gs - want_sd).abs().max()) <= 2e-2 * float(want_sd.abs().max()) + 1e-6
