@@ -364,9 +364,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     const RowConvArgs& g = mg.a[prob];
     if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
     else {
-      // The whole ring starts as zeros, once per launch: the halo columns (the DMAs only ever write in-image pixels) and --
-      // TP -- the rows the two DUMMY taps of the second tap group read (rows behind the window: their weights are zero, but
-      // 0 x stale-LDS-garbage is NaN when the garbage is not finite; 0 x any old or half-landed gradient row is 0)
+      // The whole ring starts as zeros, once per launch: the halo columns (the DMAs only ever write in-image pixels).  (The tap-packed
+      // form used to read two DUMMY rows behind the window with zero weights -- 0 x stale-LDS-garbage is NaN when the garbage is not
+      // finite, hence zeros everywhere; its 2 x 2 tap blocks have no dummies any more, the halo columns still need them.)
       for (int q = tid; q < C::RING / 16; q += NT) *(uint4*)(sRing + q * 16) = make_uint4(0, 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
