@@ -287,22 +287,27 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
 template <typename C>
 __device__ __forceinline__ void adjoint_rows(const RowConvArgs& g, int b, int e_lo, int e_hi, int obase, const char* sOut, int t, int nt) {
   constexpr int NP8 = C::N / 8, LW = C::WIDTH / 2, IPR = LW * NP8;
+  // A low-res row is IPR = 128 items (pixel j, 8-channel piece c) in every ADJ configuration: a thread keeps ITS (j, c) for the whole
+  // launch (column offsets, output offset: computed once, hoisted out of the step loop) and a wave's 64 items share the row i, so
+  // the row clamps, the out-ring slots (a modulo by ORR each) and the row bases are scalar work.  VALU instructions are step time
+  // one to one in this kernel: the index arithmetic was ~45 of ~190 per item.
+  static_assert(IPR % 64 == 0 && C::NT % IPR == 0, "a wave's items share their low-res row");
   const int LH = g.H >> 1;
-  const int total = (e_hi - e_lo + 1) * IPR;
-  for (int it = t; it < total; it += nt) {
-    const int ii = it / IPR, r = it - ii * IPR;
-    const int i = e_lo + ii, j = r / NP8, c = r - j * NP8;
-    const int64_t o = (((int64_t)b * LH + i) * LW + j) * g.ldo + c * 8;
+  const int r = t % IPR, j = r / NP8, c = r - j * NP8;
+  const int xo[4] = {max(2 * j - 1, 0) * (C::N * 2) + c * 16, 2 * j * (C::N * 2) + c * 16, (2 * j + 1) * (C::N * 2) + c * 16,
+                     min(2 * j + 2, C::WIDTH - 1) * (C::N * 2) + c * 16};
+  const int64_t o_jc = (int64_t)j * g.ldo + c * 8;
+  for (int i = e_lo + __builtin_amdgcn_readfirstlane(t / IPR); i <= e_hi; i += C::NT / IPR) {
+    const int64_t o = ((int64_t)b * LH + i) * LW * g.ldo + o_jc;
     uint4 mv = make_uint4(0, 0, 0, 0);
     if (g.mask) mv = *(const uint4*)((const bf16_t*)g.mask + o);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    const int xo[4] = {max(2 * j - 1, 0) * (C::N * 2), 2 * j * (C::N * 2), (2 * j + 1) * (C::N * 2), min(2 * j + 2, C::WIDTH - 1) * (C::N * 2)};
 #pragma unroll
     for (int a = -1; a <= 2; ++a) {
       const int oy = min(max(2 * i + a, 0), g.H - 1);
-      const char* row = sOut + ((obase + oy) % C::ORR) * C::OROWB + c * 16;
+      const char* row = sOut + ((obase + oy) % C::ORR) * C::OROWB;
       adj2x_row_bf16(acc, *(const uint4*)(row + xo[0]), *(const uint4*)(row + xo[1]), *(const uint4*)(row + xo[2]), *(const uint4*)(row + xo[3]), a == -1 || a == 2);
     }
     bf16_t res[8], m8[8];
