@@ -34,15 +34,20 @@ __device__ __forceinline__ void dll_elem(float x, float m, float ls, float& nll,
   // series below 0.25 (truncation < 4e-10 relative), hardware exp above.
   const float d = s * (2.f / 255.f);
   const float ser = d * (1.f - d * (0.5f - d * (0.16666667f - d * (0.041666668f - d * (8.3333338e-3f - d * (1.3888889e-3f - d * 1.9841270e-4f))))));
-  const float om = d < 0.25f ? ser : 1.f - __expf(-d);
+  // (the hardware exp only where a lane of the wave needs it: wave-uniform branches skip quarter-rate instructions whose results a
+  //  select would throw away -- the element function is VALU time one to one in the head's fused epilogue)
+  float om = ser;
+  if (__any(!(d < 0.25f))) om = d < 0.25f ? ser : 1.f - __expf(-d);
   const float delta = sp * sqc * om;
   // the three tf.where branches that do not diverge (edges are common: every saturated pixel):
   //   x < -0.999: log_cdf_plus = -softplus(-p) ; x > 0.999: log_one_minus_cdf_min = -softplus(q)
-  const float nll_lo = fmaxf(-p, 0.f) + log1p_unit(ep), nll_hi = fmaxf(q, 0.f) + log1p_unit(eq);
+  const bool lo = x < -0.999f, hi = x > 0.999f;
+  float nll_lo = 0.f, nll_hi = 0.f;                      // saturated pixels only (level 0 / 255): rare outside flat image regions
+  if (__any(lo)) nll_lo = fmaxf(-p, 0.f) + log1p_unit(ep);
+  if (__any(hi)) nll_hi = fmaxf(q, 0.f) + log1p_unit(eq);
   // d/dm log(delta) = s*(sigmoid(q) - (1-sigmoid(p))) ; d/dls = -p(1-sig(p)) + q sig(q) - d/expm1(d), d/expm1(d) = d*exp(-d)/om
   const float nll_mid = -__logf(delta);                // max(delta,1e-12) == delta on this branch
   const float dls_mid = p * spc - q * sq + d * (1.f - om) * __builtin_amdgcn_rcpf(om);
-  const bool lo = x < -0.999f, hi = x > 0.999f;
   nll = lo ? nll_lo : hi ? nll_hi : nll_mid;
   dm = lo ? s * spc : hi ? -s * sq : s * (spc - sq);
   dls = lo ? p * spc : hi ? -q * sq : dls_mid;
