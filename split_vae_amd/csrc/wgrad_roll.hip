@@ -90,6 +90,7 @@ struct RollLds {
   char* in;                                          // [PS + NSLOT * IN_SLOT] blended block rows (one pixel of front padding)
   char* raw;                                         // [NDMA * RAW_SLOT] raw low-res rows (DMA)
   char* dy;                                          // [NDMA * DY_SLOT] dY chunks (DMA)
+  char* bw;                                          // [512 threads][2][16 B] the blend's per-lane weight operands (read back per step: 8 VGPRs less)
 };
 
 // One workgroup's walk.  Roles per step: every wave multiplies (its channel fragment x its three x taps x all six y taps) and blends its
@@ -161,8 +162,8 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
   int wx0 = (q_lo % g.nxs) * 16, ws = -LEAD;                      // x0 / s of the step to blend
   // B operands (weights) of the two rows dyb, constant per lane: K index 4 h + q of the lane's 8 <-> low-res row h, raw column
   // jj = 4 (lane >> 4) + q; output column lane & 15 <-> patch pixel bp = 2 jj0 - 1 + dxb.  (Columns outside the image are zeroed at the store.)
-  short8_t bw[2];
   {
+    short8_t bw[2];
     const int dxb = (bp & 1) ? 0 : 1, jj0 = (bp + 1 - dxb) >> 1, gq = (lane >> 4) * 4;
 #pragma unroll
     for (int dyb = 0; dyb < 2; ++dyb)
@@ -175,7 +176,10 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
           const float wy = (h == 0) == (dyb == 0) ? 0.75f : 0.25f;
           bw[dyb][h * 4 + q] = (short)(__float_as_uint(wx * wy) >> 16);       // 0, 1/16, 3/16, 9/16: exact in bf16
         }
+    *(short8_t*)(L.bw + tid * 32) = bw[0];
+    *(short8_t*)(L.bw + tid * 32 + 16) = bw[1];
   }
+  const char* bw_lane = L.bw + tid * 32;
   short4_t ba_lo, ba_hi;                                          // raw rows of the step being blended (A operand), read at the top of the step
   ba_lo = ba_hi = (short4_t){0, 0, 0, 0};
   f32x4 bd[2];                                                    // the two rows' products in flight
@@ -192,8 +196,9 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
     if (ROLL_ABL & 2) return;
     const short8_t af = (short8_t){ba_lo[0], ba_lo[1], ba_lo[2], ba_lo[3], ba_hi[0], ba_hi[1], ba_hi[2], ba_hi[3]};
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bd[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw[0]), z, 0, 0, 0);
-    bd[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw[1]), z, 0, 0, 0);
+    const short8_t bw0 = *(const short8_t*)bw_lane, bw1 = *(const short8_t*)(bw_lane + 16);
+    bd[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw0), z, 0, 0, 0);
+    bd[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw1), z, 0, 0, 0);
   };
   auto blend_store = [&]() {
     if (ROLL_ABL & 2) return;
@@ -235,7 +240,12 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
   // iteration t: the DMAs of step t + AHEAD, the blend of step t + 1, the window update + MFMAs of step t - 1 (the blend runs two steps
   // ahead of its readers: one barrier per two iterations)
   int ms = -LEAD - 1;                                             // s of step t - 1 (iteration 0: no step)
-  auto body = [&](int t, auto BL) {
+  // PHc = -1: the window SHIFTS by two rows per step (30 v_mov per step: VALU issue is step time one to one);
+  // PHc = 0..6: it ROTATES instead -- logical row r lives in register row (r + 2 PH) % 7, nothing moves; seven consecutive steps
+  // (phases 1, 2, .., 6, 0) bring it back to the identity, so the main loop is unrolled by seven and the tail runs the shifting form.
+  auto body = [&](int t, auto BL, auto PHc) {
+    constexpr int PH = decltype(PHc)::value;
+    auto P = [](int r) constexpr { return PH < 0 ? r : (r + 2 * PH) % (KS + 1); };
     const bool mm = ms >= 0;                                      // wave-uniform: this step multiplies (not a lead-in step)
     ROLL_STAMP(0);
     if (producer) produce(t + AHEAD);
@@ -245,11 +255,13 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
       const char* rp = L.in + PS + ((t - 1) & (NSLOT - 1)) * IN_SLOT + in_lane;
 #pragma unroll
       for (int kx = 0; kx < KXW; ++kx) {
+        if constexpr (PH < 0) {
 #pragma unroll
-        for (int r = 0; r + 2 <= KS; ++r) win[r][kx] = win[r + 2][kx];
+          for (int r = 0; r + 2 <= KS; ++r) win[r][kx] = win[r + 2][kx];
+        }
         if (!(ROLL_ABL & 8)) {
-          win[KS - 1][kx] = tr16(rp + kx * PS);
-          win[KS][kx] = tr16(rp + (PW + kx) * PS);
+          win[P(KS - 1)][kx] = tr16(rp + kx * PS);
+          win[P(KS)][kx] = tr16(rp + (PW + kx) * PS);
         }
       }
     }
@@ -267,7 +279,7 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < KXW; ++kx) {
-          const short4_t lo = win[ky][kx], hi = win[ky + 1][kx];
+          const short4_t lo = win[P(ky)][kx], hi = win[P(ky + 1)][kx];
           const short8_t af = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
           for (int j = 0; j < COF; ++j)
@@ -298,8 +310,19 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
     ROLL_STAMP(6);
   };
   int t = 0;
-  for (; t + 1 < T; ++t) body(t, std::true_type{});
-  for (; t <= T; ++t) body(t, std::false_type{});
+  using std::integral_constant;
+  static const bool no_rot = false;
+  for (; !no_rot && t + 7 < T; t += 7) {                          // (every t < T - 1 here: the blending form)
+    body(t, std::true_type{}, integral_constant<int, 1>{});
+    body(t + 1, std::true_type{}, integral_constant<int, 2>{});
+    body(t + 2, std::true_type{}, integral_constant<int, 3>{});
+    body(t + 3, std::true_type{}, integral_constant<int, 4>{});
+    body(t + 4, std::true_type{}, integral_constant<int, 5>{});
+    body(t + 5, std::true_type{}, integral_constant<int, 6>{});
+    body(t + 6, std::true_type{}, integral_constant<int, 0>{});
+  }
+  for (; t + 1 < T; ++t) body(t, std::true_type{}, integral_constant<int, -1>{});
+  for (; t <= T; ++t) body(t, std::false_type{}, integral_constant<int, -1>{});
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad_roll_kernel(const RollMulti mg) {
@@ -307,13 +330,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_roll_kernel(const RollMulti mg) 
   __shared__ __attribute__((aligned(16))) char lds_in[PS + NSLOT * IN_SLOT];      // separate objects: the compiler orders LDS reads after
   __shared__ __attribute__((aligned(16))) char lds_raw[NDMA * RAW_SLOT];    // the DMAs only where they can alias
   __shared__ __attribute__((aligned(16))) char lds_dy[NDMA * DY_SLOT];
+  __shared__ __attribute__((aligned(16))) char lds_bw[512 * 32];
 #ifdef SV_ROLL_STAMP
   __shared__ long long lds_stamps[4 * 8 * NSTAMP];
   for (int i = threadIdx.x; i < 4 * 8 * NSTAMP; i += 512) lds_stamps[i] = 0;
   __syncthreads();
-  const RollLds L = {lds_stamps, lds_in, lds_raw, lds_dy};
+  const RollLds L = {lds_stamps, lds_in, lds_raw, lds_dy, lds_bw};
 #else
-  const RollLds L = {nullptr, lds_in, lds_raw, lds_dy};
+  const RollLds L = {nullptr, lds_in, lds_raw, lds_dy, lds_bw};
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cf = wave & 3, kx0 = (wave >> 2) * KXW;
