@@ -241,11 +241,17 @@ def decoder_stack(table, dtype, passes):
 
 
 # plan scope -> substrings of its HIP kernel symbol as rocprofv3 prints it (profiles/*_traffic.json keys)
-SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyphase head; the symbol also serves e1's forward (traffic = their mean)
-                "fwd.d4": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
-                "fwd.d3": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi4E"], "fwd.e2": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi0E"],
+SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyphase head
+                # (row-ring kernel: RowCfg<KH, KW, CIN, N, WIDTH, MF, NBW, KS, XG, RG, UPS, WAVES, ADJ, ...>; the tile-kernel symbols are the small-batch forms)
+                "fwd.d4": ["RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true", "tile_conv_kernelIDF16bLi32ELi4ELi4ELi6E"],
+                "fwd.d3": ["tile_conv_kernelIDF16bLi64ELi4ELi4ELi4E", "RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true"],
+                "fwd.d2": ["RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, false"],
+                "fwd.e1": ["RowCfg<3, 3, 32, 32, 32, "], "fwd.e2": ["RowCfg<3, 3, 128, 64, 16, ", "tile_conv_kernelIDF16bLi64ELi4ELi4ELi0E"],
+                "fwd.e3": ["RowCfg<2, 2, 256, 128, 16, "],
                 "wgrad.d5": ["wgrad_tile_kernel<7, 1, 2, 8, ", "wgrad_tile_kernel<11, "], "wgrad.d4": ["wgrad_roll_kernel", "wgrad_tile_kernel<9, 1, 2, 8, "],
-                "dgrad.d4": ["RowCfg<6, 6, 32, 64, 32, "], "dgrad.d5": ["RowCfg<6, 6, 8, 32, 64, "], "dgrad.d3": ["RowCfg<4, 4, 64, 128, "]}
+                "wgrad.d3": ["wgrad_tile_kernel<4, 2, 4, 8, 1, 2>"], "wgrad.e2": ["wgrad_e2_kernel"], "wgrad.e1": ["wgrad_e1_kernel"],
+                "dgrad.d4": ["RowCfg<6, 6, 32, 64, 32, "], "dgrad.d5": ["RowCfg<6, 6, 8, 32, 64, "], "dgrad.d3": ["RowCfg<4, 4, 64, 128, "],
+                "dgrad.e2": ["RowCfg<3, 3, 64, 128, 16, 4, 2, "]}
 
 
 def wgrad_main_layers(images_per_launch, dtype, world=1):
