@@ -6,8 +6,10 @@ One "step" = patch scramble (incl. the per-image random permutation) + forward +
 resident in HBM, i.e. train_step_lg_vae (vae/trainer.py:120-144) behind the augmentation of
 vae/main.py:57-61.  Workload (BASELINE.json metric: "SPLIT-VAE CelebA-64 bs512"): H=W=64,
 beta=120, patch_size=8, latents 128+128, lr 1e-4, bf16 MFMA contractions with fp32 accumulate /
-master weights / ELBO / Adam.  Per-GPU batch is fixed at 512 (weak scaling): `value` is the
-whole-job aggregate N*512*K / t.
+master weights / ELBO / Adam.  The metric's batch is GLOBAL: `--gpus N` splits 512 images evenly over the N ranks
+(strong scaling: 64 per GPU at N = 8) and `value` is the whole-job aggregate 512*K / t; the weak-scaling
+figure (512 per GPU) rides along as `weak` in the N > 1 line, and `--batch B` makes it the headline instead.  The same line
+carries the reference-precision (fp32) step as a first-class block `fp32` with its own roofline.
 
     python bench.py                                  # N=1, 200 timed steps
     python bench.py --gpus N --steps K --warmup W    # N>1: spawns N ranks itself (one per GPU, RCCL), or runs as one
@@ -18,9 +20,11 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      dominant kernel (hipEvent-timed inside the timed region on its launch stream), the decoder conv stack
                 aggregate (north_star's >= 70 % target) and the HBM-bound ELBO kernel
   cpu_baseline  the oracle restatement timed on the host cores (N=1 only; reported baseline, not the target)
+  fp32          (N=1) the same step at the reference's own precision (exact-fp32 MFMA): value, ms_per_step and a roofline block
+                (dominant kernel live + serial, decoder conv stack) against the 157.3 TFLOP/s fp32 matrix peak
   rows          the other configurations of BASELINE.md section 4 measured in the same process, outside the timed region:
-                fp32 parity path, SVHN-32 B=64, the 64- and 128-image shards of config 4 (strong scaling)
-  rccl_ranks / allreduce_ms / strong   (N>1) the collective actually used, its per-bucket time, the 512-global-batch row
+                SVHN-32 B=64, the 64- and 128-image shards of config 4 (strong scaling), SPLIT-GMVAE, SPLIT-SPAIR
+  rccl_ranks / allreduce_ms / weak   (N>1) the collective actually used, its per-bucket time, the 512-per-GPU (weak scaling) row
 The per-launch table goes to stderr.
 """
 import argparse
@@ -330,18 +334,112 @@ def gm_row(dev, B=64, steps=100, warmup=10):
             "workload": "SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4"}
 
 
+def roofline_block(table, dom, worst, prof, dtype, B, world):
+    """The `roofline` object of one precision: the dominant kernel live (hipEvents on its stream inside the timed region) and serial, the decoder
+    conv stack, the worst large launch, the top-12 table and the HBM-bound entry."""
+    if not (prof and prof[0]["launches"]):
+        return None
+    avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
+    ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype]
+    traffic, symbol, tfile = measured_traffic(SCOPE_KERNEL.get(prof[0]["name"], [])) if dtype == "bf16" else (None, None, _traffic_file())
+    rl = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
+          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+          "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            "bench, bytes per launch; null when the kernel symbol of this build is not in it)" % os.path.basename(tfile),
+          "hip_kernel": symbol,
+          "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
+          "flops_per_launch": prof[0]["flops"],
+          "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
+                    prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, dtype, world) else
+                    "main (the weight-gradient side stream runs other layers' launches beside it)",
+          "live_note": "achieved / frac are LIVE: hipEvents around the launch on its stream inside the timed region, where up to three "
+                       "launches share the chip (two weight-gradient side streams beside the input-gradient chain from 768 images per "
+                       "launch: DESIGN.md 4g); `serial` is the same launch alone on the chip",
+          "decoder_stack": decoder_stack(table, dtype, TABLE_PASSES)}
+    gs = grade(dom, dtype)
+    rl["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
+                    "note": "the same launch alone on the chip (per-launch table, side stream off)"}
+    if worst is not None:
+        gw = grade(worst, dtype)
+        rl["worst_large"] = {"kernel": worst["name"], "bound": gw["bound"], "avg_launch_ms": round(gw["avg_ms"], 4),
+                             "achieved": round(gw["tflops"] if gw["bound"] == "mfma" else gw["gbs"], 2),
+                             "unit": "TFLOP/s" if gw["bound"] == "mfma" else "GB/s", "frac": round(gw["frac"], 4),
+                             "note": "the launch >= 0.1 ms with the lowest fraction of its roofline (serial table)"}
+    rl["table"] = [{"kernel": r["name"], "ms": round(grade(r, dtype)["avg_ms"], 4), "bound": grade(r, dtype)["bound"],
+                    "frac": round(grade(r, dtype)["frac"], 4)} for r in table[:12]]
+    # the HBM-bound entry: the ELBO kernel when the step runs it, else (training steps evaluate the loss in the decoder
+    # head's epilogue) the Adam update -- 28 algorithmic bytes per parameter
+    elbo = next((r for r in table if r["name"].startswith("dlogistic")), None) or \
+        next((r for r in table if r["name"] == "adam_step"), None)
+    if elbo and elbo["launches"]:
+        ems = elbo["total_ms"] / elbo["launches"]
+        etr, esym, _ = measured_traffic(["dlogistic_kernel"] if elbo["name"].startswith("dlogistic") else ["adam_kernel"])
+        rl["hbm"] = {"bound": "hbm", "kernel": elbo["name"], "algorithmic_bytes": elbo["bytes"],
+                     "avg_launch_ms": round(ems, 4), "achieved": round(elbo["bytes"] / (ems * 1e-3) / 1e9, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(elbo["bytes"] / (ems * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     "traffic": etr, "traffic_gbs": round(etr / (ems * 1e-3) / 1e9, 1) if etr else None}
+    return rl
+
+
+def pick_rows(table, dtype):
+    """(dominant launch = the top row of the serial table with FLOPs, the worst launch >= 0.1 ms against its roofline)."""
+    dom = next(r for r in table if r["flops"] > 0)
+    large = [r for r in table if r["total_ms"] / max(r["launches"], 1) >= 0.1 and (r["flops"] or r["bytes"])]
+    worst = min(large, key=lambda r: grade(r, dtype)["frac"]) if large else None
+    return dom, worst
+
+
+def print_table(table, dtype, H, B):
+    tot = sum(r["total_ms"] for r in table)
+    sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (dtype, H, H, B))
+    for r in table:
+        g = grade(r, dtype)
+        sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline\n" %
+                         (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
+
+
+def fp32_block(dev, H, B, steps=40, warmup=5):
+    """The step at the reference's own precision (vae/model.py:12: fp32 end to end; exact-fp32 MFMA here) as a first-class measurement: the
+    same timed protocol as the headline (W untimed + K timed steps between synchronizes), its own serial table and roofline block graded
+    against the 157.3 TFLOP/s fp32 matrix peak."""
+    import torch
+    w = Workload(H, B, "f32", dev, 0, 1)
+    for _ in range(warmup):
+        w.step()
+    torch.cuda.synchronize()
+    plan, table = kernel_table(w)
+    print_table(table, "f32", H, B)
+    dom, worst = pick_rows(table, "f32")
+    plan.profile_filter(dom["name"])
+    plan.profile_enable(True)
+    dt = w.timed(steps, warmup, 1, dev)
+    prof = [r for r in plan.profile_read() if r["name"] == dom["name"]]
+    plan.profile_enable(False)
+    value = B * steps / dt
+    out = {"value": round(value, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup,
+           "dtype": "f32 operands, f32 accumulate (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the reference's precision",
+           "per_gpu_batch": B,
+           "step_tflops": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12, 2),
+           "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS["f32"], 4),
+           "roofline": roofline_block(table, dom, worst, prof, "f32", B, 1)}
+    del w
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (weak scaling: the default, 512 per GPU)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling) instead of the default global batch")
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling instead: total batch split evenly over the GPUs (e.g. 512 -> 64 per GPU at N=8, SURVEY config C4)")
+                    help="total batch split evenly over the GPUs (default 512 = BASELINE.json's metric: 64 per GPU at N=8, SURVEY config C4)")
     ap.add_argument("--size", type=int, default=64, choices=[32, 64])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rows", action="store_true", help="skip the extra configurations (fp32, SVHN-32, small shards)")
+    ap.add_argument("--no-rows", action="store_true", help="skip the extra configurations (SVHN-32, small shards, SPLIT-GMVAE, SPLIT-SPAIR)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision (fp32) block")
     ap.add_argument("--profile-all", action="store_true", help="(kept for compatibility: the per-launch table always goes to stderr)")
     args = ap.parse_args()
 
@@ -362,11 +460,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    H, B = args.size, args.batch
-    if args.global_batch:
-        if args.global_batch % world:
-            raise SystemExit("--global-batch %d is not divisible by %d GPUs" % (args.global_batch, world))
-        B = args.global_batch // world
+    H = args.size
+    if args.batch and args.global_batch:
+        raise SystemExit("--batch (per GPU, weak scaling) and --global-batch (strong scaling) exclude each other")
+    if args.batch:
+        B, strong = args.batch, False
+    else:
+        gb = args.global_batch or 512                  # BASELINE.json's metric: bs512 is the GLOBAL batch at every N
+        if gb % world:
+            raise SystemExit("global batch %d is not divisible by %d GPUs" % (gb, world))
+        B, strong = gb // world, True
     w = Workload(H, B, args.dtype, dev, rank, world, svdist.make_reducer)
     for _ in range(max(args.warmup, 1)):
         w.step()
@@ -375,19 +478,11 @@ def main():
     # per-launch table + the dominant kernel family (outside the timed region)
     plan, table = kernel_table(w)
     if rank == 0:
-        tot = sum(r["total_ms"] for r in table)
-        sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (args.dtype, H, H, B))
-        for r in table:
-            g = grade(r, args.dtype)
-            sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline\n" %
-                             (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
-    # the dominant kernel = the top row of the serial table, whatever it is (round 3: the weight gradient of d4, or d4's input gradient /
-    # forward: the three are within 2 %).  In the timed region the two streams of the backward pass overlap: `achieved` is what the hipEvents
-    # around the launch on ITS stream give there (co-running launches of the other stream included; `stream` names it), `serial` what the
-    # launch takes alone on the chip.
-    dom = next(r for r in table if r["flops"] > 0)
-    large = [r for r in table if r["total_ms"] / max(r["launches"], 1) >= 0.1 and (r["flops"] or r["bytes"])]
-    worst = min(large, key=lambda r: grade(r, args.dtype)["frac"]) if large else None
+        print_table(table, args.dtype, H, B)
+    # the dominant kernel = the top row of the serial table, whatever it is.  In the timed region the streams of the backward pass overlap:
+    # `achieved` is what the hipEvents around the launch on ITS stream give there (co-running launches of the other streams included; `stream`
+    # names it), `serial` what the launch takes alone on the chip.
+    dom, worst = pick_rows(table, args.dtype)
 
     plan.profile_filter(dom["name"])
     plan.profile_enable(True)
@@ -416,15 +511,18 @@ def main():
         extra["dist_backend"] = "sv_comm (RCCL through the C ABI)" if native else backend
         extra["allreduce_ms"] = ar
         extra["allreduce_bytes"] = {k: int(sum(e - b for b, e in v) * 4) for k, v in w.reducer.buckets.items()}
-        if world > 1 and not args.global_batch and 512 % world == 0 and H == 64:
-            # the strong-scaling row of config 4: global batch 512 split over the ranks (64 per GPU at N = 8)
-            ws = Workload(64, 512 // world, args.dtype, dev, rank, world, svdist.make_reducer)
-            ks = max(args.steps, 100)
+        if world > 1 and strong and H == 64 and not args.no_rows:
+            # the weak-scaling row: 512 images per GPU (global 512 N), what rounds 1-3 reported as the headline
+            ws = Workload(64, 512, args.dtype, dev, rank, world, svdist.make_reducer)
+            ks = max(args.steps, 60)
             dts = ws.timed(ks, 10, world, dev)
-            extra["strong"] = {"global_batch": 512, "per_gpu_batch": 512 // world, "value": round(512 * ks / dts, 1),
-                               "ms_per_step": round(1e3 * dts / ks, 4), "steps": ks, "scaling": "strong"}
+            extra["weak"] = {"global_batch": 512 * world, "per_gpu_batch": 512, "value": round(world * 512 * ks / dts, 1),
+                             "ms_per_step": round(1e3 * dts / ks, 4), "steps": ks, "scaling": "weak"}
             del ws
     rows = {}
+    fp32 = None
+    if world == 1 and not args.no_fp32 and args.dtype == "bf16":
+        fp32 = fp32_block(dev, H, B)                           # reference precision, first-class (own roofline): VERDICT r03 item 3b
     if world == 1 and not args.no_rows and H == 64 and args.dtype == "bf16" and B == 512:
         def row(Hr, Br, dt_, steps, warm=10):
             wr = Workload(Hr, Br, dt_, dev, 0, 1)
@@ -433,8 +531,6 @@ def main():
                  "step_tflops": round(Br * steps / t * TRAIN_FLOP_PER_IMAGE[Hr] / 1e12, 2)}
             r["frac_of_peak"] = round(r["step_tflops"] / PEAK_TFLOPS[dt_], 4)
             return r
-        rows["fp32"] = row(64, 512, "f32", 40, 5)              # the fp32-parity path (the reference's own precision)
-        rows["fp32"]["frac_of_157TF"] = rows["fp32"].pop("frac_of_peak")
         rows["celeba64_b256"] = row(64, 256, "bf16", 200)      # config 2 (BASELINE.json configs[1]: CelebA-64 bs256 bf16 on one MI355X)
         rows["svhn32_b64"] = row(32, 64, "bf16", 200)          # config C1's shape on the GPU
         try:
@@ -458,8 +554,10 @@ def main():
         "metric": "images/sec training step, SPLIT-VAE CelebA-64 bs512" if H == 64 else "images/sec training step, SPLIT-VAE SVHN-32",
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-        "scaling": "strong" if args.global_batch else "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "bf16 operands, fp32 accumulate (reference: fp32; the fp32 step is the `fp32` block of this line)" if args.dtype == "bf16" else "f32",
+        "dtype_short": args.dtype, "data": "synthetic",
         "config": {"workload": "SPLIT-VAE %s %dx%d beta=%g patch_size=%d latents=128+128 lr=1e-4, full train step "
                                "(scramble+fwd+ELBO+bwd+Adam%s), per-GPU batch %d" %
                                ("CelebA-64" if H == 64 else "SVHN-32", H, H, w.beta, w.patch,
@@ -474,47 +572,11 @@ def main():
         "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[args.dtype] / world, 4),
     }
     out.update(extra)
-    if prof and prof[0]["launches"]:
-        avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
-        ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        traffic, symbol, tfile = measured_traffic(SCOPE_KERNEL.get(prof[0]["name"], []))
-        out["roofline"] = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                           "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                             "bench, bytes per launch; null when the kernel symbol of this build is not in it)" % os.path.basename(tfile),
-                           "hip_kernel": symbol,
-                           "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
-                           "flops_per_launch": prof[0]["flops"],
-                           "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
-                                     prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, args.dtype, world) else
-                                     "main (the weight-gradient side stream runs other layers' launches beside it)",
-                           "live_note": "achieved / frac are LIVE: hipEvents around the launch on its stream inside the timed region, where up to three "
-                                        "launches share the chip (two weight-gradient side streams beside the input-gradient chain from 768 images per "
-                                        "launch: DESIGN.md 4g); `serial` is the same launch alone on the chip",
-                           "decoder_stack": decoder_stack(table, args.dtype, TABLE_PASSES)}
-        gs = grade(dom, args.dtype)
-        out["roofline"]["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
-                                     "note": "the same launch alone on the chip (per-launch table, side stream off)"}
-        if worst is not None:
-            gw = grade(worst, args.dtype)
-            out["roofline"]["worst_large"] = {"kernel": worst["name"], "bound": gw["bound"], "avg_launch_ms": round(gw["avg_ms"], 4),
-                                              "achieved": round(gw["tflops"] if gw["bound"] == "mfma" else gw["gbs"], 2),
-                                              "unit": "TFLOP/s" if gw["bound"] == "mfma" else "GB/s", "frac": round(gw["frac"], 4),
-                                              "note": "the launch >= 0.1 ms with the lowest fraction of its roofline (serial table)"}
-        out["roofline"]["table"] = [{"kernel": r["name"], "ms": round(grade(r, args.dtype)["avg_ms"], 4), "bound": grade(r, args.dtype)["bound"],
-                                     "frac": round(grade(r, args.dtype)["frac"], 4)} for r in table[:12]]
-        # the HBM-bound entry: the ELBO kernel when the step runs it, else (training steps evaluate the loss in the decoder
-        # head's epilogue) the Adam update -- 28 algorithmic bytes per parameter
-        elbo = next((r for r in table if r["name"].startswith("dlogistic")), None) or \
-            next((r for r in table if r["name"] == "adam_step"), None)
-        if elbo and elbo["launches"]:
-            ems = elbo["total_ms"] / elbo["launches"]
-            etr, esym, _ = measured_traffic(["dlogistic_kernel"] if elbo["name"].startswith("dlogistic") else ["adam_kernel"])
-            out["roofline"]["hbm"] = {"bound": "hbm", "kernel": elbo["name"], "algorithmic_bytes": elbo["bytes"],
-                                      "avg_launch_ms": round(ems, 4), "achieved": round(elbo["bytes"] / (ems * 1e-3) / 1e9, 1),
-                                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(elbo["bytes"] / (ems * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                      "traffic": etr, "traffic_gbs": round(etr / (ems * 1e-3) / 1e9, 1) if etr else None}
+    rl = roofline_block(table, dom, worst, prof, args.dtype, B, world)
+    if rl:
+        out["roofline"] = rl
+    if fp32 is not None:
+        out["fp32"] = fp32
     if rows:
         out["rows"] = rows
     if world == 1 and not args.no_cpu_baseline:

@@ -27,6 +27,14 @@ typedef enum { SV_ACT_NONE = 0, SV_ACT_RELU = 1, SV_ACT_ELU = 2 /* pointwise ker
 
 const char* sv_version(void);
 
+/* Fixed-order reductions for every launch that FOLLOWS: 1 = on (no split-K / m-split fp32 atomics anywhere: same inputs twice ->
+ * identical bits; SURVEY section 5's determinism test), 0 = off (the faster atomics-ordered dense layers), -1 = what the environment
+ * variable SV_DETERMINISTIC said at load time (the default).  Host-side, per launch: plans, workspaces and prepared weights do not
+ * depend on it.  The reference has no such switch (TF-2.0 GPU kernels are nondeterministic, no seed is set anywhere: SURVEY 0);
+ * the parity tests use it to compare against the oracle at the bounds of SURVEY 8c without a summation-order allowance. */
+int sv_set_deterministic(int32_t mode);
+int sv_get_deterministic(void);
+
 /* ---------------------------------------------------------------- A1: patch scramble
  * Replaces Augmentator.scramble (augmentation.py:43-57) as wired at vae/main.py:54-61:
  * extract_patches -> reshape -> shuffle -> split/unstack/concat -> concat([x, x_aug], axis=2).

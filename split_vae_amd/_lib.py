@@ -85,6 +85,8 @@ class GmArgs(C.Structure):
 _vp, _i32, _i64, _u64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 SYMBOLS = {
     "sv_version": (C.c_char_p, []),
+    "sv_set_deterministic": (C.c_int, [_i32]),
+    "sv_get_deterministic": (C.c_int, []),
     "sv_scramble_gather": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sv_scramble_gather_staged": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sv_random_perm": (C.c_int, [_vp, _i32, _i32, _u64, _u64, _i64, _vp]),

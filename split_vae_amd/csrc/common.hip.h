@@ -164,9 +164,18 @@ inline void sv_ensure_dynamic_lds(const void* kernel, size_t bytes) {
 // SV_DETERMINISTIC=1: every reduction runs in a fixed order -- no split-K / m-split fp32 atomics (one workgroup owns an output tile, or
 // partial sums go through slabs summed in index order), bias gradients through per-workgroup partials.  Same inputs twice -> identical
 // bits (SURVEY section 5's determinism test; tests/test_gpu_determinism.py).  Off by default: the split-K dense layers are faster with
-// atomics.  Read once per process.
+// atomics.  The environment is read once per process.
+// sv_set_deterministic(1 / 0) overrides the environment for the launches that FOLLOW (-1: back to the environment); the choice is made per
+// launch on the host, nothing about a plan or its workspace depends on it (tests flip it around individual comparisons).
 #include <stdlib.h>
+#include <atomic>
+inline std::atomic<int>& sv_deterministic_override() {
+  static std::atomic<int> v{-1};
+  return v;
+}
 inline bool sv_deterministic() {
+  const int o = sv_deterministic_override().load(std::memory_order_relaxed);
+  if (o >= 0) return o != 0;
   static const bool d = getenv("SV_DETERMINISTIC") != nullptr && atoi(getenv("SV_DETERMINISTIC")) != 0;
   return d;
 }

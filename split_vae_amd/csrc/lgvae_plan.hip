@@ -165,7 +165,14 @@ struct sv_lgvae_plan {
   // captured steps (sv_lgvae_graph_enable): one executable graph per distinct (phase mask, buffers, baked scalars)
   bool graph_on = false;
   const SvDynArgs* dyn = nullptr;   // non-null while a step is being captured
-  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+  // host-side flags that a phase reads on entry and leaves behind on exit: they select launches (which buffer reparam_kl_bwd reads, whether dz is
+  // re-zeroed, whether the ELBO gradient comes from the fused head), so they are part of a captured graph's key and a replay must leave the
+  // plan in the state the captured phases left it in
+  struct HostState { bool gz_clean, dz_slabs, dz_valid, gz_zero_skipped, nll_fused; };
+  HostState host_state() const { return {gz_clean, dz_slabs, dz_valid, gz_zero_skipped, nll_fused}; }
+  void set_host_state(const HostState& h) { gz_clean = h.gz_clean; dz_slabs = h.dz_slabs; dz_valid = h.dz_valid; gz_zero_skipped = h.gz_zero_skipped; nll_fused = h.nll_fused; }
+  uint64_t host_state_bits() const { return (uint64_t)gz_clean | (uint64_t)dz_slabs << 1 | (uint64_t)dz_valid << 2 | (uint64_t)gz_zero_skipped << 3 | (uint64_t)nll_fused << 4; }
+  struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; HostState exit_state{}; };
   std::map<std::vector<uint64_t>, GraphEntry> graphs;
   // profiling
   bool prof_on;
@@ -1266,7 +1273,7 @@ static std::vector<uint64_t> graph_key(const sv_lgvae_plan* p, const sv_lgvae_st
   return {(uint64_t)(uint32_t)s->phases, (uint64_t)s->params, (uint64_t)s->grads, (uint64_t)s->adam_m, (uint64_t)s->adam_v,
           (uint64_t)s->images6, (uint64_t)s->eps_x, (uint64_t)s->eps_x_hat, (uint64_t)st,
           adam ? f(s->beta1) : 0, adam ? f(s->beta2) : 0, adam ? f(s->adam_eps) : 0, adam ? f(s->grad_scale) : 0,
-          (uint64_t)s->accumulate_metrics, (uint64_t)p->gz_clean, (uint64_t)p->ws};
+          (uint64_t)s->accumulate_metrics, p->host_state_bits(), (uint64_t)p->ws};
 }
 
 extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void* stream) {
@@ -1304,10 +1311,9 @@ extern "C" int sv_lgvae_step(sv_lgvae_plan* p, const sv_lgvae_step_args* s, void
     const hipError_t hi = hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (hi != hipSuccess) { e.exec = nullptr; return (int)hi; }
+    e.exit_state = p->host_state();              // what the captured phases left behind (the entry state is part of the key)
   } else {
-    // the host-side state the phases would have left behind
-    if (ph & SV_PHASE_FWD_ENCODERS) { p->gz_clean = true; p->dz_valid = false; }
-    if (ph & SV_PHASE_BWD_DECODERS) { p->gz_clean = false; p->dz_valid = true; }
+    p->set_host_state(e.exit_state);             // the host-side state the replayed phases would have left behind
   }
   if (hipGraphLaunch(e.exec, st) != hipSuccess) return (int)hipGetLastError();
   return SV_OK;
@@ -1376,3 +1382,11 @@ extern "C" int sv_lgvae_profile_read(sv_lgvae_plan* p, int32_t max_entries, char
 }
 
 extern "C" const char* sv_version(void) { return "splitvae-hip 0.1 (gfx950)"; }
+
+extern "C" int sv_set_deterministic(int32_t mode) {
+  if (mode < -1 || mode > 1) return SV_E_BADARG;
+  sv_deterministic_override().store(mode, std::memory_order_relaxed);
+  return SV_OK;
+}
+
+extern "C" int sv_get_deterministic(void) { return sv_deterministic() ? 1 : 0; }

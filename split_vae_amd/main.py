@@ -28,7 +28,9 @@ def build_parser():
         ap.add_argument(flag, type=ty, nargs="?", default=default)
     # additions (not in the reference)
     ap.add_argument("--synthetic", action="store_true", help="synthetic batches in the reference data domain")
-    ap.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", type=str, default="f32", choices=["bf16", "f32"],
+                    help="f32 (default) = the reference's precision (vae/model.py:12: fp32 end to end; exact-fp32 MFMA); bf16 = opt-in throughput "
+                         "mode: bf16 MFMA operands, fp32 accumulation / ELBO / Adam / master weights (BASELINE.json configs[1])")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log_every", type=int, default=10000)
     ap.add_argument("--gm_dropout", type=str, default="tf2.0", choices=["tf2.0", "tf2.1"],

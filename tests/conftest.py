@@ -21,3 +21,14 @@ def lib_built():
     if os.path.exists("/opt/rocm/bin/hipcc"):
         build.build(verbose=False)
     return build.LIB
+
+
+@pytest.fixture
+def deterministic(lib_built):
+    """Fixed-order reductions (sv_set_deterministic(1), include/splitvae.h) for the launches of one test: the oracle comparisons run at
+    the bounds of SURVEY 8c without a summation-order allowance.  Back to the environment's choice afterwards."""
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    assert lib.sv_set_deterministic(1) == 0 and lib.sv_get_deterministic() == 1
+    yield
+    lib.sv_set_deterministic(-1)

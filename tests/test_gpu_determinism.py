@@ -3,9 +3,9 @@
 The switch is read once per process by the library, so every test here runs a child process with it set:
   * the whole training step (CelebA-64, 64 images: config 4's shard; bf16 and fp32; SPLIT-GMVAE too) twice from the same state:
     losses, all gradients and the updated weights bit for bit;
-  * the fp32 oracle comparison of tests/test_gpu_step.py and the one-rank RCCL test at their ORIGINAL bounds
-    (SV_TEST_STRICT=1 removes the "a ReLU gate within summation-order noise of zero fell the other way" allowance that the default,
-    atomics-ordered path needs).
+  * the strict fp32 oracle comparison of tests/test_gpu_step.py and the one-rank RCCL test three times in a row (they are the PRIMARY
+    parity tests since round 4 and run with fixed-order reductions by themselves: sv_set_deterministic / SV_DETERMINISTIC in the worker;
+    SV_TEST_STRICT=1 here also removes the allowance of their looser default-order twins).
 """
 import os
 import subprocess

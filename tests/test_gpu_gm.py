@@ -59,16 +59,30 @@ def test_gm_variable_table_matches_reference_order(ops):
     assert np.all(b["encoder_x/z_mean/bias:0"] == 0)
 
 
+STRICT_INPUT_SEED = int(os.environ.get("SV_GM_TEST_SEED", "0"))     # inputs of the strict test (no ReLU unit within fp32 rounding of its kink)
+
+
 @pytest.mark.parametrize("dropout", [False, True], ids=["tf2.0-no-dropout", "tf2.1-dropout"])
-def test_gm_step_fp32_matches_oracle(ops, dropout):
-    """fp32 MFMA path: the 14-tuple, the 5 metrics + total, all 54 gradients, weights after Adam.
-    Tolerances as for the LGVae step (tests/test_gpu_step.py): fp32 with different summation orders.
-    Both readings of `training` (oracle/gm_ref.py::encoder_gmvae): dropout off in training (tensorflow 2.0.0, the
+def test_gm_step_fp32_matches_oracle(ops, deterministic, dropout):
+    """THE fp32 parity test of the SPLIT-GMVAE step (primary): fixed-order reductions against the fp64 oracle -- the 14-tuple at
+    rtol 1e-4 / atol 1e-5 of each tensor's scale, the 5 metrics + total, all 54 gradients within 2e-3 with NO element-fraction allowance,
+    weights after Adam.  Both readings of `training` (oracle/gm_ref.py::encoder_gmvae): dropout off in training (tensorflow 2.0.0, the
     default) and on (tensorflow >= 2.1)."""
+    _gm_step_vs_oracle(dropout, strict=True, seed=STRICT_INPUT_SEED)
+
+
+@pytest.mark.parametrize("dropout", [False, True], ids=["tf2.0-no-dropout", "tf2.1-dropout"])
+def test_gm_step_fp32_default_summation_order_matches_oracle(ops, dropout):
+    """The same comparison on the DEFAULT path (split-K fp32 atomics in the Dense layers: the summation order changes from run to run),
+    with the looser output bound and the one-ReLU-gate allowance described in the body."""
+    _gm_step_vs_oracle(dropout, strict=bool(os.environ.get("SV_TEST_STRICT")), seed=0)
+
+
+def _gm_step_vs_oracle(dropout, strict, seed):
     from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae, LOSS_KEYS
     from split_vae_amd.optimizer import Adam
     B = 4
-    images, nz = _inputs(B)
+    images, nz = _inputs(B, seed=seed)
     params = _params()
     ref = gm_ref.GMRefTrainer(params, BETA, ALPHA, y_size=K, tau=TAU, dtype=torch.float64, dropout=dropout)
     model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda", seed=1, dropout_in_training=dropout)
@@ -87,7 +101,8 @@ def test_gm_step_fp32_matches_oracle(ops, dropout):
     out = model(img, training=True, eps=eps, noise=noise)
     for name, got, want in zip(NAMES14, out, fwd_ref):
         want = want.detach()
-        torch.testing.assert_close(got.double().cpu(), want, rtol=2e-4, atol=2e-4 * float(want.abs().max()), msg=lambda m: name + ": " + m)
+        torch.testing.assert_close(got.double().cpu(), want, rtol=1e-4 if strict else 2e-4,
+                                   atol=(1e-5 if strict else 2e-4) * max(1.0, float(want.abs().max())), msg=lambda m: name + ": " + m)
     assert torch.allclose(out[10].sum(dim=1).cpu(), torch.ones(B), atol=1e-5)       # Gumbel-softmax rows sum to one
 
     for t in range(1, 3):
@@ -104,7 +119,7 @@ def test_gm_step_fp32_matches_oracle(ops, dropout):
                 torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * scale + 1e-9,
                                            msg=lambda m: "step %d grad %s: %s" % (t, name, m))
             except AssertionError:
-                if os.environ.get("SV_TEST_STRICT"):     # SV_DETERMINISTIC=1 runs (tests/test_gpu_determinism.py): the plain bound, no second outcome
+                if strict:     # fixed-order reductions: the plain bound, no second outcome
                     raise
                 # About one run in twenty a ReLU unit of decoder_x (one channel of h4 at one pixel, for these inputs) has a
                 # pre-activation within fp32 summation-order noise (split-K atomics upstream) of ZERO after the first update,

@@ -124,3 +124,44 @@ def test_replay_sees_a_changed_learning_rate(ops):
         out[use_graph] = P
     d = (out[True] - out[False]).abs()
     assert float(d.max()) <= 1.1e-2 and float((d > 1e-5).float().mean()) < 2e-2, (float(d.max()), float((d > 1e-5).float().mean()))
+
+
+def test_replay_restores_the_host_flags_the_phases_leave_behind(ops):
+    """a replayed graph must leave the plan's host-side flags (dz_slabs, gz_zero_skipped, dz_valid, nll_fused, gz_clean) as
+    the captured phases left them -- they select which buffer the next phase's reparam_kl_bwd reads.  Scenario: whole training steps (the
+    slab path is live, the dz slabs hold a real gradient), then a REPLAYED forward-only call followed by an EAGER encoder backward without
+    the decoders' (the KL terms' gradient only, vae/trainer.py:12-13).  With stale flags that backward reads the heads' forward slabs as dz.
+    The encoder_x_hat head-bias gradients have a closed form in z_mean / z_sig."""
+    from split_vae_amd import data
+    from split_vae_amd._lib import PHASE_ALL, PHASE_PREP, PHASE_FORWARD, PHASE_LOSS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.model import LGVae
+    B, Hc, beta = 256, 64, 120.0
+    x = data.synthetic_images(B, Hc, Hc, seed=0, device="cuda")
+    img = Augmentator("scramble", size=8, seed=1).augment(x)
+    m = LGVae(128, 128, image_shape=[-1, Hc, Hc, 3], dtype="bf16", device=torch.device("cuda"), seed=3)
+    plan = ops.LGVaePlan(B, Hc, Hc, beta=beta, dtype=torch.bfloat16)
+    plan.graph_enable(True)
+    P, G, M, V = m.flat.clone(), torch.zeros_like(m.flat), torch.zeros_like(m.flat), torch.zeros_like(m.flat)
+    fwd = PHASE_PREP | PHASE_FORWARD | PHASE_LOSS
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for t in range(1, 4):                                     # eager, capture, replay: whole steps
+            plan.step(PHASE_ALL, params=P, grads=G, adam_m=M, adam_v=V, images6=img, seed=3, step=t, lr=1e-4, t=t)
+        for t in range(4, 7):                                     # forward-only: eager, capture, REPLAY -- each followed by the KL-only backward
+            plan.step(PHASE_ALL, params=P, grads=G, adam_m=M, adam_v=V, images6=img, seed=3, step=t, lr=1e-4, t=t)
+            plan.step(fwd, params=P, grads=G, images6=img, seed=3, step=100 + t)
+            G.zero_()
+            plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, params=P, grads=G, images6=img, seed=3, step=100 + t)
+            side.synchronize()
+            zm = plan.buffer("z_mean_xh", torch.float32, (B, 128)).double()
+            zs = plan.buffer("z_sig_xh", torch.float32, (B, 128)).double()
+            ks = beta / B
+            want_mean = (ks * zm).sum(0)
+            want_sd = (ks * (zs - 1.0 / zs) * (1.0 - torch.exp(-zs))).sum(0)
+            g = {n: G[o:o + int(np.prod(sh))].view(*sh) for n, o, sh in m.param_table}
+            gm, gs = g["encoder_x_hat/e4_mean/bias"].double(), g["encoder_x_hat/e4_sd/bias"].double()
+            assert float((gm - want_mean).abs().max()) <= 2e-2 * float(want_mean.abs().max()) + 1e-6, t
+            assert float((gs - want_sd).abs().max()) <= 2e-2 * float(want_sd.abs().max()) + 1e-6, t
+    assert plan.graph_count() >= 2

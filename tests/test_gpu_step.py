@@ -57,10 +57,22 @@ def ops(lib_built):
 
 
 @pytest.mark.parametrize("H,patch,beta,B", [(32, 1, 40.0, 4), (64, 8, 120.0, 3)])
-def test_step_fp32_matches_oracle(ops, H, patch, beta, B):
-    """fp32 MFMA path: forward 10-tuple, 5 scalars, all 40 gradients, weights after 1..3 Adam steps.
-    Tolerance (fp32, summation order differs): rtol 1e-4 on reconstructions/ELBO terms; gradients
-    2e-3 of each tensor's max |g| (atomics + long reductions); weights atol 2e-6 per step (lr 1e-4)."""
+def test_step_fp32_matches_oracle(ops, deterministic, H, patch, beta, B):
+    """THE fp32 parity test (primary, SURVEY 8c's pin): fp32 MFMA path with fixed-order reductions against the fp64 oracle -- forward
+    10-tuple and the ELBO terms at rtol 1e-4 / atol 1e-5, all 40 gradients within 2e-3 of each tensor's max |g| with NO element-fraction
+    allowance, weights after 1..3 Adam steps."""
+    _fp32_step_vs_oracle(ops, H, patch, beta, B, strict=True)
+
+
+@pytest.mark.parametrize("H,patch,beta,B", [(32, 1, 40.0, 4), (64, 8, 120.0, 3)])
+def test_step_fp32_default_summation_order_matches_oracle(ops, H, patch, beta, B):
+    """The same comparison on the DEFAULT path (split-K / m-split fp32 atomics: the summation order changes from run to run), looser:
+    atol 1e-4 on the outputs, and a ReLU unit within that noise of zero may take the other gate than the fp64 oracle (a few elements,
+    small in norm -- nothing else passes)."""
+    _fp32_step_vs_oracle(ops, H, patch, beta, B, strict=bool(os.environ.get("SV_TEST_STRICT")))
+
+
+def _fp32_step_vs_oracle(ops, H, patch, beta, B, strict):
     x, perm, eps = make_inputs(B, H, patch)
     images = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), patch)
     assert np.array_equal(images.cpu().numpy(), np_ref.scramble_batch(x, perm, patch).astype(np.float32))
@@ -82,16 +94,16 @@ def test_step_fp32_matches_oracle(ops, H, patch, beta, B):
         torch.cuda.synchronize()
         got = outputs10(plan, B, H)
         for name, r in zip(NAMES10, fwd_ref):
-            torch.testing.assert_close(got[name].cpu().double(), r.detach(), rtol=1e-4, atol=1e-4, msg=lambda m: name + ": " + m)
+            torch.testing.assert_close(got[name].cpu().double(), r.detach(), rtol=1e-4, atol=1e-5 if strict else 1e-4, msg=lambda m: name + ": " + m)
         losses = plan.buffer("losses", torch.float32, (8,)).cpu().double()
         for i, k in enumerate(LOSS_KEYS):
-            assert abs(float(losses[i]) - float(loss_ref[k])) <= 1e-4 * abs(float(loss_ref[k])) + 1e-3, k
+            assert abs(float(losses[i]) - float(loss_ref[k])) <= 1e-4 * abs(float(loss_ref[k])) + (1e-5 if strict else 1e-3), k
         for (name, off, shape), gr, gg in zip(plan.param_table, g_ref, unflat(plan, G)):
             tol = 2e-3 * float(gr.abs().max()) + 1e-7
             dlt = (gg.double() - gr).abs()
             err = float(dlt.max())
             if err > tol:
-                assert not os.environ.get("SV_TEST_STRICT"), "grad %s: err %g tol %g (strict: SV_DETERMINISTIC run)" % (name, err, tol)
+                assert not strict, "grad %s: err %g tol %g (strict: fixed-order reductions, no allowance)" % (name, err, tol)
                 # a ReLU unit within fp32 summation-order noise of zero takes the other gate than the fp64 oracle (analysis in
                 # tests/test_gpu_gm.py::test_gm_step_fp32_matches_oracle): a few elements, small in norm -- nothing else passes here
                 frac, rel = float((dlt > tol).double().mean()), float(dlt.norm() / gr.norm().clamp_min(1e-30))

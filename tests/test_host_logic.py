@@ -20,6 +20,10 @@ def test_cli_flags_match_reference():
     b = build_parser().parse_args("--beta 120 --patch_size 8 --dataset celeba64 -no_label".split())   # README.md:37
     assert (b.beta, b.patch_size, b.dataset, b.no_label) == (120.0, 8, "celeba64", True)
     assert isinstance(b.beta, float) and isinstance(b.patch_size, int)
+    # the reference is fp32 end to end (vae/model.py:12, no mixed-precision policy): a drop-in command line must run at that
+    # precision; bf16 operands are opt-in
+    assert a.dtype == "f32" and b.dtype == "f32"
+    assert build_parser().parse_args(["--dtype", "bf16"]).dtype == "bf16"
 
 
 def test_dotdict_missing_key_is_none():
