@@ -272,6 +272,11 @@ int sv_act_bwd(const void* gx, int32_t gx_dtype, int32_t ldg, const void* gx2, i
                void* ga, int32_t ga_dtype, int32_t ldga, int64_t rows, int32_t C, void* stream);
 /* out = a + b (vae/model.py:130: h = h + h_top) */
 int sv_add(const void* a, const void* b, void* out, int32_t dtype, int64_t n, void* stream);
+/* The five Mean metrics of train_step_lg_gm_vae / test_step_lg_gm_vae (vae/trainer.py:157-173) and the total loss from the per-image terms
+ * [B] fp32: out6 = {mean nll_x, mean kl_x, mean nll_xh, mean kl_xh, mean y_kl, out[0] + out[2] + beta (out[1] + out[3]) + alpha out[4]}.
+ * One launch, fixed-order sums. */
+int sv_gm_metrics(const float* nll_x, const float* kl_x, const float* nll_xh, const float* kl_xh, const float* y_kl, int32_t B,
+                  float beta, float alpha, float* out6, void* stream);
 /* Gumbel-softmax (vae/model.py:121-122): y = softmax((logits - log(-log u)) / tau, axis=1); u[B,K] (NULL: Philox,
  * written to u_out).  y[B,K] fp32 and y_lp[B,ld_lp] (zero padded).  K, ld_lp <= 128. */
 int sv_gumbel_softmax_fwd(const float* logits, int32_t ld_logits, const float* u, float* u_out, float tau, float* y,

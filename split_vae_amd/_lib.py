@@ -100,6 +100,7 @@ SYMBOLS = {
     "sv_act_bwd": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _f, _vp, _vp, _i32, _i32, _i64,
                              _i32, _vp]),
     "sv_add": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "sv_gm_metrics": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f, _f, _vp, _vp]),
     "sv_gumbel_softmax_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _f, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _u64, _i64, _vp]),
     "sv_gumbel_softmax_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _f, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "sv_gm_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32,

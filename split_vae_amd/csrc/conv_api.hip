@@ -574,6 +574,7 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
     int cfg = svg_pick_cfg(d->Cin);
     if (dx_f32_atomic) {
       a.out_f32 = 1;
+      a.accum = 1;                         // dx is an accumulator whatever the split (kernels.h)
       a.splitk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
     } else cfg = svg_im2col_cfg(a, cfg);
     rc = svk_conv_dispatch(a, d->dtype, cfg, (hipStream_t)stream);

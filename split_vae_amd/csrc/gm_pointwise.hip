@@ -245,6 +245,44 @@ extern "C" int sv_act_bwd(const void* gx, int32_t gx_dtype, int32_t ldg, const v
   return SV_OK;
 }
 
+
+// The five Mean metrics of train_step_lg_gm_vae / test_step_lg_gm_vae (vae/trainer.py:157-173) + the total loss from the per-image terms:
+// out[0..4] = batch means of (nll_x, kl(q_x || p_y), nll_xh, kl(q_xh || N(0,1)), KL(softmax(y_logits) || uniform)),
+// out[5] = out[0] + out[2] + beta (out[1] + out[3]) + alpha out[4].  One workgroup, fixed-order tree: bit-reproducible.
+static __global__ __launch_bounds__(256) void gm_metrics_kernel(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4,
+                                                         int B, float beta, float alpha, float* out) {
+  __shared__ float red[5][256];
+  const float* term[5] = {t0, t1, t2, t3, t4};
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float s = 0.f;
+    for (int b = tid; b < B; b += 256) s += term[k][b];
+    red[k][tid] = s;
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) red[k][tid] += red[k][tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float m[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { m[k] = red[k][0] / (float)B; out[k] = m[k]; }
+    out[5] = m[0] + m[2] + beta * (m[1] + m[3]) + alpha * m[4];
+  }
+}
+
+extern "C" int sv_gm_metrics(const float* nll_x, const float* kl_x, const float* nll_xh, const float* kl_xh, const float* y_kl, int32_t B,
+                             float beta, float alpha, float* out6, void* stream) {
+  if (!nll_x || !kl_x || !nll_xh || !kl_xh || !y_kl || !out6 || B <= 0) return SV_E_BADARG;
+  hipLaunchKernelGGL(gm_metrics_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll_x, kl_x, nll_xh, kl_xh, y_kl, B, beta, alpha, out6);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
 extern "C" int sv_add(const void* a, const void* b, void* out, int32_t dtype, int64_t n, void* stream) {
   if (!a || !b || !out || n <= 0 || !dt_ok(dtype)) return SV_E_BADARG;
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, dtype, n);

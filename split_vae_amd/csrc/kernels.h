@@ -46,6 +46,9 @@ struct TapGemmArgs {
                         // (n / cls_n) channel (n % cls_n), class (ph, pw) = (c >> 1, c & 1) lands on output pixel
                         // (OS * oy + ph, OS * ox + pw): the dY tile is staged once for all four classes and an A fragment feeds
                         // 4x the MFMAs (tile kernel only)
+  int accum;            // out_f32 target is an ACCUMULATOR (sv_conv2d_nhwc_dgrad's dx_f32_atomic contract: several producers add into one zeroed
+                        // fp32 buffer -- the fan-in of SPLIT-GMVAE's encoder, vae/model.py:127-133): a launch with splitk == 1 (no atomics:
+                        // small problems, and every problem under SV_DETERMINISTIC) adds with a plain read-modify-write instead of assigning
   int adj;              // input gradient of a layer whose input is a 2x bilinear upsample, FUSED with the resize adjoint: `out`
                         // is the LOW-RES gradient [B, OHF/2, OWF/2, ldo], `mask` the low-res activation (ReLU gate, may be
                         // null).  Only the row-ring kernel implements it (SV_E_UNSUPPORTED elsewhere)

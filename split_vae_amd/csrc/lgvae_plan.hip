@@ -575,6 +575,7 @@ static int run_dgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       a[m].adj = adj ? 1 : 0;           // dx = the LOW-RES gradient, mask = the low-res activation (row_conv.hip)
       if (f32_atomic) {
         a[m].out_f32 = 1;
+        a[m].accum = 1;
         int c2 = tap_cfg;
         a[m].splitk = svg_choose_splitk(a[m].M, a[m].N, (a[m].P + 7) / 8, &c2);
         if (m == 0) tap_cfg = c2;

@@ -234,9 +234,22 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
             for (int e = 0; e < EPP; ++e) ve[e] = to_f32(me[e]) > 0.f ? ve[e] : from_f32<T>(0.f);
             v = *(uint4*)ve;
           }
+          if (g.accum && g.out_f32) {                   // one workgroup owns the tile: a plain add is race-free and order-free
+            const float4 o4 = *(const float4*)((const char*)g.out + ob);
+            float4 v4 = *(float4*)&v;
+            v4.x += o4.x; v4.y += o4.y; v4.z += o4.z; v4.w += o4.w;
+            v = *(uint4*)&v4;
+          }
           *(uint4*)((char*)g.out + ob) = v;
         } else {
-          *(uint2*)((char*)g.out + ob) = *(const uint2*)(sC + rl * srow + c * 8);
+          uint2 v2 = *(const uint2*)(sC + rl * srow + c * 8);
+          if (g.accum && g.out_f32) {
+            const float2 o2 = *(const float2*)((const char*)g.out + ob);
+            float2 f2 = *(float2*)&v2;
+            f2.x += o2.x; f2.y += o2.y;
+            v2 = *(uint2*)&f2;
+          }
+          *(uint2*)((char*)g.out + ob) = v2;
         }
       }
       return;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(const TapGemmMulti mg) {
         if (g.bias) v += g.bias[n];
         if (g.act == SV_ACT_RELU) v = fmaxf(v, 0.f);
         if (g.mask) v = to_f32(((const T*)g.mask)[o]) > 0.f ? v : 0.f;
-        if (g.out_f32) ((float*)g.out)[o] = v;
+        if (g.out_f32) ((float*)g.out)[o] = g.accum ? ((float*)g.out)[o] + v : v;
         else ((T*)g.out)[o] = from_f32<T>(v);
       }
   }

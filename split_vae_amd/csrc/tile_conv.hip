@@ -474,7 +474,7 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
 // direct kernel (dense layers, huge channel counts, K-split needed) and the caller should use
 // the im2col kernel instead.
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out) {
-  if (t.splitk != 1) return false;
+  if (t.splitk != 1 || t.accum) return false;   // (accumulating fp32 targets: the im2col kernel's epilogue adds)
   if (t.lOY < 0 || t.lOX < 0 || t.S > 2) return false;    // power-of-two grids, stride <= 2 (the tile maps shift and mask)
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
   if (t.ups && t.S != 1) return false;

