@@ -42,6 +42,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -60,7 +61,7 @@ struct RowConvArgs {
 };
 struct RowConvMulti { RowConvArgs a[8]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false, bool MB_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -84,6 +85,23 @@ struct RowCfg {
   // with a zero gap of KW - 1 pixels (each half sees its own SAME padding); a unit of work is a pair of images.  Only the lane's ring
   // offset, the DMA (one instruction per image) and the store address know.  g.W = 8, g.B = images (the last pair may be half).
   static constexpr bool PAIR = PAIR_;
+  // MB (round 4): an upsampled forward layer whose 2x bilinear resize runs ON THE MATRIX PIPE.  The raw LOW-RES rows come in by LDS-DMA
+  // (no registers, no VALU) into a small raw ring two steps ahead of their readers; one step ahead, every wave blends its 16-channel
+  // fragment of the next step's hi-res rows with MFMAs against per-lane constant weight operands (mb_blend below; the scheme of
+  // wgrad_roll.hip's blend stage) and stores them into the planar row ring.  The VALU form (stage_rows: ~350 instructions per thread and
+  // step plus the exposed latency of its global loads) was 27 % of the d4 forward launch -- VALU issue is step time one to one beside
+  // MFMAs (profiles/r04_valu_mfma_overlap.txt: every v_fma per MFMA costs ~5 % of the MFMA rate).  Needs the low-res width to be
+  // the 16 K columns of one MFMA operand row and one 16-channel fragment per wave; bands == 1 (the first window needs <= NRAW raw rows).
+  static constexpr bool MB = MB_;
+  static_assert(!MB_ || (UPS_ && (WAVES_ == 4 || WAVES_ == 2) && (CIN_ / 16) % WAVES_ == 0 && WIDTH_ == 32 && !ADJ_ && !CLS_ && !S2D_ && !PAIR_ && CIN_ != 8), "matrix-pipe blend");
+  static constexpr int FPW = MB_ ? CIN_ / 16 / WAVES_ : 1;     // 16-channel fragments a wave blends
+  // WAVES == 2: ONE wave per SIMD with the whole register file (512 registers: the weights of a 16-channel block over the WHOLE K -- 288 for
+  // d4 -- stay in one wave, so there is no K-half exchange and no partner to lose the matrix pipe to); two such workgroups per CU
+  static constexpr int WPE = WAVES_ == 2 ? 1 : 2;              // waves per SIMD the kernel is compiled for
+  static constexpr int NRAW = 6;                               // raw ring depth in low-res rows: blend(s) reads 3, the DMAs of step s write the next 2; a
+                                                               // unit's first window + first step need rows 0..5 at once
+  static constexpr int RAWB = (WIDTH_ / 2) * CIN_ * 2;         // bytes per raw low-res row, [pixel][channel] as the DMA writes it
+  static constexpr int RAWR = MB_ ? NRAW * RAWB : 0;
   static constexpr bool REV = REV_ || CLS_;                   // the weight image holds the taps y-major with DESCENDING offsets (the parity classes' order)
   static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && CIN_ != 8 && (!S2D_ || CIN_ == 256)), "image pairs");
   // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
@@ -113,16 +131,20 @@ struct RowCfg {
   // TP: a fragment's lane quarters read two consecutive rows (16 pixels each, the odd quarters one pixel to the right: every 16-lane
   // group of the ds_read_b128 covers 256 contiguous bytes = each bank once); the row pitch is a multiple of 256 B and the ring's first
   // row is kept twice, behind its end, so that rows slot, slot + 1 are always linear
-  static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : TIW * 32;
+  // MB: the row pitch is WIDTH + 3 pixels, not TIW = WIDTH + 5 -- the last two (zero) halo pixels of a row ARE the first two (zero) halo pixels
+  // of the next one (nothing ever writes a halo pixel after the launch's zero fill): 3.3 KB of LDS, which pays for the sixth raw row
+  static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : MB_ ? (WIDTH_ + 3) * 32 : TIW * 32;
   static constexpr int RDUP = TP ? 1 : 0;
   static constexpr int NPL = TP ? 1 : CIN / 16, PLB = (R + RDUP) * ROWB;    // planes (two 16-B pieces each; TP: one piece), bytes per plane
-  static constexpr int RING = NPL * PLB;
-  static constexpr int EXS = 2;                               // exchange slots per wave pair
+  static constexpr int RING = NPL * PLB + (MB_ ? 64 : 0);     // (MB: the aliased halo pixels of the very last row)
+  static_assert(!MB_ || (KW_ == 6 && KH_ == 6), "MB: left halo 2, right halo 3");
+  static constexpr int EXS = MB_ ? 1 : 2;                     // exchange slots per wave pair (MB: one -- the raw ring takes the second slot's LDS)
   static constexpr int EXF = NBW * MF * 1024;                 // bytes per slot: NBW*MF accumulator fragments of 1 KB
   static constexpr int EXB = KS == 2 ? (WAVES / 2) * EXS * EXF : 0;
   // ADJ: ring of hi-res gradient rows [slot][pixel][N] bf16: STEP rows being written + STEP + 3 being read by the adjoint
   static constexpr int ORR = ADJ ? 2 * STEP + 3 : 0, OROWB = WIDTH * N * 2, OUTB = ORR * OROWB;
-  static constexpr int LDS = RING + EXB + OUTB + 64;
+  static constexpr int LDS = RING + EXB + OUTB + RAWR + 64;
+  static_assert((WAVES_ != 4 && WAVES_ != 2) || LDS <= 81920, "two workgroups per CU");
   static constexpr int SPW = WIDTH / 16 / XG;                 // strips per wave and row group
   static constexpr int CPP = CIN / 8;                         // 16-B pieces per pixel
 };
@@ -280,6 +302,142 @@ __device__ __forceinline__ void stage_rows_dma(const RowConvArgs& g, int b, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- MB (RowCfg::MB)
+// 64 lanes x 16 B, global -> LDS (lane l lands at lds + 16 l), as inline assembly: behind the DMA builtin the compiler orders every later
+// LDS read of an object the DMA may alias behind s_waitcnt vmcnt(0) -- the whole ring here -- which would park the wave on its newest
+// transfer at the first fragment read (wgrad_roll.hip has the same helper).  The only waits are the counted ones at the end of a step.
+__device__ __forceinline__ void rc_dma16(const void* base, uint32_t off, const char* lds) {    // base: wave-uniform; off: this lane's byte offset
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ short4_t rc_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
+}
+
+// The problem's geometry BY VALUE, read once per unit: a RowConvArgs reference is a pointer into the kernel-argument segment, and every
+// use inside the step loop became a scalar load + wait (with one wave per SIMD nothing hides them: ~2 000 cycles per step)
+struct MbGeom { const bf16_t* A; int H, LH, LW, lda, x_lo; };
+__device__ __forceinline__ MbGeom mb_geom(const RowConvArgs& g) { return MbGeom{(const bf16_t*)g.A, g.H, g.H >> 1, g.W >> 1, g.lda, g.x_lo}; }
+// raw low-res row r (in the image) of image b -> raw ring slot r % NRAW, half hf (pixels 8 hf .. 8 hf + 7): ONE wave-instruction
+template <typename C>
+__device__ __forceinline__ void mb_dma_half(const MbGeom& g, int b, int r, int hf, char* sRaw, int lane) {
+  constexpr int PPI = 1024 / (C::CIN * 2);                   // pixels per wave-instruction (64 channels: 8)
+  static_assert(PPI * 2 == C::WIDTH / 2, "two instructions per raw row");
+  const bf16_t* rowp = g.A + (((int64_t)b * g.LH + r) * g.LW + hf * PPI) * g.lda;    // wave-uniform
+  const uint32_t off = (uint32_t)(((lane / (64 / PPI)) * g.lda + (lane % (64 / PPI)) * 8) * 2);
+  rc_dma16(rowp, off, sRaw + (r % C::NRAW) * C::RAWB + hf * 1024);
+}
+// rows [r0, r1] (clamped to the image by the caller), two instructions each, dealt round-robin to the waves
+template <typename C>
+__device__ __forceinline__ void mb_dma_rows(const MbGeom& g, int b, int r0, int r1, char* sRaw, int wave, int lane) {
+  for (int idx = wave; idx < 2 * (r1 - r0 + 1); idx += C::WAVES) mb_dma_half<C>(g, b, r0 + (idx >> 1), idx & 1, sRaw, lane);
+}
+
+// The per-lane constant B operands of the blend: for output row parity dyb and 16-pixel segment sg,
+//   hi[Y = 2 bb + 1 + dyb][X = 16 sg + (lane & 15)] = sum over h in {0, 1}, jj in 0..15 of  wy(h, dyb) wx(jj, X) raw[clamp(bb + h)][jj]
+// with tf.image.resize's half-pixel weights (vae/model.py:163-167; blend2x2 in tile_stage.hip.h): odd Y = .75 lo + .25 hi, even Y = .25 lo + .75 hi,
+// odd X = 2i + 1: .75 raw[i] + .25 raw[min(i + 1, LW - 1)], even X = 2i: .25 raw[max(i - 1, 0)] + .75 raw[i].  K index 8 (lane >> 4) + j of the
+// MFMA <-> (h = j >> 2, jj = 4 (lane >> 4) + (j & 3)) (the transposed read's order).  All products are exact in bf16 (1/16, 3/16, 9/16, 1/4, 3/4).
+template <typename C>
+__device__ __forceinline__ void mb_weights(int lane, short8_t (&bw)[2][2]) {
+  constexpr int LW = C::WIDTH / 2;
+  const int gq = (lane >> 4) * 4;
+#pragma unroll
+  for (int dyb = 0; dyb < 2; ++dyb)
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const int X = 16 * sg + (lane & 15), i = X >> 1;
+      const int ja = (X & 1) ? i : max(i - 1, 0), jb = (X & 1) ? min(i + 1, LW - 1) : i;      // columns carrying .25 / .75 for even X, .75 / .25 for odd X
+      const float wa = (X & 1) ? 0.75f : 0.25f, wb = 1.f - wa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = j >> 2, jj = gq + (j & 3);
+        const float wx = (jj == ja ? wa : 0.f) + (jj == jb ? wb : 0.f);
+        const float wy = (h == 0) == (dyb == 0) ? 0.75f : 0.25f;
+        bw[dyb][sg][j] = (short)(__float_as_uint(wx * wy) >> 16);
+      }
+    }
+}
+
+// hi-res rows [Ya, Ya + n) of the conv's logical input -> ring slots qa .. (mod R), this wave's 16-channel fragment (plane `wave`), from the
+// raw ring (its rows must have landed and be visible: counted vmcnt + barrier).  Rows outside the image are zeros (SAME padding lives in
+// hi-res space); the halo COLUMNS were zeroed once per launch and are never written.  Per block row: two transposed reads (the A operand,
+// K = 2 raw rows x 16 columns), and per hi-res row and segment one MFMA + one 8-B store (4 consecutive channels of one pixel per lane).
+// NB block rows per call, all reads first, then all MFMAs, then the stores (a block row alone is a chain of LDS latency -> MFMA latency ->
+// convert -> store: ~400 cycles of a wave that has nothing else to issue).
+struct MbLane { int rd; char* wr; };                         // of the wave's FIRST fragment; fragment f adds 32 B / one plane
+template <typename C>
+__device__ __forceinline__ MbLane mb_lane(const MbGeom& g, char* sRing, int wave, int lane) {
+  const int g4 = lane >> 4, cf = wave * C::FPW;
+  return MbLane{(4 * g4 + ((lane & 15) >> 2)) * (C::CIN * 2) + cf * 32 + (lane & 3) * 8, sRing + cf * C::PLB + ((lane & 15) - g.x_lo) * 32 + g4 * 8};
+}
+template <typename C, int NB>
+__device__ __forceinline__ void mb_blend_rows(const MbGeom& g, int bb0, int Ya, int n, int qa, const char* sRaw, const MbLane& ml,
+                                              const short8_t (&bw)[2][2]) {
+  const int LH = g.LH;
+#pragma unroll
+  for (int f = 0; f < C::FPW; ++f) {
+    short4_t a_lo[NB], a_hi[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int rlo = min(max(bb0 + k, 0), LH - 1), rhi = min(max(bb0 + k + 1, 0), LH - 1);
+      a_lo[k] = rc_tr16(sRaw + (rlo % C::NRAW) * C::RAWB + ml.rd + f * 32);
+      a_hi[k] = rc_tr16(sRaw + (rhi % C::NRAW) * C::RAWB + ml.rd + f * 32);
+    }
+    f32x4 dd[NB][2][2];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const short8_t af = (short8_t){a_lo[k][0], a_lo[k][1], a_lo[k][2], a_lo[k][3], a_hi[k][0], a_hi[k][1], a_hi[k][2], a_hi[k][3]};
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dyb = 0; dyb < 2; ++dyb)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+          dd[k][dyb][sg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw[dyb][sg]), z, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+#pragma unroll
+      for (int dyb = 0; dyb < 2; ++dyb) {
+        const int Y = 2 * (bb0 + k) + 1 + dyb, d = Y - Ya;
+        if ((unsigned)d >= (unsigned)n) continue;            // wave-uniform
+        int slot = qa + d;
+        if (slot >= C::R) slot -= C::R;
+        const bool rowin = (unsigned)Y < (unsigned)g.H;      // wave-uniform
+        if (rowin) {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) {
+            const f32x4 v4 = dd[k][dyb][sg];
+            const bf16x2 lo2 = __builtin_convertvector((f32x2){v4[0], v4[1]}, bf16x2), hi2 = __builtin_convertvector((f32x2){v4[2], v4[3]}, bf16x2);
+            *(uint2*)(ml.wr + f * C::PLB + slot * C::ROWB + sg * 512) = make_uint2(__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2));
+          }
+        } else {
+#pragma unroll
+          for (int sg = 0; sg < 2; ++sg) *(uint2*)(ml.wr + f * C::PLB + slot * C::ROWB + sg * 512) = make_uint2(0u, 0u);
+        }
+      }
+  }
+}
+// any row range: block rows (Ya - 1) >> 1 .. (Ya + n - 2) >> 1, two per call
+template <typename C>
+__device__ __forceinline__ void mb_blend(const MbGeom& g, int Ya, int n, int qa, const char* sRaw, const MbLane& ml, const short8_t (&bw)[2][2]) {
+  const int b_lo = (Ya - 1) >> 1, b_hi = (Ya + n - 2) >> 1;
+  int bb = b_lo;
+  for (; bb + 1 <= b_hi; bb += 2) mb_blend_rows<C, 2>(g, bb, Ya, n, qa, sRaw, ml, bw);
+  if (bb <= b_hi) mb_blend_rows<C, 1>(g, bb, Ya, n, qa, sRaw, ml, bw);
+}
+
+// The raw rows of a unit's first window (rows [Ya, Ya + STEP + KH - 1)) AND of its first step's blend: low-res rows 0 .. 5 of a whole image
+// (bands == 1), all at once -- issued during the previous unit's last step (the raw ring is idle then) or, for a workgroup's first unit,
+// in front of the launch's first wait.
+template <typename C>
+__device__ __forceinline__ void mb_dma_first(const MbGeom& g, int b, int Ya, char* sRaw, int wave, int lane) {
+  constexpr int NW = C::STEP + C::KH - 1;
+  const int LH = g.LH;
+  const int r0 = min(max((Ya - 1) >> 1, 0), LH - 1), r1 = min(((Ya + NW - 1) >> 1) + 2, LH - 1);
+  mb_dma_rows<C>(g, b, r0, r1, sRaw, wave, lane);
+}
+
 // ADJ: low-res gradient rows [e_lo, e_hi] of image b from the hi-res gradient rows in the out ring:
 //   g_lo[i, j] = sum_{a, d in -1..2} wy[a] wx[d] g_hi[clamp(2i + a), clamp(2j + d)],  w = (.25, .75, .75, .25)
 // then the ReLU mask of the low-res activation -- the arithmetic (and summation order) of upsample2x_bwd_kernel
@@ -325,13 +483,14 @@ __device__ __forceinline__ void adjoint_rows(const RowConvArgs& g, int b, int e_
 #endif
 
 template <typename C>
-__global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti mg) {
+__global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMulti mg) {
   constexpr int KH = C::KH, KW = C::KW, MF = C::MF, NBW = C::NBW, CPW = C::CPW, WIN = C::WIN, R = C::R, TIW = C::TIW, STEP = C::STEP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sRing = smem;
   char* sEx = smem + C::RING;
   char* sOut = smem + C::RING + C::EXB;                      // ADJ: hi-res gradient rows
-  int* sFlag = (int*)(smem + C::RING + C::EXB + C::OUTB);    // [pairs][2]: strips produced (odd wave), consumed (even wave)
+  char* sRaw = smem + C::RING + C::EXB + C::OUTB;            // MB: raw low-res rows (DMA)
+  int* sFlag = (int*)(smem + C::RING + C::EXB + C::OUTB + C::RAWR);    // [pairs][2]: strips produced (odd wave), consumed (even wave)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int idx = wave;
@@ -354,6 +513,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
 #endif
   bf16x8 Wr[NBW][CPW][C::KWG][C::KHG];
   float bv[NBW][4];
+  short8_t mbw[2][2];                                        // MB: the blend's constant weight operands
+  MbLane mbl = MbLane{0, nullptr};
+  if constexpr (C::MB) mb_weights<C>(lane, mbw);
   int obase = 0;                                             // ADJ: out-ring slot of hi-res row 0 of the current unit
   int cur_prob = -1;
   int strips = 0;                                            // strips this wave has finished (the pair counts in lockstep)
@@ -367,6 +529,19 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     const int np = mg.units / mg.units_per_prob;
     const int prob = C::PAIR ? (int)blockIdx.x % np : (int)blockIdx.x / mg.units_per_prob, r0 = C::PAIR ? (int)blockIdx.x / np : (int)blockIdx.x - prob * mg.units_per_prob;
     const RowConvArgs& g = mg.a[prob];
+    if constexpr (C::MB) {
+      // the halo columns are zeros for the whole launch (the blend only ever writes in-image columns)
+      for (int q = tid; q < C::RING / 16; q += NT) *(uint4*)(sRing + q * 16) = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const MbGeom mg0 = mb_geom(g);
+      mbl = mb_lane<C>(mg0, sRing, wave, lane);
+      mb_dma_first<C>(mg0, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, sRaw, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      mb_blend<C>(mg0, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRaw, mbl, mbw);
+      // (the kernel's first __syncthreads() below publishes the window; the first step's raw rows are in the ring already)
+    } else
     if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
     else {
       // The whole ring starts as zeros, once per launch: the halo columns (the DMAs only ever write in-image pixels).  (The tap-packed
@@ -383,7 +558,14 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
   for (int u = blockIdx.x; u < mg.units; u += gridDim.x) {
     const int np = mg.units / mg.units_per_prob;
     const int prob = C::PAIR ? u % np : u / mg.units_per_prob;
-    const RowConvArgs& g = mg.a[prob];
+    // MB (one wave per SIMD has nobody to hide a scalar load behind): the problem BY VALUE -- as a reference every g.field in the step loop and
+    // the epilogue is a load from the kernel-argument segment + a wait
+#ifdef SV_RC_ARGS_BY_VALUE_ALL
+    using GRef = const RowConvArgs;
+#else
+    using GRef = typename std::conditional<C::MB, const RowConvArgs, const RowConvArgs&>::type;
+#endif
+    GRef g = mg.a[prob];
     const int r0 = C::PAIR ? u / np : u - prob * mg.units_per_prob;
     const int band = r0 % g.bands, b = r0 / g.bands;
     const int yb = band * g.band_rows;
@@ -425,6 +607,9 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
     if (u == (int)blockIdx.x) __syncthreads();               // the first window (and the flag words) are in place
     SV_STAMP(t_other);
     const int nsteps = g.band_rows / STEP;
+    MbGeom mgu = MbGeom{nullptr, 0, 0, 0, 0, 0}, mgn = mgu;  // MB: this unit's and the next unit's geometry, in registers
+    int mb_nb = 0, mb_nY = 0;
+    if constexpr (C::MB) { mgu = mb_geom(g); mgn = mb_geom(gn); mb_nb = rn / gn.bands; mb_nY = (rn % gn.bands) * gn.band_rows + gn.y_lo; }
     int emitted = 0;                                         // ADJ: next low-res row to emit
     for (int s = 0; s < nsteps; ++s) {
       const int y0 = yb + s * STEP;
@@ -443,6 +628,26 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
         if (e_hi >= emitted && !(dbg & 4)) adjoint_rows<C>(g, b, emitted, e_hi, obase, sOut, tid, NT);
         if (e_hi >= emitted) emitted = e_hi + 1;
       }
+      if constexpr (C::MB) {
+        // the next step's STEP rows from the raw ring (landed before the barrier that ended the previous step), then the two raw rows the
+        // blend of the step after will add to them: they land while this step computes
+        // (priority: the SIMD's other wave -- the CU's second workgroup -- is usually inside its 144-MFMA strip loop and, being older half of
+        //  the time, wins every arbitration of the matrix pipe: without it the blend's eight MFMAs waited ~2 000 cycles per step)
+        __builtin_amdgcn_s_setprio(3);
+        if (job) mb_blend_rows<C, 2>(mgu, (jY - 1) >> 1, jY, STEP, qn, sRaw, mbl, mbw);    // (jY is odd: exactly two block rows)
+        __builtin_amdgcn_s_setprio(0);
+#ifdef SV_MB_STAMP_SPLIT
+        SV_STAMP(t_exch);                                    // (diagnostic: the blend alone; the DMA issue stays in t_stage)
+#endif
+        if (s + 2 < nsteps && !(dbg & 1)) {
+          const int LHm = mgu.LH, bn = (jY + STEP - 1) >> 1;
+          const int n0 = min(bn + 1, LHm - 1), n1 = min(bn + 2, LHm - 1);
+          if (n0 > min(bn, LHm - 1)) mb_dma_rows<C>(mgu, b, n0, n1, sRaw, wave, lane);
+        } else if (!more && has_next && !(dbg & 1)) {
+          // the unit's last step: nothing reads the raw ring any more -- the next unit's first rows land while this step computes
+          mb_dma_first<C>(mgn, mb_nb, mb_nY, sRaw, wave, lane);
+        }
+      } else
       if constexpr (STAG) {
         if (job && half == 0) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid, 256, 0, 2);
       } else if constexpr (C::UPS) {
@@ -618,13 +823,17 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
       SV_STAMP(t_other);
       if constexpr (STAG) {
         if (job && half == 1) stage_rows<C>(gj, jb, jY, jrows, qn, sRing, tid - 256, 256, 1, 2);
-      } else if constexpr (!C::UPS) {
+      } else if constexpr (!C::UPS || C::MB) {
         // the DMAs of this step are older than its stores: wait for everything but the stores (ADJ: this step's only
         // global stores are the adjoint's, issued before the DMAs)
         if (!C::ADJ && (C::KS == 1 || ks == 0) && !(dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+#ifdef SV_MB_STAMP_SPLIT
+      SV_STAMP(t_bar);                                       // (diagnostic: the end-of-step vmcnt wait booked with the barrier)
+#else
       SV_STAMP(t_stage);
+#endif
       // the staged rows are in place (LDS writes drained), this step's reads are done.  A raw barrier: __syncthreads()
       // would also wait for this step's global STORES (vmcnt(0)) and expose their HBM latency once per step
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -638,6 +847,13 @@ __global__ __launch_bounds__(C::NT, 2) void row_conv_kernel(const RowConvMulti m
       obase = (obase + g.H) % C::ORR;
     }
     if (!C::PRE && has_next && !(dbg & 1)) {                 // no room to prefetch: stage the next unit's first window now
+      if constexpr (C::MB) {
+        // its raw rows were fetched during the last step and waited for at its end
+        mb_blend<C>(mgn, mb_nY, STEP + KH - 1, 0, sRaw, mbl, mbw);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        continue;
+      } else
       if constexpr (C::UPS) stage_rows<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
       else {
         stage_rows_dma<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
@@ -672,7 +888,7 @@ static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
   if (stamp) { m.stamps = stamp_buf; (void)hipMemsetAsync(stamp_buf, 0, 512 * 8 * 8 * 8, st); }
 #endif
   static const int wgs_env = getenv("SV_RC_WGS") ? atoi(getenv("SV_RC_WGS")) : 0;
-  const int wgs_max = wgs_env ? wgs_env : 256 * (8 / C::WAVES);                          // one 8-wave or two 4-wave workgroups per CU
+  const int wgs_max = wgs_env ? wgs_env : 256 * (C::WAVES == 8 ? 1 : 2);                 // one 8-wave or two 4-wave (or two 2-wave, 512-register) workgroups per CU
   int grid = m.units < wgs_max ? m.units : wgs_max;
   if (C::PAIR) grid = grid / n * n;                          // a workgroup stays on one problem (see the kernel's unit decode)
   sv_ensure_dynamic_lds((const void*)row_conv_kernel<C>, C::LDS);
@@ -703,6 +919,8 @@ static int launch_row(const RowConvArgs* a, int n, hipStream_t st) {
 
 //                  KH KW CIN   N   W MF NBW KS XG RG UPS  WAVES ADJ
 using RC_d4f  = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4>;          // d4 forward   (K 2304: pairs split the two 32-channel chunks)
+using RC_d4fm = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4, false, false, false, false, false, true>;   //   ... with the resize on the matrix pipe (MB; whole images: bands == 1)
+using RC_d4fw = RowCfg<6, 6, 64, 32, 32, 4, 1, 1, 1, 1, true, 2, false, false, false, false, false, true>;   //   ... one wave per SIMD, whole K per wave (no exchange)
 using RC_d4g  = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>;         // d4 input gradient (K 1152)
 using RC_d4ga = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true>;   //   ... fused with the resize adjoint
 using RC_d3f  = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;            // d3 forward   (K 2048)
@@ -880,7 +1098,15 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
   RowConvArgs a[8];
   const int cfg = row_plan(t, n, dtype, a, &n);
   switch (cfg) {
-    case 0: return launch_row<RC_d4f>(a, n, st);
+    case 0: {
+      static const bool no_mb = getenv("SV_RC_NO_MB") != nullptr;       // A/B: the VALU blend staging (stage_rows)
+      // two waves per SIMD with the K-half exchange (4-wave workgroups, the default) or ONE wave per SIMD holding the whole K in the 512-register
+      // file (2-wave workgroups, no exchange: SV_RC_MB_WAVES=2) -- measured equal alone on the chip (136-138 us at 1024 images), the 4-wave
+      // form 7 % faster inside the step (0.119 against 0.128 ms)
+      static const int mbw = getenv("SV_RC_MB_WAVES") ? atoi(getenv("SV_RC_MB_WAVES")) : 4;
+      if (!no_mb && a[0].bands == 1 && a[0].H == 32 && a[0].W == 32 && a[0].lda == 64) return mbw == 2 ? launch_row<RC_d4fw>(a, n, st) : launch_row<RC_d4fm>(a, n, st);
+      return launch_row<RC_d4f>(a, n, st);
+    }
     case 1: return launch_row<RC_d4g>(a, n, st);
     case 2: return launch_row<RC_d3f>(a, n, st);
     case 3: return launch_row<RC_d3g>(a, n, st);

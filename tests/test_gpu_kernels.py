@@ -356,6 +356,45 @@ def test_conv_fused_upsample_equals_materialised(ops, layer):
     torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * float(db0.abs().max()))
 
 
+def test_d4_forward_with_the_resize_on_the_matrix_pipe(ops):
+    """From 512 images per launch (whole images per unit of work: bands == 1) the d4 forward (UpSampling2D(bilinear) -> Conv2D(32, 6),
+    vae/model.py:155,:165) stages its input by LDS-DMA of the raw low-res rows and blends them with MFMAs against constant weight
+    operands (row_conv.hip: RowCfg::MB) instead of the VALU blend.  Against the fp64 composition resize -> conv on the same bf16 inputs
+    (every row and column of a sample of images: first / last units of the walk, image edges) and against the small-batch (VALU blend)
+    form on the same images: the MFMA blend rounds the upsampled activation once instead of per lerp stage, so the two agree to a bf16
+    ulp of the activations, not bitwise."""
+    name, H, Cin, Cout, k = "d4_64", 32, 64, 32, 6
+    rng = np.random.default_rng(77)
+    B = 515                                                   # 515 units over 512 workgroups: some walk two images
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act="relu", dtype=torch.bfloat16, ups_in=True)
+    conv.prep(w.cuda())
+    y = conv.fwd(x_lo.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    sel = [0, 1, 2, 255, 256, 257, 510, 511, 512, 513, 514]
+    xs = x_lo[sel].double()
+    ref = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(xs), w.bfloat16().double(), b.double(), 1, "relu")
+    got = y[sel][..., :Cout].double().cpu()
+    assert got.shape == ref.shape
+    err = got - ref
+    assert float(err.norm() / ref.norm()) < 4e-3, float(err.norm() / ref.norm())
+    assert float(err.abs().max()) < 2e-2 * float(ref.abs().max())
+    for sl in ((slice(0, 3), slice(None)), (slice(H - 3, H), slice(None)), (slice(None), slice(0, 3)), (slice(None), slice(H - 3, H))):
+        e, r = err[:, sl[0], sl[1]], ref[:, sl[0], sl[1]]
+        assert float(e.norm() / r.norm()) < 4e-3            # SAME padding rows / columns and the edge-clamped resize
+    # the same images through the small-batch form (row bands, VALU blend)
+    small = ops.Conv2D(len(sel), H, H, Cin, Cout, k, 1, act="relu", dtype=torch.bfloat16, ups_in=True)
+    small.prep(w.cuda())
+    y_s = small.fwd(x_lo[sel].contiguous().cuda(), b.cuda())[..., :Cout].double().cpu()
+    d = got - y_s
+    assert float(d.norm() / ref.norm()) < 3e-3 and float(d.abs().max()) < 2e-2 * float(ref.abs().max())
+    # deterministic: a second launch gives the same bits
+    y2 = conv.fwd(x_lo.cuda(), b.cuda())
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("B", [1, 5])
 @pytest.mark.parametrize("H", [16, 32, 64])
 def test_polyphase_head_against_upsample_then_conv_fp64(ops, H, B):
