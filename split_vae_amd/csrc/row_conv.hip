@@ -61,7 +61,7 @@ struct RowConvArgs {
 };
 struct RowConvMulti { RowConvArgs a[8]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
-template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false, bool MB_ = false>
+template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false, bool MB_ = false, bool MA_ = false>
 struct RowCfg {
   static constexpr int KH = KH_, KW = KW_, CIN = CIN_, N = N_, WIDTH = WIDTH_, MF = MF_, NBW = NBW_, KS = KS_, XG = XG_, RG = RG_;
   static constexpr bool UPS = UPS_;
@@ -93,6 +93,16 @@ struct RowCfg {
   // MFMAs (profiles/r04_valu_mfma_overlap.txt: every v_fma per MFMA costs ~5 % of the MFMA rate).  Needs the low-res width to be
   // the 16 K columns of one MFMA operand row and one 16-channel fragment per wave; bands == 1 (the first window needs <= NRAW raw rows).
   static constexpr bool MB = MB_;
+  // MA (round 4): an ADJ layer whose resize ADJOINT runs on the matrix pipe, chained from the accumulators with no LDS round trip.  The conv is
+  // computed with SWAPPED operands, X = pixels x W^T: a lane holds 4 consecutive PIXELS of one channel, which is exactly the A-operand layout of
+  // a second MFMA that contracts over the pixels (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"):
+  //   lo[i][j][c] = sum_Y wy(i, Y) sum_X wx(j, X) hi[Y][X][c]      Z[16 channels x 16 low-res pixels] += A = bf16(X rows Y)[channels x 32 pixels] . B = wy wx
+  // with B a per-lane constant (the 32 hi-res pixels of a row are the wave's two 16-pixel strips).  Per step and wave 8 adjoint MFMAs beside 288
+  // conv MFMAs; the hi-res out ring in LDS (45 KB), its stores, adjoint_rows' 16 LDS reads and ~190 VALU instructions per item are gone.
+  // The hi-res gradient is rounded to bf16 before the adjoint, as it would go to HBM (the same values the two-launch form sees); the fp32 sums run
+  // in another order than adj2x_row_bf16's, so the result equals the two-launch form to a bf16 ulp, not bitwise.
+  static constexpr bool MA = MA_;
+  static_assert(!MA_ || (ADJ_ && WIDTH_ == 32 && NBW_ == 1 && XG_ == 1 && RG_ == 1 && KS_ == 1 && MF_ == 4 && CIN_ != 8), "matrix-pipe adjoint");
   static_assert(!MB_ || (UPS_ && (WAVES_ == 4 || WAVES_ == 2) && (CIN_ / 16) % WAVES_ == 0 && WIDTH_ == 32 && !ADJ_ && !CLS_ && !S2D_ && !PAIR_ && CIN_ != 8), "matrix-pipe blend");
   static constexpr int FPW = MB_ ? CIN_ / 16 / WAVES_ : 1;     // 16-channel fragments a wave blends
   // WAVES == 2: ONE wave per SIMD with the whole register file (512 registers: the weights of a 16-channel block over the WHOLE K -- 288 for
@@ -142,8 +152,11 @@ struct RowCfg {
   static constexpr int EXF = NBW * MF * 1024;                 // bytes per slot: NBW*MF accumulator fragments of 1 KB
   static constexpr int EXB = KS == 2 ? (WAVES / 2) * EXS * EXF : 0;
   // ADJ: ring of hi-res gradient rows [slot][pixel][N] bf16: STEP rows being written + STEP + 3 being read by the adjoint
-  static constexpr int ORR = ADJ ? 2 * STEP + 3 : 0, OROWB = WIDTH * N * 2, OUTB = ORR * OROWB;
-  static constexpr int LDS = RING + EXB + OUTB + RAWR + 64;
+  static constexpr int ORR = (ADJ && !MA_) ? 2 * STEP + 3 : 0, OROWB = WIDTH * N * 2, OUTB = ORR * OROWB;
+  // MA: per thread 96 B of LDS scratch -- the adjoint's two constant B operands, its two carried accumulators between steps and the X rows of
+  // strip 0 while strip 1 computes (24 VGPRs that would otherwise live through the MFMA loops: the kernel sits at the 256-register edge)
+  static constexpr int MAWB = MA_ ? NT * 96 : 0;
+  static constexpr int LDS = RING + EXB + OUTB + RAWR + MAWB + 64;
   static_assert((WAVES_ != 4 && WAVES_ != 2) || LDS <= 81920, "two workgroups per CU");
   static constexpr int SPW = WIDTH / 16 / XG;                 // strips per wave and row group
   static constexpr int CPP = CIN / 8;                         // 16-B pieces per pixel
@@ -490,7 +503,8 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
   char* sEx = smem + C::RING;
   char* sOut = smem + C::RING + C::EXB;                      // ADJ: hi-res gradient rows
   char* sRaw = smem + C::RING + C::EXB + C::OUTB;            // MB: raw low-res rows (DMA)
-  int* sFlag = (int*)(smem + C::RING + C::EXB + C::OUTB + C::RAWR);    // [pairs][2]: strips produced (odd wave), consumed (even wave)
+  char* sMaw = smem + C::RING + C::EXB + C::OUTB + C::RAWR; // MA: [thread][2][16 B]
+  int* sFlag = (int*)(smem + C::RING + C::EXB + C::OUTB + C::RAWR + C::MAWB);    // [pairs][2]: strips produced (odd wave), consumed (even wave)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int idx = wave;
@@ -513,6 +527,26 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
 #endif
   bf16x8 Wr[NBW][CPW][C::KWG][C::KHG];
   float bv[NBW][4];
+  // MA: the adjoint's constant B operands (.25 wx and .75 wx), its two carried accumulators (low-res rows i0 - 1 and i0 at the top of a step),
+  // the bf16 X rows of the step's strips and the prefetched ReLU-mask words
+  uint2 ma_m[3];
+  if constexpr (C::MA) {
+    // B[k = 8 (lane >> 4) + j][col = lane & 15 = low-res pixel jl]: hi-res pixel X = (j < 4 ? 4 (lane >> 4) + j : 16 + 4 (lane >> 4) + j - 4);
+    // wx(jl, X): even X = 2i: .25 [jl == max(i - 1, 0)] + .75 [jl == i]; odd X = 2i + 1: .75 [jl == i] + .25 [jl == min(i + 1, LW - 1)]
+    short8_t q8, t8;
+    const int jl = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int X = (j < 4 ? 0 : 16) + 4 * (lane >> 4) + (j & 3), i = X >> 1;
+      const int ja = (X & 1) ? i : max(i - 1, 0), jb = (X & 1) ? min(i + 1, C::WIDTH / 2 - 1) : i;
+      const float wa = (X & 1) ? 0.75f : 0.25f;
+      const float wx = (jl == ja ? wa : 0.f) + (jl == jb ? 1.f - wa : 0.f);
+      q8[j] = (short)(__float_as_uint(0.25f * wx) >> 16);
+      t8[j] = (short)(__float_as_uint(0.75f * wx) >> 16);
+    }
+    *(short8_t*)(sMaw + tid * 96) = q8;                      // (every thread reads back only what it wrote itself: no barrier needed)
+    *(short8_t*)(sMaw + tid * 96 + 16) = t8;
+  }
   short8_t mbw[2][2];                                        // MB: the blend's constant weight operands
   MbLane mbl = MbLane{0, nullptr};
   if constexpr (C::MB) mb_weights<C>(lane, mbw);
@@ -622,7 +656,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       const int jb = more ? b : rn / gn.bands;
       const int jY = more ? y0 + g.y_lo + STEP + KH - 1 : (rn % gn.bands) * gn.band_rows + gn.y_lo;
       const int jrows = more ? STEP : STEP + KH - 1;
-      if constexpr (C::ADJ) {
+      if constexpr (C::ADJ && !C::MA) {
         // hi-res rows < y0 are complete: low-res row i needs hi-res rows 2i-1 .. 2i+2
         const int e_hi = (y0 - 3) >> 1;
         if (e_hi >= emitted && !(dbg & 4)) adjoint_rows<C>(g, b, emitted, e_hi, obase, sOut, tid, NT);
@@ -669,6 +703,19 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
           if (slot >= R) slot -= R;
           abase[j] = lane_off + slot * C::ROWB + x0 * C::PIXB;
         }
+        if constexpr (C::MA) {
+          if (si == C::SPW - 1) {
+            // the ReLU-mask words of the low-res rows this step completes (i0 - 1, i0, and i0 + 1 at the bottom): in flight under the last strip's MFMAs
+            const int LHa = g.H >> 1, LWa = g.W >> 1, i0 = yw >> 1;
+            const int64_t orow = ((int64_t)b * LHa + i0) * LWa * g.ldo + (int64_t)m * g.ldo + nbg * 16 + kq * 4;
+            ma_m[0] = ma_m[1] = ma_m[2] = make_uint2(0x3f803f80u, 0x3f803f80u);
+            if (g.mask) {
+              if (yw > 0) ma_m[0] = *(const uint2*)((const bf16_t*)g.mask + orow - (int64_t)LWa * g.ldo);
+              ma_m[1] = *(const uint2*)((const bf16_t*)g.mask + orow);
+              if (yw + MF == g.H) ma_m[2] = *(const uint2*)((const bf16_t*)g.mask + orow + (int64_t)LWa * g.ldo);
+            }
+          }
+        }
         f32x4 acc[NBW][MF];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
@@ -714,7 +761,8 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
                 if (j < 0 || j >= MF) continue;
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
-                  acc[nb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[nb][cc][kx][ky], win[w], acc[nb][j], 0, 0, 0);
+                  acc[nb][j] = C::MA ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(win[w], Wr[nb][cc][kx][ky], acc[nb][j], 0, 0, 0)      // X = pixels x W^T
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[nb][cc][kx][ky], win[w], acc[nb][j], 0, 0, 0);
               }
               if (it + 1 < NIT) win[w] = *(const bf16x8*)(sRing + abase[w] + ncc * 2 * C::PLB + nkx * 32);
               // pin the order: left alone, hipcc sinks every fetch to just in front of its first use (one register
@@ -747,7 +795,61 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
         }
         ++strips;
         SV_STAMP(t_exch);
-        if constexpr (C::ADJ) {
+        if constexpr (C::MA) {
+          // X rows (bf16, as the hi-res gradient would go to HBM): lane = (channel lane & 15 of the wave's block, pixel group lane >> 4), 4 pixels
+          uint2 ma_x[MF];
+#pragma unroll
+          for (int j = 0; j < MF; ++j) {
+            const bf16x2 lo2 = __builtin_convertvector((f32x2){acc[0][j][0], acc[0][j][1]}, bf16x2), hi2 = __builtin_convertvector((f32x2){acc[0][j][2], acc[0][j][3]}, bf16x2);
+            ma_x[j] = make_uint2(__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2));
+          }
+          if (si == 0) {
+            *(uint4*)(sMaw + tid * 96 + 64) = make_uint4(ma_x[0].x, ma_x[0].y, ma_x[1].x, ma_x[1].y);
+            *(uint4*)(sMaw + tid * 96 + 80) = make_uint4(ma_x[2].x, ma_x[2].y, ma_x[3].x, ma_x[3].y);
+          }
+          if (si == C::SPW - 1 && !(dbg & 4)) {
+            const bool top = yw == 0, bot = yw + MF == g.H;   // wave-uniform (ADJ units are whole images)
+            const uint4 x01 = *(const uint4*)(sMaw + tid * 96 + 64), x23 = *(const uint4*)(sMaw + tid * 96 + 80);     // strip 0's rows
+            const uint2 x0[MF] = {make_uint2(x01.x, x01.y), make_uint2(x01.z, x01.w), make_uint2(x23.x, x23.y), make_uint2(x23.z, x23.w)};
+            bf16x8 ax[MF];
+#pragma unroll
+            for (int j = 0; j < MF; ++j) ax[j] = __builtin_bit_cast(bf16x8, make_uint4(x0[j].x, x0[j].y, ma_x[j].x, ma_x[j].y));
+            const bf16x8 bq = *(const bf16x8*)(sMaw + tid * 96), bt = *(const bf16x8*)(sMaw + tid * 96 + 16);
+            f32x4 ma_p = *(const f32x4*)(sMaw + tid * 96 + 32), ma_q = *(const f32x4*)(sMaw + tid * 96 + 48);
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int LHa = g.H >> 1, LWa = g.W >> 1, i0 = yw >> 1;     // this step completes low-res rows i0 - 1 and i0 (and i0 + 1 at the bottom)
+            const int64_t orow = ((int64_t)b * LHa + i0) * LWa * g.ldo + (int64_t)m * g.ldo + nbg * 16 + kq * 4;
+            auto emit = [&](const f32x4& zv, int di, const uint2& mv) {
+              bf16_t res[4];
+              const uint32_t mw[2] = {mv.x, mv.y};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits of the low-res activation: > 0 <=> sign clear and not zero
+                res[e] = (bf16_t)((!g.mask || (!(h & 0x8000u) && (h & 0x7fffu))) ? zv[e] : 0.f);
+              }
+              *(uint2*)((bf16_t*)g.out + orow + (int64_t)di * LWa * g.ldo) = *(const uint2*)res;
+            };
+            // hi-res row Y = 2r feeds low-res rows max(r - 1, 0) (.25) and r (.75); Y = 2r + 1 feeds r (.75) and min(r + 1, LH - 1) (.25)
+            if (!top) {
+              ma_p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[0], bq, ma_p, 0, 0, 0);
+              emit(ma_p, -1, ma_m[0]);
+            } else ma_q = z4;
+            ma_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[0], bt, ma_q, 0, 0, 0);
+            if (top) ma_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[0], bq, ma_q, 0, 0, 0);
+            ma_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[1], bt, ma_q, 0, 0, 0);
+            ma_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[2], bq, ma_q, 0, 0, 0);
+            emit(ma_q, 0, ma_m[1]);
+            ma_p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[1], bq, z4, 0, 0, 0);
+            ma_p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[2], bt, ma_p, 0, 0, 0);
+            ma_p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[3], bt, ma_p, 0, 0, 0);
+            if (bot) {
+              ma_p = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[3], bq, ma_p, 0, 0, 0);
+              emit(ma_p, 1, ma_m[2]);
+            } else ma_q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax[3], bq, z4, 0, 0, 0);
+            *(f32x4*)(sMaw + tid * 96 + 32) = ma_p;
+            *(f32x4*)(sMaw + tid * 96 + 48) = ma_q;
+          }
+        } else if constexpr (C::ADJ) {
           // the hi-res gradient row goes to the out ring (bf16, as it would go to HBM); adjoint_rows picks it up
 #pragma unroll
           for (int nb = 0; nb < NBW; ++nb)
@@ -826,6 +928,12 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       } else if constexpr (!C::UPS || C::MB) {
         // the DMAs of this step are older than its stores: wait for everything but the stores (ADJ: this step's only
         // global stores are the adjoint's, issued before the DMAs)
+        if (C::MA && !(dbg & 4)) {
+          // the step's DMAs are older than its low-res stores: 1 store at the top of an image, 3 at the bottom, 2 otherwise
+          if (y0 == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else if (y0 + STEP == g.H) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else
         if (!C::ADJ && (C::KS == 1 || ks == 0) && !(dbg & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -842,7 +950,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       q0 = more ? q0 + STEP : (C::PRE ? qn : 0);             // a new unit starts at its own first window
       if (q0 >= R) q0 -= R;
     }
-    if constexpr (C::ADJ) {                                  // the image's last low-res rows (the step loop ended behind a barrier)
+    if constexpr (C::ADJ && !C::MA) {                        // the image's last low-res rows (the step loop ended behind a barrier)
       if (!(dbg & 4)) adjoint_rows<C>(g, b, emitted, (g.H >> 1) - 1, obase, sOut, tid, NT);
       obase = (obase + g.H) % C::ORR;
     }
@@ -923,6 +1031,7 @@ using RC_d4fm = RowCfg<6, 6, 64, 32, 32, 4, 1, 2, 1, 1, true, 4, false, false, f
 using RC_d4fw = RowCfg<6, 6, 64, 32, 32, 4, 1, 1, 1, 1, true, 2, false, false, false, false, false, true>;   //   ... one wave per SIMD, whole K per wave (no exchange)
 using RC_d4g  = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>;         // d4 input gradient (K 1152)
 using RC_d4ga = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true>;   //   ... fused with the resize adjoint
+using RC_d4gm = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true, false, false, false, false, false, true>;   //   ... the adjoint on the matrix pipe (MA)
 using RC_d3f  = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;            // d3 forward   (K 2048)
 using RC_d3g  = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;           // d3 input gradient (K 1024)
 using RC_d3ga = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true>;
@@ -1110,7 +1219,10 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
     case 1: return launch_row<RC_d4g>(a, n, st);
     case 2: return launch_row<RC_d3f>(a, n, st);
     case 3: return launch_row<RC_d3g>(a, n, st);
-    case 4: return launch_row<RC_d4ga>(a, n, st);
+    case 4: {
+      static const bool no_ma = getenv("SV_RC_NO_MA") != nullptr;       // A/B: the adjoint through the LDS out ring (adjoint_rows)
+      return no_ma ? launch_row<RC_d4ga>(a, n, st) : launch_row<RC_d4gm>(a, n, st);
+    }
     case 5: return launch_row<RC_d3ga>(a, n, st);
     case 6: return launch_row<RC_d5g>(a, n, st);
     case 7: return launch_row<RC_d5ga>(a, n, st);

@@ -685,7 +685,16 @@ def test_input_gradient_fused_with_resize_adjoint(ops, layer, B):
     fused = conv.dgrad_lowres(dy.cuda(), act_lo.cuda())
     assert fused is not None, "no fused kernel for %s" % name
     two = ops.upsample2x_bwd(conv.dgrad(dy.cuda()), act_lo.cuda())
-    assert torch.equal(fused, two)
+
+    def same(a, b_):
+        if name != "d4_64":
+            return torch.equal(a, b_)
+        # d4 (round 4): the adjoint runs on the matrix pipe, chained from the accumulators (row_conv.hip RowCfg::MA) -- the same bf16-rounded
+        # hi-res values and exact products, but the fp32 sums run in another order than adj2x_row_bf16's: equal to a bf16 ulp, zeros (the mask) exactly
+        a, b_ = a.float(), b_.float()
+        return bool(((a == 0) == (b_ == 0)).all()) and float((a - b_).abs().max()) <= 2.0 ** -7 * float(b_.abs().max()) and \
+            float((a != b_).float().mean()) < 0.2 and float((a - b_).norm() / b_.norm()) < 1e-3
+    assert same(fused, two)
     # fp64: d/d(pre_lo) of <conv(resize(relu(pre_lo))), dy>
     xr = pre_lo.double().requires_grad_(True)
     y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.relu(xr)), w.bfloat16().double(), None, 1, None)
@@ -696,7 +705,7 @@ def test_input_gradient_fused_with_resize_adjoint(ops, layer, B):
     torch.testing.assert_close(got, want, rtol=BF16_RTOL, atol=1.5e-2 * float(want.abs().max()))
     assert bool((got[act_lo.double() <= 0] == 0).all())                            # the mask, exactly
     nomask = conv.dgrad_lowres(dy.cuda(), None)
-    assert torch.equal(nomask, ops.upsample2x_bwd(conv.dgrad(dy.cuda()), None))
+    assert same(nomask, ops.upsample2x_bwd(conv.dgrad(dy.cuda()), None))
 
 
 def test_d5_input_gradient_on_the_row_ring_kernel(ops):
