@@ -102,7 +102,8 @@ struct RowCfg {
   // The hi-res gradient is rounded to bf16 before the adjoint, as it would go to HBM (the same values the two-launch form sees); the fp32 sums run
   // in another order than adj2x_row_bf16's, so the result equals the two-launch form to a bf16 ulp, not bitwise.
   static constexpr bool MA = MA_;
-  static_assert(!MA_ || (ADJ_ && WIDTH_ == 32 && NBW_ == 1 && XG_ == 1 && RG_ == 1 && KS_ == 1 && MF_ == 4 && CIN_ != 8), "matrix-pipe adjoint");
+  // (WIDTH 16 -- d3: one strip, the upper half of the A operand is zero and only the 8 low-res pixel columns of Z are stored)
+  static_assert(!MA_ || (ADJ_ && (WIDTH_ == 32 || WIDTH_ == 16) && NBW_ == 1 && XG_ == 1 && RG_ == 1 && KS_ == 1 && MF_ == 4 && CIN_ != 8), "matrix-pipe adjoint");
   static_assert(!MB_ || (UPS_ && (WAVES_ == 4 || WAVES_ == 2) && (CIN_ / 16) % WAVES_ == 0 && WIDTH_ == 32 && !ADJ_ && !CLS_ && !S2D_ && !PAIR_ && CIN_ != 8), "matrix-pipe blend");
   static constexpr int FPW = MB_ ? CIN_ / 16 / WAVES_ : 1;     // 16-channel fragments a wave blends
   // WAVES == 2: ONE wave per SIMD with the whole register file (512 registers: the weights of a 16-channel block over the WHOLE K -- 288 for
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       const int X = (j < 4 ? 0 : 16) + 4 * (lane >> 4) + (j & 3), i = X >> 1;
       const int ja = (X & 1) ? i : max(i - 1, 0), jb = (X & 1) ? min(i + 1, C::WIDTH / 2 - 1) : i;
       const float wa = (X & 1) ? 0.75f : 0.25f;
-      const float wx = (jl == ja ? wa : 0.f) + (jl == jb ? 1.f - wa : 0.f);
+      const float wx = X >= C::WIDTH ? 0.f : (jl == ja ? wa : 0.f) + (jl == jb ? 1.f - wa : 0.f);
       q8[j] = (short)(__float_as_uint(0.25f * wx) >> 16);
       t8[j] = (short)(__float_as_uint(0.75f * wx) >> 16);
     }
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
             const int LHa = g.H >> 1, LWa = g.W >> 1, i0 = yw >> 1;
             const int64_t orow = ((int64_t)b * LHa + i0) * LWa * g.ldo + (int64_t)m * g.ldo + nbg * 16 + kq * 4;
             ma_m[0] = ma_m[1] = ma_m[2] = make_uint2(0x3f803f80u, 0x3f803f80u);
-            if (g.mask) {
+            if (g.mask && (C::WIDTH == 32 || m < C::WIDTH / 2)) {
               if (yw > 0) ma_m[0] = *(const uint2*)((const bf16_t*)g.mask + orow - (int64_t)LWa * g.ldo);
               ma_m[1] = *(const uint2*)((const bf16_t*)g.mask + orow);
               if (yw + MF == g.H) ma_m[2] = *(const uint2*)((const bf16_t*)g.mask + orow + (int64_t)LWa * g.ldo);
@@ -803,17 +804,22 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
             const bf16x2 lo2 = __builtin_convertvector((f32x2){acc[0][j][0], acc[0][j][1]}, bf16x2), hi2 = __builtin_convertvector((f32x2){acc[0][j][2], acc[0][j][3]}, bf16x2);
             ma_x[j] = make_uint2(__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2));
           }
-          if (si == 0) {
+          if (si == 0 && C::SPW > 1) {
             *(uint4*)(sMaw + tid * 96 + 64) = make_uint4(ma_x[0].x, ma_x[0].y, ma_x[1].x, ma_x[1].y);
             *(uint4*)(sMaw + tid * 96 + 80) = make_uint4(ma_x[2].x, ma_x[2].y, ma_x[3].x, ma_x[3].y);
           }
           if (si == C::SPW - 1 && !(dbg & 4)) {
             const bool top = yw == 0, bot = yw + MF == g.H;   // wave-uniform (ADJ units are whole images)
-            const uint4 x01 = *(const uint4*)(sMaw + tid * 96 + 64), x23 = *(const uint4*)(sMaw + tid * 96 + 80);     // strip 0's rows
-            const uint2 x0[MF] = {make_uint2(x01.x, x01.y), make_uint2(x01.z, x01.w), make_uint2(x23.x, x23.y), make_uint2(x23.z, x23.w)};
             bf16x8 ax[MF];
+            if constexpr (C::SPW > 1) {
+              const uint4 x01 = *(const uint4*)(sMaw + tid * 96 + 64), x23 = *(const uint4*)(sMaw + tid * 96 + 80);     // strip 0's rows
+              const uint2 x0[MF] = {make_uint2(x01.x, x01.y), make_uint2(x01.z, x01.w), make_uint2(x23.x, x23.y), make_uint2(x23.z, x23.w)};
 #pragma unroll
-            for (int j = 0; j < MF; ++j) ax[j] = __builtin_bit_cast(bf16x8, make_uint4(x0[j].x, x0[j].y, ma_x[j].x, ma_x[j].y));
+              for (int j = 0; j < MF; ++j) ax[j] = __builtin_bit_cast(bf16x8, make_uint4(x0[j].x, x0[j].y, ma_x[j].x, ma_x[j].y));
+            } else {
+#pragma unroll
+              for (int j = 0; j < MF; ++j) ax[j] = __builtin_bit_cast(bf16x8, make_uint4(ma_x[j].x, ma_x[j].y, 0u, 0u));
+            }
             const bf16x8 bq = *(const bf16x8*)(sMaw + tid * 96), bt = *(const bf16x8*)(sMaw + tid * 96 + 16);
             f32x4 ma_p = *(const f32x4*)(sMaw + tid * 96 + 32), ma_q = *(const f32x4*)(sMaw + tid * 96 + 48);
             const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -827,7 +833,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
                 const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits of the low-res activation: > 0 <=> sign clear and not zero
                 res[e] = (bf16_t)((!g.mask || (!(h & 0x8000u) && (h & 0x7fffu))) ? zv[e] : 0.f);
               }
-              *(uint2*)((bf16_t*)g.out + orow + (int64_t)di * LWa * g.ldo) = *(const uint2*)res;
+              if (C::WIDTH == 32 || m < C::WIDTH / 2) *(uint2*)((bf16_t*)g.out + orow + (int64_t)di * LWa * g.ldo) = *(const uint2*)res;
             };
             // hi-res row Y = 2r feeds low-res rows max(r - 1, 0) (.25) and r (.75); Y = 2r + 1 feeds r (.75) and min(r + 1, LH - 1) (.25)
             if (!top) {
@@ -1035,6 +1041,7 @@ using RC_d4gm = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true, false, f
 using RC_d3f  = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;            // d3 forward   (K 2048)
 using RC_d3g  = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;           // d3 input gradient (K 1024)
 using RC_d3ga = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true>;
+using RC_d3gm = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true, false, false, false, false, false, true>;   //   ... the adjoint on the matrix pipe (MA)
 using RC_d5g  = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4>;          // d5 input gradient (8-channel pixels: four taps per K step)
 using RC_d5ga = RowCfg<6, 6, 8, 32, 64, 4, 2, 1, 4, 1, false, 4, true>;
 // e2 input gradient, merged parity classes (K 576, 4 x 32 columns): 4-wave workgroups, a wave = the two column blocks of one class.
@@ -1223,7 +1230,10 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
       static const bool no_ma = getenv("SV_RC_NO_MA") != nullptr;       // A/B: the adjoint through the LDS out ring (adjoint_rows)
       return no_ma ? launch_row<RC_d4ga>(a, n, st) : launch_row<RC_d4gm>(a, n, st);
     }
-    case 5: return launch_row<RC_d3ga>(a, n, st);
+    case 5: {
+      static const bool no_ma3 = getenv("SV_RC_NO_MA") != nullptr || getenv("SV_RC_NO_MA3") != nullptr;
+      return no_ma3 ? launch_row<RC_d3ga>(a, n, st) : launch_row<RC_d3gm>(a, n, st);
+    }
     case 6: return launch_row<RC_d5g>(a, n, st);
     case 7: return launch_row<RC_d5ga>(a, n, st);
     case 8: return launch_row<RC_e2g>(a, n, st);

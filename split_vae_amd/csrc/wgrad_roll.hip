@@ -97,6 +97,7 @@ struct RollLds {
 // share of the block row two steps ahead (its channel fragment x one of the two 16-pixel segments of the patch); wave 2 / wave 3 also
 // move the raw low-res row / the dY chunk of step t + AHEAD.
 __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f32x4 (&acc)[KS * KXW][COF], f32x4& bacc, int q_lo, int q_hi, int T) {
+  using std::integral_constant;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cf = wave & 3, kx0 = (wave >> 2) * KXW;              // this wave: input-channel fragment, first x tap of its three
   const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
@@ -228,11 +229,22 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
   // The window: input rows rho = 0..6 of the step being multiplied (hi-res rows 2c-2 .. 2c+4) x this wave's three x shifts, in registers.
   // Every step -- lead-in steps too -- shifts it by two rows and reads the block row of that step (rows 5, 6) from its LDS slot: 6
   // transposed reads per step instead of 21; tap rows ky = 0..3 do not touch the new rows, so their latency hides under 24 MFMAs.
-  short4_t win[KS + 1][KXW];
+  // Round 4: a window column is ONE 16-register vector (register row r = elements 2r, 2r + 1; row 7 mirrors row 0), so that an A operand --
+  // the register pair {row r, row r + 1} -- is four CONSECUTIVE registers of it and reaches the MFMA as a sub-register tuple: as separate
+  // 2-register values every operand cost two v_mov (36 per step, beside 36 MFMAs: VALU issue is step time one to one).
+  typedef int i32x16 __attribute__((ext_vector_type(16)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x16 win[KXW];
 #pragma unroll
-  for (int r = 0; r <= KS; ++r)
+  for (int kx = 0; kx < KXW; ++kx)
 #pragma unroll
-    for (int kx = 0; kx < KXW; ++kx) win[r][kx] = (short4_t){0, 0, 0, 0};
+    for (int e = 0; e < 16; ++e) win[kx][e] = 0;
+  auto win_set = [&](int kx, auto RR, short4_t v) {            // register row RR (compile-time) <- a transposed read
+    constexpr int rr = decltype(RR)::value;
+    const int2 w = __builtin_bit_cast(int2, v);
+    win[kx][2 * rr] = w.x; win[kx][2 * rr + 1] = w.y;
+    if constexpr (rr == 0) { win[kx][14] = w.x; win[kx][15] = w.y; }       // the mirror of row 0 behind row 6: the pair (6, 0) is (6, 7)
+  };
   short4_t nb[COF][2];                                            // dY fragments of the next step (read under this step's MFMAs)
 #pragma unroll
   for (int j = 0; j < COF; ++j) nb[j][0] = nb[j][1] = (short4_t){0, 0, 0, 0};
@@ -257,11 +269,11 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
       for (int kx = 0; kx < KXW; ++kx) {
         if constexpr (PH < 0) {
 #pragma unroll
-          for (int r = 0; r + 2 <= KS; ++r) win[r][kx] = win[r + 2][kx];
+          for (int e = 0; e + 4 < 2 * (KS + 1); ++e) win[kx][e] = win[kx][e + 4];
         }
         if (!(ROLL_ABL & 8)) {
-          win[P(KS - 1)][kx] = tr16(rp + kx * PS);
-          win[P(KS)][kx] = tr16(rp + (PW + kx) * PS);
+          win_set(kx, std::integral_constant<int, P(KS - 1)>{}, tr16(rp + kx * PS));
+          win_set(kx, std::integral_constant<int, P(KS)>{}, tr16(rp + (PW + kx) * PS));
         }
       }
     }
@@ -270,23 +282,27 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
 #pragma unroll
       for (int j = 0; j < COF; ++j)
         bfr[j] = (short8_t){nb[j][0][0], nb[j][0][1], nb[j][0][2], nb[j][0][3], nb[j][1][0], nb[j][1][1], nb[j][1][2], nb[j][1][3]};
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
+      auto do_ky = [&](auto KYc) {                                // (ky as a compile-time constant: the operand is a shufflevector of the window column)
+        constexpr int ky = decltype(KYc)::value;
         if (BL.value && ky == 1) blend_mfma();
         if (BL.value && ky == 3) blend_store();
         if (ky == 0) ROLL_STAMP(2);
         if (ky == 3) ROLL_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int ra = P(ky), rb = P(ky + 1);                 // register rows of the pair: consecutive, or (6, 0) = (6, 7: the mirror)
+        static_assert(rb == ra + 1 || (ra == KS && rb == 0), "window pair");
 #pragma unroll
         for (int kx = 0; kx < KXW; ++kx) {
-          const short4_t lo = win[P(ky)][kx], hi = win[P(ky + 1)][kx];
-          const short8_t af = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const i32x4 a4 = __builtin_shufflevector(win[kx], win[kx], 2 * ra, 2 * ra + 1, 2 * ra + 2, 2 * ra + 3);
+          const short8_t af = __builtin_bit_cast(short8_t, a4);
 #pragma unroll
           for (int j = 0; j < COF; ++j)
             if (!(ROLL_ABL & 1)) acc[ky * KXW + kx][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[j]),
                                                                             acc[ky * KXW + kx][j], 0, 0, 0);
         }
-      }
+      };
+      do_ky(integral_constant<int, 0>{}); do_ky(integral_constant<int, 1>{}); do_ky(integral_constant<int, 2>{});
+      do_ky(integral_constant<int, 3>{}); do_ky(integral_constant<int, 4>{}); do_ky(integral_constant<int, 5>{});
       if (g.bslab) {                                              // waves 4, 5: column sums of dY fragment j = wave - 4 (an all-ones A operand)
         if (wave == 4) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bfr[0]), bacc, 0, 0, 0);
         else if (wave == 5) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, bfr[1]), bacc, 0, 0, 0);
@@ -310,7 +326,6 @@ __device__ __forceinline__ void roll_loop(const RollArgs& g, const RollLds& L, f
     ROLL_STAMP(6);
   };
   int t = 0;
-  using std::integral_constant;
   static const bool no_rot = false;
   for (; !no_rot && t + 7 < T; t += 7) {                          // (every t < T - 1 here: the blending form)
     body(t, std::true_type{}, integral_constant<int, 1>{});
