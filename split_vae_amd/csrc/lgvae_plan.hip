@@ -397,10 +397,16 @@ static void build_buffers(sv_lgvae_plan* p) {
   p->add_buf("polyw_xh", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);
   {   // K-slice slabs of the heads' forward and d1's input gradient (latent_gemm.hip): [S][B][N] fp32 per network
     const int64_t Fd = (H / 8) * (W / 8) * 128;
-    const int s1 = svk_nt_gemm_pick_splitk((int)B, 2 * Lg, (int)Fd, 2), s2 = svk_nt_gemm_pick_splitk((int)B, Lg + Ll, (int)Fd, 2);
-    const int64_t a = (int64_t)s1 * B * 2 * (Lg > Ll ? Lg : Ll) * 4, b = (int64_t)s2 * B * (Lg + Ll) * 4;
-    p->add_buf("lat_ws_x", a > b ? a : b);
-    p->add_buf("lat_ws_xh", a > b ? a : b);
+    // the four launches that write them -- heads of x / x-hat (N = 2 Lg / 2 Ll), d1's input gradient of decoder_x / decoder_x-hat (N = Lg + Ll / Ll) --
+    // pick their split PER PROBLEM: sized as the maximum of the four actual (split, N) products (with unequal latent sizes a
+    // per-problem split x N could exceed a product formed from two of them); the launch sites check the capacity again and fall back
+    int64_t need = 0;
+    for (const int64_t Nq : {2 * Lg, 2 * Ll, Lg + Ll, Ll}) {
+      const int64_t b = (int64_t)svk_nt_gemm_pick_splitk((int)B, (int)Nq, (int)Fd, 2) * B * Nq * 4;
+      need = b > need ? b : need;
+    }
+    p->add_buf("lat_ws_x", need);
+    p->add_buf("lat_ws_xh", need);
   }
   p->add_buf("dyn", sizeof(SvDynArgs));
   p->add_buf("losses", 8 * 4);
@@ -778,6 +784,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
         g.splitk = svk_nt_gemm_pick_splitk(B, g.N, g.K, 2);     // (as the slab buffers were sized)
         g.slab_stride = (int64_t)B * g.ldo;
         outs[nq] = (float*)p->bp(std::string("pre_") + en[e]);
+        if ((int64_t)g.splitk * g.slab_stride * 4 > p->bbytes(std::string("lat_ws_") + en[e])) return SV_E_WORKSPACE;   // (cannot happen: sized from the same calls)
       }
       const int rc = svk_nt_gemm_multi(q, nq, 64, st);
       if (rc == SV_OK) {
@@ -992,6 +999,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
         g.M = B; g.N = dd.Cin; g.K = dd.Cout; g.out_f32 = 1;
         g.splitk = svk_nt_gemm_pick_splitk(B, g.N, g.K, 2);
         g.slab_stride = (int64_t)B * g.ldo;
+        if ((int64_t)g.splitk * g.slab_stride * 4 > p->bbytes(k == 0 ? "lat_ws_x" : "lat_ws_xh")) return SV_E_WORKSPACE;           // (cannot happen: sized from the same calls)
         outs[k] = (float*)gz[k];
         fl += conv_flops(dd); by += conv_bytes(dd, 1, p->esz());
       }

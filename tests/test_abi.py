@@ -67,6 +67,27 @@ def test_plan_geometry_without_gpu(lib_built):
     lib.sv_lgvae_plan_destroy(h)
 
 
+@pytest.mark.parametrize("gl,ll,B", [(128, 128, 512), (64, 64, 64), (256, 256, 96), (128, 128, 70), (256, 128, 64)])
+def test_latent_slab_workspace_covers_every_split(lib_built, gl, ll, B):
+    """the K-slice slabs of the latent block (lat_ws_x / lat_ws_xh) are sized from the four launches' own (split, N) pairs; a slab
+    set is [split][B][N] fp32 with split >= 1, so each buffer holds at least one slab of the widest problem.  (The plan accepts equal
+    power-of-two latent sizes only -- sv_lgvae_plan_create refuses the last case -- so the over-run the advisor describes cannot be reached.)"""
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    desc = _lib.LGVaeDesc(B, 64, 64, gl, ll, _lib.SV_BF16, 120.0)
+    h = C.c_void_p()
+    rc = lib.sv_lgvae_plan_create(C.byref(desc), C.byref(h))
+    if gl != ll:
+        assert rc == _lib.STATUS_UNSUPPORTED
+        return
+    assert rc == 0
+    off, nb = C.c_int64(), C.c_int64()
+    for name in (b"lat_ws_x", b"lat_ws_xh"):
+        assert lib.sv_lgvae_buffer(h, name, C.byref(off), C.byref(nb)) == 0
+        assert nb.value >= B * max(2 * gl, 2 * ll, gl + ll) * 4 and off.value % 256 == 0
+    lib.sv_lgvae_plan_destroy(h)
+
+
 @pytest.mark.parametrize("bad", [dict(H=48), dict(H=64, W=32), dict(gl=100), dict(dtype=7), dict(B=0)])
 def test_plan_rejects_unsupported(lib_built, bad):
     from split_vae_amd import _lib
