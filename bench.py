@@ -43,14 +43,16 @@ split_vae_amd.configure_hw_queues()                 # before any HIP call (a 4th
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}
-PROFILE_TAG = "r03"                             # profiles/<tag>_traffic.json: the committed PMC passes `traffic` cites
+PROFILE_TAGS = ("r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
 
 
 def _traffic_file():
     import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", PROFILE_TAG + "_*traffic.json"))) or \
-        sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*traffic.json")))
-    return c[-1] if c else os.path.join(ROOT, "profiles", "r01_k_traffic.json")
+    for tag in PROFILE_TAGS:
+        c = sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*traffic.json")))
+        if c:
+            return c[-1]
+    return os.path.join(ROOT, "profiles", "r01_k_traffic.json")
 
 
 def measured_traffic(kernel_stems):

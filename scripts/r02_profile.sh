@@ -4,9 +4,9 @@ T=${1:-r02_a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/${T}_prof $O/trafR $O/trafW
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -o k -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rows > $O/${T}_prof_bench.json 2>/dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/trafR -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/trafW -o w -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -o k -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-rows --no-fp32 > $O/${T}_prof_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/trafR -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows --no-fp32 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/trafW -o w -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows --no-fp32 > /dev/null 2>&1
 cd $R
 python3 - <<PY
 import csv, glob

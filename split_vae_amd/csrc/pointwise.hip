@@ -605,7 +605,8 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
   if (lo + (int64_t)blockIdx.x * 1024 >= hi && blockIdx.x) return;   // nothing for this workgroup (small tensors): skip the partial sums too
   float ss = 0.f;
   for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];   // fixed order: deterministic
-  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
+  // (clipnorm >= 1e37: "no clipping" -- the plain Keras-Adam update whatever the norm is; as a ratio an infinite norm would zero the tensor and hide it)
+  const float sc = clipnorm >= 1e37f ? gscale : gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
   int64_t a, b;
   clip_split(lo, hi, a, b);
   auto upd = [&](float gi, float& pi, float& mi, float& vi) {
@@ -663,7 +664,8 @@ __global__ __launch_bounds__(256) void adam_clip_ptrs_kernel(float* __restrict__
   if (lo + (int64_t)blockIdx.x * 1024 >= hi && blockIdx.x) return;
   float ss = 0.f;
   for (int k = 0; k < SV_CLIP_PARTS; ++k) ss += parts[(int64_t)t * SV_CLIP_PARTS + k];
-  const float sc = gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
+  // (clipnorm >= 1e37: "no clipping" -- the plain Keras-Adam update whatever the norm is; as a ratio an infinite norm would zero the tensor and hide it)
+  const float sc = clipnorm >= 1e37f ? gscale : gscale * clipnorm / fmaxf(sqrtf(ss), clipnorm);
   const float* __restrict__ g = P.g[t] - lo;                  // g[i], i in [lo, hi): the flat index of the variable buffers
   int64_t a, b;
   clip_split(lo, hi, a, b);

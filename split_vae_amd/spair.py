@@ -374,11 +374,17 @@ class _Model:
         self.device = torch.device(device)
         self.seed = seed
         self.generator = torch.Generator(device=device).manual_seed(seed + 1)
-        self._native = {}                        # (batch, training) -> spair_native.NativeStep
+        self._native = {}                        # (batch, training, baked config fields) -> spair_native.NativeStep
+        self.noise_step = 0                      # Philox step of the native NOISE nodes: one stream position per step of the MODEL
+
+    # config fields a recorded tape bakes in (ZPRES / e.tau, the report matrix of split_z_l / concat_*, the conv dtype ...): part of the cache key,
+    # so a changed or different config object records a new tape instead of silently replaying the old values
+    _TAPE_FIELDS = ("tau", "dtype", "split_z_l", "concat_z_what", "concat_z_bg", "concat_backbone", "dense_local", "dense_bg", "model",
+                    "latent_size", "bg_latent_size", "local_latent_size", "patch_size", "bg_model")
 
     def native(self, B, config, training=True):
-        """The model recorded as a native launch sequence for batch B (spair_native.NativeStep), built once."""
-        key = (B, bool(training))
+        """The model recorded as a native launch sequence for batch B (spair_native.NativeStep), built once per (batch, mode, baked config)."""
+        key = (B, bool(training)) + tuple(repr(config.get(k) if hasattr(config, "get") else getattr(config, k, None)) for k in self._TAPE_FIELDS)
         if key not in self._native:
             from .spair_native import NativeStep
             self._native[key] = NativeStep(self, config, B, training)

@@ -412,7 +412,11 @@ class NativeStep:
         wa = (C.c_float * len(w))(*w)
         a.loss_weights, a.n_weights = wa, len(w)
         a.dyn[0], a.dyn[1] = float(sc["prior_prob"]), float(sc["zoom_mean"])
-        a.seed, a.step = int(getattr(self.model, "seed", 0)) + 1, self._calls
+        # the Philox step of the NOISE nodes comes from a MODEL-level counter shared by every NativeStep of the model (other batch sizes, the
+        # last partial batch, train / test): a per-instance counter starting at 0 replayed the same eps / u_pres / render-noise streams
+        # (ADVICE r03).  A caller that resumes a run sets model.noise_step from its saved step count.
+        a.seed, a.step = int(getattr(self.model, "seed", 0)) + 1, int(getattr(self.model, "noise_step", 0))
+        self.model.noise_step = a.step + 1
         self._calls += 1
         a.pinned_noise = 1 if noise else 0
         a.phases = _lib.TAPE_PHASE_FORWARD | (_lib.TAPE_PHASE_BACKWARD if backward else 0)

@@ -74,7 +74,8 @@ class ClipnormAdam:
     def __init__(self, learning_rate=1e-4, clipnorm=1.0, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_in_apply=False):
         self.learning_rate = learning_rate
         self.clip_in_apply = bool(clip_in_apply)
-        # the kernels scale by clipnorm / max(||g||, clipnorm): a norm bound no fp32 gradient reaches makes that exactly 1
+        # clipnorm >= 1e37 selects the kernels' plain (unclipped) Keras-Adam update: the scale is exactly the gradient scale, whatever the
+        # norm is (as the ratio clipnorm / max(||g||, clipnorm) an infinite norm zeroed the tensor instead of passing through)
         self.clipnorm = clipnorm if self.clip_in_apply else 3.0e38
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
         self.iterations = 0
