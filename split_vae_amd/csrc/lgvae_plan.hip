@@ -946,7 +946,9 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     // (it works on whole images -- its low-res rows straddle row bands -- so below ~one image per workgroup slot the banded
     // plain input gradient + upsample2x_bwd is faster: 64 images per network d5 43 vs 55 us, d4 40 vs 49; 128: 69 vs 56)
     static const bool no_adj = getenv("SV_NO_FUSED_ADJOINT") != nullptr;
-    static const int adj_min = getenv("SV_RC_ADJ_MIN") ? atoi(getenv("SV_RC_ADJ_MIN")) : 256;
+    // (round 4, with the adjoint of d3 / d4 on the matrix pipe: 128 images per launch -- config 4's 64-image shard -- 0.641 -> 0.631 ms fused; the
+    //  default moved from 256 to 128)
+    static const int adj_min = getenv("SV_RC_ADJ_MIN") ? atoi(getenv("SV_RC_ADJ_MIN")) : 128;
     int frc = SV_E_UNSUPPORTED;
     if (Ls[0]->d.ups_in && Ls[1]->d.ups_in && !no_adj && 2 * B >= adj_min) frc = run_dgrad_layers(p, 2, Ls, gy, lo, (void* const*)gl, false, st, true);
     if (frc != SV_E_UNSUPPORTED) { SV_TRY(frc); continue; }

@@ -104,7 +104,8 @@ struct RowCfg {
   static constexpr bool MA = MA_;
   // (WIDTH 16 -- d3: one strip, the upper half of the A operand is zero and only the 8 low-res pixel columns of Z are stored)
   static_assert(!MA_ || (ADJ_ && (WIDTH_ == 32 || WIDTH_ == 16) && NBW_ == 1 && XG_ == 1 && RG_ == 1 && KS_ == 1 && MF_ == 4 && CIN_ != 8), "matrix-pipe adjoint");
-  static_assert(!MB_ || (UPS_ && (WAVES_ == 4 || WAVES_ == 2) && (CIN_ / 16) % WAVES_ == 0 && WIDTH_ == 32 && !ADJ_ && !CLS_ && !S2D_ && !PAIR_ && CIN_ != 8), "matrix-pipe blend");
+  // (WIDTH 16 -- d3: low-res width 8, the upper half of the blend's K is zero weights over zero-initialised LDS; 8 waves = 8 fragments)
+  static_assert(!MB_ || (UPS_ && (WAVES_ == 8 || WAVES_ == 4 || WAVES_ == 2) && (CIN_ / 16) % WAVES_ == 0 && (WIDTH_ == 32 || WIDTH_ == 16) && !ADJ_ && !CLS_ && !S2D_ && !PAIR_ && CIN_ != 8), "matrix-pipe blend");
   static constexpr int FPW = MB_ ? CIN_ / 16 / WAVES_ : 1;     // 16-channel fragments a wave blends
   // WAVES == 2: ONE wave per SIMD with the whole register file (512 registers: the weights of a 16-channel block over the WHOLE K -- 288 for
   // d4 -- stay in one wave, so there is no K-half exchange and no partner to lose the matrix pipe to); two such workgroups per CU
@@ -112,7 +113,9 @@ struct RowCfg {
   static constexpr int NRAW = 6;                               // raw ring depth in low-res rows: blend(s) reads 3, the DMAs of step s write the next 2; a
                                                                // unit's first window + first step need rows 0..5 at once
   static constexpr int RAWB = (WIDTH_ / 2) * CIN_ * 2;         // bytes per raw low-res row, [pixel][channel] as the DMA writes it
-  static constexpr int RAWR = MB_ ? NRAW * RAWB : 0;
+  static constexpr int RAWR = MB_ ? (NRAW + 1) * RAWB : 0;     // (+ one zero slot behind the ring: WIDTH 16 reads 16 K columns of 8-pixel rows)
+  static constexpr int NSG = WIDTH_ / 16;                      // 16-pixel segments of a hi-res row
+  static constexpr int HL = (KW_ - 1) / 2, HR = KW_ - 1 - HL;  // SAME padding: halo pixels left / right (k 6: 2 / 3, k 4: 1 / 2)
   static constexpr bool REV = REV_ || CLS_;                   // the weight image holds the taps y-major with DESCENDING offsets (the parity classes' order)
   static_assert(!PAIR_ || (WIDTH_ == 16 && XG_ == 1 && !UPS_ && !ADJ_ && !CLS_ && CIN_ != 8 && (!S2D_ || CIN_ == 256)), "image pairs");
   // Sub-pixels of 32 channels (e2: a K chunk = one sub-pixel) or of 8 (e1's padded RGB: a K chunk = all four, lane quarter kq = (py, px)).
@@ -136,7 +139,7 @@ struct RowCfg {
   // ring rows.  8 waves: two windows (the current one + the next step's STEP new rows, or the whole first window of the
   // workgroup's NEXT unit, staged during the last step).  4 waves: one window + one step (the next unit's first window
   // is staged between units; the other workgroup of the CU computes meanwhile)
-  static constexpr bool PRE = WAVES == 8;
+  static constexpr bool PRE = WAVES == 8 && !MB_;             // (MB: a unit's first window is blended between units -- its raw rows arrive during the last step)
   static constexpr int R = PRE ? 2 * (STEP + KH - 1) : 2 * STEP + KH - 1;
   static constexpr int PIXB = TP ? 16 : 32;                   // bytes per pixel in a plane
   // TP: a fragment's lane quarters read two consecutive rows (16 pixels each, the odd quarters one pixel to the right: every 16-lane
@@ -144,12 +147,12 @@ struct RowCfg {
   // row is kept twice, behind its end, so that rows slot, slot + 1 are always linear
   // MB: the row pitch is WIDTH + 3 pixels, not TIW = WIDTH + 5 -- the last two (zero) halo pixels of a row ARE the first two (zero) halo pixels
   // of the next one (nothing ever writes a halo pixel after the launch's zero fill): 3.3 KB of LDS, which pays for the sixth raw row
-  static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : MB_ ? (WIDTH_ + 3) * 32 : TIW * 32;
+  static constexpr int ROWB = TP ? (TIW * 16 + 255) / 256 * 256 : MB_ ? (WIDTH_ + HR) * 32 : TIW * 32;
   static constexpr int RDUP = TP ? 1 : 0;
   static constexpr int NPL = TP ? 1 : CIN / 16, PLB = (R + RDUP) * ROWB;    // planes (two 16-B pieces each; TP: one piece), bytes per plane
   static constexpr int RING = NPL * PLB + (MB_ ? 64 : 0);     // (MB: the aliased halo pixels of the very last row)
-  static_assert(!MB_ || (KW_ == 6 && KH_ == 6), "MB: left halo 2, right halo 3");
-  static constexpr int EXS = MB_ ? 1 : 2;                     // exchange slots per wave pair (MB: one -- the raw ring takes the second slot's LDS)
+  static_assert(!MB_ || (HL <= HR && KW_ == KH_), "MB: the right halo of a row aliases the left halo of the next");
+  static constexpr int EXS = (MB_ && WAVES_ <= 4) ? 1 : 2;    // exchange slots per wave pair (4-wave MB: one -- the raw ring takes the second slot's LDS)
   static constexpr int EXF = NBW * MF * 1024;                 // bytes per slot: NBW*MF accumulator fragments of 1 KB
   static constexpr int EXB = KS == 2 ? (WAVES / 2) * EXS * EXF : 0;
   // ADJ: ring of hi-res gradient rows [slot][pixel][N] bf16: STEP rows being written + STEP + 3 being read by the adjoint
@@ -353,13 +356,13 @@ __device__ __forceinline__ void mb_dma_rows(const MbGeom& g, int b, int r0, int 
 // odd X = 2i + 1: .75 raw[i] + .25 raw[min(i + 1, LW - 1)], even X = 2i: .25 raw[max(i - 1, 0)] + .75 raw[i].  K index 8 (lane >> 4) + j of the
 // MFMA <-> (h = j >> 2, jj = 4 (lane >> 4) + (j & 3)) (the transposed read's order).  All products are exact in bf16 (1/16, 3/16, 9/16, 1/4, 3/4).
 template <typename C>
-__device__ __forceinline__ void mb_weights(int lane, short8_t (&bw)[2][2]) {
+__device__ __forceinline__ void mb_weights(int lane, short8_t (&bw)[2][C::NSG]) {
   constexpr int LW = C::WIDTH / 2;
   const int gq = (lane >> 4) * 4;
 #pragma unroll
   for (int dyb = 0; dyb < 2; ++dyb)
 #pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
+    for (int sg = 0; sg < C::NSG; ++sg) {
       const int X = 16 * sg + (lane & 15), i = X >> 1;
       const int ja = (X & 1) ? i : max(i - 1, 0), jb = (X & 1) ? min(i + 1, LW - 1) : i;      // columns carrying .25 / .75 for even X, .75 / .25 for odd X
       const float wa = (X & 1) ? 0.75f : 0.25f, wb = 1.f - wa;
@@ -387,7 +390,7 @@ __device__ __forceinline__ MbLane mb_lane(const MbGeom& g, char* sRing, int wave
 }
 template <typename C, int NB>
 __device__ __forceinline__ void mb_blend_rows(const MbGeom& g, int bb0, int Ya, int n, int qa, const char* sRaw, const MbLane& ml,
-                                              const short8_t (&bw)[2][2]) {
+                                              const short8_t (&bw)[2][C::NSG]) {
   const int LH = g.LH;
 #pragma unroll
   for (int f = 0; f < C::FPW; ++f) {
@@ -398,7 +401,7 @@ __device__ __forceinline__ void mb_blend_rows(const MbGeom& g, int bb0, int Ya, 
       a_lo[k] = rc_tr16(sRaw + (rlo % C::NRAW) * C::RAWB + ml.rd + f * 32);
       a_hi[k] = rc_tr16(sRaw + (rhi % C::NRAW) * C::RAWB + ml.rd + f * 32);
     }
-    f32x4 dd[NB][2][2];
+    f32x4 dd[NB][2][C::NSG];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const short8_t af = (short8_t){a_lo[k][0], a_lo[k][1], a_lo[k][2], a_lo[k][3], a_hi[k][0], a_hi[k][1], a_hi[k][2], a_hi[k][3]};
@@ -406,7 +409,7 @@ __device__ __forceinline__ void mb_blend_rows(const MbGeom& g, int bb0, int Ya, 
 #pragma unroll
       for (int dyb = 0; dyb < 2; ++dyb)
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg)
+        for (int sg = 0; sg < C::NSG; ++sg)
           dd[k][dyb][sg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bw[dyb][sg]), z, 0, 0, 0);
     }
 #pragma unroll
@@ -420,21 +423,21 @@ __device__ __forceinline__ void mb_blend_rows(const MbGeom& g, int bb0, int Ya, 
         const bool rowin = (unsigned)Y < (unsigned)g.H;      // wave-uniform
         if (rowin) {
 #pragma unroll
-          for (int sg = 0; sg < 2; ++sg) {
+          for (int sg = 0; sg < C::NSG; ++sg) {
             const f32x4 v4 = dd[k][dyb][sg];
             const bf16x2 lo2 = __builtin_convertvector((f32x2){v4[0], v4[1]}, bf16x2), hi2 = __builtin_convertvector((f32x2){v4[2], v4[3]}, bf16x2);
             *(uint2*)(ml.wr + f * C::PLB + slot * C::ROWB + sg * 512) = make_uint2(__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2));
           }
         } else {
 #pragma unroll
-          for (int sg = 0; sg < 2; ++sg) *(uint2*)(ml.wr + f * C::PLB + slot * C::ROWB + sg * 512) = make_uint2(0u, 0u);
+          for (int sg = 0; sg < C::NSG; ++sg) *(uint2*)(ml.wr + f * C::PLB + slot * C::ROWB + sg * 512) = make_uint2(0u, 0u);
         }
       }
   }
 }
 // any row range: block rows (Ya - 1) >> 1 .. (Ya + n - 2) >> 1, two per call
 template <typename C>
-__device__ __forceinline__ void mb_blend(const MbGeom& g, int Ya, int n, int qa, const char* sRaw, const MbLane& ml, const short8_t (&bw)[2][2]) {
+__device__ __forceinline__ void mb_blend(const MbGeom& g, int Ya, int n, int qa, const char* sRaw, const MbLane& ml, const short8_t (&bw)[2][C::NSG]) {
   const int b_lo = (Ya - 1) >> 1, b_hi = (Ya + n - 2) >> 1;
   int bb = b_lo;
   for (; bb + 1 <= b_hi; bb += 2) mb_blend_rows<C, 2>(g, bb, Ya, n, qa, sRaw, ml, bw);
@@ -448,7 +451,8 @@ template <typename C>
 __device__ __forceinline__ void mb_dma_first(const MbGeom& g, int b, int Ya, char* sRaw, int wave, int lane) {
   constexpr int NW = C::STEP + C::KH - 1;
   const int LH = g.LH;
-  const int r0 = min(max((Ya - 1) >> 1, 0), LH - 1), r1 = min(((Ya + NW - 1) >> 1) + 2, LH - 1);
+  // the window's block rows (Ya - 1) >> 1 .. and the first step's (rows up to Ya + NW + STEP - 1): raw rows up to ((Ya + NW + STEP - 2) >> 1) + 1
+  const int r0 = min(max((Ya - 1) >> 1, 0), LH - 1), r1 = min(((Ya + NW + C::STEP - 2) >> 1) + 1, LH - 1);
   mb_dma_rows<C>(g, b, r0, r1, sRaw, wave, lane);
 }
 
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
   const int xg = idx % C::XG; idx /= C::XG;
   const int rg = idx;                                        // row group
   const int pair = wave >> 1, half = wave >> 2;
-  constexpr bool STAG = C::WAVES == 8 && C::UPS;            // staggered halves (only the VALU blend staging needs them)
+  constexpr bool STAG = C::WAVES == 8 && C::UPS && !C::MB;  // staggered halves (only the VALU blend staging needs them)
   constexpr int NT = C::NT;
   const int dbg0 = SV_DBG(mg.dbg);
   const int m = lane & 15, kq = lane >> 4;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
     *(short8_t*)(sMaw + tid * 96) = q8;                      // (every thread reads back only what it wrote itself: no barrier needed)
     *(short8_t*)(sMaw + tid * 96 + 16) = t8;
   }
-  short8_t mbw[2][2];                                        // MB: the blend's constant weight operands
+  short8_t mbw[2][C::MB ? C::NSG : 1];                                        // MB: the blend's constant weight operands
   MbLane mbl = MbLane{0, nullptr};
   if constexpr (C::MB) mb_weights<C>(lane, mbw);
   int obase = 0;                                             // ADJ: out-ring slot of hi-res row 0 of the current unit
@@ -565,8 +569,10 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
     const int prob = C::PAIR ? (int)blockIdx.x % np : (int)blockIdx.x / mg.units_per_prob, r0 = C::PAIR ? (int)blockIdx.x / np : (int)blockIdx.x - prob * mg.units_per_prob;
     const RowConvArgs& g = mg.a[prob];
     if constexpr (C::MB) {
-      // the halo columns are zeros for the whole launch (the blend only ever writes in-image columns)
+      // the halo columns are zeros for the whole launch (the blend only ever writes in-image columns); the raw ring too: at WIDTH 16 the
+      // blend's K columns 8..15 read the NEXT raw slot (zero weights, but 0 x non-finite garbage would be NaN)
       for (int q = tid; q < C::RING / 16; q += NT) *(uint4*)(sRing + q * 16) = make_uint4(0, 0, 0, 0);
+      for (int q = tid; q < C::RAWR / 16; q += NT) *(uint4*)(sRaw + q * 16) = make_uint4(0, 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const MbGeom mg0 = mb_geom(g);
@@ -669,15 +675,18 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
         // (priority: the SIMD's other wave -- the CU's second workgroup -- is usually inside its 144-MFMA strip loop and, being older half of
         //  the time, wins every arbitration of the matrix pipe: without it the blend's eight MFMAs waited ~2 000 cycles per step)
         __builtin_amdgcn_s_setprio(3);
-        if (job) mb_blend_rows<C, 2>(mgu, (jY - 1) >> 1, jY, STEP, qn, sRaw, mbl, mbw);    // (jY is odd: exactly two block rows)
+        if (job) {
+          if (jY & 1) mb_blend_rows<C, 2>(mgu, (jY - 1) >> 1, jY, STEP, qn, sRaw, mbl, mbw);   // k 6: the step's rows are exactly two block rows
+          else mb_blend<C>(mgu, jY, STEP, qn, sRaw, mbl, mbw);                                   // k 4: they straddle three
+        }
         __builtin_amdgcn_s_setprio(0);
 #ifdef SV_MB_STAMP_SPLIT
         SV_STAMP(t_exch);                                    // (diagnostic: the blend alone; the DMA issue stays in t_stage)
 #endif
         if (s + 2 < nsteps && !(dbg & 1)) {
-          const int LHm = mgu.LH, bn = (jY + STEP - 1) >> 1;
-          const int n0 = min(bn + 1, LHm - 1), n1 = min(bn + 2, LHm - 1);
-          if (n0 > min(bn, LHm - 1)) mb_dma_rows<C>(mgu, b, n0, n1, sRaw, wave, lane);
+          // the blend of the NEXT step reads raw rows up to ((jY + 2 STEP - 2) >> 1) + 1; this step's reached ((jY + STEP - 2) >> 1) + 1
+          const int LHm = mgu.LH, have = min(((jY + STEP - 2) >> 1) + 1, LHm - 1), want = min(((jY + 2 * STEP - 2) >> 1) + 1, LHm - 1);
+          if (want > have) mb_dma_rows<C>(mgu, b, have + 1, want, sRaw, wave, lane);
         } else if (!more && has_next && !(dbg & 1)) {
           // the unit's last step: nothing reads the raw ring any more -- the next unit's first rows land while this step computes
           mb_dma_first<C>(mgn, mb_nb, mb_nY, sRaw, wave, lane);
@@ -1039,6 +1048,7 @@ using RC_d4g  = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4>;         // d4
 using RC_d4ga = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true>;   //   ... fused with the resize adjoint
 using RC_d4gm = RowCfg<6, 6, 32, 64, 32, 4, 1, 1, 1, 1, false, 4, true, false, false, false, false, false, true>;   //   ... the adjoint on the matrix pipe (MA)
 using RC_d3f  = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true>;            // d3 forward   (K 2048)
+using RC_d3fm = RowCfg<4, 4, 128, 64, 16, 4, 1, 2, 1, 1, true, 8, false, false, false, false, false, true>;   //   ... with the resize on the matrix pipe (MB)
 using RC_d3g  = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false>;           // d3 input gradient (K 1024)
 using RC_d3ga = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true>;
 using RC_d3gm = RowCfg<4, 4, 64, 128, 16, 4, 1, 1, 1, 1, false, 8, true, false, false, false, false, false, true>;   //   ... the adjoint on the matrix pipe (MA)
@@ -1201,7 +1211,10 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
   // batches this kernel wins clearly (128 images: d3 18 vs 33 us).  SV_RC_FWD=1 / 0 forces it on / off.
   static const int fwd_mode = getenv("SV_RC_FWD") ? atoi(getenv("SV_RC_FWD")) : -1;
   // (Round 3, re-measured under the two-side-stream schedule: d4 forward 0.137 ms here against 0.146 on the tile kernel, d3 still equal: d4 always here.)
-  if ((cfg == 0 && fwd_mode == 0) || (cfg == 2 && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512)))) return SV_E_UNSUPPORTED;
+  // (Round 4: with the resize on the matrix pipe -- RowCfg::MB, whole images per unit -- d3 stays here at every size.)
+  static const bool no_mb3 = getenv("SV_RC_NO_MB") != nullptr || getenv("SV_RC_NO_MB3") != nullptr;
+  const bool d3_mb = cfg == 2 && !no_mb3 && a[0].bands == 1 && a[0].H == 16 && a[0].W == 16 && a[0].lda == 128;
+  if ((cfg == 0 && fwd_mode == 0) || (cfg == 2 && (fwd_mode == 0 || (fwd_mode < 0 && n * a[0].B > 512 && !d3_mb)))) return SV_E_UNSUPPORTED;
   return cfg;
 }
 
@@ -1224,7 +1237,11 @@ int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
       return launch_row<RC_d4f>(a, n, st);
     }
     case 1: return launch_row<RC_d4g>(a, n, st);
-    case 2: return launch_row<RC_d3f>(a, n, st);
+    case 2: {
+      static const bool no_mb3 = getenv("SV_RC_NO_MB") != nullptr || getenv("SV_RC_NO_MB3") != nullptr;
+      if (!no_mb3 && a[0].bands == 1 && a[0].H == 16 && a[0].W == 16 && a[0].lda == 128) return launch_row<RC_d3fm>(a, n, st);
+      return launch_row<RC_d3f>(a, n, st);
+    }
     case 3: return launch_row<RC_d3g>(a, n, st);
     case 4: {
       static const bool no_ma = getenv("SV_RC_NO_MA") != nullptr;       // A/B: the adjoint through the LDS out ring (adjoint_rows)

@@ -356,16 +356,16 @@ def test_conv_fused_upsample_equals_materialised(ops, layer):
     torch.testing.assert_close(db1, db0, rtol=1e-4, atol=1e-5 * float(db0.abs().max()))
 
 
-def test_d4_forward_with_the_resize_on_the_matrix_pipe(ops):
-    """From 512 images per launch (whole images per unit of work: bands == 1) the d4 forward (UpSampling2D(bilinear) -> Conv2D(32, 6),
-    vae/model.py:155,:165) stages its input by LDS-DMA of the raw low-res rows and blends them with MFMAs against constant weight
+@pytest.mark.parametrize("layer", [("d4_64", 32, 64, 32, 6, 515), ("d3_64", 16, 128, 64, 4, 259)], ids=["d4", "d3"])
+def test_forward_with_the_resize_on_the_matrix_pipe(ops, layer):
+    """From 512 (d4) / 256 (d3) images per launch (whole images per unit of work: bands == 1) the d4 / d3 forward (UpSampling2D(bilinear) ->
+    Conv2D(32, 6) / Conv2D(64, 4), vae/model.py:154-155,:163-165) stages its input by LDS-DMA of the raw low-res rows and blends them with MFMAs against constant weight
     operands (row_conv.hip: RowCfg::MB) instead of the VALU blend.  Against the fp64 composition resize -> conv on the same bf16 inputs
     (every row and column of a sample of images: first / last units of the walk, image edges) and against the small-batch (VALU blend)
     form on the same images: the MFMA blend rounds the upsampled activation once instead of per lerp stage, so the two agree to a bf16
     ulp of the activations, not bitwise."""
-    name, H, Cin, Cout, k = "d4_64", 32, 64, 32, 6
-    rng = np.random.default_rng(77)
-    B = 515                                                   # 515 units over 512 workgroups: some walk two images
+    name, H, Cin, Cout, k, B = layer                          # B: a few units more than workgroup slots (512 / 256): some walk two images
+    rng = np.random.default_rng(77 + H)
     x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).bfloat16()
     w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
     b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
@@ -373,7 +373,7 @@ def test_d4_forward_with_the_resize_on_the_matrix_pipe(ops):
     conv.prep(w.cuda())
     y = conv.fwd(x_lo.cuda(), b.cuda())
     torch.cuda.synchronize()
-    sel = [0, 1, 2, 255, 256, 257, 510, 511, 512, 513, 514]
+    sel = [0, 1, 2, 255, 256, 257] + ([510, 511, 512, 513, 514] if B > 514 else [B - 2, B - 1])
     xs = x_lo[sel].double()
     ref = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(xs), w.bfloat16().double(), b.double(), 1, "relu")
     got = y[sel][..., :Cout].double().cpu()
