@@ -175,6 +175,9 @@ int svk_wgrad_reduce_all(const WgradReduceDesc* d, int n, hipStream_t st);   // 
 // rolling-window form for the 6x6 conv over an upsampled 64-channel input (d4; wgrad_roll.hip): needs the slab workspace
 bool svk_wgrad_roll_supported(const WgradArgs* w, int n);
 int svk_wgrad_roll_multi(const WgradArgs* w, int n, hipStream_t st);
+// rolling-window form of the polyphase main term of the head's weight gradient (d5; wgrad_p5.hip): needs the slab workspace
+bool svk_wgrad_p5_supported(const WgradArgs* w, int n);
+int svk_wgrad_p5_multi(const WgradArgs* w, int n, hipStream_t st);
 // e1's weight gradient, one pipeline per wave (wgrad_e1.hip): needs the slab workspace
 bool svk_wgrad_e1_supported(const WgradArgs* w, int n);
 int svk_wgrad_e1_multi(const WgradArgs* w, int n, hipStream_t st);

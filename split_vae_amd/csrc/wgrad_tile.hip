@@ -535,6 +535,7 @@ int svk_wgrad_tile_multi(const WgradArgs* wv, int n, hipStream_t st) {
   static const char* skip = getenv("SV_WGRAD_IM2COL_IDS");    // e.g. "23": these layer ids use the im2col kernel (A/B)
   if (force_old || w.lOY < 0 || w.lOX < 0 || w.S > 2) return SV_E_UNSUPPORTED;   // power-of-two grids, stride <= 2
   if (svk_wgrad_roll_supported(wv, n)) return svk_wgrad_roll_multi(wv, n, st);
+  if (svk_wgrad_p5_supported(wv, n)) return svk_wgrad_p5_multi(wv, n, st);
   if (svk_wgrad_e1_supported(wv, n)) return svk_wgrad_e1_multi(wv, n, st);
   if (svk_wgrad_e2_supported(wv, n)) return svk_wgrad_e2_multi(wv, n, st);
   const int OY = 1 << w.lOY, OX = 1 << w.lOX;

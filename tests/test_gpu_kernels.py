@@ -748,7 +748,9 @@ def test_d5_input_gradient_ignores_stale_lds(ops):
         assert torch.equal(again, first)
 
 
-@pytest.mark.parametrize("H,B", [(32, 2), (32, 9), (64, 2), (64, 9), (128, 2)])   # 128: the frame kernel's 75.6 KB of line buffers (> the 64 KB default cap)
+# 128: the frame kernel's 75.6 KB of line buffers (> the 64 KB default cap); B = 130 / 257 at 64 x 64: the rolling-window main term (wgrad_p5.hip, from 128
+# images per launch): 257 images = 514 strips over 129 workgroups of two teams -- the last workgroup's second team has no strip
+@pytest.mark.parametrize("H,B", [(32, 2), (32, 9), (64, 2), (64, 9), (128, 2), (64, 130), (64, 257)])
 def test_polyphase_weight_gradient_of_the_head(ops, H, B):
     """Conv2DBackpropFilter + BiasAddGrad of the decoder head in polyphase form (poly_wgrad.hip; the algebra is pinned on CPU
     by tests/test_polyphase_math.py) against autograd of the fp64 resize -> conv on the same bf16 operands, and against the
