@@ -654,7 +654,9 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // the decoder head's weight gradient in polyphase form (poly_wgrad.hip) from ~768 images per launch (its three small
   // kernels cost more than they save below that: 16 images 42 vs 20 us; 1024 images 132 vs 184 us)
   static const bool no_pw = getenv("SV_NO_POLY_WGRAD") != nullptr;
-  static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 768;   // (512 images per launch: +0.4 %; 1024: -1.0 %)
+  // (round 2, tile-kernel main term: 512 images per launch +0.4 %, 1024 -1.0 % -> 768; round 4, rolling-window main term (wgrad_p5.hip): 512 images per
+  //  launch -0.7 %, 256 +2.5 % -> 512: profiles/r04_poly_wgrad_min_sweep.txt)
+  static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 512;
   if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2 &&
       svk_poly_wgrad_supported(L[0]->d.H / 2, L[0]->d.W / 2, svg_cin_pad(&L[0]->d), L[0]->d.Cout)) {   // else: the direct form below
     static const char* pw_name[2] = {"polyw_x", "polyw_xh"};
