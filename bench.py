@@ -199,11 +199,12 @@ class Workload:
 TABLE_PASSES = 3
 
 
-def kernel_table(w, passes=TABLE_PASSES):
+def kernel_table(w, passes=TABLE_PASSES, prime=True):
     """Per-launch hipEvent table of the whole step (serial launches: the weight-gradient side stream is off in this
-    mode), outside the timed region."""
+    mode), outside the timed region.  prime=False: not one overlapped step before it (--table-only under rocprofv3: every launch the
+    profiler sees ran alone on the chip)."""
     import torch
-    plan = w.step()
+    plan = w.step() if prime else w.model.plan(w.B)
     torch.cuda.synchronize()
     plan.profile_filter(None)
     plan.profile_enable(True)
@@ -442,6 +443,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra configurations (SVHN-32, small shards, SPLIT-GMVAE, SPLIT-SPAIR)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision (fp32) block")
+    ap.add_argument("--table-only", type=int, default=0, metavar="PASSES",
+                    help="run PASSES passes of the serial per-launch table and stop (for `rocprofv3 --kernel-trace --stats`: kernel durations alone on the chip, "
+                         "what `roofline.serial` and the fractions of the table quote)")
     ap.add_argument("--profile-all", action="store_true", help="(kept for compatibility: the per-launch table always goes to stderr)")
     args = ap.parse_args()
 
@@ -473,14 +477,18 @@ def main():
             raise SystemExit("global batch %d is not divisible by %d GPUs" % (gb, world))
         B, strong = gb // world, True
     w = Workload(H, B, args.dtype, dev, rank, world, svdist.make_reducer)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(0 if args.table_only else max(args.warmup, 1)):
         w.step()
     torch.cuda.synchronize()
 
     # per-launch table + the dominant kernel family (outside the timed region)
-    plan, table = kernel_table(w)
+    plan, table = kernel_table(w, passes=args.table_only or TABLE_PASSES, prime=not args.table_only)
     if rank == 0:
         print_table(table, args.dtype, H, B)
+    if args.table_only:
+        if rank == 0:
+            print(json.dumps({"table_only": args.table_only, "rows": [{"kernel": r["name"], "launches": r["launches"], "ms": round(r["total_ms"] / max(r["launches"], 1), 4)} for r in table[:12]]}))
+        return
     # the dominant kernel = the top row of the serial table, whatever it is.  In the timed region the streams of the backward pass overlap:
     # `achieved` is what the hipEvents around the launch on ITS stream give there (co-running launches of the other streams included; `stream`
     # names it), `serial` what the launch takes alone on the chip.

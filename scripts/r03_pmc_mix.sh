@@ -4,7 +4,7 @@
 T=${1:-r03}; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcmix
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcmix -o m -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcmix -o m -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rows --no-fp32 > /dev/null 2>&1
 cd $R
 python3 - <<'PY' > gpurun_out/${T}_pmc_mix.txt
 import csv, glob, collections

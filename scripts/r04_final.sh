@@ -2,7 +2,7 @@
 # round-4 evidence set, ONE gpurun call: bash scripts/r04_final.sh <tag>      -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
 #   bench line (bf16 headline + the fp32 first-class block + rows + cpu_baseline) and its per-launch tables; rocprofv3 kernel stats of the bf16 and of the
 #   fp32 step; PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes); 64-image bench; step timelines with gap accounting at 64 and 512 images;
-#   SPLIT-SPAIR / SPLIT-GMVAE kernel stats; the GPU test suite twice.
+#   per-kernel VALU / MFMA / LDS counter mix; SPLIT-SPAIR / SPLIT-GMVAE kernel stats; the GPU test suite twice.
 T=${1:-r04_a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 bash scripts/r02_profile.sh $T > $O/${T}_profile.log 2>&1
@@ -18,9 +18,22 @@ if f:
         for r in rows:
             out.write('"%s",%s,%s,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
 PY
+# serial launches only (every kernel alone on the chip) under rocprofv3: the durations `roofline.serial` and the per-launch table quote
+( cd /tmp && export TMPDIR=/tmp && rm -rf $O/${T}_prof_serial && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof_serial -o k -- python3 $R/bench.py --table-only 30 > $O/${T}_prof_serial_bench.json 2>/dev/null )
+python3 - <<PY
+import csv, glob
+f = glob.glob("$O/${T}_prof_serial/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = sorted(csv.DictReader(open(f[0])), key=lambda r: -float(r["TotalDurationNs"]))
+    with open("$O/${T}_serial_kernel_stats.csv", "w") as out:
+        out.write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n")
+        for r in rows:
+            out.write('"%s",%s,%s,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
+PY
 timeout 300 python bench.py --batch 64 --no-cpu-baseline --no-rows --no-fp32 > $O/${T}_bench_b64.json 2> $O/${T}_table_b64.txt
 timeout 400 bash scripts/r04_timeline.sh ${T} 64 > /dev/null 2>&1
 timeout 400 bash scripts/r04_timeline.sh ${T} 512 > /dev/null 2>&1
+timeout 400 bash scripts/r03_pmc_mix.sh $T > /dev/null 2>&1
 timeout 400 bash scripts/r03_spair_prof.sh $T > /dev/null 2>&1
 timeout 400 bash scripts/r03_gm_prof.sh $T > /dev/null 2>&1
 for i in 1 2; do timeout 1500 python -m pytest tests -m gpu -q > $O/${T}_gputests_$i.log 2>&1; grep -E "passed|failed" $O/${T}_gputests_$i.log | tail -1; grep -E "^FAILED" $O/${T}_gputests_$i.log; done
