@@ -289,6 +289,247 @@ bias_part:
   }
 }
 
+// ---- the same kernel as a PIPELINE, for the layers whose tiles are whole images (d2: 8 x 8 x 128 -> 128, e3: 16 x 16 x 64 -> 8 x 8 x 128) ----
+// Phase ablation of the form above on these layers (profiles/r04_abl_wt.txt, 1 024 images): staging 27 us, MFMA loop 20 us, flush + reduce 15 us
+// of d2's 93 -- ADDITIVE: the two wave groups of the NG = 2 form stage together, wait together and multiply together, nothing overlaps.  Here
+//   * ONE tile at a time for all eight waves: group g (waves 4g .. 4g + 3) multiplies the K chunks kc = g * KC/2 .. of the tile with the same
+//     tap split and the same 32 accumulators per wave as before (summed through LDS at the end: the slab order is unchanged);
+//   * the tile buffers are a ring of NBUF (2..4, whatever 160 KB holds) and the tiles arrive by global_load_lds_dwordx4 issued NBUF - 1 tiles
+//     ahead, counted with s_waitcnt vmcnt: ONE barrier per tile, no VGPR round trip, no address arithmetic in the loop -- every lane's source
+//     offsets (relative to the tile's first image) are the same for every tile and computed once (<= 8 registers);
+//   * the LDS layout is the one above (pixel records of PS / YS bytes, padded for the transposed reads): a transfer writes 64 consecutive 16-B
+//     slots, lanes on padding slots or on pixels outside the image are masked off (the ring is zeroed once: those slots stay zero).
+__device__ __forceinline__ void wt_dma16(const void* base, uint32_t off, const char* lds) {    // base: wave-uniform; off: this lane's byte offset
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ void wt_wait_vm(int n) {      // s_waitcnt vmcnt(n), n wave-uniform (the count is an immediate)
+  switch (n) {
+#define SV_WT_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    SV_WT_VM(1) SV_WT_VM(2) SV_WT_VM(3) SV_WT_VM(4) SV_WT_VM(5) SV_WT_VM(6) SV_WT_VM(7) SV_WT_VM(8) SV_WT_VM(9) SV_WT_VM(10) SV_WT_VM(11) SV_WT_VM(12)
+    SV_WT_VM(13) SV_WT_VM(14) SV_WT_VM(15) SV_WT_VM(16) SV_WT_VM(17) SV_WT_VM(18) SV_WT_VM(19) SV_WT_VM(20) SV_WT_VM(21) SV_WT_VM(22) SV_WT_VM(23) SV_WT_VM(24)
+#undef SV_WT_VM
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+constexpr int WTP_NI = 10;     // transfers per wave and tile, at most (d3: 34 for the 19 x 19 x 96-B patch + 40 for 256 dY pixels of 160 B, over 8 waves)
+
+template <int TPW, int CIF, int COF, int KC>
+__global__ __launch_bounds__(512, 1) void wgrad_tile_pipe_kernel(const WgradTileMulti mg, int nbuf) {
+  static_assert(KC % 2 == 0, "the two wave groups split the K chunks of a tile");
+  const WgradTileArgs& g = mg.a[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int stage = g.in_bytes + g.dy_bytes;
+  const int grp = (int)(threadIdx.x >> 8), gw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave group, wave of the workgroup (0..7)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = gw & 3;                                           // thread / wave WITHIN the group
+  const int tg = blockIdx.y / g.ncg, cg = blockIdx.y - tg * g.ncg;
+  const int tap0 = tg * (4 * TPW) + wave * TPW;
+  const int ci0 = cg * g.CW;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB;
+  const int cpp = 1 << g.cl2;
+  const int lg = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+
+  for (int q = threadIdx.x; q < (nbuf * stage) / 16; q += 512) *(uint4*)(smem + q * 16) = make_uint4(0, 0, 0, 0);
+
+  int in_lane, dy_lane;
+  {
+    const int r = 4 * lg + lq;
+    const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1);
+    in_lane = (ty * g.S * g.TIW + tx * g.SX) * g.PS + 4 * lp * 2;
+    dy_lane = r * g.YS + 4 * lp * 2;
+  }
+  auto in_chunk = [&](int kc, int h) -> int {
+    const int r = kc * 32 + 16 * h;
+    const int ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+    return ((bl * g.TIH + ty * g.S) * g.TIW) * g.PS;
+  };
+  auto dy_chunk = [&](int kc, int h) -> int { return (kc * 32 + 16 * h) * g.YS; };
+  int tapoff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = min(tap0 + t, g.ntaps - 1);
+    tapoff[t] = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * g.PS;
+  }
+
+  // ---- this lane's transfers of a tile: wave-transfer k (64 slots of 16 B) = gw, gw + 8, ...; k < nin: the input patch, else the dY patch
+  const int spp_in = g.PS >> 4, spp_dy = g.YS >> 4;                   // 16-B slots per pixel record (padding included)
+  const int nin = (NB * g.TIH * g.TIW * spp_in + 63) >> 6, ndy = (32 * KC * spp_dy + 63) >> 6;
+  const int ni = (nin + ndy - gw + 7) >> 3;                           // transfers of this wave per tile (wave-uniform, <= WTP_NI: checked on the host)
+  uint32_t soff[WTP_NI];                                              // source byte offset from the tile's first image / first dY pixel; ~0: lane off
+#pragma unroll
+  for (int i = 0; i < WTP_NI; ++i) {
+    const int k = gw + 8 * i;
+    soff[i] = 0xFFFFFFFFu;
+    if (k < nin) {
+      const int q = k * 64 + lane, rec = q / spp_in, c = q - rec * spp_in;
+      const int per_img = g.TIH * g.TIW, bl = rec / per_img, r2 = rec - bl * per_img, iyl = r2 / g.TIW, ixl = r2 - iyl * g.TIW;
+      const int iy = g.y_lo + iyl, ix = g.x_lo + ixl;
+      if (bl < NB && c < cpp && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+        soff[i] = (uint32_t)((((bl * g.IH + iy) * g.IW + ix) * g.lda + c * 8) * 2);
+    } else if (k < nin + ndy) {
+      const int q = (k - nin) * 64 + lane, rec = q / spp_dy, c = q - rec * spp_dy;
+      if (rec < 32 * KC && c < (g.ldy >> 3)) soff[i] = (uint32_t)((rec * g.ldy + c * 8) * 2);
+    }
+  }
+  int nact = 0;                                                       // transfers this wave really issues per tile (one with every lane off is
+#pragma unroll                                                        // branched over: it must not be counted by the s_waitcnt arithmetic)
+  for (int i = 0; i < WTP_NI; ++i)
+    if (i < ni && __builtin_amdgcn_ballot_w64(soff[i] != 0xFFFFFFFFu) != 0) ++nact;
+  nact = __builtin_amdgcn_readfirstlane(nact);
+  const bf16_t* __restrict__ Ab = (const bf16_t*)g.A + ci0;
+  const bf16_t* __restrict__ Yb = (const bf16_t*)g.dY;
+  const int64_t in_tile = (int64_t)NB * g.IH * g.IW * g.lda, dy_tile = (int64_t)32 * KC * g.ldy;     // elements per tile
+  auto issue = [&](int tile, int slot) {
+    char* buf = smem + slot * stage;
+    const bf16_t* ab = Ab + tile * in_tile;
+    const bf16_t* yb = Yb + tile * dy_tile;
+#pragma unroll
+    for (int i = 0; i < WTP_NI; ++i) {
+      const int k = gw + 8 * i;
+      if (i < ni) {                                                   // wave-uniform
+        const bool isin = k < nin;
+        const char* dst = isin ? buf + k * 1024 : buf + g.in_bytes + (k - nin) * 1024;
+        const void* base = isin ? (const void*)ab : (const void*)yb;
+        if (soff[i] != 0xFFFFFFFFu) wt_dma16(base, soff[i], dst);
+      }
+    }
+  };
+
+  f32x4 acc[TPW][CIF][COF];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < CIF; ++i)
+#pragma unroll
+      for (int j = 0; j < COF; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ycols = g.ldy;
+  auto bias_split = [&]() -> int {
+    int bsp = 1;
+    while (2 * bsp <= (int)gridDim.y && 16 * bsp <= ycols) bsp *= 2;
+    return bsp;
+  };
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bool do_bias = g.dbias != nullptr && (int)blockIdx.y < bias_split();
+
+  const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_lo = (int)blockIdx.x * per_wg, tile_hi = min(g.ntiles, tile_lo + per_wg);
+  __syncthreads();                                                    // the ring is zero
+  for (int i = 0; i < nbuf - 1; ++i)
+    if (tile_lo + i < tile_hi) issue(tile_lo + i, i);
+  int slot = 0;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    // my transfers of this tile have landed: everything but those of the (at most nbuf - 2) later tiles already issued
+    wt_wait_vm(min(nbuf - 2, tile_hi - 1 - tile) * nact);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // ... and everybody's; the previous tile is consumed
+    asm volatile("" ::: "memory");
+    {
+      int ns = slot + nbuf - 1;
+      if (ns >= nbuf) ns -= nbuf;
+      if (tile + nbuf - 1 < tile_hi) issue(tile + nbuf - 1, ns);      // into the buffer of the previous tile
+    }
+    const char* sIn = smem + slot * stage;
+    const char* sDy = sIn + g.in_bytes;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      const int kc = grp * (KC / 2) + kk;
+      short8_t bfr[COF];
+#pragma unroll
+      for (int j = 0; j < COF; ++j) {
+        const short4_t lo = tr16(sDy + dy_lane + dy_chunk(kc, 0) + j * 32), hi = tr16(sDy + dy_lane + dy_chunk(kc, 1) + j * 32);
+        bfr[j] = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      constexpr int U = TPW * CIF, PF = U < SV_WT_PF ? U : SV_WT_PF;
+      short4_t alo[PF], ahi[PF];
+      const int ic0 = in_chunk(kc, 0), ic1 = in_chunk(kc, 1);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        alo[u] = tr16(sIn + in_lane + ic0 + tapoff[u / CIF] + (u % CIF) * 32);
+        ahi[u] = tr16(sIn + in_lane + ic1 + tapoff[u / CIF] + (u % CIF) * 32);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const short4_t lo = alo[u % PF], hi = ahi[u % PF];
+        const short8_t af = (short8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (u + PF < U) {
+          alo[u % PF] = tr16(sIn + in_lane + ic0 + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
+          ahi[u % PF] = tr16(sIn + in_lane + ic1 + tapoff[(u + PF) / CIF] + ((u + PF) % CIF) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+          acc[u / CIF][u % CIF][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[j]), acc[u / CIF][u % CIF][j], 0, 0, 0);
+      }
+    }
+    if (do_bias) {                                                    // column sums of the dY patch: the first `bias_split()` workgroups of a grid column (they stage the
+                                                                      // same dY tiles) take ycols / split columns each, a thread sums a column PAIR (4-B reads) over every
+                                                                      // (512 / pairs)-th pixel
+      const int bpc = (ycols >> 1) / bias_split();
+      const int t5 = threadIdx.x, bch = t5 & (bpc - 1), brow = t5 / bpc, nbrow = 512 / bpc, bc0 = (int)blockIdx.y * bpc;
+      for (int r = brow; r < 32 * KC; r += nbrow) {
+        const uint32_t v = *(const uint32_t*)(sDy + r * g.YS + (bc0 + bch) * 4);
+        bsum0 += __uint_as_float(v << 16);
+        bsum1 += __uint_as_float(v & 0xFFFF0000u);
+      }
+    }
+    if (++slot == nbuf) slot = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- group 1 -> group 0 through LDS, half of the fragments at a time; flush in the slab order of the form above
+  {
+    constexpr int NFR_ = TPW * CIF * COF, HF = (NFR_ + 1) / 2;
+    float* xch = (float*)smem + (wave * HF * 4) * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      if (grp == 1) {
+#pragma unroll
+        for (int f = 0; f < NFR_; ++f)
+          if (f / HF == h)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) xch[((f - h * HF) * 4 + r4) * 64] = acc[f / (CIF * COF)][(f / COF) % CIF][f % COF][r4];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int f = 0; f < NFR_; ++f)
+          if (f / HF == h)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) acc[f / (CIF * COF)][(f / COF) % CIF][f % COF][r4] += xch[((f - h * HF) * 4 + r4) * 64];
+      }
+    }
+  }
+  if (grp == 0) {
+    float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * CIF * COF)) * 256 + lane;
+#pragma unroll
+    for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+      for (int i = 0; i < CIF; ++i)
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) sl[(((t2 * CIF + i) * COF + j) * 4 + r4) * 64] = acc[t2][i][j][r4];
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = (float*)smem;                                        // [512 / bpc][2 * bpc]
+    const int bpc = (ycols >> 1) / bias_split();
+    const int t5 = threadIdx.x, bch = t5 & (bpc - 1), brow = t5 / bpc, nbrow = 512 / bpc, bc0 = (int)blockIdx.y * bpc;
+    red[(brow * bpc + bch) * 2] = bsum0;
+    red[(brow * bpc + bch) * 2 + 1] = bsum1;
+    __syncthreads();
+    const int bw = 2 * bpc, col = 2 * bc0 + t5;
+    if (t5 < bw && col < g.N) {
+      float sum = 0.f;
+      for (int k = 0; k < nbrow; ++k) sum += red[k * bw + t5];
+      if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + col] = sum;
+      else atomicAdd(g.dbias + col, sum);
+    }
+  }
+}
+
 // second stage of the slab path: dW[...] += sum over the m-splits (fixed order: deterministic).
 // A block sums 32 float4 columns; its 8 thread rows take the splits x = row, row+8, ... with 16-B
 // loads (many in flight: the first version, one scalar column per thread, ran at 1.2 TB/s) and are
@@ -494,7 +735,27 @@ static int launch_wt_ng(const WgradTileArgs* a, int n, int groups, hipStream_t s
     m.a[i].bslab = (slab && a[i].dbias && a[i].ldy <= 128) ? a[i].ws + (int64_t)msplit * groups * PER : nullptr;
     r.slab[i] = m.a[i].slab; r.dW[i] = a[i].dW; r.bslab[i] = m.a[i].bslab; r.dbias[i] = a[i].dbias;
   }
-  hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>), grid, block, lds, st, m);
+  bool piped = false;
+  if constexpr (NG == 2 && KC % 2 == 0) {
+    // whole-image tiles, plain staging, slabs: the pipelined form (ring of 2..4 tile buffers filled by LDS-DMA)
+    static const bool no_pipe = getenv("SV_WT_NO_PIPE") != nullptr;
+    static const int force_nbuf = getenv("SV_WT_PIPE_NBUF") ? atoi(getenv("SV_WT_PIPE_NBUF")) : 0;
+    const WgradTileArgs& q = a[0];
+    const size_t stage = (size_t)q.in_bytes + q.dy_bytes;
+    int nbuf = (int)((160 * 1024) / stage);
+    if (nbuf > 4) nbuf = 4;
+    if (force_nbuf >= 2 && force_nbuf < nbuf) nbuf = force_nbuf;
+    const int NBi = 1 << q.lNB;
+    const int nin = (NBi * q.TIH * q.TIW * (q.PS >> 4) + 63) >> 6, ndy = (32 * KC * (q.YS >> 4) + 63) >> 6;
+    if (!no_pipe && slab && nbuf >= 2 && q.tilesX == 1 && q.tilesY == 1 && !q.ups && !q.clampin && !q.dy_s2d && !q.pairx && !q.fold_kw && q.contig &&
+        q.B % NBi == 0 && nin + ndy <= 8 * WTP_NI && (q.PS & 15) == 0 && (q.YS & 15) == 0 && (size_t)HFB <= nbuf * stage) {
+      const size_t plds = nbuf * stage;
+      sv_ensure_dynamic_lds((const void*)wgrad_tile_pipe_kernel<TPW, CIF, COF, KC>, plds);
+      hipLaunchKernelGGL((wgrad_tile_pipe_kernel<TPW, CIF, COF, KC>), grid, block, plds, st, m, nbuf);
+      piped = true;
+    }
+  }
+  if (!piped) hipLaunchKernelGGL((wgrad_tile_kernel<TPW, CIF, COF, KC, NG, OCC>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   if (ev_mid && ev_mid[0]) { (void)hipEventRecord(ev_mid[0], st); (void)hipEventRecord(ev_mid[1], st); }
   if (slab && !(dbg & 1) && a[0].defer && a[0].n_defer && *a[0].n_defer + n <= 64) {      // the caller reduces every layer's slabs in one launch later
@@ -520,7 +781,7 @@ static int launch_wt(const WgradTileArgs* a, int n, int groups, hipStream_t st, 
   // measured per layer (B = 512): e2 -13 %, d2 -8 %, e1 -4 %, d3 0; d4 / d5 (the longest MFMA sections) lose
   // 5-12 % to the lockstep of the two groups, so the wide-tile layers keep two independent workgroups per CU
   static const char* ng2 = getenv("SV_WT_NG2") ? getenv("SV_WT_NG2") : "3456";     // layer ids (see the table above)
-  const bool want = strchr(ng2, '0' + a[0].layer_id) != nullptr;
+  const bool want = strchr(ng2, '0' + a[0].layer_id) != nullptr || (a[0].layer_id == 2 && !a[0].ups);    // d3 on its written-out resized input: the pipelined form
   if (!ng1 && want && slab && two <= 160 * 1024 && HFB <= 160 * 1024 && a[0].ntiles >= 64)
     return launch_wt_ng<TPW, CIF, COF, KC, 2>(a, n, groups, st, ev_mid);
   return launch_wt_ng<TPW, CIF, COF, KC, 1>(a, n, groups, st, ev_mid);
