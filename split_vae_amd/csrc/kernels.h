@@ -186,6 +186,8 @@ bool svk_wgrad_e2_supported(const WgradArgs* w, int n);
 int svk_wgrad_e2_multi(const WgradArgs* w, int n, hipStream_t st);
 struct WgradTileMulti { WgradTileArgs a[SV_WGRAD_MAX_MULTI]; };     // blockIdx.z selects the problem
 struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WGRAD_MAX_MULTI]; const float* bslab[SV_WGRAD_MAX_MULTI]; float* dbias[SV_WGRAD_MAX_MULTI]; };
+// fp32 (the reference's precision): LDS tiles + v_mfma_f32_16x16x4_f32 + the same slabs (wgrad_tile_f32.hip); SV_E_UNSUPPORTED -> im2col kernel
+int svk_wgrad_tile_f32_multi(const WgradArgs* w, int n, hipStream_t st);
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
 int svk_wgrad_tile_multi(const WgradArgs* w, int n, hipStream_t st);   // n twin layers, one launch (own ws each)
 int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st);

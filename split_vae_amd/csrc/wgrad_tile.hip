@@ -924,6 +924,10 @@ int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipS
     const int rc = svk_wgrad_tile_multi(w, n, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
+  if (dtype == SV_F32 && !no_multi && n <= SV_WGRAD_MAX_MULTI) {
+    const int rc = svk_wgrad_tile_f32_multi(w, n, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
   // im2col kernel (no tile instantiation for this shape, or fp32): all of them in one launch
   const bool any_tile = no_multi || n > SV_WGRAD_IM2COL_MAX_MULTI;
   int rc = SV_OK;
@@ -950,6 +954,10 @@ int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipS
 int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st) {
   if (dtype == SV_BF16) {
     const int rc = svk_wgrad_tile(w, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
+  if (dtype == SV_F32) {
+    const int rc = svk_wgrad_tile_f32_multi(&w, 1, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
   if (w.ups || w.fold_kw) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor / cannot fold

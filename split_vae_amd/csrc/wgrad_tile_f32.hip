@@ -1,0 +1,235 @@
+// Weight gradient with LDS-resident tiles at the REFERENCE's precision (fp32 operands, fp32 accumulate: v_mfma_f32_16x16x4_f32):
+//
+//   dW[t][ci][co] += sum_pixels X[pix + tap t][ci] * dY[pix][co]          dbias[co] += sum_pixels dY[pix][co]
+//
+// (Conv2DBackpropFilter + BiasAddGrad of vae/trainer.py:137's tape.gradient, as the fp32 step runs them.)  The im2col form (wgrad.hip) gathers
+// every input pixel once per tap through L2 -- d5: 4.2 M pixels x 36 taps x 32 channels x 4 B = 19 GB per launch, 3.9 ms at ~5 TB/s, 9 % of the
+// fp32 matrix peak.  Here, as in wgrad_tile.hip (bf16), a workgroup stages a spatial tile of a 16-channel slice of the input with its halo ONCE
+// (plain coalesced 16-B loads, natural NHWC order) and the matching dY tile; every tap's A operand is a shifted window of the same LDS patch.
+// With K = 4 pixels per MFMA the operands are plain 4-B LDS reads (lane = (row / column lane & 15, pixel lane >> 4)): no transposed reads, and
+// one read feeds COF (A) or TPW (B) 32-cycle MFMAs, so the loop is matrix-pipe-bound and the simple stage -> barrier -> multiply form is enough.
+// Accumulators leave through the per-workgroup partial-sum slabs of wgrad_tile.hip in its fragment order <TPW, CIF = 1, COF>, summed by
+// svk_wgrad_reduce_all in workgroup order: the fp32 step's weight gradients are bit-reproducible without SV_DETERMINISTIC.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "common.hip.h"
+#include "kernels.h"
+#include "tile_stage.hip.h"
+#include "conv_geom.h"
+
+namespace {
+
+// TPW taps per wave (4 waves: 4 * TPW taps per workgroup = all of them), COF 16-column fragments of dY.  A workgroup owns a 16-channel (8 for
+// an 8-channel input) slice of the input, blockIdx.y, and walks a contiguous run of tiles, blockIdx.x.
+template <int TPW, int COF>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileMulti mg) {
+  const WgradTileArgs& g = mg.a[blockIdx.z];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sIn = smem;                       // [NB][TIH][TIW] pixels of PS = 4 * CW bytes
+  char* sDy = smem + g.in_bytes;          // [BM] pixels of YS = 4 * ldy bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  const int tap0 = wave * TPW, ci0 = (int)blockIdx.y * g.CW;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB, BM = TW * TH * NB;
+  const int ycols = g.ldy;
+
+  // lane part of the operand addresses: pixel kq of a group of four consecutive tile pixels (one tile row: TW % 4 == 0), row / column lr
+  const int in_lane = kq * g.SX * g.PS + lr * 4, dy_lane = kq * g.YS + lr * 4;
+  const bool a_on = lr < g.CW;            // an 8-channel slice fills half of the fragment's rows
+  int tapoff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = min(tap0 + t, g.ntaps - 1);
+    tapoff[t] = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * g.PS;
+  }
+  f32x4 acc[TPW][COF];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int j = 0; j < COF; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = ones^T . dY on the fragments the loop already holds: wave w takes the column fragments j = w, w + 4, ...
+  constexpr int BJ = (COF + 3) / 4;
+  f32x4 bacc[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) bacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = g.dbias != nullptr && blockIdx.y == 0;
+
+  const float* __restrict__ Ab = (const float*)g.A + ci0;
+  const float* __restrict__ Yb = (const float*)g.dY;
+  const int lycp = g.lycp, dy_total = BM << lycp;
+  const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_lo = (int)blockIdx.x * per_wg, tile_hi = min(g.ntiles, tile_lo + per_wg);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    int t = tile;
+    const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
+    const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
+    const int b0 = t << g.lNB;
+    __syncthreads();                      // the previous tile is consumed
+    {
+      const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
+      stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
+    }
+    for (int q = tid; q < dy_total; q += 256) {
+      const int r = q >> lycp, c = q & ((1 << lycp) - 1);
+      const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+      const int b = b0 + bl;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b < g.B) v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4);
+      *(uint4*)(sDy + r * g.YS + c * 16) = v;
+    }
+    __syncthreads();
+    // ---- MFMA: K = pixels, four per instruction
+#pragma unroll 2
+    for (int r = 0; r < BM; r += 4) {
+      const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);     // wave-uniform
+      const char* pin = sIn + in_lane + ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS;
+      const char* pdy = sDy + dy_lane + r * g.YS;
+      float bfr[COF];
+#pragma unroll
+      for (int j = 0; j < COF; ++j) {
+        const float v = *(const float*)(pdy + j * 64);
+        bfr[j] = j * 16 + lr < ycols ? v : 0.f;           // (ycols = 8: the head's 6 + 2 gradient columns fill half a fragment)
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+          if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[j], bacc[j >> 2], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < TPW; ++t2) {
+        const float av = *(const float*)(pin + tapoff[t2]);
+        const float af = a_on ? av : 0.f;
+#pragma unroll
+        for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr[j], acc[t2][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- flush: one slab per workgroup in the fragment order of wgrad_reduce <TPW, 1, COF>
+  {
+    float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * COF)) * 256 + lane;
+#pragma unroll
+    for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+      for (int j = 0; j < COF; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) sl[((t2 * COF + j) * 4 + r4) * 64] = acc[t2][j][r4];
+  }
+  if (do_bias) {                          // every row of a column-sum fragment is the column sum: row 0 = lanes 0..15, register 0
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < COF; ++j)
+        if ((j & 3) == wave && j * 16 + lane < ycols && j * 16 + lane < g.N) {
+          if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + j * 16 + lane] = bacc[j >> 2][0];
+          else atomicAdd(g.dbias + j * 16 + lane, bacc[j >> 2][0]);
+        }
+    }
+  }
+}
+
+template <int TPW, int COF>
+int launch_f32(const WgradTileArgs* a, int n, int msplit, int groups, size_t lds, hipStream_t st) {
+  WgradTileMulti m;
+  for (int i = 0; i < n; ++i) m.a[i] = a[i];
+  sv_ensure_dynamic_lds((const void*)wgrad_tile_f32_kernel<TPW, COF>, lds);
+  hipLaunchKernelGGL((wgrad_tile_f32_kernel<TPW, COF>), dim3(msplit, groups, n), dim3(256), lds, st, m);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+}  // namespace
+
+// The seven conv layers of the SPLIT-VAE encoders / decoders (fp32 plan: plain inputs, the resized tensors are written out).  SV_E_UNSUPPORTED:
+// any other shape, a missing / small workspace -- the caller falls back to the im2col kernel.
+#define F32_REJ(why) do { if (trace) fprintf(stderr, "wgrad_tile_f32: not taken (%s)\n", why); return SV_E_UNSUPPORTED; } while (0)
+int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
+  static const bool trace = getenv("SV_TRACE_DISPATCH") != nullptr;
+  static const bool off = getenv("SV_NO_WGRAD_TILE_F32") != nullptr;
+  if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) F32_REJ("off / problems");
+  const WgradArgs& w = wv[0];
+  if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || w.ups || w.dy_s2d || w.clampin || w.ycols != w.ldy) F32_REJ("form");
+  const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, ldy = w.ldy, nt = w.ntaps;
+  if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && !(nt == 42 && w.fold_kw))) {
+    if (trace) fprintf(stderr, "wgrad_tile_f32: OY %d OX %d ldy %d taps %d cin %d\n", OY, OX, ldy, nt, cin);
+    F32_REJ("grid / taps");
+  }
+  const int CW = cin >= 16 ? 16 : 8;
+  if (cin % CW || (cin != 8 && ilog2_exact(cin) < 0)) F32_REJ("channels");
+  const int TPW = (nt + 3) / 4, COF = (ldy + 15) / 16;      // (42 folded taps: 11 per wave, the last two slots repeat tap 41 and are dropped by the reduce)
+  if (!((TPW == 9 && (COF == 1 || COF == 2 || COF == 4)) || (TPW == 4 && (COF == 4 || COF == 8)) || (TPW == 11 && COF == 1))) F32_REJ("no instantiation");
+  int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
+  for (int i = 0; i < nt; ++i) {
+    y_lo = w.dy[i] < y_lo ? w.dy[i] : y_lo; y_hi = w.dy[i] > y_hi ? w.dy[i] : y_hi;
+    x_lo = w.dx[i] < x_lo ? w.dx[i] : x_lo; x_hi = w.dx[i] > x_hi ? w.dx[i] : x_hi;
+  }
+  // pixels per tile: the largest of 256 .. 32 whose input patch + dY tile leave two workgroups per CU their LDS
+  WgradTileArgs a;
+  static const int bm_max = getenv("SV_WTF32_BM") ? atoi(getenv("SV_WTF32_BM")) : 256;      // A/B knobs
+  static const int wgs = getenv("SV_WTF32_WGS") ? atoi(getenv("SV_WTF32_WGS")) : 512;
+  static const int lds_max = getenv("SV_WTF32_LDS") ? atoi(getenv("SV_WTF32_LDS")) : 78 * 1024;
+  int BM = bm_max;
+  for (;; BM >>= 1) {
+    if (BM < 32) F32_REJ("tile");
+    if (OY * OX < BM && (BM % (OY * OX))) continue;
+    const int lTW = OX >= 16 ? 4 : w.lOX;
+    int lTH = 0;
+    while ((1 << (lTW + lTH)) < BM && (1 << lTH) < OY) ++lTH;
+    int lNB = 0;
+    while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
+    const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
+    memset(&a, 0, sizeof(a));
+    a.lTW = lTW; a.lTH = lTH; a.lNB = lNB;
+    a.TIW = (TW - 1) * w.SX + (x_hi - x_lo) + 1; a.TIH = (TH - 1) * w.S + (y_hi - y_lo) + 1;
+    a.PS = CW * 4; a.YS = ldy * 4;
+    a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;      // slack: the masked lanes of a half-filled fragment read past the last pixel
+    a.dy_bytes = BM * a.YS + 64;
+    if (a.in_bytes + a.dy_bytes <= lds_max) break;
+  }
+  const int TW = 1 << a.lTW, TH = 1 << a.lTH, NB = 1 << a.lNB;
+  const int B = w.M >> (w.lOY + w.lOX);
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.assign = w.assign;
+  a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
+  a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
+  a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
+  a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
+  a.y_lo = y_lo; a.x_lo = x_lo;
+  a.ldy = ldy; a.lycp = ilog2_exact(ldy / 4);
+  if (a.lycp < 0) F32_REJ("dY pitch");
+  a.Cin_real = w.Cin_real; a.N = w.N; a.ntaps = nt;
+  memcpy(a.dy, w.dy, sizeof(a.dy));
+  memcpy(a.dx, w.dx, sizeof(a.dx));
+  const int groups = a.ncg;
+  // two resident workgroups per CU over the whole launch, every workgroup at least one tile
+  int msplit = (wgs + groups * n - 1) / (groups * n);
+  if (msplit > a.ntiles) msplit = a.ntiles;
+  if (msplit < 1) msplit = 1;
+  const int64_t PER = 4LL * TPW * COF * 256;
+  const int64_t need = (int64_t)msplit * groups * PER * 4 + (int64_t)msplit * 128 * 4;
+  for (int i = 0; i < n; ++i)
+    if (!wv[i].ws || wv[i].ws_bytes < need) F32_REJ("workspace");
+  WgradTileArgs av[SV_WGRAD_MAX_MULTI];
+  WgradReduceDesc rd[SV_WGRAD_MAX_MULTI];
+  for (int i = 0; i < n; ++i) {
+    av[i] = a;
+    av[i].A = wv[i].A; av[i].dY = wv[i].dY; av[i].dW = wv[i].dW; av[i].dbias = wv[i].dbias;
+    av[i].slab = wv[i].ws;
+    av[i].bslab = wv[i].dbias ? wv[i].ws + (int64_t)msplit * groups * PER : nullptr;
+    rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, nt, w.fold_kw, w.fold_c, 0, a.assign, TPW, 1, COF};
+  }
+  const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+  int rc = SV_E_UNSUPPORTED;
+  if (TPW == 9 && COF == 1) rc = launch_f32<9, 1>(av, n, msplit, groups, lds, st);
+  else if (TPW == 9 && COF == 2) rc = launch_f32<9, 2>(av, n, msplit, groups, lds, st);
+  else if (TPW == 9 && COF == 4) rc = launch_f32<9, 4>(av, n, msplit, groups, lds, st);
+  else if (TPW == 11 && COF == 1) rc = launch_f32<11, 1>(av, n, msplit, groups, lds, st);
+  else if (TPW == 4 && COF == 4) rc = launch_f32<4, 4>(av, n, msplit, groups, lds, st);
+  else if (TPW == 4 && COF == 8) rc = launch_f32<4, 8>(av, n, msplit, groups, lds, st);
+  if (rc != SV_OK) return rc;
+  if (w.ev_mid[0]) { (void)hipEventRecord(w.ev_mid[0], st); (void)hipEventRecord(w.ev_mid[1], st); }
+  if (w.defer && w.n_defer && *w.n_defer + n <= 64) {
+    for (int i = 0; i < n; ++i) w.defer[(*w.n_defer)++] = rd[i];
+    return SV_OK;
+  }
+  return svk_wgrad_reduce_all(rd, n, st);
+}
