@@ -188,6 +188,15 @@ inline bool sv_deterministic() {
 #define SV_DBG(x) 0
 #endif
 
+// (wgrad_tile.hip, wgrad_tile_f32.hip) index of (tap, ci, co) in the HWIO gradient; the x-packed conv (fold_kw > 0) has taps (ky, tx) of
+// KH x (KW+1) and columns co = px*8 + c, which fold onto tap (ky, tx - px), channel c.  -1: padding.
+__device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_real, int N, int fold_kw, int fold_c) {
+  if (!fold_kw) return ((int64_t)(tap * Cin_real + ci)) * N + co;
+  const int ky = tap / (fold_kw + 1), tx = tap - ky * (fold_kw + 1), px = co >> 3, c = co & 7, kx = tx - px;
+  if ((unsigned)kx >= (unsigned)fold_kw || c >= fold_c) return -1;
+  return ((int64_t)((ky * fold_kw + kx) * Cin_real + ci)) * fold_c + c;
+}
+
 static inline int ilog2_exact(int v) {   // -1 if not a power of two
   if (v <= 0 || (v & (v - 1))) return -1;
   int l = 0;

@@ -27,10 +27,10 @@ static inline void svg_pads(const sv_conv_desc* d, int* pt, int* pl) {
 // output columns n = px*8 + co with W'[ky][tx][ci][n] = W[ky][tx-px][ci][co] (zero outside the kernel):
 // (KW+1)/(2*KW) = 0.58x the MFMAs, A/B fragment reads and K steps for the same LDS tile per output.
 // Its dY is the ordinary [B,H,W,8] gradient viewed as [B,H,W/2,16].  Forward (tile_conv.hip, depth-to-
-// space stores) and wgrad (wgrad_tile.hip, folded reduce) use it; the dgrad keeps the direct form.
+// space stores) and wgrad (wgrad_tile.hip / wgrad_tile_f32.hip, folded reduce) use it, at both precisions; the dgrad keeps the direct form.
 static inline int svg_packx(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_PACKX") != nullptr;
-  return !off && d->dtype == SV_BF16 && d->stride == 1 && d->Cout <= 8 && !(d->Cout & 1) && d->y_f32 &&
+  return !off && d->stride == 1 && d->Cout <= 8 && !(d->Cout & 1) && d->y_f32 &&
          d->ldy == d->Cout && d->KH * (d->KW + 1) <= SV_MAX_TAPS && d->W >= 32 && d->H >= 16 &&
          svg_cin_pad(d) >= 16 && svg_cin_pad(d) <= 64;
 }
@@ -44,7 +44,7 @@ static inline int svg_packx(const sv_conv_desc* d) {
 // along the edges, subtracted by svk_poly_fix (poly_fix.hip).  bf16 only: the fp32 parity path keeps the direct form.
 static inline int svg_poly(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_POLY") != nullptr;           // A/B: the fused-upsample x-packed conv
-  return !off && svg_packx(d) && d->ups_in && d->KH == 6 && d->KW == 6 && d->Cin == svg_cin_pad(d) && d->Cin == 32 &&
+  return !off && d->dtype == SV_BF16 && svg_packx(d) && d->ups_in && d->KH == 6 && d->KW == 6 && d->Cin == svg_cin_pad(d) && d->Cin == 32 &&
          d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1)) && d->act == SV_ACT_NONE;
 }
 #define SV_POLY_FIX_ELEMS(cin) (10 * 6 * 16 * (cin))                 // [10 border classes][6 taps][16 columns][Cin]

@@ -29,15 +29,6 @@ __device__ __forceinline__ short4_t tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(p));
 }
 
-// index of (tap, ci, co) in the HWIO gradient; the x-packed conv (fold_kw > 0) has taps (ky, tx) of
-// KH x (KW+1) and columns co = px*8 + c, which fold onto tap (ky, tx - px), channel c.  -1: padding.
-__device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_real, int N, int fold_kw, int fold_c) {
-  if (!fold_kw) return ((int64_t)(tap * Cin_real + ci)) * N + co;
-  const int ky = tap / (fold_kw + 1), tx = tap - ky * (fold_kw + 1), px = co >> 3, c = co & 7, kx = tx - px;
-  if ((unsigned)kx >= (unsigned)fold_kw || c >= fold_c) return -1;
-  return ((int64_t)((ky * fold_kw + kx) * Cin_real + ci)) * fold_c + c;
-}
-
 // TPW taps per wave (4 waves: tap group = 4*TPW taps), CIF ci-fragments (16 channels) per
 // workgroup slice, COF co-fragments (all of Cout_pad16), KC = 32-pixel K chunks per tile.
 // NG wave groups of 4 waves: with NG = 2 the workgroup has two tile buffers, each group walks every other tile of the

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
 
   // lane part of the operand addresses: pixel kq of a group of four consecutive tile pixels (one tile row: TW % 4 == 0), row / column lr
   const int in_lane = kq * g.SX * g.PS + lr * 4, dy_lane = kq * g.YS + lr * 4;
-  const bool a_on = lr < g.CW;            // an 8-channel slice fills half of the fragment's rows
+  // an 8-channel slice fills half of the fragment's rows; with pairx (e1) rows 8..15 are the NEXT pixel in x (the pixel records are 32 B: lane
+  // lr reads channel lr & 7 of pixel + (lr >> 3)) = the operand of tap (ky, kx + 1): one MFMA serves two taps, the tap list holds every other x tap
+  const bool a_on = lr < g.CW || g.pairx;
   int tapoff[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -106,8 +108,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
     }
   }
 
-  // ---- flush: one slab per workgroup in the fragment order of wgrad_reduce <TPW, 1, COF>
-  {
+  // ---- flush: one slab per workgroup in the fragment order of wgrad_reduce <TPW, 1, COF>; without a workspace, fp32 atomics into dW
+  if (!g.slab) {                          // D row = channel (lane >> 4) * 4 + register, column = output channel lane & 15
+#pragma unroll
+    for (int t2 = 0; t2 < TPW; ++t2) {
+      const int tap = tap0 + t2;
+      if (tap >= g.ntaps) continue;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int cl = kq * 4 + r4, ci = g.pairx ? (cl & 7) : ci0 + cl;
+        if (ci >= g.Cin_real || (!g.pairx && cl >= g.CW)) continue;
+        const int otap = g.pairx ? 2 * tap + (cl >> 3) : tap;
+#pragma unroll
+        for (int j = 0; j < COF; ++j) {
+          const int co = j * 16 + lr;
+          const int64_t di = co < g.N ? dw_index(otap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
+          if (di >= 0) atomicAdd(g.dW + di, acc[t2][j][r4]);
+        }
+      }
+    }
+  } else {
     float* sl = g.slab + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPW * COF)) * 256 + lane;
 #pragma unroll
     for (int t2 = 0; t2 < TPW; ++t2)
@@ -121,8 +141,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
 #pragma unroll
       for (int j = 0; j < COF; ++j)
         if ((j & 3) == wave && j * 16 + lane < ycols && j * 16 + lane < g.N) {
-          if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + j * 16 + lane] = bacc[j >> 2][0];
-          else atomicAdd(g.dbias + j * 16 + lane, bacc[j >> 2][0]);
+          const int col = j * 16 + lane;
+          if (g.bslab) g.bslab[(int64_t)blockIdx.x * 128 + col] = bacc[j >> 2][0];     // (folded columns: the reduce adds px 0 and px 1)
+          else if (!g.fold_kw || (col & 7) < g.fold_c) atomicAdd(g.dbias + (g.fold_kw ? (col & 7) : col), bacc[j >> 2][0]);
         }
     }
   }
@@ -156,8 +177,13 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   }
   const int CW = cin >= 16 ? 16 : 8;
   if (cin % CW || (cin != 8 && ilog2_exact(cin) < 0)) F32_REJ("channels");
-  const int TPW = (nt + 3) / 4, COF = (ldy + 15) / 16;      // (42 folded taps: 11 per wave, the last two slots repeat tap 41 and are dropped by the reduce)
-  if (!((TPW == 9 && (COF == 1 || COF == 2 || COF == 4)) || (TPW == 4 && (COF == 4 || COF == 8)) || (TPW == 11 && COF == 1))) F32_REJ("no instantiation");
+  // 8-channel inputs (e1's padded RGB), even KW, taps y-major: tap pairs (wgrad_tile.hip's pairx)
+  static const bool no_pairx = getenv("SV_WTF32_NO_PAIRX") != nullptr;
+  bool pairx = CW == 8 && cin == 8 && nt == 36 && !w.fold_kw && !no_pairx;
+  for (int u = 0; u < nt / 2 && pairx; ++u) pairx = w.dy[2 * u + 1] == w.dy[2 * u] && w.dx[2 * u + 1] == w.dx[2 * u] + 1;
+  const int ntk = pairx ? nt / 2 : nt;                      // taps the kernel walks
+  const int TPW = (ntk + 3) / 4, COF = (ldy + 15) / 16;      // (42 folded taps: 11 per wave, the last two slots repeat tap 41 and are dropped by the reduce)
+  if (!((TPW == 9 && (COF == 1 || COF == 2 || COF == 4)) || (TPW == 4 && (COF == 4 || COF == 8)) || (TPW == 11 && COF == 1) || (TPW == 5 && COF == 2))) F32_REJ("no instantiation");
   int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
   for (int i = 0; i < nt; ++i) {
     y_lo = w.dy[i] < y_lo ? w.dy[i] : y_lo; y_hi = w.dy[i] > y_hi ? w.dy[i] : y_hi;
@@ -196,9 +222,8 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   a.y_lo = y_lo; a.x_lo = x_lo;
   a.ldy = ldy; a.lycp = ilog2_exact(ldy / 4);
   if (a.lycp < 0) F32_REJ("dY pitch");
-  a.Cin_real = w.Cin_real; a.N = w.N; a.ntaps = nt;
-  memcpy(a.dy, w.dy, sizeof(a.dy));
-  memcpy(a.dx, w.dx, sizeof(a.dx));
+  a.Cin_real = w.Cin_real; a.N = w.N; a.ntaps = ntk; a.pairx = pairx ? 1 : 0;
+  for (int u = 0; u < ntk; ++u) { a.dy[u] = w.dy[pairx ? 2 * u : u]; a.dx[u] = w.dx[pairx ? 2 * u : u]; }
   const int groups = a.ncg;
   // two resident workgroups per CU over the whole launch, every workgroup at least one tile
   int msplit = (wgs + groups * n - 1) / (groups * n);
@@ -206,27 +231,30 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   if (msplit < 1) msplit = 1;
   const int64_t PER = 4LL * TPW * COF * 256;
   const int64_t need = (int64_t)msplit * groups * PER * 4 + (int64_t)msplit * 128 * 4;
-  for (int i = 0; i < n; ++i)
-    if (!wv[i].ws || wv[i].ws_bytes < need) F32_REJ("workspace");
+  bool slab = true;                      // no (or a small) workspace: fp32 atomics straight into dW -- kept for the x-packed head, which the im2col
+  for (int i = 0; i < n; ++i) slab = slab && wv[i].ws && wv[i].ws_bytes >= need;          // kernel cannot fold; every other shape falls back to it
+  if (!slab && !w.fold_kw) F32_REJ("workspace");
   WgradTileArgs av[SV_WGRAD_MAX_MULTI];
   WgradReduceDesc rd[SV_WGRAD_MAX_MULTI];
   for (int i = 0; i < n; ++i) {
     av[i] = a;
     av[i].A = wv[i].A; av[i].dY = wv[i].dY; av[i].dW = wv[i].dW; av[i].dbias = wv[i].dbias;
-    av[i].slab = wv[i].ws;
-    av[i].bslab = wv[i].dbias ? wv[i].ws + (int64_t)msplit * groups * PER : nullptr;
-    rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, nt, w.fold_kw, w.fold_c, 0, a.assign, TPW, 1, COF};
+    av[i].slab = slab ? wv[i].ws : nullptr;
+    av[i].bslab = slab && wv[i].dbias ? wv[i].ws + (int64_t)msplit * groups * PER : nullptr;
+    rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, ntk, w.fold_kw, w.fold_c, a.pairx, a.assign, TPW, 1, COF};
   }
   const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
   int rc = SV_E_UNSUPPORTED;
   if (TPW == 9 && COF == 1) rc = launch_f32<9, 1>(av, n, msplit, groups, lds, st);
   else if (TPW == 9 && COF == 2) rc = launch_f32<9, 2>(av, n, msplit, groups, lds, st);
   else if (TPW == 9 && COF == 4) rc = launch_f32<9, 4>(av, n, msplit, groups, lds, st);
+  else if (TPW == 5 && COF == 2) rc = launch_f32<5, 2>(av, n, msplit, groups, lds, st);
   else if (TPW == 11 && COF == 1) rc = launch_f32<11, 1>(av, n, msplit, groups, lds, st);
   else if (TPW == 4 && COF == 4) rc = launch_f32<4, 4>(av, n, msplit, groups, lds, st);
   else if (TPW == 4 && COF == 8) rc = launch_f32<4, 8>(av, n, msplit, groups, lds, st);
   if (rc != SV_OK) return rc;
   if (w.ev_mid[0]) { (void)hipEventRecord(w.ev_mid[0], st); (void)hipEventRecord(w.ev_mid[1], st); }
+  if (!slab) return SV_OK;
   if (w.defer && w.n_defer && *w.n_defer + n <= 64) {
     for (int i = 0; i < n; ++i) w.defer[(*w.n_defer)++] = rd[i];
     return SV_OK;

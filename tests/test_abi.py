@@ -114,8 +114,8 @@ def test_kernel_entry_points_validate_arguments(lib_built):
     d = _lib.ConvDesc(4, 32, 32, 32, 6, 6, 6, 1, 0, 1, 32, 6, 1)
     # bf16 head (Cout 6): the x-pixel-packed image, 16 columns (2 pixels x 8) x 6x7 taps x Cin
     assert lib.sv_conv2d_wprep_elems(C.byref(d), 0) == 16 * 42 * 32
-    d32 = _lib.ConvDesc(4, 32, 32, 32, 6, 6, 6, 1, 0, 0, 32, 6, 1)           # fp32 parity path: direct form, one 16-row block
-    assert lib.sv_conv2d_wprep_elems(C.byref(d32), 0) == 16 * 36 * 32
+    d32 = _lib.ConvDesc(4, 32, 32, 32, 6, 6, 6, 1, 0, 0, 32, 6, 1)           # fp32 (the reference's precision): the same x-packed image since round 4
+    assert lib.sv_conv2d_wprep_elems(C.byref(d32), 0) == 16 * 42 * 32
     assert lib.sv_conv2d_wprep_elems(C.byref(d), 1) == 32 * 36 * 8        # dgrad contracts over Cout padded to 8
     assert lib.sv_dlogistic_nll_workspace_bytes(8, 64, 64) == 8 * 4 * 4
 
