@@ -301,10 +301,11 @@ static void build_layers(sv_lgvae_plan* p) {
     p->dec[k][2] = mk(pre + "d3", H / 4, W / 4, 128, 64, 4, 1, SV_ACT_RELU, 128, 64, 0, pb + 4, true);
     p->dec[k][3] = mk(pre + "d4", H / 2, W / 2, 64, 32, 6, 1, SV_ACT_RELU, 64, 32, 0, pb + 6, true);
     p->dec[k][4] = mk(pre + "d5", H, W, 32, 6, 6, 1, SV_ACT_NONE, 32, 6, 1, pb + 8, true);
-    // bf16: the three bilinear resizes are fused into the staging of d3/d4/d5's forward and wgrad
-    // tiles (needs >= 16 output pixels per image for the tile kernels: any H >= 16 here)
+    // the three bilinear resizes are fused into the staging of d3/d4/d5's forward and wgrad tiles (needs >= 16 output pixels per image for
+    // the tile kernels: any H >= 16 here); fp32 since round 4 too (wgrad_tile_f32.hip; SV_F32_MATERIALISE_UPSAMPLE=1: u2 / u3 / u4 written out)
     static const bool no_fuse = getenv("SV_NO_FUSED_UPSAMPLE") != nullptr;
-    if (d.dtype == SV_BF16 && !no_fuse && H >= 16)
+    static const bool f32_mat = getenv("SV_F32_MATERIALISE_UPSAMPLE") != nullptr;
+    if ((d.dtype == SV_BF16 || !f32_mat) && !no_fuse && H >= 16)
       for (int l = 2; l <= 4; ++l) p->dec[k][l].d.ups_in = 1;
   }
 }

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
     __syncthreads();                      // the previous tile is consumed
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
-      stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
+      // (ups: the layer's input is the 2x bilinear resize of the LOW-RES tensor A, blended on the fly with upsample2x_fwd's own arithmetic)
+      if (g.ups) stage_tile_upsampled<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
+      else stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
     }
     for (int q = tid; q < dy_total; q += 256) {
       const int r = q >> lycp, c = q & ((1 << lycp) - 1);
@@ -169,7 +171,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   static const bool off = getenv("SV_NO_WGRAD_TILE_F32") != nullptr;
   if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) F32_REJ("off / problems");
   const WgradArgs& w = wv[0];
-  if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || w.ups || w.dy_s2d || w.clampin || w.ycols != w.ldy) F32_REJ("form");
+  if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || (w.ups && w.S != 1) || w.dy_s2d || w.clampin || w.ycols != w.ldy) F32_REJ("form");
   const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, ldy = w.ldy, nt = w.ntaps;
   if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && !(nt == 42 && w.fold_kw))) {
     if (trace) fprintf(stderr, "wgrad_tile_f32: OY %d OX %d ldy %d taps %d cin %d\n", OY, OX, ldy, nt, cin);
@@ -214,7 +216,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   }
   const int TW = 1 << a.lTW, TH = 1 << a.lTH, NB = 1 << a.lNB;
   const int B = w.M >> (w.lOY + w.lOX);
-  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.assign = w.assign;
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.assign = w.assign; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
   a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
   a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
