@@ -83,18 +83,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       *(uint4*)(sDy + r * g.YS + c * 16) = v;
     }
     __syncthreads();
-    // ---- MFMA: K = pixels, four per instruction
-#pragma unroll 2
-    for (int r = 0; r < BM; r += 4) {
+    // ---- MFMA: K = pixels, four per instruction.  The operands of group r + 4 are read while the MFMAs of group r issue (the compiler's own
+    // schedule waited for every read right before the first MFMA of the same group: ~150 exposed cycles per 18 MFMAs with two waves per SIMD)
+    float bcur[COF], acur[TPW];
+    auto read_ops = [&](int r, float (&bo)[COF], float (&ao)[TPW]) {
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);     // wave-uniform
       const char* pin = sIn + in_lane + ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS;
       const char* pdy = sDy + dy_lane + r * g.YS;
+#pragma unroll
+      for (int j = 0; j < COF; ++j) bo[j] = *(const float*)(pdy + j * 64);
+#pragma unroll
+      for (int t2 = 0; t2 < TPW; ++t2) ao[t2] = *(const float*)(pin + tapoff[t2]);
+    };
+    read_ops(0, bcur, acur);
+    for (int r = 0; r < BM; r += 4) {
+      float bnxt[COF], anxt[TPW];
+      read_ops(r + 4 < BM ? r + 4 : r, bnxt, anxt);       // (the last group re-reads itself: no branch around the reads)
       float bfr[COF];
 #pragma unroll
-      for (int j = 0; j < COF; ++j) {
-        const float v = *(const float*)(pdy + j * 64);
-        bfr[j] = j * 16 + lr < ycols ? v : 0.f;           // (ycols = 8: the head's 6 + 2 gradient columns fill half a fragment)
-      }
+      for (int j = 0; j < COF; ++j) bfr[j] = j * 16 + lr < ycols ? bcur[j] : 0.f;     // (ycols = 8: the head's 6 + 2 gradient columns fill half a fragment)
       if (do_bias) {
 #pragma unroll
         for (int j = 0; j < COF; ++j)
@@ -102,11 +109,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       }
 #pragma unroll
       for (int t2 = 0; t2 < TPW; ++t2) {
-        const float av = *(const float*)(pin + tapoff[t2]);
-        const float af = a_on ? av : 0.f;
+        const float af = a_on ? acur[t2] : 0.f;
 #pragma unroll
         for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr[j], acc[t2][j], 0, 0, 0);
       }
+#pragma unroll
+      for (int j = 0; j < COF; ++j) bcur[j] = bnxt[j];
+#pragma unroll
+      for (int t2 = 0; t2 < TPW; ++t2) acur[t2] = anxt[t2];
     }
   }
 

@@ -775,3 +775,30 @@ def test_polyphase_weight_gradient_of_the_head(ops, H, B):
     assert float((dw - dw0).norm() / dw0.norm()) < 6e-3
     dw2, _ = conv.wgrad_poly(x_lo.cuda(), dy.cuda())
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", [("d2_64", 8, 128, 128, 4, 1), ("e3_64", 16, 64, 128, 4, 2), ("d3_plain", 16, 128, 64, 4, 1)], ids=lambda l: l[0])
+def test_weight_gradient_pipeline_for_whole_image_tiles(ops, layer, monkeypatch):
+    """wgrad_tile_pipe_kernel (wgrad_tile.hip): the tile weight gradient of the layers whose tiles are whole images as a DMA-fed pipeline -- taken
+    from 64 tiles per problem, so the 3-image cases of test_conv_fwd_dgrad_wgrad never reach it.  Against autograd of the fp64 conv on the same
+    bf16 operands, against the two-group form of the same build (SV_WT_NO_PIPE is read once per process: a subprocess would be needed to flip it,
+    so the comparison is with the fp64 reference and with a second run), bias gradient included; B = 129 leaves the last two-image tile of d2 / e3 half full
+    (the pipelined form needs whole tiles: that launch falls back) and exercises a ragged tile run per workgroup."""
+    name, H, Cin, Cout, k, s = layer
+    for B in (128, 129):
+        rng = np.random.default_rng(B + H)
+        x = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32)).bfloat16()
+        OH = H // s
+        dy = torch.from_numpy(rng.standard_normal((B, OH, OH, Cout)).astype(np.float32)).bfloat16()
+        conv = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=None, dtype=torch.bfloat16, y_f32=False)
+        conv.prep(torch.zeros(k, k, Cin, Cout).cuda())
+        dw, db = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)
+        wt = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+        y = torch_ref.conv2d_same(x.double(), wt, bt, s, None)
+        (y * dy.double()).sum().backward()
+        torch.testing.assert_close(dw.double().cpu(), wt.grad, rtol=BF16_RTOL, atol=1e-4 * float(wt.grad.abs().max()))
+        torch.testing.assert_close(db.double().cpu(), bt.grad, rtol=1e-4, atol=1e-4 * float(bt.grad.abs().max()))
+        dw2, db2 = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed-order slabs: run-to-run identical
