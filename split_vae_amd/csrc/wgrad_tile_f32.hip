@@ -22,8 +22,14 @@ namespace {
 
 // TPW taps per wave (4 waves: 4 * TPW taps per workgroup = all of them), COF 16-column fragments of dY.  A workgroup owns a 16-channel (8 for
 // an 8-channel input) slice of the input, blockIdx.y, and walks a contiguous run of tiles, blockIdx.x.
-template <int TPW, int COF>
+// LDY (dY floats per pixel), CW (channels of the slice), SX (x stride) and G4 (pixel groups of four per tile row) are compile-time: inside a tile row
+// every operand address is the row's base register + an immediate, the reads of a whole row are issued before its MFMAs, and nothing but the
+// MFMAs and one address add per tap and row is left in the loop (the first version -- run-time pitches -- issued ~35 VALU instructions per
+// 18 MFMAs: address adds, masks, register rotation).
+template <int TPW, int COF, int LDY, int CW, int SX, int G4>
 __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileMulti mg) {
+  constexpr int PS = 4 * CW, YS = 4 * LDY;
+  constexpr bool MASKB = LDY < 16 * COF;              // the last column fragment is half empty (the direct 8-column head)
   const WgradTileArgs& g = mg.a[blockIdx.z];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sIn = smem;                       // [NB][TIH][TIW] pixels of PS = 4 * CW bytes
@@ -35,15 +41,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
   const int ycols = g.ldy;
 
   // lane part of the operand addresses: pixel kq of a group of four consecutive tile pixels (one tile row: TW % 4 == 0), row / column lr
-  const int in_lane = kq * g.SX * g.PS + lr * 4, dy_lane = kq * g.YS + lr * 4;
-  // an 8-channel slice fills half of the fragment's rows; with pairx (e1) rows 8..15 are the NEXT pixel in x (the pixel records are 32 B: lane
-  // lr reads channel lr & 7 of pixel + (lr >> 3)) = the operand of tap (ky, kx + 1): one MFMA serves two taps, the tap list holds every other x tap
-  const bool a_on = lr < g.CW || g.pairx;
+  const int in_lane = kq * SX * PS + lr * 4, dy_lane = kq * YS + lr * 4;
+  // an 8-channel slice (e1) fills the fragment's rows 8..15 with the NEXT pixel in x (the pixel records are 32 B: lane lr reads channel lr & 7 of
+  // pixel + (lr >> 3)) = the operand of tap (ky, kx + 1): one MFMA serves two taps, the tap list holds every other x tap (pairx; the host
+  // only takes 8-channel inputs in this form)
   int tapoff[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tap = min(tap0 + t, g.ntaps - 1);
-    tapoff[t] = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * g.PS;
+    tapoff[t] = (((int)g.dy[tap] - g.y_lo) * g.TIW + ((int)g.dx[tap] - g.x_lo)) * PS + in_lane;
   }
   f32x4 acc[TPW][COF];
 #pragma unroll
@@ -80,43 +86,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       const int b = b0 + bl;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (b < g.B) v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4);
-      *(uint4*)(sDy + r * g.YS + c * 16) = v;
+      *(uint4*)(sDy + r * YS + c * 16) = v;
     }
     __syncthreads();
-    // ---- MFMA: K = pixels, four per instruction.  The operands of group r + 4 are read while the MFMAs of group r issue (the compiler's own
-    // schedule waited for every read right before the first MFMA of the same group: ~150 exposed cycles per 18 MFMAs with two waves per SIMD)
-    float bcur[COF], acur[TPW];
-    auto read_ops = [&](int r, float (&bo)[COF], float (&ao)[TPW]) {
-      const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);     // wave-uniform
-      const char* pin = sIn + in_lane + ((bl * g.TIH + ty * g.S) * g.TIW + tx * g.SX) * g.PS;
-      const char* pdy = sDy + dy_lane + r * g.YS;
+    // ---- MFMA: K = pixels, four per instruction; one tile row (G4 groups of four pixels) at a time
+    const int nrow = BM / (4 * G4);
+    for (int row = 0; row < nrow; ++row) {
+      const int ty = row & (TH - 1), bl = row >> g.lTH;                                   // wave-uniform
+      const char* pin = sIn + ((bl * g.TIH + ty * g.S) * g.TIW) * PS;
+      const char* pdy = sDy + dy_lane + row * (4 * G4 * YS);
+      float bfr[G4][COF], afr[G4][TPW];
 #pragma unroll
-      for (int j = 0; j < COF; ++j) bo[j] = *(const float*)(pdy + j * 64);
+      for (int q = 0; q < G4; ++q)
 #pragma unroll
-      for (int t2 = 0; t2 < TPW; ++t2) ao[t2] = *(const float*)(pin + tapoff[t2]);
-    };
-    read_ops(0, bcur, acur);
-    for (int r = 0; r < BM; r += 4) {
-      float bnxt[COF], anxt[TPW];
-      read_ops(r + 4 < BM ? r + 4 : r, bnxt, anxt);       // (the last group re-reads itself: no branch around the reads)
-      float bfr[COF];
-#pragma unroll
-      for (int j = 0; j < COF; ++j) bfr[j] = j * 16 + lr < ycols ? bcur[j] : 0.f;     // (ycols = 8: the head's 6 + 2 gradient columns fill half a fragment)
-      if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < COF; ++j)
-          if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[j], bacc[j >> 2], 0, 0, 0);
-      }
+        for (int j = 0; j < COF; ++j) {
+          const float v = *(const float*)(pdy + q * 4 * YS + j * 64);
+          bfr[q][j] = (MASKB && j * 16 + lr >= LDY) ? 0.f : v;
+        }
 #pragma unroll
       for (int t2 = 0; t2 < TPW; ++t2) {
-        const float af = a_on ? acur[t2] : 0.f;
+        const char* pa = pin + tapoff[t2];
 #pragma unroll
-        for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bfr[j], acc[t2][j], 0, 0, 0);
+        for (int q = 0; q < G4; ++q) afr[q][t2] = *(const float*)(pa + q * 4 * SX * PS);
       }
 #pragma unroll
-      for (int j = 0; j < COF; ++j) bcur[j] = bnxt[j];
+      for (int q = 0; q < G4; ++q) {
+        if (do_bias) {
 #pragma unroll
-      for (int t2 = 0; t2 < TPW; ++t2) acur[t2] = anxt[t2];
+          for (int j = 0; j < COF; ++j)
+            if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[q][j], bacc[j >> 2], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+          for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q][t2], bfr[q][j], acc[t2][j], 0, 0, 0);
+      }
     }
   }
 
@@ -161,12 +165,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
   }
 }
 
-template <int TPW, int COF>
+template <int TPW, int COF, int LDY, int CW, int SX, int G4>
 int launch_f32(const WgradTileArgs* a, int n, int msplit, int groups, size_t lds, hipStream_t st) {
   WgradTileMulti m;
   for (int i = 0; i < n; ++i) m.a[i] = a[i];
-  sv_ensure_dynamic_lds((const void*)wgrad_tile_f32_kernel<TPW, COF>, lds);
-  hipLaunchKernelGGL((wgrad_tile_f32_kernel<TPW, COF>), dim3(msplit, groups, n), dim3(256), lds, st, m);
+  sv_ensure_dynamic_lds((const void*)wgrad_tile_f32_kernel<TPW, COF, LDY, CW, SX, G4>, lds);
+  hipLaunchKernelGGL((wgrad_tile_f32_kernel<TPW, COF, LDY, CW, SX, G4>), dim3(msplit, groups, n), dim3(256), lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -195,7 +199,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   for (int u = 0; u < nt / 2 && pairx; ++u) pairx = w.dy[2 * u + 1] == w.dy[2 * u] && w.dx[2 * u + 1] == w.dx[2 * u] + 1;
   const int ntk = pairx ? nt / 2 : nt;                      // taps the kernel walks
   const int TPW = (ntk + 3) / 4, COF = (ldy + 15) / 16;      // (42 folded taps: 11 per wave, the last two slots repeat tap 41 and are dropped by the reduce)
-  if (!((TPW == 9 && (COF == 1 || COF == 2 || COF == 4)) || (TPW == 4 && (COF == 4 || COF == 8)) || (TPW == 11 && COF == 1) || (TPW == 5 && COF == 2))) F32_REJ("no instantiation");
+  if (CW == 8 && !pairx) F32_REJ("8-channel input without tap pairs");
   int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
   for (int i = 0; i < nt; ++i) {
     y_lo = w.dy[i] < y_lo ? w.dy[i] : y_lo; y_hi = w.dy[i] > y_hi ? w.dy[i] : y_hi;
@@ -243,9 +247,9 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   if (msplit < 1) msplit = 1;
   const int64_t PER = 4LL * TPW * COF * 256;
   const int64_t need = (int64_t)msplit * groups * PER * 4 + (int64_t)msplit * 128 * 4;
-  bool slab = true;                      // no (or a small) workspace: fp32 atomics straight into dW -- kept for the x-packed head, which the im2col
-  for (int i = 0; i < n; ++i) slab = slab && wv[i].ws && wv[i].ws_bytes >= need;          // kernel cannot fold; every other shape falls back to it
-  if (!slab && !w.fold_kw) F32_REJ("workspace");
+  bool slab = true;                      // no (or a small) workspace: fp32 atomics straight into dW -- kept for the x-packed head and the layers behind
+  for (int i = 0; i < n; ++i) slab = slab && wv[i].ws && wv[i].ws_bytes >= need;          // a fused resize, which the im2col kernel cannot do; every other shape falls back to it
+  if (!slab && !w.fold_kw && !w.ups) F32_REJ("workspace");
   WgradTileArgs av[SV_WGRAD_MAX_MULTI];
   WgradReduceDesc rd[SV_WGRAD_MAX_MULTI];
   for (int i = 0; i < n; ++i) {
@@ -256,14 +260,23 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
     rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, ntk, w.fold_kw, w.fold_c, a.pairx, a.assign, TPW, 1, COF};
   }
   const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+  // <taps per wave, column fragments, dY floats per pixel, slice channels, x stride, pixel groups per tile row>: the layers of the model
+  const int G4 = TW / 4, SXv = w.SX;
   int rc = SV_E_UNSUPPORTED;
-  if (TPW == 9 && COF == 1) rc = launch_f32<9, 1>(av, n, msplit, groups, lds, st);
-  else if (TPW == 9 && COF == 2) rc = launch_f32<9, 2>(av, n, msplit, groups, lds, st);
-  else if (TPW == 9 && COF == 4) rc = launch_f32<9, 4>(av, n, msplit, groups, lds, st);
-  else if (TPW == 5 && COF == 2) rc = launch_f32<5, 2>(av, n, msplit, groups, lds, st);
-  else if (TPW == 11 && COF == 1) rc = launch_f32<11, 1>(av, n, msplit, groups, lds, st);
-  else if (TPW == 4 && COF == 4) rc = launch_f32<4, 4>(av, n, msplit, groups, lds, st);
-  else if (TPW == 4 && COF == 8) rc = launch_f32<4, 8>(av, n, msplit, groups, lds, st);
+#define F32_CASE(T, C, L, W, X, G) else if (TPW == T && COF == C && ldy == L && CW == W && SXv == X && G4 == G) rc = launch_f32<T, C, L, W, X, G>(av, n, msplit, groups, lds, st)
+#define F32_LAYER(T, C, L, W, X) F32_CASE(T, C, L, W, X, 4); F32_CASE(T, C, L, W, X, 2); F32_CASE(T, C, L, W, X, 1)     // 16-, 8-, 4-pixel tile rows
+  if (false) {}
+  F32_LAYER(11, 1, 16, 16, 2);      // d5, x-packed (pixel pairs)
+  F32_LAYER(9, 1, 8, 16, 1);        // d5, direct form (SV_NO_PACKX)
+  F32_LAYER(9, 2, 32, 16, 1);       // d4
+  F32_LAYER(4, 4, 64, 16, 1);       // d3
+  F32_LAYER(4, 8, 128, 16, 1);      // d2
+  F32_LAYER(4, 8, 128, 16, 2);      // e3
+  F32_LAYER(9, 4, 64, 16, 2);       // e2
+  F32_LAYER(5, 2, 32, 8, 2);        // e1 (tap pairs)
+#undef F32_LAYER
+#undef F32_CASE
+  else F32_REJ("no instantiation");
   if (rc != SV_OK) return rc;
   if (w.ev_mid[0]) { (void)hipEventRecord(w.ev_mid[0], st); (void)hipEventRecord(w.ev_mid[1], st); }
   if (!slab) return SV_OK;
