@@ -53,12 +53,16 @@ struct RowConvArgs {
   int lda, ldo, Ktot, act;
   int y_lo, x_lo;       // tap (ky, kx) reads input pixel (y + ky + y_lo, x + kx + x_lo)
   int bands, band_rows; // an image is cut into `bands` row bands of band_rows rows (a unit of work = one band)
+  int lead;             // ADJ configs with bands > 1: every band but the first starts `lead` (= one step) rows early and keeps those rows' low-res
+                        // output to itself -- the warm-up step rebuilds what the adjoint carries across the band edge (low-res row i needs the hi-res
+                        // rows 2i - 1 .. 2i + 2) -- so a band is independent of its neighbour.  0 otherwise
   int os, ooy, oox;     // output pixel of grid pixel (y, x): (os * y + ooy, os * x + oox) of a [B, os * H, os * W, ldo] tensor (os = 2: one parity
                         // class of a stride-2 layer's input gradient; 1, 0, 0 otherwise)
   const void* mask;     // ADJ configs: the low-res activation whose ReLU mask (> 0) gates the low-res gradient (or null);
                         // `out` is then the LOW-RES gradient [B, H/2, W/2, ldo].
                         // CLS configs: the layer input [B, 2H, 2W, ldo] whose ReLU mask gates the gradient `out` of the same shape (or null)
 };
+__device__ __forceinline__ int band_row0(const RowConvArgs& g, int band) { return band * g.band_rows - (band ? g.lead : 0); }   // first row a band computes
 struct RowConvMulti { RowConvArgs a[8]; int units_per_prob, units, dbg; unsigned long long* stamps; };   // dbg: timing ablations (SV_DEBUG_KNOBS builds only)
 
 template <int KH_, int KW_, int CIN_, int N_, int WIDTH_, int MF_, int NBW_, int KS_, int XG_, int RG_, bool UPS_, int WAVES_ = 8, bool ADJ_ = false, bool CLS_ = false, bool S2D_ = false, bool PAIR_ = false, bool REV_ = false, bool MB_ = false, bool MA_ = false>
@@ -577,13 +581,13 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       __builtin_amdgcn_s_barrier();
       const MbGeom mg0 = mb_geom(g);
       mbl = mb_lane<C>(mg0, sRing, wave, lane);
-      mb_dma_first<C>(mg0, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, sRaw, wave, lane);
+      mb_dma_first<C>(mg0, r0 / g.bands, band_row0(g, r0 % g.bands) + g.y_lo, sRaw, wave, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      mb_blend<C>(mg0, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRaw, mbl, mbw);
+      mb_blend<C>(mg0, band_row0(g, r0 % g.bands) + g.y_lo, STEP + KH - 1, 0, sRaw, mbl, mbw);
       // (the kernel's first __syncthreads() below publishes the window; the first step's raw rows are in the ring already)
     } else
-    if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
+    if constexpr (C::UPS) stage_rows<C>(g, r0 / g.bands, band_row0(g, r0 % g.bands) + g.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
     else {
       // The whole ring starts as zeros, once per launch: the halo columns (the DMAs only ever write in-image pixels).  (The tap-packed
       // form used to read two DUMMY rows behind the window with zero weights -- 0 x stale-LDS-garbage is NaN when the garbage is not
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       for (int q = tid; q < C::RING / 16; q += NT) *(uint4*)(sRing + q * 16) = make_uint4(0, 0, 0, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      stage_rows_dma<C>(g, r0 / g.bands, (r0 % g.bands) * g.band_rows + g.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
+      stage_rows_dma<C>(g, r0 / g.bands, band_row0(g, r0 % g.bands) + g.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
     GRef g = mg.a[prob];
     const int r0 = C::PAIR ? u / np : u - prob * mg.units_per_prob;
     const int band = r0 % g.bands, b = r0 / g.bands;
-    const int yb = band * g.band_rows;
+    const int yb = band_row0(g, band);
     const int un = u + gridDim.x;                            // the next unit of this workgroup
     const bool has_next = un < mg.units;
     const int nprob = has_next ? (C::PAIR ? un % np : un / mg.units_per_prob) : prob;
@@ -647,11 +651,13 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
     }
     if (u == (int)blockIdx.x) __syncthreads();               // the first window (and the flag words) are in place
     SV_STAMP(t_other);
-    const int nsteps = g.band_rows / STEP;
+    const int nsteps = (g.band_rows + (band ? g.lead : 0)) / STEP;
     MbGeom mgu = MbGeom{nullptr, 0, 0, 0, 0, 0}, mgn = mgu;  // MB: this unit's and the next unit's geometry, in registers
     int mb_nb = 0, mb_nY = 0;
-    if constexpr (C::MB) { mgu = mb_geom(g); mgn = mb_geom(gn); mb_nb = rn / gn.bands; mb_nY = (rn % gn.bands) * gn.band_rows + gn.y_lo; }
-    int emitted = 0;                                         // ADJ: next low-res row to emit
+    if constexpr (C::MB) { mgu = mb_geom(g); mgn = mb_geom(gn); mb_nb = rn / gn.bands; mb_nY = band_row0(gn, rn % gn.bands) + gn.y_lo; }
+    // ADJ: next low-res row to emit.  A later band starts at the row its predecessor cannot finish (low-res row i needs hi-res rows up to 2i + 2)
+    int emitted = band ? ((band * g.band_rows) >> 1) - 1 : 0;
+    const bool mute0 = C::ADJ && band > 0 && g.lead > 0;        // the band's first step is the warm-up: nothing of it is emitted
     for (int s = 0; s < nsteps; ++s) {
       const int y0 = yb + s * STEP;
       const bool more = s + 1 < nsteps;
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       const bool job = (more || (has_next && C::PRE)) && !(dbg & 1);
       const RowConvArgs& gj = more ? g : gn;
       const int jb = more ? b : rn / gn.bands;
-      const int jY = more ? y0 + g.y_lo + STEP + KH - 1 : (rn % gn.bands) * gn.band_rows + gn.y_lo;
+      const int jY = more ? y0 + g.y_lo + STEP + KH - 1 : band_row0(gn, rn % gn.bands) + gn.y_lo;
       const int jrows = more ? STEP : STEP + KH - 1;
       if constexpr (C::ADJ && !C::MA) {
         // hi-res rows < y0 are complete: low-res row i needs hi-res rows 2i-1 .. 2i+2
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
                 const uint32_t h = (mw[e >> 1] >> ((e & 1) * 16)) & 0xffffu;      // bf16 bits of the low-res activation: > 0 <=> sign clear and not zero
                 res[e] = (bf16_t)((!g.mask || (!(h & 0x8000u) && (h & 0x7fffu))) ? zv[e] : 0.f);
               }
-              if (C::WIDTH == 32 || m < C::WIDTH / 2) *(uint2*)((bf16_t*)g.out + orow + (int64_t)di * LWa * g.ldo) = *(const uint2*)res;
+              if (!(mute0 && s == 0) && (C::WIDTH == 32 || m < C::WIDTH / 2)) *(uint2*)((bf16_t*)g.out + orow + (int64_t)di * LWa * g.ldo) = *(const uint2*)res;
             };
             // hi-res row Y = 2r feeds low-res rows max(r - 1, 0) (.25) and r (.75); Y = 2r + 1 feeds r (.75) and min(r + 1, LH - 1) (.25)
             if (!top) {
@@ -945,7 +951,8 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
         // global stores are the adjoint's, issued before the DMAs)
         if (C::MA && !(dbg & 4)) {
           // the step's DMAs are older than its low-res stores: 1 store at the top of an image, 3 at the bottom, 2 otherwise
-          if (y0 == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          if (mute0 && s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a warm-up step stores nothing)
+          else if (y0 == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
           else if (y0 + STEP == g.H) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else
@@ -966,7 +973,8 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
       if (q0 >= R) q0 -= R;
     }
     if constexpr (C::ADJ && !C::MA) {                        // the image's last low-res rows (the step loop ended behind a barrier)
-      if (!(dbg & 4)) adjoint_rows<C>(g, b, emitted, (g.H >> 1) - 1, obase, sOut, tid, NT);
+      const int e_end = band + 1 == g.bands ? (g.H >> 1) - 1 : ((band + 1) * g.band_rows - 3) >> 1;     // (rows below it belong to the next band)
+      if (!(dbg & 4) && e_end >= emitted) adjoint_rows<C>(g, b, emitted, e_end, obase, sOut, tid, NT);
       obase = (obase + g.H) % C::ORR;
     }
     if (!C::PRE && has_next && !(dbg & 1)) {                 // no room to prefetch: stage the next unit's first window now
@@ -977,9 +985,9 @@ __global__ __launch_bounds__(C::NT, C::WPE) void row_conv_kernel(const RowConvMu
         __builtin_amdgcn_s_barrier();
         continue;
       } else
-      if constexpr (C::UPS) stage_rows<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
+      if constexpr (C::UPS) stage_rows<C>(gn, rn / gn.bands, band_row0(gn, rn % gn.bands) + gn.y_lo, STEP + KH - 1, 0, sRing, tid, NT, 0, 1);
       else {
-        stage_rows_dma<C>(gn, rn / gn.bands, (rn % gn.bands) * gn.band_rows + gn.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
+        stage_rows_dma<C>(gn, rn / gn.bands, band_row0(gn, rn % gn.bands) + gn.y_lo, STEP + KH - 1, 0, sRing, wave, C::WAVES, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1201,9 +1209,14 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
     // small batches: cut the images into row bands until there is a unit of work for every workgroup slot (not with the
     // fused adjoint: its low-res rows straddle band edges)
     const bool four = c == 0 || c == 1 || c == 4 || c == 6 || c == 7 || c == 8;
+    // (fused adjoint, round 4: bands of >= two steps, every band but the first preceded by a warm-up step -- RowConvArgs::lead; 64 images per
+    //  network used to leave half of the CUs without a workgroup in the three decoder input gradients: serial dgrad.d5 47 -> 26 us, d4 40 -> 32,
+    //  step 0.640 -> 0.630 ms; a second workgroup per CU at 128 images per network does not pay for its warm-up steps: +0.3 %.
+    //  SV_RC_ADJ_BANDS=0: whole images)
+    static const bool adj_bands = getenv("SV_RC_ADJ_BANDS") == nullptr || atoi(getenv("SV_RC_ADJ_BANDS")) != 0;
     int bands = 1;
-    while (!p.adj && n * r.B * bands < (four ? 512 : 256) && OY / (bands * 2) >= step && (OY / (bands * 2)) % step == 0) bands *= 2;
-    r.bands = bands; r.band_rows = OY / bands;
+    while ((!p.adj || adj_bands) && n * r.B * bands < ((four && !p.adj) ? 512 : 256) && OY / (bands * 2) >= (p.adj ? 2 * step : step) && (OY / (bands * 2)) % step == 0) bands *= 2;
+    r.bands = bands; r.band_rows = OY / bands; r.lead = p.adj && bands > 1 ? step : 0;
     if (i && (r.B != a[0].B || r.H != a[0].H || r.bands != a[0].bands)) return SV_E_UNSUPPORTED;
   }
   // The upsampled forward layers: in the training step at B = 512 the LDS-tile kernel is as fast (fwd.d4 0.140 vs 0.141 ms,
@@ -1219,12 +1232,12 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
 }
 
 bool svk_row_conv_supported(const TapGemmArgs* t, int n, int dtype) {
-  RowConvArgs a[8];
+  RowConvArgs a[8] = {};
   return row_plan(t, n, dtype, a) >= 0;
 }
 
 int svk_row_conv_try(const TapGemmArgs* t, int n, int dtype, hipStream_t st) {
-  RowConvArgs a[8];
+  RowConvArgs a[8] = {};
   const int cfg = row_plan(t, n, dtype, a, &n);
   switch (cfg) {
     case 0: {
