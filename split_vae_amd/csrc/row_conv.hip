@@ -1095,6 +1095,7 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
     static const bool no_cls = getenv("SV_RC_NO_CLS") != nullptr;     // A/B: merged parity classes on the tile kernel
     static const bool no_s2d = getenv("SV_RC_NO_S2D") != nullptr;     // A/B: the stride-2 forward on the tile kernel
     static const bool no_pair_s2d = getenv("SV_RC_NO_E3") != nullptr; // A/B: e3's forward on the tile kernel
+    static const int e3_min = getenv("SV_RC_E3_MIN") ? atoi(getenv("SV_RC_E3_MIN")) : 256;
     const bool cls = p.cls_n > 0;
     if (p.S == 2 && p.SX == 2 && !cls) {                               // stride-2 forward: the space-to-depth form
       if (no_s2d || p.OS != 1 || p.splitk != 1 || p.d2s || p.out_f32 || p.ooy || p.oox || p.mask || p.adj || p.ups) return SV_E_UNSUPPORTED;
@@ -1103,7 +1104,9 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
       int c = -1;
       if (cin == 32 && p.N == 64 && OX == 16) c = 9;                   // e2
       else if (cin == 8 && p.N == 32 && OX == 32) c = 10;              // e1
-      else if (cin == 64 && p.N == 128 && OX == 8 && OY == 8 && !no_pair_s2d) c = 12;    // e3 (k 4)
+      // e3 (k 4): image pairs per strip -- from 256 images per launch (64 images per network are 64 pairs = 64 workgroups: the tile kernel is
+      // 0.6 % of the step faster there, 0.2 % / 0.8 % slower at 128 / 256: profiles/r04_b64_sweep3.txt)
+      else if (cin == 64 && p.N == 128 && OX == 8 && OY == 8 && !no_pair_s2d && n * (p.M >> (p.lOY + p.lOX)) >= e3_min) c = 12;
       const int kk = c == 12 ? 4 : 6, pad = c == 12 ? 1 : 2;
       if (c < 0 || p.lda != cin || p.ntaps != kk * kk || p.Ktot != kk * kk * cin || p.ldo < p.N) return SV_E_UNSUPPORTED;
       for (int q = 0; q < kk * kk; ++q)                                // the layer's own order: y-major
@@ -1145,8 +1148,10 @@ static int row_plan(const TapGemmArgs* t, int n, int dtype, RowConvArgs* a, int*
     }
     if (n > 2) return SV_E_UNSUPPORTED;                               // every other form: one problem or the x / x-hat twins
     static const bool no_pair = getenv("SV_RC_NO_PAIR") != nullptr;   // A/B: the 8 x 8-grid layer d2 on the tile kernel
-    // (measured, 2 x 512 images: forward 0.053 -> 0.048 ms; the input gradient 0.056 -> 0.058, so only SV_RC_PAIR_DGRAD=1 sends it here)
-    static const bool pair_dgrad = getenv("SV_RC_PAIR_DGRAD") != nullptr;
+    // (measured, 2 x 512 images: forward 0.053 -> 0.048 ms; the input gradient 0.056 -> 0.058 -- but up to 2 x 256 images it is the faster
+    //  form: the step -1.1 % / -0.3 % / -0.6 % at 64 / 128 / 256 images per network (profiles/r04_b64_sweep3.txt).  SV_RC_PAIR_DGRAD=1 / 0 forces it)
+    static const int pair_dgrad_env = getenv("SV_RC_PAIR_DGRAD") ? atoi(getenv("SV_RC_PAIR_DGRAD")) : -1;
+    const bool pair_dgrad = pair_dgrad_env >= 0 ? pair_dgrad_env != 0 : n * (p.M >> (p.lOY + p.lOX)) <= 512;
     if (!no_pair && !cls && p.S == 1 && p.SX == 1 && p.OS == 1 && p.lOX == 3 && p.lOY == 3 && p.ntaps == 16 && p.N == 128 && !p.ups && !p.adj && (!p.mask || pair_dgrad)) {
       // d2 forward / input gradient: image pairs per strip, two output-channel halves per problem (RC_d2)
       const int cin = (1 << p.cl2) * 8;
