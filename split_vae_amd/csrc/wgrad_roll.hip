@@ -399,11 +399,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_roll_kernel(const RollMulti mg) 
 
 // workgroups per problem: one per CU over the launch, and at least `SV_ROLL_MIN_STRIPS` strips each (every workgroup flushes a 295-KB slab
 // whatever it computed: at 64 images per network 128 one-strip workgroups wrote and re-read 75 MB for 19 steps of work each)
+// (round 4: with two strips or fewer per workgroup, half as many workgroups -- 64 images per network: two strips each, step 0.607 -> 0.600 ms; 128: four
+//  each, 0.766 -> 0.754; SV_ROLL_MIN_STRIPS forces a minimum instead: profiles/r04_b64_sweep4.txt)
 static int roll_wgs(int n, int nstrips) {
-  static const int min_strips = getenv("SV_ROLL_MIN_STRIPS") ? atoi(getenv("SV_ROLL_MIN_STRIPS")) : 1;
+  static const int min_strips = getenv("SV_ROLL_MIN_STRIPS") ? atoi(getenv("SV_ROLL_MIN_STRIPS")) : 0;
   int X = 256 / n;
-  const int cap = (nstrips + min_strips - 1) / min_strips;
-  if (X > cap) X = cap;
+  if (min_strips > 0) {
+    const int cap = (nstrips + min_strips - 1) / min_strips;
+    if (X > cap) X = cap;
+  } else {
+    if (nstrips <= 2 * X) X /= 2;
+    if (X > nstrips) X = nstrips;
+  }
   return X < 1 ? 1 : X;
 }
 
