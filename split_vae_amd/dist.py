@@ -67,7 +67,9 @@ def param_buckets(param_table, n_params):
     convs = span(lambda n: n.startswith("encoder") and "/e4_" not in n)
     covered = sum(e - b for rs in (dec, heads, convs) for b, e in rs)
     assert covered == n_params, (covered, n_params)
-    return {"decoders": dec, "enc_heads": heads, "enc_convs": convs}
+    # "encoders" = heads + convs as ONE bucket (small shards: trainer.train_step launches two buckets instead of three -- every all-reduce call
+    # costs ~30 us of host time, which a 0.6 ms step cannot hide: profiles/r04_dp_one_rank.txt)
+    return {"decoders": dec, "enc_heads": heads, "enc_convs": convs, "encoders": span(lambda n: n.startswith("encoder"))}
 
 
 def make_reducer(param_table, n_params):

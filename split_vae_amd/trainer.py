@@ -59,6 +59,9 @@ def _check_images(model, images):
         raise ValueError("images must be contiguous fp32 on the HIP device")
 
 
+_DP_TWO_BUCKETS_MAX = int(os.environ.get("SV_DP_TWO_BUCKETS_MAX", "256"))     # per-GPU batch up to which the data-parallel step uses two buckets
+
+
 def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0, accumulate_metrics=True, keep_recon=True):
     """train_step_lg_vae (vae/trainer.py:120-144): forward, total = recon_x + recon_x_hat +
     beta*KL, gradients of the 40 variables, Adam update, metric update.  `images` [B,H,W,6] fp32
@@ -103,10 +106,17 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
     # data parallel: launch each bucket's all-reduce as soon as the phase that fills it is enqueued
     plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS | nr, **kw)
     reducer.launch(model.grad_flat, "decoders")
-    plan.step(PHASE_BWD_ENC_HEADS, **kw)
-    reducer.launch(model.grad_flat, "enc_heads")
-    plan.step(PHASE_BWD_ENC_CONVS, **kw)
-    reducer.launch(model.grad_flat, "enc_convs")
+    if B <= _DP_TWO_BUCKETS_MAX:
+        # shards of the global batch 512 (256 / 128 / 64 images per GPU): the encoders' backward is 0.15-0.2 ms of GPU time, less than the host
+        # needs to enqueue two more phases and five more all-reduce calls (~30 us each); one encoder phase + one contiguous bucket.  One rank,
+        # no link time: 0.740 -> 0.707 ms at 64 images, 0.916 -> 0.866 at 128, 1.250 -> 1.189 at 256 (profiles/r04_dp_one_rank.txt)
+        plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)
+        reducer.launch(model.grad_flat, "encoders")
+    else:
+        plan.step(PHASE_BWD_ENC_HEADS, **kw)
+        reducer.launch(model.grad_flat, "enc_heads")
+        plan.step(PHASE_BWD_ENC_CONVS, **kw)
+        reducer.launch(model.grad_flat, "enc_convs")
     reducer.wait()
     plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
     return plan

@@ -69,11 +69,14 @@ def test_shard_bounds_and_buckets(lib_built):
     # decoders are one contiguous tail; heads and convs interleave per encoder
     assert len(b["decoders"]) == 1 and b["decoders"][0][1] == n
     assert len(b["enc_heads"]) == 2 and len(b["enc_convs"]) == 2
-    cover = np.zeros(n, int)
-    for rs in b.values():
-        for lo, hi in rs:
-            cover[lo:hi] += 1
-    assert np.all(cover == 1)
+    # "encoders" = heads + convs as one bucket (the two-bucket schedule of small shards): one contiguous head of the buffer
+    assert b["encoders"] == [(0, b["decoders"][0][0])]
+    for names in (("decoders", "enc_heads", "enc_convs"), ("decoders", "encoders")):     # either schedule covers every parameter exactly once
+        cover = np.zeros(n, int)
+        for k in names:
+            for lo, hi in b[k]:
+                cover[lo:hi] += 1
+        assert np.all(cover == 1)
     sizes = {k: sum(hi - lo for lo, hi in v) for k, v in b.items()}
     assert sizes["enc_heads"] > 4_000_000 and sizes["decoders"] > 4_000_000 and sizes["enc_convs"] < 500_000
 
