@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32_f32", deterministic=False):
+def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32_f32", deterministic=False, buckets=None):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -33,6 +33,10 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32
             env["SV_DIST_FORCE"] = "1"
         if deterministic:
             env["SV_DETERMINISTIC"] = "1"         # fixed-order reductions in the worker (include/splitvae.h: sv_set_deterministic)
+        if buckets == 3:
+            env["SV_DP_TWO_BUCKETS_MAX"] = "0"    # the three-bucket schedule of shards above 256 images (trainer.train_step) at this small shard
+        elif buckets == 2:
+            env["SV_DP_TWO_BUCKETS_MAX"] = "1024"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps), config],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -41,9 +45,10 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32
     return np.load(out)
 
 
-def test_two_ranks_equal_one(lib_built, tmp_path):
+@pytest.mark.parametrize("buckets", [2, 3])
+def test_two_ranks_equal_one(lib_built, tmp_path, buckets):
     one = _run(1, str(tmp_path / "one.npz"))
-    two = _run(2, str(tmp_path / "two.npz"))
+    two = _run(2, str(tmp_path / "two.npz"), buckets=buckets)
     # rank 0's loss scalars are its SHARD means; gradients and weights are global
     g1, g2 = one["grads"], two["grads"] / 2.0                 # all-reduce(sum); 1/world lives in the Adam kernel
     assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)          # (bounds: see test_one_rank_through_the_rccl_path_equals_the_plain_step)
@@ -80,14 +85,16 @@ def test_two_ranks_over_rccl_equal_one(lib_built, tmp_path, backend):
     assert np.linalg.norm(one["params"] - two["params"]) <= 5e-2 * np.linalg.norm(one["params"] - _init_params())
 
 
+@pytest.mark.parametrize("buckets", [2, 3])
 @pytest.mark.parametrize("backend", ["nccl", "sv_comm"])
-def test_one_rank_through_the_rccl_path_equals_the_plain_step(lib_built, tmp_path, backend):
+def test_one_rank_through_the_rccl_path_equals_the_plain_step(lib_built, tmp_path, backend, buckets):
     """The production data-parallel path on the ONE device of this box (SV_DIST_FORCE=1): process group on the `nccl` backend
-    (= RCCL) resp. the library's own communicator, the four-call phase split of train_step, the three gradient buckets all-reduced
-    asynchronously over a world of one rank, 1/world inside Adam -- against the plain single-call step.  Primary form: fixed-order
-    reductions in both runs (SV_DETERMINISTIC=1 in the workers), the original tight bounds."""
+    (= RCCL) resp. the library's own communicator, the phase split of train_step -- both schedules: three gradient buckets (shards above
+    256 images) and two (decoders, then the encoders as one contiguous range) -- all-reduced asynchronously over a world of one rank,
+    1/world inside Adam -- against the plain single-call step.  Primary form: fixed-order reductions in both runs (SV_DETERMINISTIC=1 in
+    the workers), the original tight bounds."""
     one = _run(1, str(tmp_path / "one.npz"), deterministic=True)
-    dp = _run(1, str(tmp_path / "dp.npz"), backend=backend, force=True, deterministic=True)
+    dp = _run(1, str(tmp_path / "dp.npz"), backend=backend, force=True, deterministic=True, buckets=buckets)
     g1, g2 = one["grads"], dp["grads"]
     assert np.linalg.norm(g1 - g2) <= 1e-3 * np.linalg.norm(g1)
     assert np.linalg.norm(one["params"] - dp["params"]) <= 1e-2 * np.linalg.norm(one["params"] - _init_params())
