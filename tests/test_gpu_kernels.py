@@ -802,3 +802,38 @@ def test_weight_gradient_pipeline_for_whole_image_tiles(ops, layer, monkeypatch)
         torch.testing.assert_close(db.double().cpu(), bt.grad, rtol=1e-4, atol=1e-4 * float(bt.grad.abs().max()))
         dw2, db2 = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)
         assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed-order slabs: run-to-run identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", [l for l in LAYERS if l[0] in ("d3", "d4", "d4_64", "d5", "d5_64")], ids=lambda l: l[0])
+def test_fp32_fused_upsample_forward_and_weight_gradient(ops, layer):
+    """The fp32 step fuses the bilinear resizes into the tile staging since round 4 (forward: tile_conv_kernel<float>, weight gradient:
+    wgrad_tile_f32_kernel with stage_tile_upsampled<float>, the head in the x-packed form): against the written-out resize + plain conv of the
+    same build (the resize itself is bitwise upsample2x_fwd's) and against the fp64 composition; with and without a workspace (fixed-order
+    slabs / fp32 atomics -- the im2col kernel cannot take a fused resize)."""
+    name, H, Cin, Cout, k, s, act, yf32 = layer
+    rng = np.random.default_rng(sum(map(ord, name)) + 7)
+    B = 3
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)).cuda() * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)).cuda() * 0.1
+    plain = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.float32, y_f32=yf32)
+    fused = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=act, dtype=torch.float32, y_f32=yf32, ups_in=True)
+    plain.prep(w); fused.prep(w)
+    x_hi = ops.upsample2x_fwd(x_lo)
+    y0 = plain.fwd(x_hi, b)
+    y1 = fused.fwd(x_lo, b)
+    torch.testing.assert_close(y1[..., :Cout], y0[..., :Cout], rtol=F32_RTOL, atol=F32_ATOL * float(y0.abs().max()))
+    yr = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(x_lo.cpu().double()), w.cpu().double(), b.cpu().double(), s, act)
+    torch.testing.assert_close(y1[..., :Cout].double().cpu(), yr, rtol=F32_RTOL, atol=F32_ATOL * float(yr.abs().max()))
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, (Cout + 7) // 8 * 8)).astype(np.float32)).cuda()
+    if Cout % 8:
+        dy[..., Cout:] = 0
+    dw0, db0 = plain.wgrad(x_hi, dy, workspace=True)
+    dw1, db1 = fused.wgrad(x_lo, dy, workspace=True)
+    dw2, db2 = fused.wgrad(x_lo, dy)                       # no workspace: the tile kernel's atomics flush
+    for dw, db in ((dw1, db1), (dw2, db2)):
+        torch.testing.assert_close(dw, dw0, rtol=F32_RTOL, atol=F32_ATOL * float(dw0.abs().max()))
+        torch.testing.assert_close(db, db0, rtol=F32_RTOL, atol=F32_ATOL * float(db0.abs().max()))
+    dw3, _ = fused.wgrad(x_lo, dy, workspace=True)
+    assert torch.equal(dw1, dw3)
