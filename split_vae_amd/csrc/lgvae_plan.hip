@@ -633,7 +633,11 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   const bool big = n * L[0]->d.B >= 768;
   // With TWO side streams (whole bf16 steps at this size, see run_phases) only the two tail layers stay: "e1,e2" 2.004 / 2.006 ms,
   // "e1,e2,d1" 2.008, "e1" / "e2" 2.03, "" 2.039, "e1,e2,d4" 2.061, "e1,e2,d5" 2.119.
-  const char* on_main = on_main_env ? on_main_env : (!big || p->side_use >= 2) ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" : "e1,e2,d5";
+  // fp32 (round 4, with the tile weight gradients: every launch is matrix-pipe-bound, two of them side by side only slow each other): the three
+  // encoder layers on the main stream, the decoders' on the side stream -- "e1,e2,e3" 11.65-11.72 ms against "e1,e2,d5" 12.05-12.08, no side stream
+  // at all 11.87, "e1,e2" 11.74, "e1" 11.80, "e1,e2,e3,d2" 11.77 (profiles/r04_f32_streams.txt)
+  const char* on_main = on_main_env ? on_main_env : (!big || p->side_use >= 2) ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" :
+                        L[0]->d.dtype == SV_F32 ? "e1,e2,e3" : "e1,e2,d5";
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
   if (latent_gemm_on(p) && L[0]->d.H == 1 && L[0]->d.W == 1 && L[0]->d.KH == 1 && n <= 4) {     // Dense (d1): latent_gemm.hip, whole batch per tile
