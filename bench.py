@@ -267,9 +267,9 @@ def wgrad_main_layers(images_per_launch, dtype, world=1):
     if env is not None:
         return env.split(",")
     if images_per_launch < 768:
-        return ["e1", "e2"]
+        return ["e1"] if images_per_launch >= 512 else ["e1", "e2"]
     if dtype == "bf16" and world == 1 and int(os.environ.get("SV_SIDE_STREAMS", "2")) >= 2:
-        return ["e1", "e2"]                      # whole steps: two side streams take everything else
+        return ["e1"]                            # whole steps: two side streams take everything else
     if dtype == "f32":
         return ["e1", "e2", "e3"]                # fp32: the encoders' on the main stream, the decoders' on the side stream
     return ["e1", "e2", "d4"] if dtype == "bf16" and os.environ.get("SV_NO_WGRAD_ROLL") is None else ["e1", "e2", "d5"]

@@ -636,7 +636,10 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // fp32 (round 4, with the tile weight gradients: every launch is matrix-pipe-bound, two of them side by side only slow each other): the three
   // encoder layers on the main stream, the decoders' on the side stream -- "e1,e2,e3" 11.65-11.72 ms against "e1,e2,d5" 12.05-12.08, no side stream
   // at all 11.87, "e1,e2" 11.74, "e1" 11.80, "e1,e2,e3,d2" 11.77 (profiles/r04_f32_streams.txt)
-  const char* on_main = on_main_env ? on_main_env : (!big || p->side_use >= 2) ? "e1,e2" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" :
+  // (two side streams, re-measured with round 4's kernels: "e1" 1.643-1.647 ms, "e1,e2" 1.651-1.653, "e1,d1" 1.650-1.655, "e2" 1.668, "e1,e3" 1.663:
+  //  profiles/r04_b512_streams.txt;
+  //  512 images per launch, one side stream: "e1" 1.067-1.070 against 1.071-1.074 (profiles/r04_b256_sweep.txt); 256 and 128: "e1,e2" stays)
+  const char* on_main = on_main_env ? on_main_env : !big ? (n * L[0]->d.B >= 512 ? "e1" : "e1,e2") : p->side_use >= 2 ? "e1" : (L[0]->d.dtype == SV_BF16 && !roll_off) ? "e1,e2,d4" :
                         L[0]->d.dtype == SV_F32 ? "e1,e2,e3" : "e1,e2,d5";
   if (strstr(on_main, ln.c_str())) p->side_slot = sv_lgvae_plan::SIDE_MAX - 1;   // its own slab workspace: the side streams' slots are in use concurrently
   else st = p->wgrad_stream(st);
