@@ -280,7 +280,7 @@ struct sv_tape {
   std::vector<PrepJob> jobs;
   int prep_blocks = 0;
   int64_t arena_elems = 0, act_floats = 0, grad_floats = 0, scratch_floats = 0;
-  int64_t off_jobs = 0, off_arena = 0, off_act = 0, off_grad = 0, off_scratch = 0, off_loss = 0, ws_bytes = 0;
+  int64_t off_jobs = 0, off_arena = 0, off_act = 0, off_grad = 0, off_scratch = 0, off_loss = 0, off_wgrad = -1, ws_bytes = 0;      // off_wgrad: the conv weight gradients' partial-sum slabs (shared: stream-ordered)
   int n_loss = 0, B = 0, dtype = SV_F32;
   float report[SV_TAPE_MAX_LOSS * SV_TAPE_MAX_LOSS];
   int n_report = 0;
@@ -290,6 +290,8 @@ struct sv_tape {
   float* act(int t) const { return (float*)(ws + off_act) + tens[t].off; }
   float* grad(int t) const { return tens[t].goff < 0 ? nullptr : (float*)(ws + off_grad) + tens[t].goff; }
   float* scr(int64_t o) const { return (float*)(ws + off_scratch) + o; }
+  // LDS-tile weight gradients (wgrad_tile*.hip) flush per-workgroup slabs here and sum them in a fixed order; SV_TAPE_NO_WGRAD_WS: atomics / im2col
+  void* wgrad_ws() const { static const bool off = getenv("SV_TAPE_NO_WGRAD_WS") != nullptr; return (off || off_wgrad < 0) ? nullptr : ws + off_wgrad; }
   float* loss_sums() const { return (float*)(ws + off_loss); }                                   // [n_loss][B]
   float* loss_out() const { return loss_sums() + (int64_t)SV_TAPE_MAX_LOSS * B; }                 // total, reported[16], means[16]
   float* metric() const { return loss_out() + 2 * SV_TAPE_MAX_LOSS + 2; }                         // sums of total / reported, count
@@ -473,6 +475,9 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
   t->off_grad = o; o += al(t->grad_floats * 4);
   t->off_scratch = o; o += al(t->scratch_floats * 4 + 256);
   t->off_loss = o; o += al(((int64_t)SV_TAPE_MAX_LOSS * t->B + 4 * SV_TAPE_MAX_LOSS + 8) * 4);
+  bool any_conv = false;
+  for (const sv_tape::Extra& e : t->ex) any_conv = any_conv || e.has_conv;
+  if (any_conv) { t->off_wgrad = o; o += al(SV_WGRAD_WS_BYTES); }
   t->ws_bytes = o;
   t->finalized = true;
   return SV_OK;
@@ -639,11 +644,11 @@ int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t s
         const int64_t n4 = y.rows * y.ld / 4;
         hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n4)), dim3(256), 0, st, gy, (bf16_t*)t->scr(e.scratch2), n4);
         SV_LAUNCH_CHECK();
-        SV_TRY(sv_conv2d_nhwc_wgrad(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, st));
+        SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(), SV_WGRAD_WS_BYTES, st));
         if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, t->scr(e.scratch2), t->ws + t->off_arena + e.wd_off * es, nullptr, gx, 1, st));
         return SV_OK;
       }
-      SV_TRY(sv_conv2d_nhwc_wgrad(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, st));
+      SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(), SV_WGRAD_WS_BYTES, st));
       if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, gy, t->ws + t->off_arena + e.wd_off * es, nullptr, gx, multi(n.x) ? 1 : 0, st));
       return SV_OK;
     }

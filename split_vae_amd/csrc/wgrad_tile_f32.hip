@@ -177,7 +177,7 @@ int launch_f32(const WgradTileArgs* a, int n, int msplit, int groups, size_t lds
 
 }  // namespace
 
-// The seven conv layers of the SPLIT-VAE encoders / decoders (fp32 plan: plain inputs, the resized tensors are written out).  SV_E_UNSUPPORTED:
+// The seven conv layers of the SPLIT-VAE encoders / decoders and the 3 x 3 layers of LG-SPAIR's object networks.  SV_E_UNSUPPORTED:
 // any other shape, a missing / small workspace -- the caller falls back to the im2col kernel.
 #define F32_REJ(why) do { if (trace) fprintf(stderr, "wgrad_tile_f32: not taken (%s)\n", why); return SV_E_UNSUPPORTED; } while (0)
 int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
@@ -187,7 +187,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const WgradArgs& w = wv[0];
   if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || (w.ups && w.S != 1) || w.dy_s2d || w.clampin || w.ycols != w.ldy) F32_REJ("form");
   const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, ldy = w.ldy, nt = w.ntaps;
-  if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && !(nt == 42 && w.fold_kw))) {
+  if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && nt != 9 && !(nt == 42 && w.fold_kw))) {
     if (trace) fprintf(stderr, "wgrad_tile_f32: OY %d OX %d ldy %d taps %d cin %d\n", OY, OX, ldy, nt, cin);
     F32_REJ("grid / taps");
   }
@@ -274,6 +274,11 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   F32_LAYER(4, 8, 128, 16, 2);      // e3
   F32_LAYER(9, 4, 64, 16, 2);       // e2
   F32_LAYER(5, 2, 32, 8, 2);        // e1 (tap pairs)
+  // the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses (9 taps on 12 slots: three per wave, the reduce drops the padding)
+  F32_LAYER(3, 4, 64, 16, 2);       // object encoder conv2
+  F32_LAYER(3, 4, 64, 16, 1);       // object decoder d2
+  F32_LAYER(3, 2, 32, 16, 1);       // object decoder d3
+  F32_LAYER(3, 1, 8, 16, 1);        // object decoder d5 (RGB + alpha)
 #undef F32_LAYER
 #undef F32_CASE
   else F32_REJ("no instantiation");

@@ -837,3 +837,38 @@ def test_fp32_fused_upsample_forward_and_weight_gradient(ops, layer):
         torch.testing.assert_close(db, db0, rtol=F32_RTOL, atol=F32_ATOL * float(db0.abs().max()))
     dw3, _ = fused.wgrad(x_lo, dy, workspace=True)
     assert torch.equal(dw1, dw3)
+
+
+SPAIR_OBJECT_LAYERS = [  # name, H, Cin, Cout, k, stride: the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses
+    ("obj_conv2", 16, 32, 64, 3, 2),
+    ("obj_d2", 8, 32, 64, 3, 1),
+    ("obj_d3", 16, 64, 32, 3, 1),
+    ("obj_d5", 32, 32, 4, 3, 1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [5, 64])
+@pytest.mark.parametrize("layer", SPAIR_OBJECT_LAYERS, ids=lambda l: l[0])
+def test_fp32_three_by_three_weight_gradient_on_lds_tiles(ops, layer, B):
+    """wgrad_tile_f32_kernel<3, ...>: nine taps on twelve slots (three per wave; the fixed-order reduce drops the padding).  Against the fp64
+    gradient of Conv2D(padding='same') from the same operands, against the im2col kernel of the same build (no workspace), bitwise run to run;
+    B = 5: a ragged last image group."""
+    name, H, Cin, Cout, k, s = layer
+    rng = np.random.default_rng(sum(map(ord, name)) + B)
+    x = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32))
+    OH = H // s
+    cp = (Cout + 7) // 8 * 8
+    dy = torch.zeros((B, OH, OH, cp))
+    dy[..., :Cout] = torch.from_numpy(rng.standard_normal((B, OH, OH, Cout)).astype(np.float32))
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, s, act=None, dtype=torch.float32)
+    wr = torch.zeros((k, k, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    br = torch.zeros((Cout,), dtype=torch.float64, requires_grad=True)
+    torch_ref.conv2d_same(x.double(), wr, br, s, None).backward(dy[..., :Cout].double())
+    dw_t, db_t = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)          # LDS tiles + slabs
+    dw_i, db_i = conv.wgrad(x.cuda(), dy.cuda())                          # im2col + atomics
+    for dw, db in ((dw_t, db_t), (dw_i, db_i)):
+        torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=F32_RTOL, atol=F32_ATOL * float(wr.grad.abs().max()))
+        torch.testing.assert_close(db.double().cpu(), br.grad, rtol=F32_RTOL, atol=F32_ATOL * float(br.grad.abs().max()))
+    dw_u, db_u = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)
+    assert torch.equal(dw_t, dw_u) and torch.equal(db_t, db_u)
