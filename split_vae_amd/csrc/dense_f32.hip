@@ -165,8 +165,10 @@ int launch(const DenseArgs& a, hipStream_t st) {
 int pick_splitk(int M, int N, int K) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nks = (K + BK - 1) / BK;
   if (tiles >= 128 || nks < 8) return 1;
-  int s = (256 + tiles - 1) / tiles;
-  if (s > nks / 2) s = nks / 2;
+  static const int target = getenv("SV_DENSE_SPLIT_WGS") ? atoi(getenv("SV_DENSE_SPLIT_WGS")) : 256;      // A/B knob
+  static const int min_steps = getenv("SV_DENSE_SPLIT_MIN_STEPS") ? atoi(getenv("SV_DENSE_SPLIT_MIN_STEPS")) : 2;
+  int s = (target + tiles - 1) / tiles;
+  if (s > nks / min_steps) s = nks / min_steps;
   return s < 1 ? 1 : s;
 }
 
