@@ -179,3 +179,39 @@ def test_tape_host_logic_without_gpu(lib_built):
     assert lib.sv_tape_bind(h, None, ws, None) == _lib.STATUS_BADARG
     assert lib.sv_tape_run(h, None, None) == _lib.STATUS_BADARG
     lib.sv_tape_destroy(h)
+
+
+def test_tape_with_conv_layers_reserves_the_weight_gradient_slabs(lib_built):
+    """A tape that holds a Conv2D node reserves sv_conv2d_wgrad_workspace_bytes for the LDS-tile weight gradients' partial-sum slabs (one region,
+    shared by its layers in stream order); a tape of Dense layers only does not.  Host logic: no GPU."""
+    from split_vae_amd import _lib
+    lib = _lib.load()
+
+    def build(with_conv):
+        h = C.c_void_p()
+        assert lib.sv_tape_create(C.byref(h), 4, _lib.SV_F32) == 0
+        x = lib.sv_tape_tensor(h, 4 * 16 * 16, 32, 32, 0)
+        y = lib.sv_tape_tensor(h, 4 * 16 * 16, 32, 32, 1)
+        n = _lib.TapeNode()
+        for f in ("x", "y", "t2", "t3", "t4", "t5", "t6"):
+            setattr(n, f, -1)
+        n.dyn_idx = n.loss_idx = -1
+        n.rep = 1
+        n.x, n.y, n.w_off = x, y, 0
+        if with_conv:
+            n.kind, n.b_off = _lib.TAPE_CONV, 3 * 3 * 32 * 32
+            n.B, n.H, n.W, n.C, n.Cout, n.k, n.stride = 4, 16, 16, 32, 32, 3, 1
+        else:
+            n.kind, n.b_off = _lib.TAPE_DENSE, 32 * 32
+        assert lib.sv_tape_add(h, C.byref(n)) == 0
+        assert lib.sv_tape_finalize(h) == 0
+        ws = lib.sv_tape_workspace_bytes(h)
+        lib.sv_tape_destroy(h)
+        return ws
+
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = 4, 16, 16, 32, 32, 3, 3, 1
+    d.dtype, d.ldx, d.ldy = _lib.SV_F32, 32, 32
+    slabs = lib.sv_conv2d_wgrad_workspace_bytes(C.byref(d))
+    assert slabs > 0
+    assert build(True) >= slabs and build(False) < slabs
