@@ -1,0 +1,4 @@
+# the tape's step-start zero fills: one 16-B-store launch vs two hipMemsetAsync calls
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_spair_model.py -q -x -m gpu 2>&1 | grep -E "passed|failed" | tail -2
+for r in 1 2 3; do for dt in f32 bf16; do for v in BASE=1 SV_TAPE_MEMSET=1; do echo -n "$dt $v: "; env $v python scripts/bench_spair_native.py 32 $dt 2>/dev/null | tail -1; done; done; done
