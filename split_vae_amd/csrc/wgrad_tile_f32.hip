@@ -199,7 +199,9 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   for (int u = 0; u < nt / 2 && pairx; ++u) pairx = w.dy[2 * u + 1] == w.dy[2 * u] && w.dx[2 * u + 1] == w.dx[2 * u] + 1;
   const int ntk = pairx ? nt / 2 : nt;                      // taps the kernel walks
   const int TPW = (ntk + 3) / 4, COF = (ldy + 15) / 16;      // (42 folded taps: 11 per wave, the last two slots repeat tap 41 and are dropped by the reduce)
-  if (CW == 8 && !pairx) F32_REJ("8-channel input without tap pairs");
+  // (an 8-channel input with an odd kernel width -- the first 3 x 3 layer of LG-SPAIR's object encoder -- runs without pairs: fragment rows 8..15
+  //  hold the next pixel's channels and are dropped by the flush / the reduce)
+  if (CW == 8 && !pairx && nt != 9) F32_REJ("8-channel input without tap pairs");
   int y_lo = 127, y_hi = -127, x_lo = 127, x_hi = -127;
   for (int i = 0; i < nt; ++i) {
     y_lo = w.dy[i] < y_lo ? w.dy[i] : y_lo; y_hi = w.dy[i] > y_hi ? w.dy[i] : y_hi;
@@ -279,6 +281,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   F32_LAYER(3, 4, 64, 16, 1);       // object decoder d2
   F32_LAYER(3, 2, 32, 16, 1);       // object decoder d3
   F32_LAYER(3, 1, 8, 16, 1);        // object decoder d5 (RGB + alpha)
+  F32_LAYER(3, 2, 32, 8, 2);        // object encoder conv1 (RGB padded to 8 channels, no tap pairs: half of every fragment is dropped)
 #undef F32_LAYER
 #undef F32_CASE
   else F32_REJ("no instantiation");

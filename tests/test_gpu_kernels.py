@@ -840,6 +840,7 @@ def test_fp32_fused_upsample_forward_and_weight_gradient(ops, layer):
 
 
 SPAIR_OBJECT_LAYERS = [  # name, H, Cin, Cout, k, stride: the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses
+    ("obj_conv1", 32, 3, 32, 3, 2),      # RGB padded to 8 channels: fragment rows 8..15 are dropped (no tap pairs at an odd kernel width)
     ("obj_conv2", 16, 32, 64, 3, 2),
     ("obj_d2", 8, 32, 64, 3, 1),
     ("obj_d3", 16, 64, 32, 3, 1),
@@ -865,10 +866,11 @@ def test_fp32_three_by_three_weight_gradient_on_lds_tiles(ops, layer, B):
     wr = torch.zeros((k, k, Cin, Cout), dtype=torch.float64, requires_grad=True)
     br = torch.zeros((Cout,), dtype=torch.float64, requires_grad=True)
     torch_ref.conv2d_same(x.double(), wr, br, s, None).backward(dy[..., :Cout].double())
-    dw_t, db_t = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)          # LDS tiles + slabs
-    dw_i, db_i = conv.wgrad(x.cuda(), dy.cuda())                          # im2col + atomics
+    xg = _pad_c(x, conv.desc.ldx).cuda()
+    dw_t, db_t = conv.wgrad(xg, dy.cuda(), workspace=True)                # LDS tiles + slabs
+    dw_i, db_i = conv.wgrad(xg, dy.cuda())                                # im2col + atomics
     for dw, db in ((dw_t, db_t), (dw_i, db_i)):
         torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=F32_RTOL, atol=F32_ATOL * float(wr.grad.abs().max()))
         torch.testing.assert_close(db.double().cpu(), br.grad, rtol=F32_RTOL, atol=F32_ATOL * float(br.grad.abs().max()))
-    dw_u, db_u = conv.wgrad(x.cuda(), dy.cuda(), workspace=True)
+    dw_u, db_u = conv.wgrad(xg, dy.cuda(), workspace=True)
     assert torch.equal(dw_t, dw_u) and torch.equal(db_t, db_u)
