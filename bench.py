@@ -46,20 +46,21 @@ TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}   # BASELINE.md section 
 PROFILE_TAGS = ("r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
 
 
-def _traffic_file():
+def _traffic_file(dtype="bf16"):
+    """The newest committed PMC summary of the step at this precision (`<tag>_traffic.json`: bf16; `<tag>_f32_traffic.json`: the fp32 step)."""
     import glob
     for tag in PROFILE_TAGS:
-        c = sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*traffic.json")))
+        c = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", tag + "_*traffic.json")) if f.endswith("_f32_traffic.json") == (dtype == "f32"))
         if c:
             return c[-1]
-    return os.path.join(ROOT, "profiles", "r01_k_traffic.json")
+    return os.path.join(ROOT, "profiles", "r01_k_traffic.json" if dtype != "f32" else "none_f32_traffic.json")
 
 
-def measured_traffic(kernel_stems):
+def measured_traffic(kernel_stems, dtype="bf16"):
     """(HBM bytes per launch, kernel symbol, file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc
     WRITE_SIZE in separate runs, gfx950 x2 read correction) for the first stem that matches exactly one kernel; the
     value is CACHED evidence of that profile run, not measured by this process: None when no symbol matches."""
-    path = _traffic_file()
+    path = _traffic_file(dtype)
     try:
         kernels = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
@@ -261,6 +262,13 @@ SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyp
                 "dgrad.e2": ["RowCfg<3, 3, 64, 128, 16, 4, 2, "]}
 
 
+# the fp32 step's weight gradients: wgrad_tile_f32_kernel<TPW, COF, LDY, CW, SX, G4> (profiles/*_f32_traffic.json; the forward / input-gradient tile kernels
+# serve several layers per symbol and are not mapped)
+SCOPE_KERNEL_F32 = {"wgrad.d5": ["wgrad_tile_f32_kernel<11, 1, 16, 16, 2, "], "wgrad.d4": ["wgrad_tile_f32_kernel<9, 2, 32, 16, 1, "],
+                    "wgrad.d3": ["wgrad_tile_f32_kernel<4, 4, 64, 16, 1, "], "wgrad.e2": ["wgrad_tile_f32_kernel<9, 4, 64, 16, 2, "],
+                    "wgrad.e1": ["wgrad_tile_f32_kernel<5, 2, 32, 8, 2, "]}
+
+
 def wgrad_main_layers(images_per_launch, dtype, world=1):
     """The layers whose weight gradient the plan keeps on the main stream (csrc/lgvae_plan.hip: run_wgrad_layers; the rest go to the side stream)."""
     env = os.environ.get("SV_WGRAD_MAIN")
@@ -347,7 +355,7 @@ def roofline_block(table, dom, worst, prof, dtype, B, world):
     avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
     ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype]
-    traffic, symbol, tfile = measured_traffic(SCOPE_KERNEL.get(prof[0]["name"], [])) if dtype == "bf16" else (None, None, _traffic_file())
+    traffic, symbol, tfile = measured_traffic((SCOPE_KERNEL if dtype == "bf16" else SCOPE_KERNEL_F32).get(prof[0]["name"], []), dtype)
     rl = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
           "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
           "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -379,7 +387,7 @@ def roofline_block(table, dom, worst, prof, dtype, B, world):
         next((r for r in table if r["name"] == "adam_step"), None)
     if elbo and elbo["launches"]:
         ems = elbo["total_ms"] / elbo["launches"]
-        etr, esym, _ = measured_traffic(["dlogistic_kernel"] if elbo["name"].startswith("dlogistic") else ["adam_kernel"])
+        etr, esym, _ = measured_traffic(["dlogistic_kernel"] if elbo["name"].startswith("dlogistic") else ["adam_kernel"], dtype)
         rl["hbm"] = {"bound": "hbm", "kernel": elbo["name"], "algorithmic_bytes": elbo["bytes"],
                      "avg_launch_ms": round(ems, 4), "achieved": round(elbo["bytes"] / (ems * 1e-3) / 1e9, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(elbo["bytes"] / (ems * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),

@@ -836,6 +836,63 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
   }
 }
 
+// The same adjoint at fp32 with the hi-res window in registers: a thread walks RB consecutive low-res rows of one (image, column, 4-channel
+// piece); rows 2i+1 and 2i+2 of output row i are rows 2(i+1)-1 and 2(i+1) of the next one, so every step loads two hi-res rows (8 x 16 B)
+// instead of four and no hi-res row is fetched by two different waves except at a band's edge.  The plain kernel left the row overlap to
+// the caches: 1.67 x the algorithmic bytes from HBM on the fp32 step's three launches (PMC, profiles/r04_i_f32_traffic.json), 2.5 TB/s.
+// Same products, same summation order (a outer, d inner) as upsample2x_bwd_kernel<float>: bitwise the same result.
+template <int RB>
+__global__ __launch_bounds__(256) void upsample2x_bwd_rows_kernel(const float* __restrict__ g_hi, const float* __restrict__ mask,
+                                                                  float* __restrict__ g_lo, int B, int H, int W, int C) {
+  const int cp = C / 4, nb = H / RB;
+  const int64_t total = (int64_t)B * nb * W * cp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cp);
+    int64_t t = idx / cp;
+    const int j = (int)(t % W); t /= W;
+    const int band = (int)(t % nb);
+    const int b = (int)(t / nb);
+    const float* base = g_hi + (int64_t)b * 4 * H * W * C + c * 4;
+    const int64_t xo[4] = {(int64_t)max(2 * j - 1, 0) * C, (int64_t)2 * j * C, (int64_t)(2 * j + 1) * C, (int64_t)min(2 * j + 2, 2 * W - 1) * C};
+    const int i0 = band * RB;
+    float4 win[4][4];
+    {
+      const float* r0 = base + (int64_t)max(2 * i0 - 1, 0) * 2 * W * C;
+      const float* r1 = base + (int64_t)(2 * i0) * 2 * W * C;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { win[0][d] = *(const float4*)(r0 + xo[d]); win[1][d] = *(const float4*)(r1 + xo[d]); }
+    }
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+      const int i = i0 + s;
+      const float* r2 = base + (int64_t)(2 * i + 1) * 2 * W * C;
+      const float* r3 = base + (int64_t)min(2 * i + 2, 2 * H - 1) * 2 * W * C;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { win[2][d] = *(const float4*)(r2 + xo[d]); win[3][d] = *(const float4*)(r3 + xo[d]); }
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float wy = (a == 0 || a == 3) ? 0.25f : 0.75f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float w = wy * ((d == 0 || d == 3) ? 0.25f : 0.75f);
+          const float4 v = win[a][d];
+          acc[0] += w * v.x; acc[1] += w * v.y; acc[2] += w * v.z; acc[3] += w * v.w;
+        }
+      }
+      const int64_t o = (((int64_t)b * H + i) * W + j) * C + c * 4;
+      float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (mask) {
+        const float4 mv = *(const float4*)(mask + o);
+        r.x = mv.x > 0.f ? r.x : 0.f; r.y = mv.y > 0.f ? r.y : 0.f; r.z = mv.z > 0.f ? r.z : 0.f; r.w = mv.w > 0.f ? r.w : 0.f;
+      }
+      *(float4*)(g_lo + o) = r;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { win[0][d] = win[2][d]; win[1][d] = win[3][d]; }
+    }
+  }
+}
+
 static inline unsigned grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
   if (b > 256 * 32) b = 256 * 32;
@@ -870,8 +927,14 @@ extern "C" int sv_upsample2x_bwd(const void* g_hi, const void* y_lo_mask, void* 
                        dim3(256), 0, st, (const bf16_t*)g_hi, (const bf16_t*)y_lo_mask, (bf16_t*)g_lo, B, H, W, C);
   } else if (dtype == SV_F32) {
     if (C % 4) return SV_E_UNSUPPORTED;
-    hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), dim3(grid_for((int64_t)B * H * W * (C / 4))),
-                       dim3(256), 0, st, (const float*)g_hi, (const float*)y_lo_mask, (float*)g_lo, B, H, W, C);
+    static const bool plain = getenv("SV_UPS_BWD_PLAIN") != nullptr;            // A/B knob: one thread per output, sixteen loads each
+    const int64_t band_threads = (int64_t)B * (H / 8) * W * (C / 4);
+    if (!plain && H % 8 == 0 && band_threads >= 256 * 256)                      // (small launches keep the per-output form: more threads)
+      hipLaunchKernelGGL((upsample2x_bwd_rows_kernel<8>), dim3(grid_for(band_threads)), dim3(256), 0, st, (const float*)g_hi,
+                         (const float*)y_lo_mask, (float*)g_lo, B, H, W, C);
+    else
+      hipLaunchKernelGGL((upsample2x_bwd_kernel<float>), dim3(grid_for((int64_t)B * H * W * (C / 4))),
+                         dim3(256), 0, st, (const float*)g_hi, (const float*)y_lo_mask, (float*)g_lo, B, H, W, C);
   } else
     return SV_E_BADARG;
   SV_LAUNCH_CHECK();

@@ -228,6 +228,39 @@ def test_upsample_fwd_bwd(ops, dtype, tol):
     torch.testing.assert_close(glo2.cpu().double(), xr.grad, rtol=tol, atol=4 * tol)
 
 
+def test_fp32_resize_adjoint_row_window_is_bitwise_the_per_output_kernel(lib_built, tmp_path):
+    """upsample2x_bwd_rows_kernel (a thread walks eight low-res rows with the 4 x 4 hi-res window in registers) against the one-thread-per-output
+    kernel (SV_UPS_BWD_PLAIN=1, latched at first use: separate processes): same products in the same order, bit-identical; and against the fp64
+    adjoint of the resize.  Shapes: the fp32 step's three launches at a small batch (band edges, image edges, with and without the ReLU mask)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "outs = []\n"
+        "for (B, H, C) in ((70, 32, 32), (130, 16, 64), (260, 8, 128)):\n"
+        "    ghi = torch.randn(B, 2 * H, 2 * H, C, generator=g).cuda()\n"
+        "    mask = torch.randn(B, H, H, C, generator=g).cuda()\n"
+        "    outs += [ops.upsample2x_bwd(ghi, mask).cpu().numpy(), ops.upsample2x_bwd(ghi, None).cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env in (("rows", {}), ("plain", {"SV_UPS_BWD_PLAIN": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    for key in res[0].files:
+        assert np.array_equal(res[0][key], res[1][key]), key
+        assert np.abs(res[0][key]).max() > 0
+    # the fp64 adjoint on the first shape (no mask)
+    g = torch.Generator().manual_seed(11)
+    ghi = torch.randn(70, 64, 64, 32, generator=g)
+    xr = torch.zeros(70, 32, 32, 32, dtype=torch.float64, requires_grad=True)
+    torch_ref.resize_bilinear_2x(xr).backward(ghi.double())
+    torch.testing.assert_close(torch.from_numpy(res[0]["arr_1"]).double(), xr.grad, rtol=1e-6, atol=4e-6)
+
+
 def test_upsample_stencil_kat(ops):
     """tf.image.resize half-pixel stencil on i^2: [0, .25, .75, 1.75, ...]."""
     H = 8
