@@ -5,11 +5,12 @@ One "step" = patch scramble (incl. the per-image random permutation) + forward +
 + Keras-Adam (+ RCCL gradient all-reduce for N>1) on one synthetic CelebA-64 batch that is already
 resident in HBM, i.e. train_step_lg_vae (vae/trainer.py:120-144) behind the augmentation of
 vae/main.py:57-61.  Workload (BASELINE.json metric: "SPLIT-VAE CelebA-64 bs512"): H=W=64,
-beta=120, patch_size=8, latents 128+128, lr 1e-4, bf16 MFMA contractions with fp32 accumulate /
-master weights / ELBO / Adam.  The metric's batch is GLOBAL: `--gpus N` splits 512 images evenly over the N ranks
-(strong scaling: 64 per GPU at N = 8) and `value` is the whole-job aggregate 512*K / t; the weak-scaling
-figure (512 per GPU) rides along as `weak` in the N > 1 line, and `--batch B` makes it the headline instead.  The same line
-carries the reference-precision (fp32) step as a first-class block `fp32` with its own roofline.
+beta=120, patch_size=8, latents 128+128, lr 1e-4.  The headline (`value`, `ms_per_step`, `dtype`, `roofline`) is the step at the
+REFERENCE'S precision: fp32 operands and accumulation (exact-fp32 MFMA, graded against the 157.3 TFLOP/s fp32 matrix peak); the bf16-operand
+step (BASELINE config 2's throughput mode) rides along as the named block `bf16` with its own roofline (`--dtype bf16` swaps the two).
+The metric's batch is GLOBAL: `--gpus N` splits 512 images evenly over the N ranks (strong scaling: 64 per GPU at N = 8, SURVEY 8d
+config C4) and `value` is the whole-job aggregate 512*K / t; the weak-scaling figure (512 per GPU) rides along as `weak` in the N > 1
+line, and `--batch B` makes it the headline instead.
 
     python bench.py                                  # N=1, 200 timed steps
     python bench.py --gpus N --steps K --warmup W    # N>1: spawns N ranks itself (one per GPU, RCCL), or runs as one
@@ -20,10 +21,11 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      dominant kernel (hipEvent-timed inside the timed region on its launch stream), the decoder conv stack
                 aggregate (north_star's >= 70 % target) and the HBM-bound ELBO kernel
   cpu_baseline  the oracle restatement timed on the host cores (N=1 only; reported baseline, not the target)
-  fp32          (N=1) the same step at the reference's own precision (exact-fp32 MFMA): value, ms_per_step and a roofline block
-                (dominant kernel live + serial, decoder conv stack) against the 157.3 TFLOP/s fp32 matrix peak
+  bf16          the same step with bf16 operands (fp32 accumulate / master weights / ELBO / Adam): value, ms_per_step and (N=1) a roofline
+                block (dominant kernel live + serial, decoder conv stack) against the 2.5 PFLOP/s bf16 peak
   rows          the other configurations of BASELINE.md section 4 measured in the same process, outside the timed region:
-                SVHN-32 B=64, the 64- and 128-image shards of config 4 (strong scaling), SPLIT-GMVAE, SPLIT-SPAIR
+                CelebA-64 bs256 bf16 (configs[1]), SVHN-32 B=64, the 64- and 128-image shards of config 4 at both precisions, one rank
+                through the data-parallel path (dp_path_b64), SPLIT-GMVAE, SPLIT-SPAIR (Multi-Bird-Hard and -Easy flag sets)
   rccl_ranks / allreduce_ms / weak   (N>1) the collective actually used, its per-bucket time, the 512-per-GPU (weak scaling) row
 The per-launch table goes to stderr.
 """
@@ -43,7 +45,7 @@ split_vae_amd.configure_hw_queues()                 # before any HIP call (a 4th
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}
-PROFILE_TAGS = ("r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
+PROFILE_TAGS = ("r05", "r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
 
 
 def _traffic_file(dtype="bf16"):
@@ -283,19 +285,34 @@ def wgrad_main_layers(images_per_launch, dtype, world=1):
     return ["e1", "e2", "d4"] if dtype == "bf16" and os.environ.get("SV_NO_WGRAD_ROLL") is None else ["e1", "e2", "d5"]
 
 
-def spair_row(dev, B=32, steps=60, warmup=5):
-    """SPLIT-SPAIR (config 5, README.md:93: lg_spair -split_z_l -concat_z_what -dense_local -dense_bg; 48x48 canvases, batch 32 as the
-    reference hard-codes) train step: forward + losses + autograd backward over the split_vae::* operators + clipnorm Adam, captured
-    into one hipGraph and replayed (spair_trainer.GraphedTrainStep); fp32 like the reference and with bf16 convolutions."""
+SPAIR_FLAGS = {
+    # README.md:107 (SPLIT-VAE on Multi-Bird-Hard, dataset cub_ckb_rot_6) -- BASELINE configs[4]
+    "hard": dict(model="lg_spair", latent_size=64, bg_latent_size=64, local_latent_size=64, patch_size=8, z_bg_beta=1.0, z_what_beta=0.5,
+                 split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True),
+    # README.md:93 (SPLIT-VAE on Multi-Bird-Easy, dataset cub_solid_fixed)
+    "easy": dict(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
+                 split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True),
+}
+SPAIR_WORKLOAD = {
+    "hard": "SPLIT-SPAIR (lg_spair) Multi-Bird-Hard flag set, README.md:107: --z_bg_beta 1 --patch_size 8 --latent_size 64 --bg_latent_size 64 "
+            "--local_latent_size 64 -split_z_l --z_what_beta 0.5 -concat_z_what -dense_local -dense_bg; batch 32 (spair/main.py default); canvases "
+            "48x48 (the reference hard-codes 48x48 and a 4x4 cell grid, spair/spair.py:99,411: BASELINE's '128x128' label is stale), synthetic",
+    "easy": "SPLIT-SPAIR (lg_spair) Multi-Bird-Easy flag set, README.md:93: --z_bg_beta 10 --patch_size 8 --latent_size 64 --bg_latent_size 4 "
+            "--local_latent_size 4 -split_z_l -concat_z_what -dense_local -dense_bg; batch 32; canvases 48x48 (hard-coded in the reference), synthetic",
+}
+
+
+def spair_row(dev, which="hard", B=32, steps=60, warmup=5):
+    """SPLIT-SPAIR (config 5; `which` picks README.md:107 Multi-Bird-Hard -- what BASELINE names -- or README.md:93 Multi-Bird-Easy) train step:
+    forward + losses + backward + clipnorm Adam as one native launch sequence (sv_tape_run); fp32 like the reference and with bf16 convolutions."""
     import torch
     from split_vae_amd import spair, spair_main, spair_trainer
     from split_vae_amd.augmentation import Augmentator
-    out = {"unit": "images/s", "batch": B, "steps": steps,
+    out = {"unit": "images/s", "batch": B, "steps": steps, "workload": SPAIR_WORKLOAD[which],
            "launch": "one native launch sequence per step (sv_tape_run: forward, losses, adjoint, Adam; eager launches); f32 = the reference's "
                      "precision, bf16 = bf16 operands in the spatial convolutions only"}
     for dt_ in ("f32", "bf16"):
-        cfg = spair_main.default_config(model="lg_spair", latent_size=64, bg_latent_size=4, local_latent_size=4, patch_size=8, z_bg_beta=10.0,
-                                        split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True, dtype=dt_)
+        cfg = spair_main.default_config(dtype=dt_, **SPAIR_FLAGS[which])
         model = spair.get_model(cfg, device=dev, seed=0)
         x, _ = spair_main.synthetic_canvases(B, seed=1, device=dev)
         images = Augmentator("scramble", size=cfg.patch_size, seed=2).augment(x)
@@ -412,18 +429,22 @@ def print_table(table, dtype, H, B):
                          (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
 
 
-def fp32_block(dev, H, B, steps=40, warmup=5):
-    """The step at the reference's own precision (vae/model.py:12: fp32 end to end; exact-fp32 MFMA here) as a first-class measurement: the
-    same timed protocol as the headline (W untimed + K timed steps between synchronizes), its own serial table and roofline block graded
-    against the 157.3 TFLOP/s fp32 matrix peak."""
+DTYPE_NOTE = {"f32": "f32 operands, f32 accumulate (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the reference's precision (vae/model.py:12)",
+              "bf16": "bf16 operands, fp32 accumulate / master weights / ELBO / Adam (BASELINE config 2's throughput mode; narrower than the reference's fp32)"}
+
+
+def precision_block(dev, H, B, dtype, steps=40, warmup=5):
+    """The same step at the OTHER precision as a first-class measurement (the headline is the reference's fp32; this is the bf16 throughput
+    mode of BASELINE config 2 -- or the fp32 step when --dtype bf16 makes bf16 the headline): the same timed protocol (W untimed + K timed
+    steps between synchronizes), its own serial table and roofline block graded against that precision's dense MFMA peak."""
     import torch
-    w = Workload(H, B, "f32", dev, 0, 1)
+    w = Workload(H, B, dtype, dev, 0, 1)
     for _ in range(warmup):
         w.step()
     torch.cuda.synchronize()
     plan, table = kernel_table(w)
-    print_table(table, "f32", H, B)
-    dom, worst = pick_rows(table, "f32")
+    print_table(table, dtype, H, B)
+    dom, worst = pick_rows(table, dtype)
     plan.profile_filter(dom["name"])
     plan.profile_enable(True)
     dt = w.timed(steps, warmup, 1, dev)
@@ -431,11 +452,10 @@ def fp32_block(dev, H, B, steps=40, warmup=5):
     plan.profile_enable(False)
     value = B * steps / dt
     out = {"value": round(value, 1), "unit": "images/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps, "warmup": warmup,
-           "dtype": "f32 operands, f32 accumulate (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the reference's precision",
-           "per_gpu_batch": B,
+           "dtype": DTYPE_NOTE[dtype], "per_gpu_batch": B,
            "step_tflops": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12, 2),
-           "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS["f32"], 4),
-           "roofline": roofline_block(table, dom, worst, prof, "f32", B, 1)}
+           "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[dtype], 4),
+           "roofline": roofline_block(table, dom, worst, prof, dtype, B, 1)}
     del w
     return out
 
@@ -449,10 +469,12 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="total batch split evenly over the GPUs (default 512 = BASELINE.json's metric: 64 per GPU at N=8, SURVEY config C4)")
     ap.add_argument("--size", type=int, default=64, choices=[32, 64])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="f32", choices=["bf16", "f32"],
+                    help="the headline's precision: f32 = the reference's (default); the other precision rides along as a named block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the extra configurations (SVHN-32, small shards, SPLIT-GMVAE, SPLIT-SPAIR)")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the reference-precision (fp32) block")
+    ap.add_argument("--no-other-precision", "--no-fp32", dest="no_other", action="store_true",
+                    help="skip the block of the other precision (`bf16` beside the fp32 headline)")
     ap.add_argument("--table-only", type=int, default=0, metavar="PASSES",
                     help="run PASSES passes of the serial per-launch table and stop (for `rocprofv3 --kernel-trace --stats`: kernel durations alone on the chip, "
                          "what `roofline.serial` and the fractions of the table quote)")
@@ -540,30 +562,63 @@ def main():
                              "ms_per_step": round(1e3 * dts / ks, 4), "steps": ks, "scaling": "weak"}
             del ws
     rows = {}
-    fp32 = None
-    if world == 1 and not args.no_fp32 and args.dtype == "bf16":
-        fp32 = fp32_block(dev, H, B)                           # reference precision, first-class (own roofline): VERDICT r03 item 3b
-    if world == 1 and not args.no_rows and H == 64 and args.dtype == "bf16" and B == 512:
-        def row(Hr, Br, dt_, steps, warm=10):
-            wr = Workload(Hr, Br, dt_, dev, 0, 1)
+    other = None
+    other_dt = "bf16" if args.dtype == "f32" else "f32"
+    if world == 1 and not args.no_other:
+        # N = 1: the full block (own serial table + roofline), 200 timed steps for the sub-2-ms bf16 step, 40 for fp32
+        other = precision_block(dev, H, B, other_dt, steps=200 if other_dt == "bf16" else 40, warmup=10 if other_dt == "bf16" else 5)
+    elif world > 1 and not args.no_other:
+        # N > 1: the other precision's whole-job rate through the same data-parallel path (no table: the serial table is an N = 1 measurement)
+        wo = Workload(H, B, other_dt, dev, rank, world, svdist.make_reducer)
+        ko = max(args.steps, 60)
+        dto = wo.timed(ko, 10, world, dev)
+        other = {"value": round(world * B * ko / dto, 1), "unit": "images/s", "ms_per_step": round(1e3 * dto / ko, 4), "steps": ko, "warmup": 10,
+                 "dtype": DTYPE_NOTE[other_dt], "per_gpu_batch": B, "global_batch": world * B}
+        del wo
+    if world == 1 and not args.no_rows and H == 64 and B == 512:
+        def row(Hr, Br, dt_, steps, warm=10, reducer_cls=None, workload=None):
+            wr = Workload(Hr, Br, dt_, dev, 0, 1, reducer_cls)
             t = wr.timed(steps, warm, 1, dev)
-            r = {"value": round(Br * steps / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t / steps, 4), "steps": steps,
+            r = {"value": round(Br * steps / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t / steps, 4), "steps": steps, "dtype": dt_,
                  "step_tflops": round(Br * steps / t * TRAIN_FLOP_PER_IMAGE[Hr] / 1e12, 2)}
             r["frac_of_peak"] = round(r["step_tflops"] / PEAK_TFLOPS[dt_], 4)
+            if workload:
+                r["workload"] = workload
             return r
-        rows["celeba64_b256"] = row(64, 256, "bf16", 200)      # config 2 (BASELINE.json configs[1]: CelebA-64 bs256 bf16 on one MI355X)
+        rows["celeba64_b256"] = row(64, 256, "bf16", 200, workload="BASELINE configs[1]: SPLIT-VAE CelebA-64 beta=120 patch_size=8 bs256 bf16 on one MI355X")
+        rows["celeba64_b256_f32"] = row(64, 256, "f32", 60)
         rows["svhn32_b64"] = row(32, 64, "bf16", 200)          # config C1's shape on the GPU
+        rows["svhn32_b64_f32"] = row(32, 64, "f32", 200, workload="BASELINE configs[0]'s shape (SVHN-32 beta=40 patch_size=1 bs64) at the reference's precision")
         try:
             rows["lggmvae_svhn32_b64"] = gm_row(dev)             # config 3 (SPLIT-GMVAE)
         except Exception as e:
             rows["lggmvae_svhn32_b64"] = {"error": repr(e)[:200]}
-        rows["celeba64_b64"] = row(64, 64, "bf16", 200)        # config 4's per-GPU shard (512 / 8)
+        # config 4's per-GPU shards (global 512 over 8 / 4 GPUs), both precisions: what bounds strong scaling before any link time
+        rows["celeba64_b64"] = row(64, 64, "bf16", 200)
         rows["celeba64_b128"] = row(64, 128, "bf16", 200)
-        rows["long_run"] = {"steps": 400, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
+        rows["celeba64_b64_f32"] = row(64, 64, "f32", 100)
+        rows["celeba64_b128_f32"] = row(64, 128, "f32", 100)
+        rows["long_run"] = {"steps": 400, "dtype": args.dtype, "ms_per_step": round(1e3 * w.timed(400, 0, 1, dev) / 400, 4)}
         try:
-            rows["lg_spair_b32"] = spair_row(dev)                  # config 5 (SPLIT-SPAIR), the next row of SURVEY 8f
+            rows["lg_spair_b32"] = spair_row(dev, "hard")          # config 5 (SPLIT-SPAIR, Multi-Bird-Hard: README.md:107), SURVEY 8f F4
+            rows["lg_spair_easy_b32"] = spair_row(dev, "easy")     # README.md:93 (Multi-Bird-Easy)
         except Exception as e:                                    # never at the headline's expense
             rows["lg_spair_b32"] = {"error": repr(e)[:200]}
+        # config 4's shard through the DATA-PARALLEL path with a world of one rank (process group, phase split, RCCL all-reduce of every bucket
+        # over one rank): what the DP host path costs on top of rows.celeba64_b64*.  In a FRESH process each, as a rank of a real job is (this
+        # process has run five model families by now: its streams and allocator state are not a rank's).
+        rows["dp_path_b64"] = {"workload": "config 4's 64-image shard, one rank through the RCCL path (SV_DIST_FORCE=1), a fresh process per precision"}
+        for k in ("f32", "bf16"):
+            try:
+                env = dict(os.environ, SV_DIST_FORCE="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", "64", "--dtype", k, "--steps", "200" if k == "bf16" else "100",
+                                    "--warmup", "10", "--no-rows", "--no-other-precision", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+                c = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                base = rows["celeba64_b64" + ("_f32" if k == "f32" else "")]["ms_per_step"]
+                rows["dp_path_b64"][k] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "steps": c["steps"],
+                                          "backend": c.get("dist_backend"), "vs_plain_step": round(c["ms_per_step"] / base, 4)}
+            except Exception as e:
+                rows["dp_path_b64"][k] = {"error": repr(e)[:200]}
 
     if rank != 0:
         if torch.distributed.is_initialized():
@@ -576,7 +631,7 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
-        "dtype": "bf16 operands, fp32 accumulate (reference: fp32; the fp32 step is the `fp32` block of this line)" if args.dtype == "bf16" else "f32",
+        "dtype": DTYPE_NOTE[args.dtype] + ("" if args.dtype == "f32" else "; the fp32 step is the `fp32` block of this line"),
         "dtype_short": args.dtype, "data": "synthetic",
         "config": {"workload": "SPLIT-VAE %s %dx%d beta=%g patch_size=%d latents=128+128 lr=1e-4, full train step "
                                "(scramble+fwd+ELBO+bwd+Adam%s), per-GPU batch %d" %
@@ -595,8 +650,8 @@ def main():
     rl = roofline_block(table, dom, worst, prof, args.dtype, B, world)
     if rl:
         out["roofline"] = rl
-    if fp32 is not None:
-        out["fp32"] = fp32
+    if other is not None:
+        out["bf16" if other_dt == "bf16" else "fp32"] = other
     if rows:
         out["rows"] = rows
     if world == 1 and not args.no_cpu_baseline:

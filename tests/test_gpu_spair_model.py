@@ -16,6 +16,9 @@ CONFIGS = {
     # the conv image encoders / decoders, the backbone concat and the un-split loss branch
     "lg_spair_conv": dict(model="lg_spair", latent_size=32, bg_latent_size=8, local_latent_size=16, concat_backbone=True,
                           concat_z_what=True),
+    # README.md:107 (SPLIT-SPAIR on Multi-Bird-Hard: BASELINE.json configs[4]): 64-wide background / local latents, z_bg_beta 1, z_what_beta 0.5
+    "lg_spair_hard": dict(model="lg_spair", latent_size=64, bg_latent_size=64, local_latent_size=64, patch_size=8, z_bg_beta=1.0, z_what_beta=0.5,
+                          split_z_l=True, concat_z_what=True, dense_local=True, dense_bg=True),
 }
 OUT_NAMES = ["x_recon", "z_what", "z_what_mean", "z_what_sigma", "z_where", "z_where_mean", "z_where_sigma", "z_depth", "z_depth_mean",
              "z_depth_sigma", "z_pres", "z_pres_logits", "z_pres_pre_sigmoid", "all_glimpses", "obj_recon_unnorm", "obj_recon_alpha",
@@ -220,9 +223,10 @@ def test_spair_cli_trains_on_synthetic_canvases(lib_built, capsys, extra):
     assert all(np.isfinite(v) for v in hist[-1]["train"].values())
 
 
-def test_spair_step_matches_the_golden_fixture(lib_built):
-    """The committed SPLIT-SPAIR vectors (tests/golden/lgspair_b2.npz: README.md:93's model, batch 2, step 41; made from the fp64
-    restatement) against the device step: inputs from the fixture, variables and draws regenerated from their seeds."""
+@pytest.mark.parametrize("fixture", ["lgspair_b2.npz", "lgspair_hard_b2.npz"])
+def test_spair_step_matches_the_golden_fixture(lib_built, fixture):
+    """The committed SPLIT-SPAIR vectors (tests/golden/lgspair_b2.npz: README.md:93's model; lgspair_hard_b2.npz: README.md:107's = BASELINE
+    config 5; batch 2, step 41; made from the fp64 restatement) against the device step: inputs from the fixture, variables and draws regenerated from their seeds."""
     import os
     from oracle import spair_model_ref as R
     from split_vae_amd import spair, spair_trainer
@@ -232,8 +236,8 @@ def test_spair_step_matches_the_golden_fixture(lib_built):
     spec = importlib.util.spec_from_file_location("make_golden_spair", os.path.join(sys_path, "make_golden_spair.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
-    G = np.load(os.path.join(sys_path, "lgspair_b2.npz"))
-    cfg = R.default_config(**mk.CONFIG)
+    G = np.load(os.path.join(sys_path, fixture))
+    cfg = R.default_config(**mk.FIXTURES[fixture])
     p = R.init_params(cfg, seed=mk.SEED_W)
     noise = {k: v.float().cuda() for k, v in R.draw_noise(cfg, mk.B, seed=mk.SEED_N).items()}
     model = spair.get_model(dotdict(cfg), seed=0)
@@ -255,10 +259,13 @@ def test_spair_step_matches_the_golden_fixture(lib_built):
         s = f[mk.sample_idx(f.size)]
         assert np.linalg.norm(s - G["sample/" + k]) <= 5e-4 * max(np.linalg.norm(G["sample/" + k]), 1e-12), k
     gn = np.array([float(g.norm()) for g in grads])
-    np.testing.assert_allclose(gn, G["grad_norms"], rtol=5e-3)
+    # bound per variable: 5e-3, or 3x what fp32 rounding alone does to this norm on the CPU (the fixture's grad_norms_f32: the same graph in fp32)
+    tol = np.maximum(5e-3, 3.0 * np.abs(G["grad_norms_f32"] - G["grad_norms"]) / np.maximum(G["grad_norms"], 1e-30))
+    bad = np.abs(gn - G["grad_norms"]) > tol * np.abs(G["grad_norms"])
+    assert not bad.any(), (np.nonzero(bad)[0], gn[bad], G["grad_norms"][bad], tol[bad])
 
 
-@pytest.mark.parametrize("name", ["spair", "lg_spair_readme"])
+@pytest.mark.parametrize("name", ["spair", "lg_spair_readme", "lg_spair_hard"])
 def test_native_step_tracks_the_autograd_step(lib_built, name, monkeypatch):
     """The native launch sequence (spair_native.NativeStep: one sv_tape_run per step) against the torch-autograd graph over the same
     kernels' operators, four Adam steps from the same variables and pinned draws: same losses (2e-4), variables within 1e-3 of the
@@ -277,7 +284,9 @@ def test_native_step_tracks_the_autograd_step(lib_built, name, monkeypatch):
             monkeypatch.setenv("SV_SPAIR_AUTOGRAD", "1")
         model = spair.get_model(cfg, seed=2)
         start = model.store.flat.clone()
-        opt = spair_trainer.ClipnormAdam(learning_rate=1e-3, clipnorm=1.0)
+        # (lg_spair_hard: at the reference's own learning rate, spair/main.py:20 -- at 1e-3 its two 64-wide KL terms drift 6e-3 apart in three
+        #  steps through the sign-of-noise moves described below, 16x as many entries as the 4-wide latents of README.md:93)
+        opt = spair_trainer.ClipnormAdam(learning_rate=1e-4 if name == "lg_spair_hard" else 1e-3, clipnorm=1.0)
         hist = []
         for step in range(7, 11):
             _, losses = spair_trainer.train_step(model, images, opt, step, cfg, noise=noise)

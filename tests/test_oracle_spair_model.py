@@ -114,8 +114,9 @@ def test_clipnorm_adam_first_step():
     assert torch.allclose(m2[0], 0.1 * g[0]) and torch.allclose(m2[1], 0.1 * g[1])
 
 
-def test_oracle_reproduces_the_committed_spair_fixture():
-    """tests/golden/lgspair_b2.npz (made by tests/golden/make_golden_spair.py from this restatement): any change to the oracle's
+@pytest.mark.parametrize("fixture", ["lgspair_b2.npz", "lgspair_hard_b2.npz"])
+def test_oracle_reproduces_the_committed_spair_fixture(fixture):
+    """tests/golden/lgspair_b2.npz (README.md:93, Multi-Bird-Easy) and lgspair_hard_b2.npz (README.md:107, Multi-Bird-Hard = BASELINE config 5) (made by tests/golden/make_golden_spair.py from this restatement): any change to the oracle's
     arithmetic shows up here before it silently moves the GPU tests' target."""
     import importlib.util
     import os
@@ -123,8 +124,8 @@ def test_oracle_reproduces_the_committed_spair_fixture():
     spec = importlib.util.spec_from_file_location("make_golden_spair", os.path.join(here, "golden", "make_golden_spair.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    got = mod.compute()
-    with np.load(os.path.join(here, "golden", "lgspair_b2.npz")) as G:
+    got = mod.compute(mod.FIXTURES[fixture])
+    with np.load(os.path.join(here, "golden", fixture)) as G:
         assert set(G.files) == set(got)
         for k in G.files:
             np.testing.assert_allclose(got[k], G[k], rtol=1e-9, atol=1e-12, err_msg=k)
