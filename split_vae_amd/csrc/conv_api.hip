@@ -14,6 +14,43 @@
 template <typename T>
 __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
                                            T* __restrict__ arena, int block_in_job) {
+  if (j.poly >= 3) {
+    // per-class polyphase (conv_geom.h: svg_polyc); source: the pk x pk HWIO master
+    const int total = j.poly == 3 ? j.rows * j.ntaps * j.inner : 2 * (j.pk - 1) * j.pk * j.rows * j.inner;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* w = params + j.src_off;
+    const int K = j.pk, pad = (K - 1) / 2, ci = idx % j.inner;
+    float v = 0.f;
+    if (j.poly == 3) {
+      // [co][t = txi * nty + tyi][ci]: W'_c[ty,tx] = sum_{ky,kx} cy(py,ky,ty) cx(px,kx,tx) w[ky,kx]
+      const int py = j.pcls >> 1, px = j.pcls & 1;
+      int ty0, tx0;
+      const int nty = svg_polyc_taps(K, py, &ty0);
+      (void)svg_polyc_taps(K, px, &tx0);
+      const int t = (idx / j.inner) % j.ntaps, co = idx / (j.inner * j.ntaps);
+      const int ty = ty0 + t % nty, tx = tx0 + t / nty;
+      if (co < j.Cout && ci < j.Cin)
+        for (int ky = 0; ky < K; ++ky) {
+          const float cy = svg_pcoef(py, ky, ty, pad);
+          if (cy == 0.f) continue;
+          for (int kx = 0; kx < K; ++kx) {
+            const float cx = svg_pcoef(px, kx, tx, pad);
+            if (cx != 0.f) v += cy * cx * w[((int64_t)(ky * K + kx) * j.Cin + ci) * j.Cout + co];
+          }
+        }
+    } else {
+      // [cls][tap][co][ci] = -(sum over the taps k that leave the image at border class cls % (K-1)); classes 0 .. K-2: hi-res ROWS (tap = kx, the sum
+      // runs over ky), K-1 .. 2K-3: COLUMNS (tap = ky, the sum runs over kx)
+      const int co = (idx / j.inner) % j.rows, tap = (idx / (j.inner * j.rows)) % K, cls = idx / (j.inner * j.rows * K);
+      const int c = cls % (K - 1);
+      if (co < j.Cout && ci < j.Cin)
+        for (int k = 0; k < K; ++k)
+          if (svg_polyc_excl(K, c, k)) v -= w[((int64_t)(cls < K - 1 ? k * K + tap : tap * K + k) * j.Cin + ci) * j.Cout + co];
+    }
+    arena[j.dst_off + idx] = from_f32<T>(v);
+    return;
+  }
   if (j.poly) {
     // composite images of the polyphase head (conv_geom.h: svg_poly); source: the 6x6 HWIO master
     const int total = j.rows * j.ntaps * j.inner;
@@ -426,6 +463,55 @@ void svg_prep_job_polyfix(const sv_conv_desc* d, PrepJob* j) {
   j->nblocks = (j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);
 }
 
+// ---- per-class polyphase (conv_geom.h: svg_polyc)
+void svg_polyc_fwd_args(const sv_conv_desc* d, int cls, TapGemmArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int epp = svg_epp(d), cpad = svg_cin_pad(d), h = d->H / 2, w = d->W / 2, K = d->KH;
+  const int py = cls >> 1, px = cls & 1;
+  int ty0, tx0;
+  const int nty = svg_polyc_taps(K, py, &ty0), ntx = svg_polyc_taps(K, px, &tx0);
+  a->M = d->B * h * w;
+  a->lOY = ilog2_exact(h); a->lOX = ilog2_exact(w); a->OY = h; a->OX = w;
+  a->IH = h; a->IW = w; a->lda = d->ldx;
+  a->cl2 = ilog2_exact(cpad / epp);
+  a->ntaps = nty * ntx; a->Ktot = a->ntaps * cpad; a->P = a->Ktot / epp;
+  a->S = 1; a->SX = 1; a->N = d->Cout;
+  a->OHF = d->H; a->OWF = d->W; a->OS = 2; a->ooy = py; a->oox = px; a->ldo = d->ldy;
+  a->act = d->act; a->out_f32 = 0; a->splitk = 1; a->ups = 0; a->clampin = 1;
+  a->fix_nc = svg_polyc_nclass(K); a->fix_pad = (K - 1) / 2;
+  for (int txi = 0; txi < ntx; ++txi)
+    for (int tyi = 0; tyi < nty; ++tyi) { a->dy[txi * nty + tyi] = (int8_t)(ty0 + tyi); a->dx[txi * nty + tyi] = (int8_t)(tx0 + txi); }
+}
+
+void svg_prep_job_polyc(const sv_conv_desc* d, int cls, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  static const int BNt[4] = {128, 64, 32, 16};
+  int t0;
+  j->Cin = d->Cin; j->Cout = d->Cout;
+  j->rows = round_up(d->Cout, BNt[svg_pick_cfg(d->Cout)]);
+  j->inner = svg_cin_pad(d); j->inner_ld = j->inner;
+  j->ntaps = svg_polyc_taps(d->KH, cls >> 1, &t0) * svg_polyc_taps(d->KH, cls & 1, &t0);
+  j->poly = 3; j->pk = d->KH; j->pcls = cls;
+  j->nblocks = (j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);
+}
+
+void svg_prep_job_polyc_fix(const sv_conv_desc* d, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  j->Cin = d->Cin; j->Cout = d->Cout;
+  j->rows = d->Cout; j->inner = svg_cin_pad(d); j->inner_ld = j->inner; j->ntaps = d->KH;
+  j->poly = 4; j->pk = d->KH;
+  j->nblocks = (int)((svg_polyc_fix_elems(d) + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS));
+}
+
+int64_t svg_polyc_class_elems(const sv_conv_desc* d, int cls) {
+  PrepJob j;
+  svg_prep_job_polyc(d, cls, &j);
+  return ((int64_t)j.rows * j.ntaps * j.inner + 127) / 128 * 128;      // every class image 128-element aligned
+}
+int64_t svg_polyc_fix_elems(const sv_conv_desc* d) { return (int64_t)2 * (d->KH - 1) * d->KH * d->Cout * svg_cin_pad(d); }
+// row-class terms [B][K-1][W][Cout] + column-class terms [B][H][K-1][Cout], fp32 (H, W: the hi-res extent)
+int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d) { return (int64_t)d->B * (d->KH - 1) * (d->H + d->W) * d->Cout * 4; }
+
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
   memset(j, 0, sizeof(*j));
   static const int BNt[4] = {128, 64, 32, 16};
@@ -442,6 +528,11 @@ void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
 
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
   PrepJob j;
+  if (!for_dgrad && svg_polyc(d)) {          // the four class images, then the border-class image
+    int64_t n = svg_polyc_fix_elems(d);
+    for (int c = 0; c < 4; ++c) n += svg_polyc_class_elems(d, c);
+    return n;
+  }
   if (for_dgrad) svg_prep_job_dgrad(d, cls, &j); else svg_prep_job_fwd(d, &j);
   return (int64_t)j.rows * j.ntaps * j.inner + (!for_dgrad && svg_poly(d) ? SV_POLY_FIX_ELEMS(svg_cin_pad(d)) : 0);
 }
@@ -461,7 +552,21 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
   if (rc != SV_OK) return rc;
   if (!w_hwio) return SV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (w_fwd) {
+  if (w_fwd && svg_polyc(d)) {
+    PrepJob j;
+    int64_t off = 0;
+    for (int c = 0; c < 4; ++c) {
+      svg_prep_job_polyc(d, c, &j);
+      j.dst_off = off;
+      rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
+      if (rc) return rc;
+      off += svg_polyc_class_elems(d, c);
+    }
+    svg_prep_job_polyc_fix(d, &j);
+    j.dst_off = off;
+    rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
+    if (rc) return rc;
+  } else if (w_fwd) {
     PrepJob j;
     svg_prep_job_fwd(d, &j);
     rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
@@ -492,7 +597,37 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
 // (fix kernel first, added by the conv's epilogue); without one they are added to y with atomics after the conv.
 extern "C" int64_t sv_conv2d_fwd_workspace_bytes(const sv_conv_desc* d) {
   if (svg_check(d) != SV_OK) return -1;
+  if (svg_polyc(d)) return svg_polyc_fix_ws_bytes(d);
   return svg_poly(d) ? svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) : 0;
+}
+
+// the four class problems + the border kernel of n <= 2 per-class polyphase layers (svg_polyc) of one geometry; w_fwd[i] = the image
+// sv_conv2d_prep_weights / the plan's jobs laid out (classes 0..3, then the border classes), fixws[i] = svg_polyc_fix_ws_bytes(d) bytes
+int svk_polyc_fwd_multi(const sv_conv_desc* d, int n, const void* const* x, const void* const* w_fwd, const float* const* bias, void* const* y,
+                        void* const* fixws, hipStream_t st) {
+  if (n < 1 || n > 2) return SV_E_BADARG;
+  const size_t esz = d->dtype == SV_BF16 ? 2 : 4;
+  const int K = d->KH, nc = svg_polyc_nclass(K);
+  int64_t coff[5] = {0, 0, 0, 0, 0};
+  for (int c = 0; c < 4; ++c) coff[c + 1] = coff[c] + svg_polyc_class_elems(d, c);
+  const void* wfix[2];
+  float *frow[2], *fcol[2];
+  for (int i = 0; i < n; ++i) {
+    wfix[i] = (const char*)w_fwd[i] + coff[4] * esz;
+    frow[i] = (float*)fixws[i];
+    fcol[i] = frow[i] + (int64_t)d->B * nc * d->W * d->Cout;
+  }
+  int rc = svk_polyc_fix_multi(n, x, wfix, frow, fcol, d->B, d->H / 2, d->W / 2, svg_cin_pad(d), d->Cout, K, d->dtype, st);
+  if (rc) return rc;
+  TapGemmArgs a[SV_MAX_MULTI];
+  for (int i = 0; i < n; ++i)
+    for (int c = 0; c < 4; ++c) {
+      TapGemmArgs& t = a[i * 4 + c];
+      svg_polyc_fwd_args(d, c, &t);
+      t.A = x[i]; t.Wt = (const char*)w_fwd[i] + coff[c] * esz; t.bias = bias ? bias[i] : nullptr; t.out = y[i];
+      t.fix = frow[i]; t.fix2 = fcol[i];
+    }
+  return svk_conv_dispatch_multi(a, 4 * n, d->dtype, svg_pick_cfg(d->Cout), st);
 }
 
 // im2col tile for a layer the tile kernel does not plan (non-power-of-two grids, stride 3: SPAIR's backbone): when the
@@ -510,6 +645,10 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
   int rc = svg_check(d);
   if (rc != SV_OK) return rc;
   if (!x || !w_fwd || !y) return SV_E_BADARG;
+  if (svg_polyc(d)) {
+    if (!ws || ws_bytes < svg_polyc_fix_ws_bytes(d)) return SV_E_WORKSPACE;    // the border terms travel through the workspace
+    return svk_polyc_fwd_multi(d, 1, &x, &w_fwd, &bias, &y, &ws, (hipStream_t)stream);
+  }
   TapGemmArgs a;
   svg_fwd_args(d, &a);
   a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
@@ -528,17 +667,17 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
     }
     return svk_conv_dispatch(a, d->dtype, svg_im2col_cfg(a, svg_pick_cfg(d->Cout)), (hipStream_t)stream);
   }
-  const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * 2;
+  const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * (d->dtype == SV_BF16 ? 2 : 4);
   float* yf = (float*)y;
   float* fixbuf = ws && ws_bytes >= svk_poly_fix_ws_bytes(d->B, d->H / 2, d->W / 2) ? (float*)ws : nullptr;
   if (fixbuf) {
-    rc = svk_poly_fix_multi(1, &x, &wfix, nullptr, &fixbuf, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream);
+    rc = svk_poly_fix_multi(1, &x, &wfix, nullptr, &fixbuf, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream, d->dtype);
     if (rc) return rc;
     a.fix = fixbuf;
   }
   rc = svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cout), (hipStream_t)stream);
   if (rc == SV_OK && !fixbuf)
-    rc = svk_poly_fix_multi(1, &x, &wfix, &yf, nullptr, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream);
+    rc = svk_poly_fix_multi(1, &x, &wfix, &yf, nullptr, d->B, d->H / 2, d->W / 2, d->ldx, d->Cout, (hipStream_t)stream, d->dtype);
   return rc;
 }
 
@@ -630,14 +769,14 @@ void svg_poly_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
 // accumulated like sv_conv2d_nhwc_wgrad; workspace of sv_conv2d_wgrad_poly_workspace_bytes, whose first use must find it zeroed.
 extern "C" int64_t sv_conv2d_wgrad_poly_workspace_bytes(const sv_conv_desc* d) {
   if (svg_check(d) != SV_OK) return -1;
-  if (!svg_poly(d)) return 0;
+  if (!svg_poly(d) || d->dtype != SV_BF16) return 0;         // (fp32: the x-packed weight gradient, sv_conv2d_nhwc_wgrad_ws)
   return SV_WGRAD_WS_BYTES + svk_poly_wgrad_ws_floats(svg_cin_pad(d), SV_POLY_WGRAD_NWG) * 4;
 }
 extern "C" int sv_conv2d_nhwc_wgrad_poly(const sv_conv_desc* d, const void* x_lo, const void* dy, float* dw, float* dbias, void* workspace,
                                          int64_t workspace_bytes, void* stream) {
   int rc = svg_check(d);
   if (rc != SV_OK) return rc;
-  if (!svg_poly(d)) return SV_E_UNSUPPORTED;
+  if (!svg_poly(d) || d->dtype != SV_BF16) return SV_E_UNSUPPORTED;
   if (!x_lo || !dy || !dw || !workspace || workspace_bytes < sv_conv2d_wgrad_poly_workspace_bytes(d)) return SV_E_BADARG;
   float* pw = (float*)((char*)workspace + SV_WGRAD_WS_BYTES);
   const int Cin = svg_cin_pad(d);

@@ -42,10 +42,54 @@ static inline int svg_packx(const sv_conv_desc* d) {
 // edge-clamped (= the resize's own clamp) this equals the conv over the REPLICATE-padded upsampled image; the reference
 // zero-pads it, and the difference -- taps of the 5 hi-res border rows / columns that leave the image -- is 1-D convs
 // along the edges, subtracted by svk_poly_fix (poly_fix.hip).  bf16 only: the fp32 parity path keeps the direct form.
+// (fp32 since round 5: the composite weights are formed in fp32 from the fp32 masters -- the result differs from the direct form by fp32 rounding only)
 static inline int svg_poly(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_POLY") != nullptr;           // A/B: the fused-upsample x-packed conv
-  return !off && d->dtype == SV_BF16 && svg_packx(d) && d->ups_in && d->KH == 6 && d->KW == 6 && d->Cin == svg_cin_pad(d) && d->Cin == 32 &&
+  static const bool off32 = getenv("SV_NO_POLY_F32") != nullptr;     // A/B: fp32 keeps the x-packed form
+  return !off && (d->dtype == SV_BF16 || !off32) && svg_packx(d) && d->ups_in && d->KH == 6 && d->KW == 6 && d->Cin == svg_cin_pad(d) && d->Cin == 32 &&
          d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1)) && d->act == SV_ACT_NONE;
+}
+// PER-CLASS POLYPHASE form of the wide upsample -> conv layers (d4: UpSampling2D -> Conv2D(32, 6); d3: -> Conv2D(64, 4); vae/model.py:154-155,
+// :163-165).  The same identity as svg_poly, but every output parity class c = (py, px) is its OWN conv over the low-res tensor with only the
+// low-res offsets that parity touches: k = 6 (pad 2): parity 0 reads offsets -2..2, parity 1 reads -1..2; k = 4 (pad 1): -1..1 and -1..2.
+//   y[2i+py, 2j+px] = sum_{ty in T(py), tx in T(px)} W'_c[ty,tx] . x~[i+ty, j+tx]  -  border terms,      x~ = the edge-clamped low-res tensor
+// (5+4)^2 = 81 tap-class products instead of 4 x 36 = 144 hi-res taps per low-res pixel (0.5625 of the direct form's MFMAs; k = 4: 49 / 64), no blend
+// arithmetic, a quarter of the pixels to stage.  Four problems per network in one launch (like the parity classes of a stride-2 input gradient), each
+// scattering to its sub-pixel (OS = 2, ooy / oox); the border terms (poly_fix.hip: polyc_fix_kernel) are added by the epilogue BEFORE the activation.
+// tests/test_polyphase_math.py pins the algebra for both kernel sizes.
+static inline int svg_polyc(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_POLYC") != nullptr;
+  static const char* ks = getenv("SV_POLYC_K") ? getenv("SV_POLYC_K") : "64";       // kernel sizes that take the form (A/B)
+  static const bool bf = getenv("SV_POLYC_BF16") != nullptr;
+  if (off || !(d->dtype == SV_F32 || bf) || !d->ups_in || d->stride != 1 || d->KH != d->KW || (d->KH != 6 && d->KH != 4)) return 0;
+  if (!strchr(ks, d->KH == 6 ? '6' : '4')) return 0;
+  if (d->y_f32 || d->Cout % 32 || d->Cout > 128 || d->ldy != d->Cout) return 0;
+  if (d->Cin != svg_cin_pad(d) || d->Cin < 16 || (d->Cin & (d->Cin - 1)) || d->ldx != d->Cin) return 0;
+  return d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1));
+}
+// blend coefficient of hi-res tap k of output parity p on the low-res offset t (kernel size K, SAME pad before = (K-1)/2): the hi-res offset from row 2i is
+// h = p + k - pad; even h = 2m reads low-res rows i+m-1 (.25) and i+m (.75), odd h = 2m+1 rows i+m (.75) and i+m+1 (.25)
+static inline __host__ __device__ float svg_pcoef(int p, int k, int t, int pad) {
+  const int h = p + k - pad, m = h >> 1;                              // arithmetic shift = floor
+  if (h & 1) return t == m ? 0.75f : t == m + 1 ? 0.25f : 0.f;
+  return t == m - 1 ? 0.25f : t == m ? 0.75f : 0.f;
+}
+// low-res offsets parity p touches: [*t_lo, *t_lo + n)
+static inline __host__ __device__ int svg_polyc_taps(int K, int p, int* t_lo) {
+  const int pad = (K - 1) / 2;
+  const int h0 = p - pad, h1 = p + K - 1 - pad;                       // first / last hi-res offset
+  const int lo = (h0 & 1) ? (h0 >> 1) : (h0 >> 1) - 1, hi = (h1 & 1) ? (h1 >> 1) + 1 : (h1 >> 1);
+  *t_lo = lo;
+  return hi - lo + 1;
+}
+// border classes of one direction: hi-res rows 0 .. pad-1 (taps k < pad - Y leave the image) and 2h-nb .. 2h-1, nb = K-1-pad (taps k > 2h-1-Y+pad): K-1 classes
+static inline __host__ __device__ int svg_polyc_nclass(int K) { return K - 1; }
+// tap k leaves the (zero-padded) image at border class c (0 .. K-2) of a K-tap kernel
+static inline __host__ __device__ bool svg_polyc_excl(int K, int c, int k) {
+  const int pad = (K - 1) / 2;
+  if (c < pad) return k < pad - c;                                    // hi-res row Y = c
+  const int below = K - 1 - pad - (c - pad);                          // rows from Y to the last row, inclusive (nb .. 1)
+  return k > below - 1 + pad;                                         // Y + k - pad > 2h - 1  <=>  k > (2h - 1 - Y) + pad, 2h - 1 - Y = below - 1
 }
 #define SV_POLY_FIX_ELEMS(cin) (10 * 6 * 16 * (cin))                 // [10 border classes][6 taps][16 columns][Cin]
 // N tile selection of the tap GEMM: 0: 128, 1: 64, 2: 32, 3: 16 columns
@@ -117,4 +161,14 @@ void svg_wgrad_set_msplit(WgradArgs* a, int cfg, int dtype, int target_wgs);
 void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j);
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j);
 void svg_prep_job_polyfix(const sv_conv_desc* d, PrepJob* j);     // second forward job of a svg_poly layer (follows the main image)
+// per-class polyphase (svg_polyc): forward problem of class cls = py*2 + px; its composite-weight image; the border-class image; element counts
+void svg_polyc_fwd_args(const sv_conv_desc* d, int cls, TapGemmArgs* a);
+void svg_prep_job_polyc(const sv_conv_desc* d, int cls, PrepJob* j);
+void svg_prep_job_polyc_fix(const sv_conv_desc* d, PrepJob* j);
+int64_t svg_polyc_class_elems(const sv_conv_desc* d, int cls);
+int64_t svg_polyc_fix_elems(const sv_conv_desc* d);
+int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d);
+// n <= 2 svg_polyc layers of one geometry (the twin networks): border kernel + all class problems in one launch (conv_api.hip)
+int svk_polyc_fwd_multi(const sv_conv_desc* d, int n, const void* const* x, const void* const* w_fwd, const float* const* bias, void* const* y,
+                        void* const* fixws, hipStream_t st);
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls);

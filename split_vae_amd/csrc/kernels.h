@@ -41,6 +41,9 @@ struct TapGemmArgs {
   const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale;
   int nll_noout;              // fused loss: the reconstruction (out6) is not stored (SV_PHASE_NO_RECON: dead after the loss in a training step)
   const float* fix;     // with d2s_y: border terms [B][10][max(OHF, OWF)][8] added by the epilogue (poly_fix.hip), or null
+  // without d2s_y (per-class polyphase, conv_geom.h: svg_polyc): fix = row-class terms [B][fix_nc][OWF][N], fix2 = column-class terms [B][OHF][fix_nc][N],
+  // added before the activation to the pixels of hi-res rows / columns 0 .. fix_pad-1 and OHF-nb .. OHF-1 (nb = fix_nc - fix_pad)
+  const float* fix2; int fix_nc, fix_pad;
   int cls_n;            // > 0: MERGED PARITY CLASSES of a stride-2 input gradient whose classes share one tap window (k = 6, pad 2:
                         // every class reads dy rows / columns -1..1): ONE problem with N = 4 * cls_n columns, column n = class
                         // (n / cls_n) channel (n % cls_n), class (ph, pw) = (c >> 1, c & 1) lands on output pixel
@@ -88,6 +91,7 @@ struct TileConvArgs {
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
   const float* fix;           // TapGemmArgs::fix
+  const float* fix2; int fix_nc, fix_pad;   // TapGemmArgs::fix2 / fix_nc / fix_pad (per-class polyphase)
   const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale; int nll_noout;   // TapGemmArgs: fused loss
   int8_t dy[SV_MAX_TAPS];
   int8_t dx[SV_MAX_TAPS];
@@ -232,6 +236,9 @@ struct PrepJob {
                        // tap (ky, tx) of KH x (KW+1) <- source tap (ky, tx - px), zero outside the kernel
   int32_t poly;        // 1: polyphase forward image of (2x bilinear upsample -> 6x6 conv) [32][25][Cin]; 2: its border-fix image
                        // [10 classes][6 taps][16][Cin] (conv_api.hip: prep_poly)
+                       // 3: per-class polyphase image [rows][nty*ntx (x-major)][Cin] of class pcls of a pk x pk kernel (conv_geom.h: svg_polyc)
+                       // 4: its border-class image [2*(pk-1) classes][pk taps][rows][Cin] = -(sum over the taps that leave the image)
+  int32_t pk, pcls;    // poly 3 / 4: kernel size; parity class py*2 + px
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap
@@ -244,7 +251,10 @@ int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob*
 // with atomics AFTER the conv.  n <= 2 twin problems per launch.
 int64_t svk_poly_fix_ws_bytes(int B, int h, int w);
 int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* out6, float* const* fixbuf, int B,
-                       int h, int w, int lda, int Cout, hipStream_t st);
+                       int h, int w, int lda, int Cout, hipStream_t st, int dtype = 1 /* SV_BF16 */);
+// the same for the per-class form (svg_polyc): any K in {4, 6}, Cout a multiple of 16; fixrow [B][K-1][2w][Cout], fixcol [B][2h][K-1][Cout]
+int svk_polyc_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* fixrow, float* const* fixcol, int B, int h, int w,
+                        int Cin, int Cout, int K, int dtype, hipStream_t st);
 
 // polyphase weight gradient of the decoder head, the small terms (poly_wgrad.hip)
 int64_t svk_poly_wgrad_ws_floats(int Cin, int nwg);

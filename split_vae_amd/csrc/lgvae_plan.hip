@@ -7,6 +7,7 @@
 // The phase mask lets the data-parallel driver slip its RCCL all-reduce between the decoder
 // backward, the encoder backward and Adam.
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <map>
 #include <stdio.h>
@@ -320,7 +321,32 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
   };
   auto align = [&]() { arena = (arena + 127) / 128 * 128; };
   auto do_layer = [&](Layer& L, bool is_head) {
-    if (!is_head) {
+    if (!is_head && svg_polyc(&L.d)) {
+      // per-class polyphase forward (conv_geom.h: svg_polyc): four class images + the border-class image, contiguous from wf_off in the
+      // order svk_polyc_fwd_multi expects; the input / weight gradients keep their own forms
+      align(); L.wf_off = arena;
+      for (int c = 0; c < 4; ++c) {
+        PrepJob j;
+        svg_prep_job_polyc(&L.d, c, &j);
+        j.src_off = p->params[L.kparam].off; j.dst_off = arena;
+        arena += svg_polyc_class_elems(&L.d, c);
+        push(j);
+      }
+      PrepJob jf;
+      svg_prep_job_polyc_fix(&L.d, &jf);
+      jf.src_off = p->params[L.kparam].off; jf.dst_off = arena;
+      arena += svg_polyc_fix_elems(&L.d);
+      push(jf);
+      if (L.need_dgrad)
+        for (int c = 0; c < svg_dgrad_classes(&L.d); ++c) {
+          PrepJob jd;
+          svg_prep_job_dgrad(&L.d, c, &jd);
+          jd.src_off = p->params[L.kparam].off;
+          align(); L.wd_off[c] = arena; jd.dst_off = arena;
+          arena += (int64_t)jd.rows * jd.ntaps * jd.inner;
+          push(jd);
+        }
+    } else if (!is_head) {
       PrepJob j;
       svg_prep_job_fwd(&L.d, &j);
       j.src_off = p->params[L.kparam].off;
@@ -394,6 +420,13 @@ static void build_buffers(sv_lgvae_plan* p) {
   if (getenv("SV_DEFER_REDUCE")) p->add_buf("wslab", SV_WGRAD_WS_BYTES * SV_WGRAD_MAX_MULTI * 7);    // per tile-wgrad layer (e1 e2 e3 d2 d3 d4 d5) and problem: deferred reduces
   p->add_buf("polyfix_x", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));   // border terms of the polyphase head (poly_fix.hip)
   p->add_buf("polyfix_xh", svk_poly_fix_ws_bytes((int)B, (int)H / 2, (int)W / 2));
+  {   // border terms of the per-class polyphase layers (d3, d4): one region per network, sized for the largest layer (the layers run one after the other)
+    int64_t need = 256;
+    for (int l = 2; l <= 4; ++l)
+      if (svg_polyc(&p->dec[0][l].d)) need = std::max<int64_t>(need, svg_polyc_fix_ws_bytes(&p->dec[0][l].d));
+    p->add_buf("polycfix_x", need);
+    p->add_buf("polycfix_xh", need);
+  }
   p->add_buf("polyw_x", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);        // polyphase weight gradient of the head: dW', dbias', frame slabs
   p->add_buf("polyw_xh", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);
   {   // K-slice slabs of the heads' forward and d1's input gradient (latent_gemm.hip): [S][B][N] fp32 per network
@@ -527,6 +560,14 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     const int rc = svk_nt_gemm_multi(q, n, L[0]->d.B >= 256 ? 128 : 64, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
+  if (svg_polyc(&L[0]->d) && !nll && n <= 2) {
+    // per-class polyphase (d4, d3): border kernel, then the four class problems of both networks in one launch
+    const void* wf[2];
+    const float* bs[2];
+    void* fws[2] = {p->bp("polycfix_x"), p->bp("polycfix_xh")};
+    for (int i = 0; i < n; ++i) { wf[i] = a[i].Wt; bs[i] = a[i].bias; }
+    return svk_polyc_fwd_multi(&L[0]->d, n, x, wf, bs, y, fws, st);
+  }
   if (svg_poly(&L[0]->d)) {
     // polyphase head: the out-of-image taps of the border rows / columns go to a workspace first; the conv's epilogue adds them
     const void* wfix[2];
@@ -538,7 +579,7 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
       fixbuf[i] = (float*)p->bp(fb_name[i]);
       a[i].fix = fixbuf[i];
     }
-    SV_TRY(svk_poly_fix_multi(n, x, wfix, nullptr, fixbuf, d.B, d.H / 2, d.W / 2, d.ldx, d.Cout, st));
+    SV_TRY(svk_poly_fix_multi(n, x, wfix, nullptr, fixbuf, d.B, d.H / 2, d.W / 2, d.ldx, d.Cout, st, d.dtype));
   }
   return svk_conv_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
@@ -665,7 +706,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   // (round 2, tile-kernel main term: 512 images per launch +0.4 %, 1024 -1.0 % -> 768; round 4, rolling-window main term (wgrad_p5.hip): 512 images per
   //  launch -0.7 %, 256 +2.5 % -> 512: profiles/r04_poly_wgrad_min_sweep.txt)
   static const int pw_min = getenv("SV_POLY_WGRAD_MIN") ? atoi(getenv("SV_POLY_WGRAD_MIN")) : 512;
-  if (!no_pw && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2 &&
+  if (!no_pw && L[0]->d.dtype == SV_BF16 && svg_poly(&L[0]->d) && n * L[0]->d.B >= pw_min && n <= 2 &&
       svk_poly_wgrad_supported(L[0]->d.H / 2, L[0]->d.W / 2, svg_cin_pad(&L[0]->d), L[0]->d.Cout)) {   // else: the direct form below
     static const char* pw_name[2] = {"polyw_x", "polyw_xh"};
     float* pw[2];

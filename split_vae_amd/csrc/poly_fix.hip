@@ -22,12 +22,42 @@
 
 namespace {
 
-struct PolyFixMulti { const bf16_t* x[2]; const bf16_t* wfix[2]; float* out6[2]; float* fixbuf[2]; };   // blockIdx.y: the twin networks
+struct PolyFixMulti { const void* x[2]; const void* wfix[2]; float* out6[2]; float* fixbuf[2]; };   // blockIdx.y: the twin networks
 
+// one 16-B piece of each operand: bf16 = 8 channels x 4 lane groups = 32 channels in ONE v_mfma_f32_16x16x32_bf16; fp32 = 4 channels x 4 lane groups =
+// 16 channels in FOUR v_mfma_f32_16x16x4_f32 (instruction e contracts channel 4 * group + e of both operands): exact fp32, the reference's arithmetic
+template <typename T> struct FixMma;
+template <> struct FixMma<bf16_t> {
+  static constexpr int CPG = 32;
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct FixMma<float> {
+  static constexpr int CPG = 16;
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    const float4 af = __builtin_bit_cast(float4, a), bf = __builtin_bit_cast(float4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
+  }
+};
+
+// one pixel of an upsampled edge line: hi coordinate u (clamped by the caller) of a line of n low-res pixels -> the two low-res indices and the weight of the second
+__device__ __forceinline__ void line_src(int u, int n, int& i0, int& i1, float& f) {
+  const int m = u >> 1;
+  i0 = (u & 1) ? m : max(m - 1, 0); i1 = (u & 1) ? min(m + 1, n - 1) : m;
+  f = (u & 1) ? 0.25f : 0.75f;                             // weight of the second sample (common.hip.h: lerp2)
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, int h, int w, int lda, int Cout, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bf16_t* __restrict__ x = mg.x[blockIdx.y];
-  const bf16_t* __restrict__ wfix = mg.wfix[blockIdx.y];
+  constexpr int EPP = ElemTraits<T>::EPP, NPC = 32 / EPP, PSB = 32 * (int)sizeof(T) + (sizeof(T) == 4 ? 16 : 0), NG = 32 / FixMma<T>::CPG;   // pieces / bytes per line pixel (fp32: +16 B, the
+                                                                                     // 16 pixels of a fragment read on different banks), MFMA groups per tap
+  const T* __restrict__ x = (const T*)mg.x[blockIdx.y];
+  const T* __restrict__ wfix = (const T*)mg.wfix[blockIdx.y];
   float* __restrict__ out6 = mg.out6[blockIdx.y];
   float* __restrict__ fixbuf = mg.fixbuf[blockIdx.y];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -39,17 +69,19 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
   const int H2 = 2 * h, W2 = 2 * w;
   const int L = H2 > W2 ? H2 : W2, LW = L + 5;            // line index li = hi coordinate + 2, hi coordinate in -2 .. 2n+2
   // this wave's first class: its weight fragments are in flight while the lines are built
-  uint4 wv[6];
+  uint4 wv[6][NG];
   auto load_w = [&](int cls) {
-    const bf16_t* wp = wfix + ((int64_t)cls * 6 * 16 + lr) * 32 + lg * 8;
+    const T* wp = wfix + ((int64_t)cls * 6 * 16 + lr) * 32 + lg * EPP;
 #pragma unroll
-    for (int tap = 0; tap < 6; ++tap) wv[tap] = *(const uint4*)(wp + tap * 16 * 32);
+    for (int tap = 0; tap < 6; ++tap)
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) wv[tap][gq] = *(const uint4*)(wp + tap * 16 * 32 + gq * FixMma<T>::CPG);
   };
   load_w(wave);
-  const bf16_t* xb = x + (int64_t)b * h * w * lda;
-  // ---- the four lines: [line][li][32 channels] bf16
-  for (int it = tid; it < 4 * LW * 4 && !(SV_DBG(dbg) & 1); it += 256) {
-    const int ch = it & 3, li = (it >> 2) % LW, line = (it >> 2) / LW;
+  const T* xb = x + (int64_t)b * h * w * lda;
+  // ---- the four lines: [line][li][32 channels] of T
+  for (int it = tid; it < 4 * LW * NPC && !(SV_DBG(dbg) & 1); it += 256) {
+    const int ch = it % NPC, li = (it / NPC) % LW, line = (it / NPC) / LW;
     const bool is_row = line < 2;
     const int n = is_row ? w : h;                          // low-res extent along the line
     int u = li - 2;                                        // hi coordinate
@@ -61,14 +93,14 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
       const float f = (u & 1) ? 0.25f : 0.75f;             // weight of the second sample (common.hip.h: lerp2)
       const int64_t o0 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * lda : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * lda;
       const int64_t o1 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * lda : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * lda;
-      const uint4 a0 = *(const uint4*)(xb + o0 + ch * 8), a1 = *(const uint4*)(xb + o1 + ch * 8);
-      f32x2 p0[4], p1[4], r[4];
-      Piece<bf16_t>::unpack(a0, p0); Piece<bf16_t>::unpack(a1, p1);
+      const uint4 a0 = *(const uint4*)(xb + o0 + ch * EPP), a1 = *(const uint4*)(xb + o1 + ch * EPP);
+      f32x2 p0[Piece<T>::NP], p1[Piece<T>::NP], r[Piece<T>::NP];
+      Piece<T>::unpack(a0, p0); Piece<T>::unpack(a1, p1);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = lerp2(p0[e], p1[e], f);
-      v = Piece<bf16_t>::pack(r);
+      for (int e = 0; e < Piece<T>::NP; ++e) r[e] = lerp2(p0[e], p1[e], f);
+      v = Piece<T>::pack(r);
     }
-    *(uint4*)(smem + ((line * LW + li) * 4 + ch) * 16) = v;
+    *(uint4*)(smem + (line * LW + li) * PSB + ch * 16) = v;
   }
   __syncthreads();
   // ---- classes 0..4: hi-res rows 0, 1, 2h-3, 2h-2, 2h-1 (tap = kx); 5..9: the columns (tap = ky)
@@ -78,9 +110,11 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
     const int n2 = rows ? W2 : H2, nf = n2 >> 4;           // pixels / fragments along the line
     const int m2 = rows ? H2 : W2;
     const int edge = c5 == 0 ? 0 : c5 == 1 ? 1 : m2 - 5 + c5;                   // 0, 1, m-3, m-2, m-1
-    uint4 wc[6];
+    uint4 wc[6][NG];
 #pragma unroll
-    for (int tap = 0; tap < 6; ++tap) wc[tap] = wv[tap];
+    for (int tap = 0; tap < 6; ++tap)
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) wc[tap][gq] = wv[tap][gq];
     if (cls + 4 < 10) load_w(cls + 4);                     // next class of this wave
     for (int f0 = 0; f0 < nf; f0 += 4) {
       f32x4 acc[4];
@@ -91,8 +125,11 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (f0 + q >= nf) continue;
-          const uint4 pv = *(const uint4*)(smem + (line * LW + 16 * (f0 + q) + lr + tap) * 64 + lg * 16);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[tap]), __builtin_bit_cast(bf16x8, pv), acc[q], 0, 0, 0);
+#pragma unroll
+          for (int gq = 0; gq < NG; ++gq) {
+            const uint4 pv = *(const uint4*)(smem + (line * LW + 16 * (f0 + q) + lr + tap) * PSB + gq * (FixMma<T>::CPG * (int)sizeof(T)) + lg * 16);
+            FixMma<T>::run(wc[tap][gq], pv, acc[q]);
+          }
         }
       // lane (lr, lg): channels lg*4 .. lg*4+3 of line pixel 16 f + lr
 #pragma unroll
@@ -127,25 +164,128 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same border terms for the PER-CLASS polyphase form (conv_geom.h: svg_polyc; d4 / d3): any kernel size K in {4, 6} (K - 1 border classes per
+// direction: hi-res rows 0 .. pad-1 and 2h-nb .. 2h-1, nb = K-1-pad), Cin a multiple of the MFMA group, Cout a multiple of 16.  One workgroup per image:
+// the four upsampled edge lines go to LDS, then (class, 16 output channels, 16 line pixels) units are dealt to the waves; a unit is K taps x Cin / CPG
+// operand pairs, the class weights (-sum over the excluded taps, conv_api.hip prep poly == 4: [2(K-1)][K][Cout][Cin]) come straight from L2.
+//   fixrow[b][c][X][co]  (c < K-1: hi-res row class, X < 2w)        fixcol[b][Y][c][co]  (Y < 2h, c: hi-res column class)
+// added by the conv's epilogue before the activation (tile_conv.hip).
+struct PolycFixMulti { const void* x[2]; const void* wfix[2]; float* frow[2]; float* fcol[2]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void polyc_fix_kernel(const PolycFixMulti mg, int h, int w, int Cin, int Cout, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG;
+  const T* __restrict__ x = (const T*)mg.x[blockIdx.y];
+  const T* __restrict__ wfix = (const T*)mg.wfix[blockIdx.y];
+  float* __restrict__ frow = mg.frow[blockIdx.y];
+  float* __restrict__ fcol = mg.fcol[blockIdx.y];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2, nc = K - 1, nb = K - 1 - pad;
+  const int L = H2 > W2 ? H2 : W2, LW = L + K - 1;          // line index li = hi coordinate + pad
+  const int npc = Cin / EPP, PSB = Cin * (int)sizeof(T) + 16;   // 16-B pieces / bytes per line pixel (+16: the pixels of a fragment on different banks)
+  const T* xb = x + (int64_t)b * h * w * Cin;
+  // ---- the four lines (0 top row, 1 bottom row: replicate-extended; 2 left column, 3 right column: zero outside the image)
+  for (int it = tid; it < 4 * LW * npc; it += 256) {
+    const int ch = it % npc, li = (it / npc) % LW, line = it / (npc * LW);
+    const bool is_row = line < 2;
+    const int n = is_row ? w : h;
+    int u = li - pad;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (li < 2 * n + K - 1 && (is_row || (u >= 0 && u < 2 * n))) {
+      u = min(max(u, 0), 2 * n - 1);
+      int i0, i1;
+      float f;
+      line_src(u, n, i0, i1, f);
+      const int64_t o0 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * Cin : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * Cin;
+      const int64_t o1 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * Cin : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * Cin;
+      const uint4 a0 = *(const uint4*)(xb + o0 + ch * EPP), a1 = *(const uint4*)(xb + o1 + ch * EPP);
+      f32x2 p0[Piece<T>::NP], p1[Piece<T>::NP], r[Piece<T>::NP];
+      Piece<T>::unpack(a0, p0); Piece<T>::unpack(a1, p1);
+#pragma unroll
+      for (int e = 0; e < Piece<T>::NP; ++e) r[e] = lerp2(p0[e], p1[e], f);
+      v = Piece<T>::pack(r);
+    }
+    *(uint4*)(smem + (line * LW + li) * PSB + ch * 16) = v;
+  }
+  __syncthreads();
+  // ---- units: (class, channel fragment, pixel fragment)
+  const int ncf = Cout >> 4, npf_r = W2 >> 4, npf_c = H2 >> 4;
+  const int units_r = nc * ncf * npf_r, units = units_r + nc * ncf * npf_c;
+  const int ngrp = Cin / CPG;
+  for (int u = wave; u < units; u += 4) {
+    const bool rows = u < units_r;
+    const int v = rows ? u : u - units_r, npf = rows ? npf_r : npf_c;
+    const int pf = v % npf, cf = (v / npf) % ncf, c = v / (npf * ncf);
+    const int cls = rows ? c : nc + c;
+    const int line = (rows ? 0 : 2) + (c >= pad ? 1 : 0);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const T* wp = wfix + (((int64_t)cls * K) * Cout + cf * 16 + lr) * Cin + lg * EPP;
+    const char* lp = smem + (line * LW + 16 * pf + lr) * PSB + lg * 16;
+    for (int tap = 0; tap < K; ++tap)
+      for (int gq = 0; gq < ngrp; ++gq) {
+        const uint4 wv = *(const uint4*)(wp + (int64_t)tap * Cout * Cin + gq * CPG);
+        const uint4 pv = *(const uint4*)(lp + tap * PSB + gq * (CPG * (int)sizeof(T)));
+        FixMma<T>::run(wv, pv, acc);                       // D rows = output channels 4 * lg .., columns = line pixels
+      }
+    const int pos = 16 * pf + lr, co = cf * 16 + lg * 4;
+    float* p = rows ? frow + (((int64_t)b * nc + c) * W2 + pos) * Cout + co : fcol + (((int64_t)b * H2 + pos) * nc + c) * Cout + co;
+    *(float4*)p = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
 }  // namespace
+
+int svk_polyc_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* fixrow, float* const* fixcol, int B, int h, int w,
+                        int Cin, int Cout, int K, int dtype, hipStream_t st) {
+  if (n < 1 || n > 2 || B < 1 || h < 8 || w < 8 || (h & 7) || (w & 7) || (Cout & 15) || (K != 4 && K != 6)) return SV_E_BADARG;
+  const int cpg = dtype == SV_BF16 ? 32 : 16, esz = dtype == SV_BF16 ? 2 : 4;
+  if (Cin % cpg) return SV_E_UNSUPPORTED;
+  const int LW = 2 * (h > w ? h : w) + K - 1;
+  const size_t lds = (size_t)4 * LW * (Cin * esz + 16);
+  if (lds > 150 * 1024) return SV_E_UNSUPPORTED;
+  PolycFixMulti m;
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    m.x[i] = x_lo[k]; m.wfix[i] = wfix[k]; m.frow[i] = fixrow[k]; m.fcol[i] = fixcol[k];
+    if (!m.x[i] || !m.wfix[i] || !m.frow[i] || !m.fcol[i]) return SV_E_BADARG;
+  }
+  if (dtype == SV_BF16) {
+    sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<bf16_t>, lds);
+    hipLaunchKernelGGL(polyc_fix_kernel<bf16_t>, dim3(B, n), dim3(256), lds, st, m, h, w, Cin, Cout, K);
+  } else {
+    sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<float>, lds);
+    hipLaunchKernelGGL(polyc_fix_kernel<float>, dim3(B, n), dim3(256), lds, st, m, h, w, Cin, Cout, K);
+  }
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
 
 int64_t svk_poly_fix_ws_bytes(int B, int h, int w) { return (int64_t)B * (5 * 2 * w + 6 * 2 * h) * 8 * 4; }   // sized for Cout <= 8
 
 int svk_poly_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* out6, float* const* fixbuf, int B,
-                       int h, int w, int lda, int Cout, hipStream_t st) {
+                       int h, int w, int lda, int Cout, hipStream_t st, int dtype) {
   if (n < 1 || n > 2 || B < 1 || h < 8 || w < 8 || (h & 7) || (w & 7) || Cout < 2 || Cout > 8 || (Cout & 1) || lda < 32) return SV_E_BADARG;
   const int LW = 2 * (h > w ? h : w) + 5;
-  const size_t lds = (size_t)4 * LW * 64;
-  if (lds > 64 * 1024) return SV_E_UNSUPPORTED;
+  const size_t lds = (size_t)4 * LW * (dtype == SV_BF16 ? 64 : 144);
+  if (lds > 150 * 1024) return SV_E_UNSUPPORTED;
   PolyFixMulti m;
   for (int i = 0; i < 2; ++i) {
     const int k = i < n ? i : 0;
-    m.x[i] = (const bf16_t*)x_lo[k]; m.wfix[i] = (const bf16_t*)wfix[k];
+    m.x[i] = x_lo[k]; m.wfix[i] = wfix[k];
     m.out6[i] = out6 ? out6[k] : nullptr; m.fixbuf[i] = fixbuf ? fixbuf[k] : nullptr;
     if (!m.out6[i] && !m.fixbuf[i]) return SV_E_BADARG;
   }
   static const int dbg = SV_DBG(getenv("SV_PF_DBG") ? atoi(getenv("SV_PF_DBG")) : 0);   // ablation: 1 skip the lines, 2 skip the classes, 4 skip the stores
-  hipLaunchKernelGGL(poly_fix_kernel, dim3(B, n), dim3(256), lds, st, m, h, w, lda, Cout, dbg);
+  if (dtype == SV_BF16) {
+    sv_ensure_dynamic_lds((const void*)poly_fix_kernel<bf16_t>, lds);
+    hipLaunchKernelGGL(poly_fix_kernel<bf16_t>, dim3(B, n), dim3(256), lds, st, m, h, w, lda, Cout, dbg);
+  } else {
+    sv_ensure_dynamic_lds((const void*)poly_fix_kernel<float>, lds);
+    hipLaunchKernelGGL(poly_fix_kernel<float>, dim3(B, n), dim3(256), lds, st, m, h, w, lda, Cout, dbg);
+  }
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

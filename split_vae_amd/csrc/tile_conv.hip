@@ -289,14 +289,30 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
     const int r = wave * WM + i * 16 + lr;
+    // PER-CLASS POLYPHASE (conv_geom.h: svg_polyc): the out-of-image taps of the hi-res border rows / columns (poly_fix.hip: polyc_fix_kernel wrote them)
+    // are added before the activation; only the lanes of border pixels load anything
+    const float *frp = nullptr, *fcp = nullptr;
+    if (g.fix_nc) {
+      const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+      const int b = b0 + bl, R = (ty0 + ty) * g.OS + g.ooy, Cc = (tx0 + tx) * g.OS + g.oox, nbot = g.fix_nc - g.fix_pad;
+      const int rc = R < g.fix_pad ? R : R >= g.OHF - nbot ? g.fix_pad + R - (g.OHF - nbot) : -1;
+      const int cc = Cc < g.fix_pad ? Cc : Cc >= g.OWF - nbot ? g.fix_pad + Cc - (g.OWF - nbot) : -1;
+      if (b < g.B && rc >= 0) frp = g.fix + (((int64_t)b * g.fix_nc + rc) * g.OWF + Cc) * g.N + n0;
+      if (b < g.B && cc >= 0) fcp = g.fix2 + (((int64_t)b * g.OHF + R) * g.fix_nc + cc) * g.N + n0;
+    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
       const int nl = j * 16 + lg * 4;
       if (nl >= ncols) continue;
       float v[4];
+      float4 fr = make_float4(0.f, 0.f, 0.f, 0.f), fc = fr;
+      if (frp) fr = *(const float4*)(frp + nl);
+      if (fcp) fc = *(const float4*)(fcp + nl);
+      const float fv[4] = {fr.x + fc.x, fr.y + fc.y, fr.z + fc.z, fr.w + fc.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + bv[j][e];
+        if (g.fix_nc) v[e] += fv[e];
         if (relu) v[e] = fmaxf(v[e], 0.f);
       }
       if (g.d2s) {                                      // n = px*8 + co -> column px*C + co (co < C)
@@ -481,6 +497,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s && ((t.N != 16 && !(t.N == 32 && t.d2s_y)) || !t.out_f32)) return false;
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
+  if (t.fix_nc && !t.d2s_y && (!t.fix || !t.fix2 || (t.N & 15) || t.OS != 2 || t.out_f32)) return false;
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
@@ -594,6 +611,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
     a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n; a->d2s_y = t.d2s_y; a->clampin = t.clampin; a->fix = t.fix;
+    a->fix2 = t.fix2; a->fix_nc = t.d2s_y ? 0 : t.fix_nc; a->fix_pad = t.fix_pad;
     a->nll_img = t.nll_img; a->nll_grad = t.nll_grad; a->nll_part = t.nll_part; a->nll_ch = t.nll_ch; a->nll_gscale = t.nll_gscale; a->nll_noout = t.nll_noout;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
@@ -695,7 +713,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   for (int i = 0; i < n && none_tile; ++i) {
     TileConvArgs b;
     int c;
-    none_tile = !(t[i].ups || t[i].d2s || t[i].cls_n) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
+    none_tile = !(t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
   }
   if (none_tile) {
     for (int i = 0; i < n; i += SV_TAP_MAX_MULTI) {
@@ -711,7 +729,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c)) {
       b.dbg = dbg;
       rc = svk_tile_conv(b, dtype, c, st);
-    } else if (t[i].ups || t[i].d2s || t[i].cls_n) {
+    } else if (t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc) {
       rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor / has no depth-to-space store
     } else {
       rc = svk_tap_gemm(t[i], dtype, tap_cfg, st);

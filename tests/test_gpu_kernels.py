@@ -872,6 +872,35 @@ def test_fp32_fused_upsample_forward_and_weight_gradient(ops, layer):
     assert torch.equal(dw1, dw3)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5])
+@pytest.mark.parametrize("layer", [("d3_64", 16, 128, 64, 4, "relu", False), ("d4", 16, 64, 32, 6, "relu", False), ("d4_64", 32, 64, 32, 6, "relu", False),
+                                   ("d4_128", 64, 64, 32, 6, "relu", False), ("d5", 32, 32, 6, 6, None, True), ("d5_64", 64, 32, 6, 6, None, True)], ids=lambda l: l[0])
+def test_fp32_polyphase_forward_against_fp64(ops, layer, B):
+    """UpSampling2D(bilinear) -> Conv2D(padding='same') (vae/model.py:154-156,:163-167) at the reference's precision in POLYPHASE form: the head as one 5 x 5 conv over
+    the low-res tensor (svg_poly), d4 / d3 as four per-parity-class convs (svg_polyc; 81 of 144 / 49 of 64 tap products), border rows / columns
+    corrected by poly_fix.hip.  Against the fp64 composition resize -> zero-padded conv from the same fp32 operands: every pixel at the fp32 bar, the
+    border ring (whose taps leave the image) on its own, bias and ReLU included; bitwise run to run."""
+    name, H, Cin, Cout, k, act, yf32 = layer
+    rng = np.random.default_rng(H * 100 + Cin + B)
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=act, dtype=torch.float32, y_f32=yf32, ups_in=True)
+    conv.prep(w.cuda())
+    y = conv.fwd(x_lo.cuda(), b.cuda())
+    ref = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(x_lo.double()), w.double(), b.double(), 1, act)
+    got = y[..., :Cout].double().cpu()
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(got, ref, rtol=F32_RTOL, atol=F32_ATOL * scale)
+    ring = torch.ones(H, H, dtype=torch.bool)
+    ring[3:H - 3, 3:H - 3] = False
+    torch.testing.assert_close(got[:, ring], ref[:, ring], rtol=F32_RTOL, atol=F32_ATOL * scale)
+    y2 = conv.fwd(x_lo.cuda(), b.cuda())
+    assert torch.equal(y, y2)
+
+
 SPAIR_OBJECT_LAYERS = [  # name, H, Cin, Cout, k, stride: the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses
     ("obj_conv1", 32, 3, 32, 3, 2),      # RGB padded to 8 channels: fragment rows 8..15 are dropped (no tap pairs at an odd kernel width)
     ("obj_conv2", 16, 32, 64, 3, 2),

@@ -139,3 +139,102 @@ def test_polyphase_weight_gradient_identity():
                         dW[k, tap] -= np.outer(rv, dy[b, edge, pos])         # row class: ky = k, kx = tap
                         dW[tap, k] -= np.outer(cv, dy[b, pos, edge])         # column class: ky = tap, kx = k
     np.testing.assert_allclose(dW, want, rtol=1e-9, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# PER-CLASS polyphase (csrc/conv_geom.h: svg_polyc; d4 = UpSampling2D -> Conv2D(32, 6), d3 = -> Conv2D(64, 4): vae/model.py:154-155,:163-165): every output
+# parity class is its own conv over the edge-clamped low-res tensor with only the offsets that parity touches; any kernel size K, SAME pad before = (K-1)//2.
+# The helpers below are the device code's closed forms (svg_pcoef, svg_polyc_taps, svg_polyc_excl).
+
+def _pcoef(p, k, t, pad):
+    h = p + k - pad
+    m = h >> 1
+    if h & 1:
+        return 0.75 if t == m else 0.25 if t == m + 1 else 0.0
+    return 0.25 if t == m - 1 else 0.75 if t == m else 0.0
+
+
+def _polyc_taps(K, p):
+    pad = (K - 1) // 2
+    h0, h1 = p - pad, p + K - 1 - pad
+    lo = (h0 >> 1) if (h0 & 1) else (h0 >> 1) - 1
+    hi = (h1 >> 1) + 1 if (h1 & 1) else (h1 >> 1)
+    return list(range(lo, hi + 1))
+
+
+def _polyc_excl(K, c, k):
+    pad = (K - 1) // 2
+    if c < pad:
+        return k < pad - c
+    below = K - 1 - pad - (c - pad)
+    return k > below - 1 + pad
+
+
+def _class_edge(K, c, H):
+    pad = (K - 1) // 2
+    return c if c < pad else H - (K - 1 - pad) + (c - pad)
+
+
+def _composite(w, K):
+    pad = (K - 1) // 2
+    out = {}
+    for py in range(2):
+        for px in range(2):
+            for ty in _polyc_taps(K, py):
+                for tx in _polyc_taps(K, px):
+                    acc = np.zeros(w.shape[2:])
+                    for ky in range(K):
+                        for kx in range(K):
+                            acc = acc + _pcoef(py, ky, ty, pad) * _pcoef(px, kx, tx, pad) * w[ky, kx]
+                    out[(py, px, ty, tx)] = acc
+    return out
+
+
+def test_per_class_tap_sets_cover_exactly_the_nonzero_coefficients():
+    for K in (4, 6):
+        pad = (K - 1) // 2
+        for p in range(2):
+            nz = [t for t in range(-6, 7) if any(_pcoef(p, k, t, pad) for k in range(K))]
+            assert _polyc_taps(K, p) == list(range(min(nz), max(nz) + 1))
+    assert [len(_polyc_taps(6, p)) for p in (0, 1)] == [5, 4] and [len(_polyc_taps(4, p)) for p in (0, 1)] == [3, 4]
+    for K, H in ((6, 16), (4, 16)):
+        pad = (K - 1) // 2
+        for c in range(K - 1):
+            Y = _class_edge(K, c, H)
+            assert [k for k in range(K) if _polyc_excl(K, c, k)] == [k for k in range(K) if not 0 <= Y + k - pad < H]
+
+
+import pytest
+
+
+@pytest.mark.parametrize("K", [6, 4])
+def test_per_class_polyphase_forward_identity(K):
+    rng = np.random.default_rng(K)
+    B, h, C, Co = 2, 8, 5, 3
+    H, pad = 2 * h, (K - 1) // 2
+    x = rng.standard_normal((B, h, h, C))
+    w = rng.standard_normal((K, K, C, Co)) * 0.2
+    bias = rng.standard_normal(Co)
+    ref = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.from_numpy(x)), torch.from_numpy(w), torch.from_numpy(bias), 1, None).numpy()
+    Wc = _composite(w, K)
+    P = 3
+    xp = np.pad(x, ((0, 0), (P, P), (P, P), (0, 0)), mode="edge")
+    out = np.zeros((B, H, H, Co)) + bias
+    for (py, px, ty, tx), M in Wc.items():
+        out[:, py::2, px::2] += np.einsum("bijc,co->bijo", xp[:, P + ty:P + ty + h, P + tx:P + tx + h], M)
+    for b in range(B):
+        top, bot = _line_up(x[b, 0]), _line_up(x[b, h - 1])
+        left, right = _line_up(x[b, :, 0]), _line_up(x[b, :, h - 1])
+        for c in range(K - 1):
+            edge = _class_edge(K, c, H)
+            rline, cline = (top, left) if c < pad else (bot, right)
+            for pos in range(H):
+                for tap in range(K):
+                    q = pos + tap - pad
+                    rv = rline[min(max(q, 0), H - 1)]
+                    cv = cline[q] if 0 <= q < H else np.zeros(C)
+                    for k in range(K):
+                        if _polyc_excl(K, c, k):
+                            out[b, edge, pos] -= rv @ w[k, tap]
+                            out[b, pos, edge] -= cv @ w[tap, k]
+    np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
