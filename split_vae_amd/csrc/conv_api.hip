@@ -790,9 +790,10 @@ extern "C" int sv_conv2d_nhwc_wgrad_poly(const sv_conv_desc* d, const void* x_lo
                                (hipStream_t)stream);
 }
 
+// (layers with a polyphase weight gradient at fp32 -- polyc_wgrad.hip -- keep dW' and the frame slabs behind the partial-sum slabs)
 extern "C" int64_t sv_conv2d_wgrad_workspace_bytes(const sv_conv_desc* d) {
   if (svg_check(d) != SV_OK) return -1;
-  return SV_WGRAD_WS_BYTES;
+  return SV_WGRAD_WS_BYTES + svk_polyc_wgrad_ws_floats(d) * 4;
 }
 
 extern "C" int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
@@ -800,6 +801,12 @@ extern "C" int sv_conv2d_nhwc_wgrad_ws(const sv_conv_desc* d, const void* x, con
   int rc = svg_check(d);
   if (rc != SV_OK) return rc;
   if (!x || !dy || !dw) return SV_E_BADARG;
+  if (svg_polyc_wgrad_form(d) && workspace && workspace_bytes >= sv_conv2d_wgrad_workspace_bytes(d)) {
+    float* slab = (float*)workspace;
+    float* pw = (float*)((char*)workspace + SV_WGRAD_WS_BYTES);
+    rc = svk_polyc_wgrad_multi(d, 1, &x, &dy, &dw, &dbias, &slab, SV_WGRAD_WS_BYTES, &pw, (hipStream_t)stream);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
   WgradArgs a;
   svg_wgrad_args(d, &a);
   a.A = x; a.dY = dy; a.dW = dw; a.dbias = dbias;

@@ -168,6 +168,12 @@ void svg_prep_job_polyc_fix(const sv_conv_desc* d, PrepJob* j);
 int64_t svg_polyc_class_elems(const sv_conv_desc* d, int cls);
 int64_t svg_polyc_fix_elems(const sv_conv_desc* d);
 int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d);
+// polyphase weight gradient at fp32 (polyc_wgrad.hip): 0 none, 1 per class (svg_polyc), 2 merged head (svg_poly); workspace floats per problem; class problem
+int svg_polyc_wgrad_form(const sv_conv_desc* d);
+int64_t svk_polyc_wgrad_ws_floats(const sv_conv_desc* d);
+void svg_polyc_wgrad_args(const sv_conv_desc* d, int cls, WgradArgs* a);
+int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo, const void* const* dy, float* const* dW, float* const* dbias,
+                          float* const* slab_ws, int64_t slab_bytes, float* const* pw, hipStream_t st);
 // n <= 2 svg_polyc layers of one geometry (the twin networks): border kernel + all class problems in one launch (conv_api.hip)
 int svk_polyc_fwd_multi(const sv_conv_desc* d, int n, const void* const* x, const void* const* w_fwd, const float* const* bias, void* const* y,
                         void* const* fixws, hipStream_t st);

@@ -123,6 +123,8 @@ struct WgradArgs {
   int ups;            // A is the low-res tensor, the layer input is its 2x bilinear upsample (tile kernel only)
   int clampin;        // input coordinates outside the image clamp to the edge (polyphase weight gradient; tile kernel only)
   int dy_s2d;         // dY is the hi-res gradient [B, 2*OY, 2*OX, 8] read as its space-to-depth view [B, OY, OX, 32]
+  int dy_os, dy_oy, dy_ox;   // dy_os = 2: dY is the hi-res gradient [B, 2*OY, 2*OX, ldy] and iteration pixel (oy, ox) reads its pixel (2 oy + dy_oy, 2 ox + dy_ox):
+                             // one parity class of the per-class polyphase weight gradient (conv_geom.h: svg_polyc; wgrad_tile_f32.hip only)
   int assign;         // slab path: the reduce WRITES dW (every element has one owner) instead of adding to it
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
@@ -162,6 +164,7 @@ struct WgradTileArgs {
   int dbg;                  // ablation: 1 = skip the atomic flush
   int ups;                  // fused 2x bilinear upsample of the input
   int clampin, dy_s2d, assign;   // WgradArgs::clampin / dy_s2d / assign
+  int dy_os, dy_oy, dy_ox;       // WgradArgs::dy_os / dy_oy / dy_ox
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];

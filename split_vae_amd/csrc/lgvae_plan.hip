@@ -426,6 +426,13 @@ static void build_buffers(sv_lgvae_plan* p) {
       if (svg_polyc(&p->dec[0][l].d)) need = std::max<int64_t>(need, svg_polyc_fix_ws_bytes(&p->dec[0][l].d));
     p->add_buf("polycfix_x", need);
     p->add_buf("polycfix_xh", need);
+    // polyphase weight gradients at fp32 (polyc_wgrad.hip): dW' + frame slabs per layer and network (the layers' launches may overlap across streams)
+    for (int l = 2; l <= 4; ++l) {
+      const int64_t fl = svk_polyc_wgrad_ws_floats(&p->dec[0][l].d);
+      if (!fl) continue;
+      p->add_buf("polycw" + std::to_string(l) + "_x", fl * 4);
+      p->add_buf("polycw" + std::to_string(l) + "_xh", fl * 4);
+    }
   }
   p->add_buf("polyw_x", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);        // polyphase weight gradient of the head: dW', dbias', frame slabs
   p->add_buf("polyw_xh", svk_poly_wgrad_ws_floats(32, SV_POLY_WGRAD_NWG) * 4);
@@ -724,6 +731,22 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     SV_TRY(svk_wgrad_tile_multi(a, n, st));
     const sv_conv_desc& d = L[0]->d;
     return svk_poly_wgrad_finish(n, x, dy, pw, dwv, dbv, d.B, d.H / 2, d.W / 2, d.ldx, Cin, d.Cout, SV_POLY_WGRAD_NWG, st);
+  }
+  // fp32: the polyphase weight gradient of the upsample -> conv layers (polyc_wgrad.hip: d4 per parity class, the head merged)
+  static const int pcw_min = getenv("SV_POLYC_WGRAD_MIN") ? atoi(getenv("SV_POLYC_WGRAD_MIN")) : 0;
+  if (L[0]->d.dtype == SV_F32 && n <= 2 && n * L[0]->d.B >= pcw_min && svg_polyc_wgrad_form(&L[0]->d) && p->bufidx.count("polycw" + std::to_string(ln[1] - '0' - 1) + "_x")) {
+    const std::string base = "polycw" + std::to_string(ln[1] - '0' - 1);          // layer name d<k>: index k - 1 in dec[]
+    float *dwv[2], *dbv[2], *slab[2], *pw[2];
+    for (int i = 0; i < n; ++i) {
+      dwv[i] = grads + p->params[L[i]->kparam].off; dbv[i] = grads + p->params[L[i]->bparam].off;
+      slab[i] = (float*)((char*)p->bp("wgrad_ws") + (p->side_slot * SV_WGRAD_MAX_MULTI + i) * wsb);
+      pw[i] = (float*)p->bp(base + (i == 0 ? "_x" : "_xh"));
+      fl += conv_flops(L[i]->d);
+    }
+    Scope sc(p, st, nm, fl, by);
+    const int rc = svk_polyc_wgrad_multi(&L[0]->d, n, x, dy, dwv, dbv, slab, wsb, pw, st);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+    fl = 0;
   }
   // measured (profiles/r03_f_defer.txt): one launch instead of seven saves 20-26 us of SERIAL time, but the slabs (~250 MB a step) are then read
   // cold from HBM on the critical path after the join instead of warm from L2 / MALL on the side stream: B = 512 -0.5..1 %, B = 64 +5 %.  Opt-in.

@@ -1,0 +1,263 @@
+// POLYPHASE WEIGHT GRADIENT at the reference's precision (fp32), for every (UpSampling2D(bilinear) -> Conv2D(padding='same')) layer of the decoders
+// (vae/model.py:154-156,:163-167: d4 = Conv2D(32, 6), d5 = Conv2D(6, 6); Conv2DBackpropFilter + BiasAddGrad of vae/trainer.py:137):
+//
+//   dW[ky,kx] = sum_{classes c = (py,px)} sum_{ty,tx} cy(py,ky,ty) cx(px,kx,tx) dW'_c[ty,tx]  -  dW_frame[ky,kx]
+//
+//   dW'_c[ty,tx][ci][co] = sum_{b,i,j} x~[b, i+ty, j+tx, ci] dy[b, 2i+py, 2j+px, co]      on the LOW-RES grid, x~ = the edge-clamped low-res input
+//
+// (tests/test_polyphase_math.py pins the algebra).  The main terms run on wgrad_tile_f32.hip: per parity class with only the offsets that parity touches
+// (svg_polyc: 25 / 20 / 20 / 16 taps, 81 of the direct form's 144 tap products) or, for the thin head, as ONE 25-tap problem whose 32 columns are the four
+// parities x 8 channels (svg_poly; the x-packed direct form issues 44 tap slots x 16 columns per pixel pair).  This file holds the small terms:
+//   * polyc_wgrad_frame_kernel: dW_frame = the taps of the K-1 border rows / columns per side that leave the zero-padded image: per border class c and
+//     tap t, G[c][t][ci][co] = sum_b sum_pos line_b[pos + t - pad][ci] dy_b[class pixel pos][co] -- 1-D weight gradients along the upsampled edge lines
+//     (rows replicate-extended, columns zero-extended: poly_fix.hip's lines), K = line pixels, four per v_mfma_f32_16x16x4_f32.  A workgroup owns one
+//     class and a group of images, accumulates in registers and leaves one slab;
+//   * polyc_wgrad_project_kernel: the projection above, the frame slabs summed in group order (deterministic), added into dW.
+#include <stdlib.h>
+#include <string.h>
+#include "common.hip.h"
+#include "kernels.h"
+#include "conv_geom.h"
+
+namespace {
+
+constexpr int FRAME_GROUPS = 16;     // image groups per border class (workgroups = 2 (K-1) x groups x networks)
+
+struct PolycFrameMulti { const float* x[2]; const float* dy[2]; float* slab[2]; };
+
+// CIF / COF: 16-channel fragments of the input / of dY (the head's 6 -> 8 channels fill half a fragment); NFW = fragments per wave = ceil(K CIF COF / 4)
+template <int K, int CIF, int COF>
+__global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrameMulti mg, int B, int h, int w, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CIN = 16 * CIF, NFRAG = K * CIF * COF, NFW = (NFRAG + 3) / 4, NC = K - 1, PAD = (K - 1) / 2;
+  constexpr int PSL = CIN * 4 + 64, YSL = COF * 64 + 64;      // pitches: the four pixels of an operand (lane >> 4) land 16 banks apart
+  static_assert(4 % COF == 0, "a wave keeps one dY column fragment");
+  const float* __restrict__ x = mg.x[blockIdx.z];
+  const float* __restrict__ dy = mg.dy[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  const int cls = blockIdx.x, c = cls % NC;
+  const bool rows = cls < NC;
+  const int H2 = 2 * h, W2 = 2 * w, L = H2 > W2 ? H2 : W2, LW = L + K - 1;
+  const int npos = rows ? W2 : H2, m2 = rows ? H2 : W2;
+  const int edge = c < PAD ? c : m2 - (K - 1 - PAD) + (c - PAD);
+  const int line = (rows ? 0 : 2) + (c >= PAD ? 1 : 0), n = rows ? w : h;
+  char* sLine = smem;                    // [LW] pixels of PSL bytes
+  char* sDy = smem + LW * PSL;           // [L] pixels of YSL bytes
+  f32x4 acc[NFW];
+  int aoff[NFW];
+#pragma unroll
+  for (int q = 0; q < NFW; ++q) {
+    acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int f = min(wave + 4 * q, NFRAG - 1), gq = f / COF, tap = gq / CIF, cif = gq % CIF;
+    aoff[q] = (tap + kq) * PSL + (cif * 16 + lr) * 4;
+  }
+  const int boff = kq * YSL + ((wave % COF) * 16 + lr) * 4;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    __syncthreads();                     // the previous image is consumed
+    const float* xb = x + (int64_t)b * h * w * CIN;
+    for (int it = tid; it < LW * (CIN / 4); it += 256) {
+      const int ch = it % (CIN / 4), li = it / (CIN / 4);
+      int u = li - PAD;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
+        u = min(max(u, 0), 2 * n - 1);
+        const int m = u >> 1;
+        const int i0 = (u & 1) ? m : max(m - 1, 0), i1 = (u & 1) ? min(m + 1, n - 1) : m;
+        const float fw = (u & 1) ? 0.25f : 0.75f;
+        const int64_t o0 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * CIN : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * CIN;
+        const int64_t o1 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * CIN : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * CIN;
+        const uint4 a0 = *(const uint4*)(xb + o0 + ch * 4), a1 = *(const uint4*)(xb + o1 + ch * 4);
+        f32x2 p0[2], p1[2], r[2];
+        Piece<float>::unpack(a0, p0); Piece<float>::unpack(a1, p1);
+        r[0] = lerp2(p0[0], p1[0], fw); r[1] = lerp2(p0[1], p1[1], fw);          // the arithmetic of the forward's lines (poly_fix.hip)
+        v = __builtin_bit_cast(float4, Piece<float>::pack(r));
+      }
+      *(float4*)(sLine + li * PSL + ch * 16) = v;
+    }
+    const float* dyb = dy + (int64_t)b * H2 * W2 * ldy;
+    for (int it = tid; it < L * (COF * 4); it += 256) {
+      const int ch = it % (COF * 4), pos = it / (COF * 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pos < npos && ch * 4 < ldy) v = *(const float4*)(dyb + ((int64_t)(rows ? edge : pos) * W2 + (rows ? pos : edge)) * ldy + ch * 4);
+      *(float4*)(sDy + pos * YSL + ch * 16) = v;
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < npos; p0 += 4) {
+      const float bv = *(const float*)(sDy + p0 * YSL + boff);
+#pragma unroll
+      for (int q = 0; q < NFW; ++q) {
+        const float av = *(const float*)(sLine + p0 * PSL + aoff[q]);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);     // D rows = input channels, columns = dY channels
+      }
+    }
+  }
+  // slab[group][class][fragment f = (tap * CIF + cif) * COF + cof][register][lane]
+  float* sl = mg.slab[blockIdx.z] + ((int64_t)blockIdx.y * (2 * NC) + cls) * (NFRAG * 256) + lane;
+#pragma unroll
+  for (int q = 0; q < NFW; ++q) {
+    const int f = wave + 4 * q;
+    if (f >= NFRAG) continue;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) sl[(f * 4 + r4) * 64] = acc[q][r4];
+  }
+}
+
+struct PolycProject {
+  const float* dWp[2]; float* dbp[2]; const float* slab[2]; float* dW[2]; float* dbias[2];
+  int K, Cin, Cout, merged, groups, coff[4];      // coff: float offsets of the class buffers in dWp (per-class form)
+};
+
+__global__ __launch_bounds__(256) void polyc_wgrad_project_kernel(const PolycProject f) {
+  const int z = blockIdx.y, K = f.K, Cin = f.Cin, Cout = f.Cout, pad = (K - 1) / 2, nc = K - 1;
+  const int CIF = Cin / 16, COF = (Cout + 15) / 16, NFRAG = K * CIF * COF;
+  const int idx = blockIdx.x * 256 + threadIdx.x, total = K * K * Cin * Cout;
+  const float* __restrict__ dWp = f.dWp[z];
+  const float* __restrict__ gs = f.slab[z];
+  if (idx < total) {
+    const int co = idx % Cout, ci = (idx / Cout) % Cin, kk = idx / (Cout * Cin), ky = kk / K, kx = kk % K;
+    float v = 0.f;
+    for (int py = 0; py < 2; ++py) {
+      int ty0;
+      const int nty = svg_polyc_taps(K, py, &ty0);
+      for (int tyi = 0; tyi < nty; ++tyi) {
+        const float cy = svg_pcoef(py, ky, ty0 + tyi, pad);
+        if (cy == 0.f) continue;
+        for (int px = 0; px < 2; ++px) {
+          int tx0;
+          const int ntx = svg_polyc_taps(K, px, &tx0);
+          for (int txi = 0; txi < ntx; ++txi) {
+            const float cx = svg_pcoef(px, kx, tx0 + txi, pad);
+            if (cx == 0.f) continue;
+            const int cls = py * 2 + px;
+            // merged head: dW'[t = (tx+2)*5 + (ty+2)][ci][(py*2+px)*8 + co] (conv_api.hip: svg_poly_wgrad_args); per class: dW'_c[t = txi*nty + tyi][ci][co]
+            const float g = f.merged ? dWp[(((tx0 + txi + 2) * 5 + (ty0 + tyi + 2)) * Cin + ci) * 32 + cls * 8 + co]
+                                     : dWp[f.coff[cls] + ((txi * nty + tyi) * Cin + ci) * Cout + co];
+            v += cy * cx * g;
+          }
+        }
+      }
+    }
+    // frame: the fragment element of (class, tap, ci, co), summed over the image groups in group order
+    const int cl = ci & 15, lane = (cl >> 2) * 16 + (co & 15), r4 = cl & 3;
+    auto gsum = [&](int cls, int tap) {
+      const int fr = (tap * CIF + (ci >> 4)) * COF + (co >> 4);
+      const float* p = gs + (int64_t)cls * (NFRAG * 256) + (fr * 4 + r4) * 64 + lane;
+      float s = 0.f;
+      for (int g = 0; g < f.groups; ++g) s += p[(int64_t)g * (2 * nc) * (NFRAG * 256)];
+      return s;
+    };
+    for (int c = 0; c < nc; ++c) {
+      if (svg_polyc_excl(K, c, ky)) v -= gsum(c, kx);            // row class: excluded ky, tap = kx
+      if (svg_polyc_excl(K, c, kx)) v -= gsum(nc + c, ky);       // column class: excluded kx, tap = ky
+    }
+    f.dW[z][idx] += v;
+  }
+  if (f.merged) {                       // the head's dbias' has the four parities side by side; the class problems of the per-class form add into dbias themselves
+    if (blockIdx.x == 0 && threadIdx.x < Cout && f.dbias[z]) {
+      float s = 0.f;
+      for (int p = 0; p < 4; ++p) s += f.dbp[z][p * 8 + threadIdx.x];
+      f.dbias[z][threadIdx.x] += s;
+    }
+  }
+}
+
+static inline int64_t frame_per(int K, int Cin, int Cout) { return (int64_t)K * (Cin / 16) * ((Cout + 15) / 16) * 256; }
+static inline int64_t dwp_floats(const sv_conv_desc* d, int merged, int coff[4]) {
+  if (merged) return (int64_t)25 * svg_cin_pad(d) * 32;
+  int64_t n = 0;
+  for (int c = 0; c < 4; ++c) {
+    int t0;
+    if (coff) coff[c] = (int)n;
+    n += (int64_t)svg_polyc_taps(d->KH, c >> 1, &t0) * svg_polyc_taps(d->KH, c & 1, &t0) * svg_cin_pad(d) * d->Cout;
+  }
+  return n;
+}
+
+}  // namespace
+
+// does the layer have a polyphase weight gradient at fp32?  1: per class (svg_polyc), 2: merged head (svg_poly)
+int svg_polyc_wgrad_form(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_POLYC_WGRAD") != nullptr;
+  if (off || d->dtype != SV_F32) return 0;
+  const int cin = svg_cin_pad(d);
+  if (svg_polyc(d) && d->KH == 6 && d->Cout == 32 && (cin == 64 || cin == 32) && d->H / 2 >= 8 && d->W / 2 >= 8) return 1;    // (instantiations: d4)
+  if (svg_poly(d) && cin == 32 && d->H / 2 >= 8 && d->W / 2 >= 8) return 2;
+  return 0;
+}
+
+// floats of the per-problem workspace: [dW' of every class | the merged dW'] [dbias' 32] [frame slabs]
+int64_t svk_polyc_wgrad_ws_floats(const sv_conv_desc* d) {
+  const int form = svg_polyc_wgrad_form(d);
+  if (!form) return 0;
+  return dwp_floats(d, form == 2, nullptr) + 32 + (int64_t)FRAME_GROUPS * 2 * (d->KH - 1) * frame_per(d->KH, svg_cin_pad(d), d->Cout);
+}
+
+void svg_polyc_wgrad_args(const sv_conv_desc* d, int cls, WgradArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int h = d->H / 2, w = d->W / 2, cpad = svg_cin_pad(d), K = d->KH, py = cls >> 1, px = cls & 1;
+  int ty0, tx0;
+  const int nty = svg_polyc_taps(K, py, &ty0), ntx = svg_polyc_taps(K, px, &tx0);
+  a->M = d->B * h * w; a->lOY = ilog2_exact(h); a->lOX = ilog2_exact(w); a->OY = h; a->OX = w;
+  a->IH = h; a->IW = w; a->lda = d->ldx; a->S = 1; a->SX = 1;
+  a->ldy = svg_gdy(d); a->ycols = svg_gdy(d); a->cl2 = ilog2_exact(cpad / svg_epp(d));
+  a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout; a->ntaps = nty * ntx; a->Nrows = a->ntaps * cpad;
+  a->clampin = 1; a->dy_os = 2; a->dy_oy = py; a->dy_ox = px; a->assign = 1; a->msplit = a->M;
+  for (int txi = 0; txi < ntx; ++txi)
+    for (int tyi = 0; tyi < nty; ++tyi) { a->dy[txi * nty + tyi] = (int8_t)(ty0 + tyi); a->dx[txi * nty + tyi] = (int8_t)(tx0 + txi); }
+}
+
+// n <= 2 twin layers: main terms (one launch per parity class, both networks each) + frame + projection.  dW / dbias are ADDED to.  slab_ws[i]: >= slab_bytes
+// of partial-sum workspace (SV_WGRAD_WS_BYTES), pw[i]: svk_polyc_wgrad_ws_floats(d) floats (no state between calls).  SV_E_UNSUPPORTED (nothing launched)
+// when the layer has no such form.
+int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo, const void* const* dy, float* const* dW, float* const* dbias,
+                          float* const* slab_ws, int64_t slab_bytes, float* const* pw, hipStream_t st) {
+  const int form = svg_polyc_wgrad_form(d);
+  if (!form || n < 1 || n > 2) return SV_E_UNSUPPORTED;
+  const int merged = form == 2, K = d->KH, cin = svg_cin_pad(d), h = d->H / 2, w = d->W / 2;
+  PolycProject pj;
+  memset(&pj, 0, sizeof(pj));
+  const int64_t ndwp = dwp_floats(d, merged, pj.coff);
+  WgradArgs a[2];
+  if (merged)                          // the head's dbias' (four parities side by side): the main term's reduce ADDS its bias partials
+    for (int i = 0; i < n; ++i)
+      if (hipMemsetAsync(pw[i] + ndwp, 0, 32 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+  for (int c = 0; c < (merged ? 1 : 4); ++c) {
+    for (int i = 0; i < n; ++i) {
+      if (merged) svg_poly_wgrad_args(d, &a[i]); else svg_polyc_wgrad_args(d, c, &a[i]);
+      a[i].A = x_lo[i]; a[i].dY = dy[i];
+      a[i].dW = pw[i] + (merged ? 0 : pj.coff[c]);
+      a[i].dbias = merged ? pw[i] + ndwp : (dbias ? dbias[i] : nullptr);
+      a[i].ws = slab_ws[i]; a[i].ws_bytes = slab_bytes;
+    }
+    const int rc = svk_wgrad_tile_f32_multi(a, n, st);
+    if (rc) return c == 0 ? rc : (rc == SV_E_UNSUPPORTED ? SV_E_STATE : rc);    // (a later class cannot fail where class 0 passed: same geometry)
+  }
+  PolycFrameMulti m;
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    m.x[i] = (const float*)x_lo[k]; m.dy[i] = (const float*)dy[k]; m.slab[i] = pw[k] + ndwp + 32;
+    pj.dWp[i] = pw[k]; pj.dbp[i] = pw[k] + ndwp; pj.slab[i] = m.slab[i]; pj.dW[i] = dW[k]; pj.dbias[i] = dbias ? dbias[k] : nullptr;
+  }
+  pj.K = K; pj.Cin = cin; pj.Cout = d->Cout; pj.merged = merged; pj.groups = FRAME_GROUPS;
+  const int L = 2 * (h > w ? h : w), LW = L + K - 1;
+  const dim3 grid(2 * (K - 1), FRAME_GROUPS, n);
+  const int ldy = svg_gdy(d);
+  if (cin == 64 && d->Cout == 32) {
+    const size_t lds = (size_t)LW * (64 * 4 + 64) + (size_t)L * (2 * 64 + 64);
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 4, 2>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 4, 2>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+  } else if (cin == 32 && d->Cout == 32) {
+    const size_t lds = (size_t)LW * (32 * 4 + 64) + (size_t)L * (2 * 64 + 64);
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 2>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 2>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+  } else if (cin == 32 && d->Cout <= 16) {
+    const size_t lds = (size_t)LW * (32 * 4 + 64) + (size_t)L * (64 + 64);
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 1>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 1>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+  } else return SV_E_STATE;                                                       // (svg_polyc_wgrad_form admits only these)
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(polyc_wgrad_project_kernel, dim3((K * K * cin * d->Cout + 255) / 256, n), dim3(256), 0, st, pj);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}

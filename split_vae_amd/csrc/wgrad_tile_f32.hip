@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       // (ups: the layer's input is the 2x bilinear resize of the LOW-RES tensor A, blended on the fly with upsample2x_fwd's own arithmetic)
       if (g.ups) stage_tile_upsampled<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
+      else if (g.clampin) stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);   // polyphase forms: the edge-clamped low-res tensor
       else stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
     }
     for (int q = tid; q < dy_total; q += 256) {
@@ -85,7 +86,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (b < g.B) v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4);
+      if (b < g.B) {
+        if (g.dy_s2d)          // merged polyphase head: column c * 4 = (py * 2 + px) * 8 + co of low-res pixel (i, j) is channel co of hi-res pixel (2i + py, 2j + px)
+          v = *(const uint4*)(Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 2)) * (2 * g.OX) + 2 * (tx0 + tx) + ((c >> 1) & 1)) * 8 + (c & 1) * 4);
+        else if (g.dy_os)      // one parity class of the per-class polyphase form: hi-res pixel (2i + dy_oy, 2j + dy_ox)
+          v = *(const uint4*)(Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + g.dy_oy) * (2 * g.OX) + 2 * (tx0 + tx) + g.dy_ox) * g.ldy + c * 4);
+        else v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4);
+      }
       *(uint4*)(sDy + r * YS + c * 16) = v;
     }
     __syncthreads();
@@ -185,9 +192,13 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   static const bool off = getenv("SV_NO_WGRAD_TILE_F32") != nullptr;
   if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) F32_REJ("off / problems");
   const WgradArgs& w = wv[0];
-  if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || (w.ups && w.S != 1) || w.dy_s2d || w.clampin || w.ycols != w.ldy) F32_REJ("form");
+  if (w.lOY < 0 || w.lOX < 0 || w.S > 2 || (w.S != w.SX && !w.fold_kw) || (w.ups && w.S != 1) || w.ycols != w.ldy) F32_REJ("form");
+  // polyphase forms (conv_geom.h: svg_poly / svg_polyc): edge-clamped low-res input, dY through its space-to-depth view (merged head: 32 columns) or one parity class
+  const bool polyf = w.clampin != 0;
+  if (polyf && (w.S != 1 || w.ups || w.fold_kw || !(w.dy_s2d == 8 ? w.ldy == 32 : w.dy_os == 2))) F32_REJ("polyphase form");
+  if (!polyf && (w.dy_s2d || w.dy_os)) F32_REJ("dY view");
   const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, ldy = w.ldy, nt = w.ntaps;
-  if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && nt != 9 && !(nt == 42 && w.fold_kw))) {
+  if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && nt != 9 && !(nt == 42 && w.fold_kw) && !(polyf && (nt == 25 || nt == 20 || nt == 12 || nt == 9)))) {
     if (trace) fprintf(stderr, "wgrad_tile_f32: OY %d OX %d ldy %d taps %d cin %d\n", OY, OX, ldy, nt, cin);
     F32_REJ("grid / taps");
   }
@@ -234,6 +245,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const int B = w.M >> (w.lOY + w.lOX);
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.assign = w.assign; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
+  a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.dy_os = w.dy_os; a.dy_oy = w.dy_oy; a.dy_ox = w.dy_ox;
   a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
   a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
   a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
@@ -271,6 +283,9 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   F32_LAYER(11, 1, 16, 16, 2);      // d5, x-packed (pixel pairs)
   F32_LAYER(9, 1, 8, 16, 1);        // d5, direct form (SV_NO_PACKX)
   F32_LAYER(9, 2, 32, 16, 1);       // d4
+  F32_LAYER(7, 2, 32, 16, 1);       // polyphase: the head's merged 25-tap form (32 = 4 parities x 8 columns) and d4's class (0, 0) (25 taps on 28 slots)
+  F32_LAYER(5, 2, 32, 16, 1);       // d4's classes (0, 1) and (1, 0): 20 taps
+  F32_LAYER(4, 2, 32, 16, 1);       // d4's class (1, 1): 16 taps
   F32_LAYER(4, 4, 64, 16, 1);       // d3
   F32_LAYER(4, 8, 128, 16, 1);      // d2
   F32_LAYER(4, 8, 128, 16, 2);      // e3

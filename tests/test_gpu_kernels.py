@@ -901,6 +901,41 @@ def test_fp32_polyphase_forward_against_fp64(ops, layer, B):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5, 40])
+@pytest.mark.parametrize("layer", [("d4", 16, 64, 32, 6, False), ("d4_64", 32, 64, 32, 6, False), ("d4_128", 64, 64, 32, 6, False),
+                                   ("d5", 32, 32, 6, 6, True), ("d5_64", 64, 32, 6, 6, True)], ids=lambda l: l[0])
+def test_fp32_polyphase_weight_gradient_against_fp64(ops, layer, B):
+    """Conv2DBackpropFilter + BiasAddGrad of UpSampling2D(bilinear) -> Conv2D (vae/model.py:154-156,:163-167) at the reference's precision in POLYPHASE form
+    (polyc_wgrad.hip: d4 per parity class -- 25 / 20 / 20 / 16 taps on the low-res grid --, the head as one 25-tap problem over the space-to-depth view of dY;
+    frame term for the taps that leave the image; projection onto the 6 x 6 kernel) against the fp64 autograd of resize -> conv from the same fp32 operands;
+    accumulated INTO dw / db; bitwise run to run (fixed-order slabs and frame groups)."""
+    name, H, Cin, Cout, k, yf32 = layer
+    rng = np.random.default_rng(H * 7 + Cin + B)
+    x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32))
+    c8 = (Cout + 7) // 8 * 8
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, c8)).astype(np.float32))
+    dy[..., Cout:] = 0
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.float32, y_f32=yf32, ups_in=True)
+    dw, db = conv.wgrad(x_lo.cuda(), dy.cuda(), workspace=True)
+    wt = torch.zeros(k, k, Cin, Cout, dtype=torch.float64, requires_grad=True)
+    bt = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(x_lo.double()), wt, bt, 1, None)
+    (y * dy[..., :Cout].double()).sum().backward()
+    torch.testing.assert_close(dw.double().cpu(), wt.grad, rtol=F32_RTOL, atol=F32_ATOL * float(wt.grad.abs().max()))
+    torch.testing.assert_close(db.double().cpu(), bt.grad, rtol=F32_RTOL, atol=F32_ATOL * float(bt.grad.abs().max()))
+    # every tap of the kernel on its own (the border taps carry the frame term)
+    for ky in range(k):
+        for kx in range(k):
+            torch.testing.assert_close(dw[ky, kx].double().cpu(), wt.grad[ky, kx], rtol=F32_RTOL, atol=F32_ATOL * float(wt.grad.abs().max()))
+    dw2, db2 = conv.wgrad(x_lo.cuda(), dy.cuda(), workspace=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # accumulation: a second call into the same buffers doubles them
+    conv.wgrad(x_lo.cuda(), dy.cuda(), workspace=True, dw=dw2, db=db2)
+    torch.testing.assert_close(dw2, 2 * dw, rtol=1e-5, atol=0)
+    torch.testing.assert_close(db2, 2 * db, rtol=1e-5, atol=0)
+
+
 SPAIR_OBJECT_LAYERS = [  # name, H, Cin, Cout, k, stride: the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses
     ("obj_conv1", 32, 3, 32, 3, 2),      # RGB padded to 8 channels: fragment rows 8..15 are dropped (no tap pairs at an odd kernel width)
     ("obj_conv2", 16, 32, 64, 3, 2),

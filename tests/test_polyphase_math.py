@@ -238,3 +238,47 @@ def test_per_class_polyphase_forward_identity(K):
                             out[b, edge, pos] -= rv @ w[k, tap]
                             out[b, pos, edge] -= cv @ w[tap, k]
     np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("K", [6, 4])
+def test_per_class_polyphase_weight_gradient_identity(K):
+    """dW = sum_c P_c(dW'_c) - dW_frame with dW'_c the weight gradient of class c's conv on the low-res grid (edge-clamped input, dY read at the class's
+    sub-pixel) -- csrc/polyc_wgrad.hip -- against autograd of the oracle's resize + conv."""
+    rng = np.random.default_rng(10 + K)
+    B, h, C, Co = 2, 8, 4, 3
+    H, pad = 2 * h, (K - 1) // 2
+    x = rng.standard_normal((B, h, h, C))
+    w = rng.standard_normal((K, K, C, Co)) * 0.2
+    dy = rng.standard_normal((B, H, H, Co))
+    wt = torch.from_numpy(w).requires_grad_(True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(torch.from_numpy(x)), wt, torch.zeros(Co, dtype=torch.float64), 1, None)
+    (y * torch.from_numpy(dy)).sum().backward()
+    want = wt.grad.numpy()
+    P = 3
+    xp = np.pad(x, ((0, 0), (P, P), (P, P), (0, 0)), mode="edge")
+    dW = np.zeros_like(w)
+    for py in range(2):
+        for px in range(2):
+            dys = dy[:, py::2, px::2, :]
+            for ty in _polyc_taps(K, py):
+                for tx in _polyc_taps(K, px):
+                    dWp = np.einsum("bijc,bijo->co", xp[:, P + ty:P + ty + h, P + tx:P + tx + h, :], dys)
+                    for ky in range(K):
+                        for kx in range(K):
+                            dW[ky, kx] += _pcoef(py, ky, ty, pad) * _pcoef(px, kx, tx, pad) * dWp
+    for b in range(B):
+        top, bot = _line_up(x[b, 0]), _line_up(x[b, h - 1])
+        left, right = _line_up(x[b, :, 0]), _line_up(x[b, :, h - 1])
+        for c in range(K - 1):
+            edge = _class_edge(K, c, H)
+            rline, cline = (top, left) if c < pad else (bot, right)
+            for pos in range(H):
+                for tap in range(K):
+                    q = pos + tap - pad
+                    rv = rline[min(max(q, 0), H - 1)]
+                    cv = cline[q] if 0 <= q < H else np.zeros(C)
+                    for k in range(K):
+                        if _polyc_excl(K, c, k):
+                            dW[k, tap] -= np.outer(rv, dy[b, edge, pos])
+                            dW[tap, k] -= np.outer(cv, dy[b, pos, edge])
+    np.testing.assert_allclose(dW, want, rtol=1e-9, atol=1e-9)
