@@ -224,6 +224,13 @@ int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const void* w_dg
  * sv_conv2d_nhwc_dgrad followed by sv_upsample2x_bwd instead (bitwise the same result). */
 int sv_conv2d_nhwc_dgrad_lowres(const sv_conv_desc* d, const void* dy, const void* w_dgrad,
                                 const void* relu_mask_lo, void* dx_lo, void* stream);
+/* The same with a caller-owned workspace (sv_conv2d_dgrad_lowres_workspace_bytes; 0: the layer needs none).  At the reference's precision (SV_F32) the
+ * 6 x 6 upsample -> conv layers (vae/model.py:155-156 behind :165 / :167: d4, d5) take the POLYPHASE form: the transposed conv and the resize adjoint collapse
+ * into one stride-2 conv with 9 x 9 taps over the hi-res dy (81 tap products per low-res pixel instead of 4 x 36), the zero-padding / edge-clamp terms of the
+ * first and last low-res row and column travel through the workspace (csrc/polyd_dgrad.hip).  Without a (large enough) workspace: sv_conv2d_nhwc_dgrad_lowres. */
+int64_t sv_conv2d_dgrad_lowres_workspace_bytes(const sv_conv_desc* d);
+int sv_conv2d_nhwc_dgrad_lowres_ws(const sv_conv_desc* d, const void* dy, const void* w_dgrad, const void* relu_mask_lo, void* dx_lo,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
 /* dw[KH,KW,Cin,Cout] += x^T*dy, dbias[Cout] += colsum(dy) (fp32 HWIO, atomically accumulated:
  * zero them first). */
 int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,

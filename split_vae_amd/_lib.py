@@ -133,6 +133,8 @@ SYMBOLS = {
     "sv_conv2d_nhwc_fwd_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sv_conv2d_nhwc_dgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp]),
     "sv_conv2d_nhwc_dgrad_lowres": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "sv_conv2d_dgrad_lowres_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
+    "sv_conv2d_nhwc_dgrad_lowres_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "sv_conv2d_nhwc_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sv_conv2d_wgrad_workspace_bytes": (_i64, [C.POINTER(ConvDesc)]),
     "sv_conv2d_nhwc_wgrad_ws": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -14,6 +14,54 @@
 template <typename T>
 __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __restrict__ params,
                                            T* __restrict__ arena, int block_in_job) {
+  if (j.poly >= 5) {
+    // polyphase INPUT gradient (conv_geom.h: svg_polyd); source: the pk x pk HWIO master.  rows = ci (Cin padded), inner = dY channels (padded)
+    const int K = j.pk, pad = (K - 1) / 2, R = svg_polyd_radius(K), NT = 2 * R + 1;
+    const int total = j.poly == 5 ? j.rows * NT * NT * j.inner : j.poly == 6 ? 4 * 4 * NT * j.rows * j.inner : 4 * 4 * 4 * j.inner * j.rows;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* w = params + j.src_off;
+    auto W = [&](int ky, int kx, int ci, int co) -> float {
+      return (ky < 0 || kx < 0 || ci >= j.Cin || co >= j.Cout) ? 0.f : w[((int64_t)(ky * K + kx) * j.Cin + ci) * j.Cout + co];
+    };
+    float v = 0.f;
+    if (j.poly == 5) {
+      // [ci][t = dxi * NT + dyi][co] = W'_(py,px)[ty,tx][ci][co], (py, ty) from dyh = dyi - R, (px, tx) from dxh = dxi - R
+      const int co = idx % j.inner, t = (idx / j.inner) % (NT * NT), ci = idx / (j.inner * NT * NT);
+      int py, ty, px, tx;
+      const bool oky = svg_polyd_hitap(K, t % NT - R, &py, &ty), okx = svg_polyd_hitap(K, t / NT - R, &px, &tx);
+      if (oky && okx)
+        for (int ky = 0; ky < K; ++ky) {
+          const float cy = svg_pcoef(py, ky, ty, pad);
+          if (cy == 0.f) continue;
+          for (int kx = 0; kx < K; ++kx) {
+            const float cx = svg_pcoef(px, kx, tx, pad);
+            if (cx != 0.f) v += cy * cx * W(ky, kx, ci, co);
+          }
+        }
+    } else if (j.poly == 6) {
+      // [edge e: top, bottom, left, right][q][di][ci][co] = .25 sum_k c(p,k,t) (w[k+(q)][k] - w[k-(q)][k])   (rows; columns with the roles of ky / kx swapped)
+      const int co = idx % j.inner, ci = (idx / j.inner) % j.rows, di = (idx / (j.inner * j.rows)) % NT, q = (idx / (j.inner * j.rows * NT)) & 3, e = idx / (j.inner * j.rows * NT * 4);
+      int pp, tt, kp, km;
+      const bool ok = svg_polyd_hitap(K, di - R, &pp, &tt);
+      svg_polyd_kpm(K, e & 1, q, &kp, &km);
+      if (ok && kp >= 0)                                 // (k+ < 0: q beyond this edge's rows: zero)
+        for (int k = 0; k < K; ++k) {
+          const float c = svg_pcoef(pp, k, tt, pad);
+          if (c == 0.f) continue;
+          v += 0.25f * c * (e < 2 ? W(kp, k, ci, co) - W(km, k, ci, co) : W(k, kp, ci, co) - W(k, km, ci, co));
+        }
+    } else {
+      // [corner: TL, TR, BL, BR][qr][qs][co][ci] = .0625 (w[k+r][k+s] - w[k+r][k-s] - w[k-r][k+s] + w[k-r][k-s])
+      const int ci = idx % j.rows, co = (idx / j.rows) % j.inner, qs = (idx / (j.rows * j.inner)) & 3, qr = (idx / (j.rows * j.inner * 4)) & 3, c = idx / (j.rows * j.inner * 16);
+      int kpr, kmr, kps, kms;
+      svg_polyd_kpm(K, c >> 1, qr, &kpr, &kmr);
+      svg_polyd_kpm(K, c & 1, qs, &kps, &kms);
+      if (kpr >= 0 && kps >= 0) v = 0.0625f * (W(kpr, kps, ci, co) - W(kpr, kms, ci, co) - W(kmr, kps, ci, co) + W(kmr, kms, ci, co));
+    }
+    arena[j.dst_off + idx] = from_f32<T>(v);
+    return;
+  }
   if (j.poly >= 3) {
     // per-class polyphase (conv_geom.h: svg_polyc); source: the pk x pk HWIO master
     const int total = j.poly == 3 ? j.rows * j.ntaps * j.inner : 2 * (j.pk - 1) * j.pk * j.rows * j.inner;
@@ -512,6 +560,40 @@ int64_t svg_polyc_fix_elems(const sv_conv_desc* d) { return (int64_t)2 * (d->KH 
 // row-class terms [B][K-1][W][Cout] + column-class terms [B][H][K-1][Cout], fp32 (H, W: the hi-res extent)
 int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d) { return (int64_t)d->B * (d->KH - 1) * (d->H + d->W) * d->Cout * 4; }
 
+// ---- polyphase input gradient (conv_geom.h: svg_polyd)
+void svg_polyd_args(const sv_conv_desc* d, TapGemmArgs* a) {
+  memset(a, 0, sizeof(*a));
+  const int epp = svg_epp(d), gdy = svg_gdy(d), h = d->H / 2, w = d->W / 2, R = svg_polyd_radius(d->KH), NT = 2 * R + 1;
+  a->M = d->B * h * w;
+  a->lOY = ilog2_exact(h); a->lOX = ilog2_exact(w); a->OY = h; a->OX = w;
+  a->IH = d->H; a->IW = d->W; a->lda = gdy;             // the input is the hi-res dY
+  a->cl2 = ilog2_exact(gdy / epp);
+  a->ntaps = NT * NT; a->Ktot = a->ntaps * gdy; a->P = a->Ktot / epp;
+  a->S = 2; a->SX = 2; a->N = d->Cin;
+  a->OHF = h; a->OWF = w; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldx;
+  a->act = SV_ACT_NONE; a->out_f32 = 0; a->splitk = 1;
+  a->fix_nc = 2; a->fix_pad = 1;                        // edge terms: first / last low-res row and column
+  for (int dxi = 0; dxi < NT; ++dxi)
+    for (int dyi = 0; dyi < NT; ++dyi) { a->dy[dxi * NT + dyi] = (int8_t)(dyi - R); a->dx[dxi * NT + dyi] = (int8_t)(dxi - R); }
+}
+
+void svg_prep_job_polyd(const sv_conv_desc* d, int which, PrepJob* j) {
+  memset(j, 0, sizeof(*j));
+  static const int BNt[4] = {128, 64, 32, 16};
+  const int NT = 2 * svg_polyd_radius(d->KH) + 1;
+  j->Cin = d->Cin; j->Cout = d->Cout; j->pk = d->KH; j->poly = 5 + which;
+  if (which == 0) { j->rows = round_up(d->Cin, BNt[svg_pick_cfg(d->Cin)]); j->inner = svg_gdy(d); j->ntaps = NT * NT; }
+  else { j->rows = svg_cin_pad(d); j->inner = svg_polyd_cop(d); j->ntaps = which == 1 ? 16 * NT : 64; }
+  j->inner_ld = j->inner;
+  j->nblocks = (int)(((int64_t)j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS));
+}
+int64_t svg_polyd_elems(const sv_conv_desc* d, int which) {
+  PrepJob j;
+  svg_prep_job_polyd(d, which, &j);
+  return ((int64_t)j.rows * j.ntaps * j.inner + 127) / 128 * 128;
+}
+int64_t svg_polyd_ws_bytes(const sv_conv_desc* d) { return (int64_t)d->B * 2 * (d->H / 2 + d->W / 2) * svg_cin_pad(d) * 4; }
+
 void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
   memset(j, 0, sizeof(*j));
   static const int BNt[4] = {128, 64, 32, 16};
@@ -538,11 +620,18 @@ int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
 }
 
 // ============================================================================ public API
+// (for_dgrad: the direct-form class images; a layer with a polyphase input gradient -- svg_polyd -- keeps its main / edge / corner images behind them, 128-element aligned)
+static int64_t svg_polyd_base(const sv_conv_desc* d) {
+  int64_t n = 0;
+  for (int c = 0; c < svg_dgrad_classes(d); ++c) n += svg_wprep_elems_class(d, 1, c);
+  return (n + 127) / 128 * 128;
+}
 extern "C" int64_t sv_conv2d_wprep_elems(const sv_conv_desc* d, int32_t for_dgrad) {
   if (svg_check(d) != SV_OK) return -1;
   if (!for_dgrad) return svg_wprep_elems_class(d, 0, 0);
   int64_t n = 0;
   for (int c = 0; c < svg_dgrad_classes(d); ++c) n += svg_wprep_elems_class(d, 1, c);
+  if (svg_polyd(d)) n = svg_polyd_base(d) + svg_polyd_elems(d, 0) + svg_polyd_elems(d, 1) + svg_polyd_elems(d, 2);
   return n;
 }
 
@@ -588,6 +677,17 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
       rc = prep_single(w_hwio, w_dgrad, d->dtype, j, st);
       if (rc) return rc;
       off += (int64_t)j.rows * j.ntaps * j.inner;
+    }
+    if (svg_polyd(d)) {
+      off = svg_polyd_base(d);
+      for (int which = 0; which < 3; ++which) {
+        PrepJob j;
+        svg_prep_job_polyd(d, which, &j);
+        j.dst_off = off;
+        rc = prep_single(w_hwio, w_dgrad, d->dtype, j, st);
+        if (rc) return rc;
+        off += svg_polyd_elems(d, which);
+      }
     }
   }
   return SV_OK;
@@ -737,6 +837,23 @@ extern "C" int sv_conv2d_nhwc_dgrad_lowres(const sv_conv_desc* d, const void* dy
   svg_dgrad_args(d, 0, &a, srctap);
   a.A = dy; a.Wt = w_dgrad; a.out = dx_lo; a.mask = relu_mask_lo; a.adj = 1;
   return svk_conv_dispatch(a, d->dtype, svg_pick_cfg(d->Cin), (hipStream_t)stream);
+}
+
+// The same with a workspace: layers with a polyphase input gradient (svg_polyd: the fp32 step's d4 / d5) deliver their edge terms through it.
+extern "C" int64_t sv_conv2d_dgrad_lowres_workspace_bytes(const sv_conv_desc* d) {
+  if (svg_check(d) != SV_OK) return -1;
+  return svg_polyd(d) ? svg_polyd_ws_bytes(d) : 0;
+}
+extern "C" int sv_conv2d_nhwc_dgrad_lowres_ws(const sv_conv_desc* d, const void* dy, const void* w_dgrad, const void* relu_mask_lo, void* dx_lo,
+                                              void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = svg_check(d);
+  if (rc != SV_OK) return rc;
+  if (!dy || !w_dgrad || !dx_lo) return SV_E_BADARG;
+  if (svg_polyd(d) && workspace && workspace_bytes >= svg_polyd_ws_bytes(d)) {
+    const void* wp = (const char*)w_dgrad + svg_polyd_base(d) * (d->dtype == SV_BF16 ? 2 : 4);
+    return svk_polyd_dgrad_multi(d, 1, &dy, &wp, &relu_mask_lo, &dx_lo, &workspace, (hipStream_t)stream);
+  }
+  return sv_conv2d_nhwc_dgrad_lowres(d, dy, w_dgrad, relu_mask_lo, dx_lo, stream);
 }
 
 extern "C" int sv_conv2d_nhwc_wgrad(const sv_conv_desc* d, const void* x, const void* dy, float* dw,

@@ -59,12 +59,15 @@ static inline int svg_poly(const sv_conv_desc* d) {
 // tests/test_polyphase_math.py pins the algebra for both kernel sizes.
 static inline int svg_polyc(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_POLYC") != nullptr;
-  static const char* ks = getenv("SV_POLYC_K") ? getenv("SV_POLYC_K") : "64";       // kernel sizes that take the form (A/B)
+  // kernel sizes that take the form.  Measured (fp32, 2 x 512 images): d4 (k 6) forward 1.182 -> 0.88 ms; d3 (k 4: 49 of 64 tap products, four launches' worth of
+  // staging and a border pass) 0.549 -> 0.567 ms: k 4 stays on the fused-resize direct form (SV_POLYC_K=64 enables it)
+  const char* ks = getenv("SV_POLYC_K") ? getenv("SV_POLYC_K") : "6";       // (read per call: tests/test_gpu_kernels.py switches it for the k = 4 case)
   static const bool bf = getenv("SV_POLYC_BF16") != nullptr;
   if (off || !(d->dtype == SV_F32 || bf) || !d->ups_in || d->stride != 1 || d->KH != d->KW || (d->KH != 6 && d->KH != 4)) return 0;
   if (!strchr(ks, d->KH == 6 ? '6' : '4')) return 0;
-  if (d->y_f32 || d->Cout % 32 || d->Cout > 128 || d->ldy != d->Cout) return 0;
-  if (d->Cin != svg_cin_pad(d) || d->Cin < 16 || (d->Cin & (d->Cin - 1)) || d->ldx != d->Cin) return 0;
+  if (d->y_f32 || d->ldy != d->Cout || d->ldx != d->Cin) return 0;
+  // (the border kernel's instantiations, poly_fix.hip)
+  if (!((d->KH == 6 && d->Cout == 32 && (d->Cin == 64 || d->Cin == 32)) || (d->KH == 4 && d->Cout == 64 && d->Cin == 128))) return 0;
   return d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1));
 }
 // blend coefficient of hi-res tap k of output parity p on the low-res offset t (kernel size K, SAME pad before = (K-1)/2): the hi-res offset from row 2i is
@@ -168,6 +171,58 @@ void svg_prep_job_polyc_fix(const sv_conv_desc* d, PrepJob* j);
 int64_t svg_polyc_class_elems(const sv_conv_desc* d, int cls);
 int64_t svg_polyc_fix_elems(const sv_conv_desc* d);
 int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d);
+// POLYPHASE INPUT GRADIENT of an upsample -> conv layer, delivered at the LOW-RES tensor (ResizeBilinearGrad o Conv2DBackpropInput o ReluGrad in one pass;
+// polyd_dgrad.hip, tests/test_polyphase_math.py).  The transposed per-class polyphase conv reads dy[2(i'-ty)+py, 2(j'-tx)+px] for (class, offset) pairs: every
+// hi-res offset dh = p - 2t in [-R, R] (R = 4 for k = 6, 3 for k = 4) belongs to exactly one (parity p, low-res offset t), so the main term is ONE stride-2
+// conv with (2R+1)^2 taps over the hi-res dY:   dx[i',j'] = sum_{dyh,dxh} V[dyh,dxh]^T dy[2i'+dyh, 2j'+dxh],   V[dyh,dxh] = W'_(py,px)[ty,tx]
+// -- 81 tap products per low-res pixel instead of 4 x 36 -- with dy zero outside the image.  That is the gradient of the conv over an UNPADDED, unclamped
+// resize; the reference zero-pads the upsampled image (no gradient flows through the pad rows) and the resize clamps at the edge (the .25 weight of the
+// missing neighbour folds onto the edge row).  Both corrections land on the first / last low-res row and column only:
+//   rows:    dx[0, j']   += .25 sum_{q, dxh} (Vx[k+(q)][dxh] - Vx[k-(q)][dxh])^T dy[q, 2j'+dxh]          k+(q) = pad - q, k-(q) = pad - 1 - q   (q <= pad)
+//            dx[h-1, j'] += .25 sum_{q, dxh} (...)^T dy[2h-1-q, 2j'+dxh]                                k+(q) = pad + q, k-(q) = pad + 1 + q   (q <= K-1-pad)
+//   (Vx[ky][dxh] = sum_kx cx(px,kx,tx) w[ky,kx]: the x-only composite; indices outside the kernel drop out), the same for columns, and the four corner
+//   pixels += .0625 sum_{qr,qs} (w[k+r,k+s] - w[k+r,k-s] - w[k-r,k+s] + w[k-r,k-s])^T dy[row qr, column qs].
+// The main term runs on the tile kernel (S = 2); the edge terms come from polyd_edge_kernel through the epilogue's border-term path (TapGemmArgs::fix).
+static inline int svg_polyd(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_POLYD") != nullptr;
+  if (off || d->dtype != SV_F32 || !d->ups_in || d->stride != 1 || d->KH != 6 || d->KW != 6 || d->ldx != d->Cin) return 0;
+  if (d->H < 32 || d->W < 32 || (d->H & (d->H - 1)) || (d->W & (d->W - 1))) return 0;      // (the edge kernel works on 16-pixel fragments of the low-res lines)
+  // (the edge kernel's instantiations: d4 = 64 -> 32, its 32-channel variant, the head 32 -> 6)
+  return (d->Cout == 32 && (d->Cin == 64 || d->Cin == 32)) || (d->Cout <= 8 && d->Cin == 32);
+}
+// hi-res offsets of the stride-2 form: [-R, R]; k = 6: R = 4 (81 taps), k = 4: R = 3
+static inline __host__ __device__ int svg_polyd_radius(int K) {
+  int r = 0;
+  for (int p = 0; p < 2; ++p) {
+    int t0;
+    const int n = svg_polyc_taps(K, p, &t0), hi = p - 2 * t0, lo = p - 2 * (t0 + n - 1);
+    r = hi > r ? hi : r;
+    r = -lo > r ? -lo : r;
+  }
+  return r;
+}
+// (parity, low-res offset) of hi-res offset dh: p = dh mod 2, t = (p - dh) / 2; false when that parity has no such offset
+static inline __host__ __device__ bool svg_polyd_hitap(int K, int dh, int* p, int* t) {
+  const int pp = dh & 1, tt = (pp - dh) / 2;
+  int t0;
+  const int n = svg_polyc_taps(K, pp, &t0);
+  *p = pp; *t = tt;
+  return tt >= t0 && tt < t0 + n;
+}
+// kernel rows k+ / k- of distance q from a low (first row / column) or high (last) edge; -1: outside the kernel
+static inline __host__ __device__ void svg_polyd_kpm(int K, int hi_edge, int q, int* kp, int* km) {
+  const int pad = (K - 1) / 2;
+  int a = hi_edge ? pad + q : pad - q, b = hi_edge ? pad + 1 + q : pad - 1 - q;
+  *kp = (a >= 0 && a < K) ? a : -1;
+  *km = (b >= 0 && b < K) ? b : -1;
+}
+static inline int svg_polyd_cop(const sv_conv_desc* d) { const int g = svg_gdy(d), m = d->dtype == SV_BF16 ? 32 : 16; return g < m ? m : g; }   // dY channels per edge operand (padded to one MFMA group)
+void svg_polyd_args(const sv_conv_desc* d, TapGemmArgs* a);
+void svg_prep_job_polyd(const sv_conv_desc* d, int which, PrepJob* j);          // which: 0 main, 1 edges, 2 corners
+int64_t svg_polyd_elems(const sv_conv_desc* d, int which);                      // (128-element aligned)
+int64_t svg_polyd_ws_bytes(const sv_conv_desc* d);                              // row terms [B][2][w][Cin] + column terms [B][h][2][Cin], fp32
+int svk_polyd_dgrad_multi(const sv_conv_desc* d, int n, const void* const* dy, const void* const* w_polyd, const void* const* mask_lo, void* const* dx_lo,
+                          void* const* edgews, hipStream_t st);
 // polyphase weight gradient at fp32 (polyc_wgrad.hip): 0 none, 1 per class (svg_polyc), 2 merged head (svg_poly); workspace floats per problem; class problem
 int svg_polyc_wgrad_form(const sv_conv_desc* d);
 int64_t svk_polyc_wgrad_ws_floats(const sv_conv_desc* d);

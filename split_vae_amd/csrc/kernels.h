@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define SV_MAX_TAPS 42      // 6 x 7: the x-pixel-packed form of a 6x6 stride-1 conv (conv_geom.h svg_packx)
+#define SV_MAX_TAPS 81      // 9 x 9: the stride-2 hi-res tap form of the polyphase input gradient (conv_geom.h: svg_polyd); 6 x 7 = 42: the x-packed 6x6 conv (svg_packx)
 
 // ---- generic "tap GEMM": out[m, n] = sum_{t, c} A[pix(m) + tap t, c] * Wt[n][t][c]
 // rows m enumerate (b, oy, ox) over a power-of-two OY x OX grid; taps are (dy, dx) offsets on an
@@ -241,7 +241,9 @@ struct PrepJob {
                        // [10 classes][6 taps][16][Cin] (conv_api.hip: prep_poly)
                        // 3: per-class polyphase image [rows][nty*ntx (x-major)][Cin] of class pcls of a pk x pk kernel (conv_geom.h: svg_polyc)
                        // 4: its border-class image [2*(pk-1) classes][pk taps][rows][Cin] = -(sum over the taps that leave the image)
-  int32_t pk, pcls;    // poly 3 / 4: kernel size; parity class py*2 + px
+                       // 5: main image of the polyphase INPUT gradient [rows = ci][(2R+1)^2 hi-res taps (x-major)][co]; 6: its edge images
+                       // [4 edges: top, bottom, left, right][4 rows from the edge][2R+1][ci][co]; 7: its corner images [4 corners][4][4][co][ci] (conv_geom.h: svg_polyd)
+  int32_t pk, pcls;    // poly 3 .. 7: kernel size; poly 3: parity class py*2 + px
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap

@@ -81,6 +81,7 @@ struct Layer {
   int kparam, bparam;           // indices into the param table (kernel, bias); head uses two kernels
   int64_t wf_off;               // prepared forward weights (element offset in arena)
   int64_t wd_off[4];            // prepared dgrad weights per parity class
+  int64_t wdp_off;              // polyphase input gradient (svg_polyd): main / edge / corner images, or -1
   bool need_dgrad;
 };
 
@@ -279,7 +280,7 @@ static void build_layers(sv_lgvae_plan* p) {
     L.name = name;
     L.d = sv_conv_desc{B, h, w, cin, cout, k, k, s, act, d.dtype, ldx, ldy, yf32, 0};
     L.kparam = kparam; L.bparam = kparam + 1; L.need_dgrad = need_dgrad;
-    L.wf_off = 0;
+    L.wf_off = 0; L.wdp_off = -1;
     for (int i = 0; i < 4; ++i) L.wd_off[i] = 0;
     return L;
   };
@@ -320,6 +321,17 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
     p->jobs.push_back(j);
   };
   auto align = [&]() { arena = (arena + 127) / 128 * 128; };
+  auto polyd_jobs = [&](Layer& L) {                       // polyphase input gradient (conv_geom.h: svg_polyd): main, edge and corner images
+    if (!L.need_dgrad || !svg_polyd(&L.d)) return;
+    align(); L.wdp_off = arena;
+    for (int which = 0; which < 3; ++which) {
+      PrepJob j;
+      svg_prep_job_polyd(&L.d, which, &j);
+      j.src_off = p->params[L.kparam].off; j.dst_off = arena;
+      arena += svg_polyd_elems(&L.d, which);
+      push(j);
+    }
+  };
   auto do_layer = [&](Layer& L, bool is_head) {
     if (!is_head && svg_polyc(&L.d)) {
       // per-class polyphase forward (conv_geom.h: svg_polyc): four class images + the border-class image, contiguous from wf_off in the
@@ -346,6 +358,7 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
           arena += (int64_t)jd.rows * jd.ntaps * jd.inner;
           push(jd);
         }
+      polyd_jobs(L);
     } else if (!is_head) {
       PrepJob j;
       svg_prep_job_fwd(&L.d, &j);
@@ -370,6 +383,7 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
           arena += (int64_t)jd.rows * jd.ntaps * jd.inner;
           push(jd);
         }
+      polyd_jobs(L);
     } else {
       // two Keras tensors [F,L] (mean at kparam, sd at kparam+2) -> one [2L][F] forward image
       // and one [F][2L] dgrad image
@@ -426,6 +440,11 @@ static void build_buffers(sv_lgvae_plan* p) {
       if (svg_polyc(&p->dec[0][l].d)) need = std::max<int64_t>(need, svg_polyc_fix_ws_bytes(&p->dec[0][l].d));
     p->add_buf("polycfix_x", need);
     p->add_buf("polycfix_xh", need);
+    int64_t needd = 256;                                  // edge terms of the polyphase input gradients (d4, d5): one region per network
+    for (int l = 2; l <= 4; ++l)
+      if (svg_polyd(&p->dec[0][l].d)) needd = std::max<int64_t>(needd, svg_polyd_ws_bytes(&p->dec[0][l].d));
+    p->add_buf("polyd_x", needd);
+    p->add_buf("polyd_xh", needd);
     // polyphase weight gradients at fp32 (polyc_wgrad.hip): dW' + frame slabs per layer and network (the layers' launches may overlap across streams)
     for (int l = 2; l <= 4; ++l) {
       const int64_t fl = svk_polyc_wgrad_ws_floats(&p->dec[0][l].d);
@@ -1024,7 +1043,19 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
     //  default moved from 256 to 128)
     static const int adj_min = getenv("SV_RC_ADJ_MIN") ? atoi(getenv("SV_RC_ADJ_MIN")) : 128;
     int frc = SV_E_UNSUPPORTED;
-    if (Ls[0]->d.ups_in && Ls[1]->d.ups_in && !no_adj && 2 * B >= adj_min) frc = run_dgrad_layers(p, 2, Ls, gy, lo, (void* const*)gl, false, st, true);
+    if (Ls[0]->wdp_off >= 0 && Ls[1]->wdp_off >= 0) {
+      // fp32: the polyphase form (polyd_dgrad.hip): conv-transpose + resize adjoint + ReLU gate as one stride-2 conv over dY, edge terms through a workspace
+      const void* wp[2];
+      void* ews[2] = {p->bp("polyd_x"), p->bp("polyd_xh")};
+      double fl = 0, by = 0;
+      for (int k = 0; k < 2; ++k) {
+        wp[k] = (const char*)p->bp("warena") + Ls[k]->wdp_off * p->esz();
+        fl += conv_flops(Ls[k]->d); by += conv_bytes(Ls[k]->d, 1, p->esz());
+      }
+      Scope sc(p, st, "dgrad." + Ls[0]->name.substr(Ls[0]->name.find('.') + 1), fl, by);
+      frc = svk_polyd_dgrad_multi(&Ls[0]->d, 2, gy, wp, lo, (void* const*)gl, ews, st);
+    }
+    if (frc == SV_E_UNSUPPORTED && Ls[0]->d.ups_in && Ls[1]->d.ups_in && !no_adj && 2 * B >= adj_min) frc = run_dgrad_layers(p, 2, Ls, gy, lo, (void* const*)gl, false, st, true);
     if (frc != SV_E_UNSUPPORTED) { SV_TRY(frc); continue; }
     // ... else the hi-res gradient goes through HBM and a stand-alone adjoint pass
     SV_TRY(run_dgrad_layers(p, 2, Ls, gy, none, (void* const*)gu, false, st));

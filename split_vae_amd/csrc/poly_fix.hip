@@ -18,31 +18,12 @@
 //                   the path of callers without a workspace (sv_conv2d_nhwc_fwd), ~10x slower
 #include "common.hip.h"
 #include "kernels.h"
+#include "fix_mma.hip.h"
 #include <stdlib.h>
 
 namespace {
 
 struct PolyFixMulti { const void* x[2]; const void* wfix[2]; float* out6[2]; float* fixbuf[2]; };   // blockIdx.y: the twin networks
-
-// one 16-B piece of each operand: bf16 = 8 channels x 4 lane groups = 32 channels in ONE v_mfma_f32_16x16x32_bf16; fp32 = 4 channels x 4 lane groups =
-// 16 channels in FOUR v_mfma_f32_16x16x4_f32 (instruction e contracts channel 4 * group + e of both operands): exact fp32, the reference's arithmetic
-template <typename T> struct FixMma;
-template <> struct FixMma<bf16_t> {
-  static constexpr int CPG = 32;
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct FixMma<float> {
-  static constexpr int CPG = 16;
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-    const float4 af = __builtin_bit_cast(float4, a), bf = __builtin_bit_cast(float4, b);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
-  }
-};
 
 // one pixel of an upsampled edge line: hi coordinate u (clamped by the caller) of a line of n low-res pixels -> the two low-res indices and the weight of the second
 __device__ __forceinline__ void line_src(int u, int n, int& i0, int& i1, float& f) {
@@ -173,67 +154,89 @@ __global__ __launch_bounds__(256) void poly_fix_kernel(const PolyFixMulti mg, in
 // added by the conv's epilogue before the activation (tile_conv.hip).
 struct PolycFixMulti { const void* x[2]; const void* wfix[2]; float* frow[2]; float* fcol[2]; };
 
-template <typename T>
-__global__ __launch_bounds__(256) void polyc_fix_kernel(const PolycFixMulti mg, int h, int w, int Cin, int Cout, int K) {
+// A workgroup owns ONE border class and a group of images: every wave keeps the class weights of its 16 output channels in registers (K taps x NGRP operand
+// pieces) for all of them; the class's edge line of NB images at a time goes to LDS (one barrier pair per NB images), a wave then runs its pixel fragments
+// of each image: K x NGRP operand pairs per fragment.  (The first version -- one workgroup per image, weights re-read from L2 for every fragment -- took
+// 122 us per launch at 2 x 512 images; the work is 4 GFLOP.)
+template <typename T, int K, int NGRP, int NCF, int NB>
+__global__ __launch_bounds__(256) void polyc_fix_kernel(const PolycFixMulti mg, int B, int h, int w) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG;
-  const T* __restrict__ x = (const T*)mg.x[blockIdx.y];
-  const T* __restrict__ wfix = (const T*)mg.wfix[blockIdx.y];
-  float* __restrict__ frow = mg.frow[blockIdx.y];
-  float* __restrict__ fcol = mg.fcol[blockIdx.y];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG, CIN = NGRP * CPG, COUT = NCF * 16, NPC = CIN / EPP;
+  constexpr int PSB = CIN * (int)sizeof(T) + 16, PAD = (K - 1) / 2, NC = K - 1;   // +16: the pixels of a fragment on different banks
+  static_assert(4 % NCF == 0, "a wave keeps one channel fragment");
+  const T* __restrict__ x = (const T*)mg.x[blockIdx.z];
+  const T* __restrict__ wfix = (const T*)mg.wfix[blockIdx.z];
+  float* __restrict__ frow = mg.frow[blockIdx.z];
+  float* __restrict__ fcol = mg.fcol[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
-  const int H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2, nc = K - 1, nb = K - 1 - pad;
-  const int L = H2 > W2 ? H2 : W2, LW = L + K - 1;          // line index li = hi coordinate + pad
-  const int npc = Cin / EPP, PSB = Cin * (int)sizeof(T) + 16;   // 16-B pieces / bytes per line pixel (+16: the pixels of a fragment on different banks)
-  const T* xb = x + (int64_t)b * h * w * Cin;
-  // ---- the four lines (0 top row, 1 bottom row: replicate-extended; 2 left column, 3 right column: zero outside the image)
-  for (int it = tid; it < 4 * LW * npc; it += 256) {
-    const int ch = it % npc, li = (it / npc) % LW, line = it / (npc * LW);
-    const bool is_row = line < 2;
-    const int n = is_row ? w : h;
-    int u = li - pad;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (li < 2 * n + K - 1 && (is_row || (u >= 0 && u < 2 * n))) {
-      u = min(max(u, 0), 2 * n - 1);
-      int i0, i1;
-      float f;
-      line_src(u, n, i0, i1, f);
-      const int64_t o0 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * Cin : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * Cin;
-      const int64_t o1 = is_row ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * Cin : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * Cin;
-      const uint4 a0 = *(const uint4*)(xb + o0 + ch * EPP), a1 = *(const uint4*)(xb + o1 + ch * EPP);
-      f32x2 p0[Piece<T>::NP], p1[Piece<T>::NP], r[Piece<T>::NP];
-      Piece<T>::unpack(a0, p0); Piece<T>::unpack(a1, p1);
+  const int cls = blockIdx.x, c = cls % NC;
+  const bool rows = cls < NC;
+  const int H2 = 2 * h, W2 = 2 * w, L = H2 > W2 ? H2 : W2, LW = L + K - 1;
+  const int npos = rows ? W2 : H2, n = rows ? w : h, line = (rows ? 0 : 2) + (c >= PAD ? 1 : 0);
+  const int cf = wave % NCF;
+  uint4 wv[K][NGRP];
+  {
+    const T* wp = wfix + (((int64_t)cls * K) * COUT + cf * 16 + lr) * CIN + lg * EPP;
 #pragma unroll
-      for (int e = 0; e < Piece<T>::NP; ++e) r[e] = lerp2(p0[e], p1[e], f);
-      v = Piece<T>::pack(r);
-    }
-    *(uint4*)(smem + (line * LW + li) * PSB + ch * 16) = v;
-  }
-  __syncthreads();
-  // ---- units: (class, channel fragment, pixel fragment)
-  const int ncf = Cout >> 4, npf_r = W2 >> 4, npf_c = H2 >> 4;
-  const int units_r = nc * ncf * npf_r, units = units_r + nc * ncf * npf_c;
-  const int ngrp = Cin / CPG;
-  for (int u = wave; u < units; u += 4) {
-    const bool rows = u < units_r;
-    const int v = rows ? u : u - units_r, npf = rows ? npf_r : npf_c;
-    const int pf = v % npf, cf = (v / npf) % ncf, c = v / (npf * ncf);
-    const int cls = rows ? c : nc + c;
-    const int line = (rows ? 0 : 2) + (c >= pad ? 1 : 0);
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const T* wp = wfix + (((int64_t)cls * K) * Cout + cf * 16 + lr) * Cin + lg * EPP;
-    const char* lp = smem + (line * LW + 16 * pf + lr) * PSB + lg * 16;
     for (int tap = 0; tap < K; ++tap)
-      for (int gq = 0; gq < ngrp; ++gq) {
-        const uint4 wv = *(const uint4*)(wp + (int64_t)tap * Cout * Cin + gq * CPG);
-        const uint4 pv = *(const uint4*)(lp + tap * PSB + gq * (CPG * (int)sizeof(T)));
-        FixMma<T>::run(wv, pv, acc);                       // D rows = output channels 4 * lg .., columns = line pixels
-      }
-    const int pos = 16 * pf + lr, co = cf * 16 + lg * 4;
-    float* p = rows ? frow + (((int64_t)b * nc + c) * W2 + pos) * Cout + co : fcol + (((int64_t)b * H2 + pos) * nc + c) * Cout + co;
-    *(float4*)p = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+      for (int gq = 0; gq < NGRP; ++gq) wv[tap][gq] = *(const uint4*)(wp + (int64_t)tap * COUT * CIN + gq * CPG);
   }
+  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
+  for (int b0 = b_lo; b0 < b_hi; b0 += NB) {
+    __syncthreads();                     // the previous batch is consumed
+    for (int it = tid; it < NB * LW * NPC; it += 256) {
+      const int ch = it % NPC, li = (it / NPC) % LW, ib = it / (NPC * LW), b = b0 + ib;
+      int u = li - PAD;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b < b_hi && li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
+        u = min(max(u, 0), 2 * n - 1);
+        int i0, i1;
+        float f;
+        line_src(u, n, i0, i1, f);
+        const T* xb = x + (int64_t)b * h * w * CIN;
+        const int64_t o0 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * CIN : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * CIN;
+        const int64_t o1 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * CIN : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * CIN;
+        const uint4 a0 = *(const uint4*)(xb + o0 + ch * EPP), a1 = *(const uint4*)(xb + o1 + ch * EPP);
+        f32x2 p0[Piece<T>::NP], p1[Piece<T>::NP], r[Piece<T>::NP];
+        Piece<T>::unpack(a0, p0); Piece<T>::unpack(a1, p1);
+#pragma unroll
+        for (int e = 0; e < Piece<T>::NP; ++e) r[e] = lerp2(p0[e], p1[e], f);
+        v = Piece<T>::pack(r);
+      }
+      *(uint4*)(smem + (ib * LW + li) * PSB + ch * 16) = v;
+    }
+    __syncthreads();
+    const int npf = npos >> 4;
+    for (int u = wave / NCF; u < NB * npf; u += 4 / NCF) {       // (image of the batch, pixel fragment)
+      const int ib = u / npf, pf = u - ib * npf, b = b0 + ib;
+      if (b >= b_hi) break;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const char* lp = smem + (ib * LW + 16 * pf + lr) * PSB + lg * 16;
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap)
+#pragma unroll
+        for (int gq = 0; gq < NGRP; ++gq) FixMma<T>::run(wv[tap][gq], *(const uint4*)(lp + tap * PSB + gq * (CPG * (int)sizeof(T))), acc);   // D rows = output channels 4 * lg .., columns = line pixels
+      const int pos = 16 * pf + lr, co = cf * 16 + lg * 4;
+      float* p = rows ? frow + (((int64_t)b * NC + c) * W2 + pos) * COUT + co : fcol + (((int64_t)b * H2 + pos) * NC + c) * COUT + co;
+      *(float4*)p = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+}
+
+template <typename T, int K, int NGRP, int NCF>
+static int launch_polyc_fix(const PolycFixMulti& m, int n, int B, int h, int w, hipStream_t st) {
+  constexpr int NB = 4;
+  const int LW = 2 * (h > w ? h : w) + K - 1;
+  const size_t lds = (size_t)NB * LW * (NGRP * FixMma<T>::CPG * sizeof(T) + 16);
+  if (lds > 150 * 1024) return SV_E_UNSUPPORTED;
+  int groups = (B + 15) / 16;                               // ~16 images per workgroup: four batches of NB
+  if (groups < 1) groups = 1;
+  sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<T, K, NGRP, NCF, NB>, lds);
+  hipLaunchKernelGGL((polyc_fix_kernel<T, K, NGRP, NCF, NB>), dim3(2 * (K - 1), groups, n), dim3(256), lds, st, m, B, h, w);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 }  // namespace
@@ -241,26 +244,23 @@ __global__ __launch_bounds__(256) void polyc_fix_kernel(const PolycFixMulti mg, 
 int svk_polyc_fix_multi(int n, const void* const* x_lo, const void* const* wfix, float* const* fixrow, float* const* fixcol, int B, int h, int w,
                         int Cin, int Cout, int K, int dtype, hipStream_t st) {
   if (n < 1 || n > 2 || B < 1 || h < 8 || w < 8 || (h & 7) || (w & 7) || (Cout & 15) || (K != 4 && K != 6)) return SV_E_BADARG;
-  const int cpg = dtype == SV_BF16 ? 32 : 16, esz = dtype == SV_BF16 ? 2 : 4;
-  if (Cin % cpg) return SV_E_UNSUPPORTED;
-  const int LW = 2 * (h > w ? h : w) + K - 1;
-  const size_t lds = (size_t)4 * LW * (Cin * esz + 16);
-  if (lds > 150 * 1024) return SV_E_UNSUPPORTED;
   PolycFixMulti m;
   for (int i = 0; i < 2; ++i) {
     const int k = i < n ? i : 0;
     m.x[i] = x_lo[k]; m.wfix[i] = wfix[k]; m.frow[i] = fixrow[k]; m.fcol[i] = fixcol[k];
     if (!m.x[i] || !m.wfix[i] || !m.frow[i] || !m.fcol[i]) return SV_E_BADARG;
   }
-  if (dtype == SV_BF16) {
-    sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<bf16_t>, lds);
-    hipLaunchKernelGGL(polyc_fix_kernel<bf16_t>, dim3(B, n), dim3(256), lds, st, m, h, w, Cin, Cout, K);
+  // instantiations: the layers of the model (d4: 6 x 6, 64 -> 32; d3: 4 x 4, 128 -> 64) and the 32-channel variant of d4
+  if (dtype == SV_F32) {
+    if (K == 6 && Cin == 64 && Cout == 32) return launch_polyc_fix<float, 6, 4, 2>(m, n, B, h, w, st);
+    if (K == 6 && Cin == 32 && Cout == 32) return launch_polyc_fix<float, 6, 2, 2>(m, n, B, h, w, st);
+    if (K == 4 && Cin == 128 && Cout == 64) return launch_polyc_fix<float, 4, 8, 4>(m, n, B, h, w, st);
   } else {
-    sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<float>, lds);
-    hipLaunchKernelGGL(polyc_fix_kernel<float>, dim3(B, n), dim3(256), lds, st, m, h, w, Cin, Cout, K);
+    if (K == 6 && Cin == 64 && Cout == 32) return launch_polyc_fix<bf16_t, 6, 2, 2>(m, n, B, h, w, st);
+    if (K == 6 && Cin == 32 && Cout == 32) return launch_polyc_fix<bf16_t, 6, 1, 2>(m, n, B, h, w, st);
+    if (K == 4 && Cin == 128 && Cout == 64) return launch_polyc_fix<bf16_t, 4, 4, 4>(m, n, B, h, w, st);
   }
-  SV_LAUNCH_CHECK();
-  return SV_OK;
+  return SV_E_UNSUPPORTED;
 }
 
 int64_t svk_poly_fix_ws_bytes(int B, int h, int w) { return (int64_t)B * (5 * 2 * w + 6 * 2 * h) * 8 * 4; }   // sized for Cout <= 8

@@ -21,12 +21,15 @@
 
 namespace {
 
-constexpr int FRAME_GROUPS = 16;     // image groups per border class (workgroups = 2 (K-1) x groups x networks)
+// image groups per border class (workgroups = 2 (K-1) x groups x networks) and images staged per barrier pair.  Measured (2 x 512 images, d4 / d5 frame kernel + projection):
+// 16 groups, 1 image: 177 / 131 + 30 us; 32 groups, 4 images (72-86 KB of LDS: one workgroup per CU): 160 / 165 + 52 us
+constexpr int FRAME_GROUPS = 16;
+constexpr int FRAME_NB = 2;
 
 struct PolycFrameMulti { const float* x[2]; const float* dy[2]; float* slab[2]; };
 
 // CIF / COF: 16-channel fragments of the input / of dY (the head's 6 -> 8 channels fill half a fragment); NFW = fragments per wave = ceil(K CIF COF / 4)
-template <int K, int CIF, int COF>
+template <int K, int CIF, int COF, int NB>
 __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrameMulti mg, int B, int h, int w, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CIN = 16 * CIF, NFRAG = K * CIF * COF, NFW = (NFRAG + 3) / 4, NC = K - 1, PAD = (K - 1) / 2;
@@ -42,8 +45,8 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
   const int npos = rows ? W2 : H2, m2 = rows ? H2 : W2;
   const int edge = c < PAD ? c : m2 - (K - 1 - PAD) + (c - PAD);
   const int line = (rows ? 0 : 2) + (c >= PAD ? 1 : 0), n = rows ? w : h;
-  char* sLine = smem;                    // [LW] pixels of PSL bytes
-  char* sDy = smem + LW * PSL;           // [L] pixels of YSL bytes
+  char* sLine = smem;                    // [NB][LW] pixels of PSL bytes
+  char* sDy = smem + NB * LW * PSL;      // [NB][L] pixels of YSL bytes
   f32x4 acc[NFW];
   int aoff[NFW];
 #pragma unroll
@@ -53,18 +56,20 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
     aoff[q] = (tap + kq) * PSL + (cif * 16 + lr) * 4;
   }
   const int boff = kq * YSL + ((wave % COF) * 16 + lr) * 4;
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
-    __syncthreads();                     // the previous image is consumed
-    const float* xb = x + (int64_t)b * h * w * CIN;
-    for (int it = tid; it < LW * (CIN / 4); it += 256) {
-      const int ch = it % (CIN / 4), li = it / (CIN / 4);
+  // NB images per barrier pair (one image at a time the loop was all latency: 177 us per launch for 4 GFLOP)
+  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
+  for (int b0 = b_lo; b0 < b_hi; b0 += NB) {
+    __syncthreads();                     // the previous batch is consumed
+    for (int it = tid; it < NB * LW * (CIN / 4); it += 256) {
+      const int ch = it % (CIN / 4), li = (it / (CIN / 4)) % LW, ib = it / ((CIN / 4) * LW), b = b0 + ib;
       int u = li - PAD;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
+      if (b < b_hi && li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
         u = min(max(u, 0), 2 * n - 1);
         const int m = u >> 1;
         const int i0 = (u & 1) ? m : max(m - 1, 0), i1 = (u & 1) ? min(m + 1, n - 1) : m;
         const float fw = (u & 1) ? 0.25f : 0.75f;
+        const float* xb = x + (int64_t)b * h * w * CIN;
         const int64_t o0 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * CIN : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * CIN;
         const int64_t o1 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * CIN : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * CIN;
         const uint4 a0 = *(const uint4*)(xb + o0 + ch * 4), a1 = *(const uint4*)(xb + o1 + ch * 4);
@@ -73,24 +78,26 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
         r[0] = lerp2(p0[0], p1[0], fw); r[1] = lerp2(p0[1], p1[1], fw);          // the arithmetic of the forward's lines (poly_fix.hip)
         v = __builtin_bit_cast(float4, Piece<float>::pack(r));
       }
-      *(float4*)(sLine + li * PSL + ch * 16) = v;
+      *(float4*)(sLine + (ib * LW + li) * PSL + ch * 16) = v;
     }
-    const float* dyb = dy + (int64_t)b * H2 * W2 * ldy;
-    for (int it = tid; it < L * (COF * 4); it += 256) {
-      const int ch = it % (COF * 4), pos = it / (COF * 4);
+    for (int it = tid; it < NB * L * (COF * 4); it += 256) {
+      const int ch = it % (COF * 4), pos = (it / (COF * 4)) % L, ib = it / (COF * 4 * L), b = b0 + ib;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pos < npos && ch * 4 < ldy) v = *(const float4*)(dyb + ((int64_t)(rows ? edge : pos) * W2 + (rows ? pos : edge)) * ldy + ch * 4);
-      *(float4*)(sDy + pos * YSL + ch * 16) = v;
+      if (b < b_hi && pos < npos && ch * 4 < ldy)
+        v = *(const float4*)(dy + (int64_t)b * H2 * W2 * ldy + ((int64_t)(rows ? edge : pos) * W2 + (rows ? pos : edge)) * ldy + ch * 4);
+      *(float4*)(sDy + (ib * L + pos) * YSL + ch * 16) = v;
     }
     __syncthreads();
-    for (int p0 = 0; p0 < npos; p0 += 4) {
-      const float bv = *(const float*)(sDy + p0 * YSL + boff);
+    for (int ib = 0; ib < NB; ++ib)      // (images past the group's end were staged as zeros)
+#pragma unroll 4
+      for (int p0 = 0; p0 < npos; p0 += 4) {
+        const float bv = *(const float*)(sDy + (ib * L + p0) * YSL + boff);
 #pragma unroll
-      for (int q = 0; q < NFW; ++q) {
-        const float av = *(const float*)(sLine + p0 * PSL + aoff[q]);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);     // D rows = input channels, columns = dY channels
+        for (int q = 0; q < NFW; ++q) {
+          const float av = *(const float*)(sLine + (ib * LW + p0) * PSL + aoff[q]);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);     // D rows = input channels, columns = dY channels
+        }
       }
-    }
   }
   // slab[group][class][fragment f = (tap * CIF + cif) * COF + cof][register][lane]
   float* sl = mg.slab[blockIdx.z] + ((int64_t)blockIdx.y * (2 * NC) + cls) * (NFRAG * 256) + lane;
@@ -244,17 +251,17 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
   const dim3 grid(2 * (K - 1), FRAME_GROUPS, n);
   const int ldy = svg_gdy(d);
   if (cin == 64 && d->Cout == 32) {
-    const size_t lds = (size_t)LW * (64 * 4 + 64) + (size_t)L * (2 * 64 + 64);
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 4, 2>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 4, 2>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+    const size_t lds = FRAME_NB * ((size_t)LW * (64 * 4 + 64) + (size_t)L * (2 * 64 + 64));
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 4, 2, FRAME_NB>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 4, 2, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
   } else if (cin == 32 && d->Cout == 32) {
-    const size_t lds = (size_t)LW * (32 * 4 + 64) + (size_t)L * (2 * 64 + 64);
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 2>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 2>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+    const size_t lds = FRAME_NB * ((size_t)LW * (32 * 4 + 64) + (size_t)L * (2 * 64 + 64));
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 2, FRAME_NB>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 2, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
   } else if (cin == 32 && d->Cout <= 16) {
-    const size_t lds = (size_t)LW * (32 * 4 + 64) + (size_t)L * (64 + 64);
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 1>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 1>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
+    const size_t lds = FRAME_NB * ((size_t)LW * (32 * 4 + 64) + (size_t)L * (64 + 64));
+    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 1, FRAME_NB>, lds);
+    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 1, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
   } else return SV_E_STATE;                                                       // (svg_polyc_wgrad_form admits only these)
   SV_LAUNCH_CHECK();
   hipLaunchKernelGGL(polyc_wgrad_project_kernel, dim3((K * K * cin * d->Cout + 255) / 256, n), dim3(256), 0, st, pj);

@@ -1,0 +1,156 @@
+// POLYPHASE INPUT GRADIENT of the upsample -> conv layers (conv_geom.h: svg_polyd has the algebra; tests/test_polyphase_math.py pins it):
+//   Conv2DBackpropInput + ResizeBilinearGrad + ReluGrad of vae/model.py:163-167 (d4 / d5) in one pass, delivered at the LOW-RES tensor.
+// The main term -- one stride-2 conv with 9 x 9 taps over the hi-res dY -- runs on the tile kernel (tile_conv.hip); this file holds
+//   * polyd_edge_kernel: the corrections of the first / last low-res row and column (zero padding of the upsampled image + the resize's edge clamp):
+//     per edge a conv along the border strip of dY (up to four hi-res rows / columns from the edge) with (row from the edge q, hi-res offset d) taps,
+//     stride 2 along the strip, K = dY channels.  A workgroup owns (edge, 16 input channels, a group of images); wave q holds the 2R+1 taps of strip
+//     row q in registers, the four partial sums are added through LDS in wave order (deterministic).  Output in the layout of the epilogue's border
+//     terms: rows [B][2][w][Cin], columns [B][h][2][Cin];
+//   * polyd_corner_kernel: the four corner pixels' cross term (<= 4 x 4 dY pixels each), one thread per (corner, input channel), added into the row terms.
+#include <stdlib.h>
+#include <string.h>
+#include "common.hip.h"
+#include "kernels.h"
+#include "conv_geom.h"
+#include "fix_mma.hip.h"
+
+namespace {
+
+struct PolydEdgeMulti { const void* dy[2]; const void* wedge[2]; const void* wcorner[2]; float* erow[2]; float* ecol[2]; };
+
+// NT = 2R+1 taps along the strip, NGRP = MFMA groups over the (padded) dY channels, NB images per barrier pair
+template <typename T, int NT, int NGRP, int NB>
+__global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG, COP = NGRP * CPG, NPC = COP / EPP, R = (NT - 1) / 2;
+  constexpr int PSB = COP * (int)sizeof(T) + 16;              // strip pixel pitch (+16: lanes two pixels apart on different banks)
+  const T* __restrict__ dy = (const T*)mg.dy[blockIdx.z];
+  const T* __restrict__ wedge = (const T*)mg.wedge[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int ncif = Cin >> 4, e = (int)blockIdx.x / ncif, cif = (int)blockIdx.x % ncif;       // edge: 0 top, 1 bottom, 2 left, 3 right
+  const bool rows = e < 2, hi_edge = e & 1;
+  const int H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2;
+  const int nq = hi_edge ? K - pad : pad + 1;                 // strip rows (distance 0 .. nq-1 from the edge)
+  const int n = rows ? w : h, L2 = 2 * n, SW = L2 + 2 * R;    // low-res positions along the strip; strip width with the zero halo
+  // this wave's taps: strip row q = wave
+  uint4 wv[NT][NGRP];
+  {
+    const T* wp = wedge + ((((int64_t)e * 4 + wave) * NT) * Cin + cif * 16 + lr) * COP + lg * EPP;
+#pragma unroll
+    for (int d = 0; d < NT; ++d)
+#pragma unroll
+      for (int gq = 0; gq < NGRP; ++gq) wv[d][gq] = *(const uint4*)(wp + (int64_t)d * Cin * COP + gq * CPG);
+  }
+  char* sStrip = smem;                                         // [NB][4][SW] pixels of PSB bytes
+  float* sRed = (float*)(smem + NB * 4 * SW * PSB);           // [4 waves][NB * npf][256] partial sums
+  const int npf = n >> 4;
+  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
+  for (int b0 = b_lo; b0 < b_hi; b0 += NB) {
+    __syncthreads();                                           // the previous batch is consumed
+    for (int it = tid; it < NB * 4 * SW * NPC; it += 256) {
+      const int ch = it % NPC, a = (it / NPC) % SW - R, q = (it / (NPC * SW)) & 3, ib = it / (NPC * SW * 4), b = b0 + ib;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b < b_hi && q < nq && a >= 0 && a < L2 && ch * EPP < gdy) {
+        const int across = hi_edge ? (rows ? H2 : W2) - 1 - q : q;
+        const int64_t pix = rows ? (int64_t)across * W2 + a : (int64_t)a * W2 + across;
+        v = *(const uint4*)(dy + ((int64_t)b * H2 * W2 + pix) * gdy + ch * EPP);
+      }
+      *(uint4*)(sStrip + ((ib * 4 + q) * SW + a + R) * PSB + ch * 16) = v;
+    }
+    __syncthreads();
+    for (int u = 0; u < NB * npf; ++u) {                       // (image of the batch, pixel fragment): every wave its strip row
+      const int ib = u / npf, pf = u - ib * npf;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (wave < nq) {
+        const char* sp = sStrip + ((ib * 4 + wave) * SW + 2 * (16 * pf + lr)) * PSB + lg * 16;      // pixel 2 pos + d (d = 0 .. 2R: the halo shifts it by R)
+#pragma unroll
+        for (int d = 0; d < NT; ++d)
+#pragma unroll
+          for (int gq = 0; gq < NGRP; ++gq) FixMma<T>::run(wv[d][gq], *(const uint4*)(sp + d * PSB + gq * (CPG * (int)sizeof(T))), acc);
+      }
+      *(float4*)(sRed + ((wave * NB * npf + u) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    for (int it = tid; it < NB * npf * 64; it += 256) {        // sum the four strip rows in wave order; lane (lr = position, lg -> channels 4 lg ..)
+      const int ln = it & 63, u = it >> 6, ib = u / npf, pf = u - ib * npf, b = b0 + ib;
+      if (b >= b_hi) continue;
+      float4 s = *(const float4*)(sRed + ((0 * NB * npf + u) * 64 + ln) * 4);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const float4 v = *(const float4*)(sRed + ((q * NB * npf + u) * 64 + ln) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int pos = 16 * pf + (ln & 15), ci = cif * 16 + (ln >> 4) * 4;
+      float* p = rows ? mg.erow[blockIdx.z] + (((int64_t)b * 2 + (e & 1)) * w + pos) * Cin + ci
+                      : mg.ecol[blockIdx.z] + (((int64_t)b * h + pos) * 2 + (e & 1)) * Cin + ci;
+      *(float4*)p = s;
+    }
+  }
+}
+
+// corner (cr, cc) = (bottom?, right?): dx[row edge][column edge][ci] += sum_{qr, qs, co} Wc[corner][qr][qs][co][ci] dy[row qr from the edge][column qs from the edge][co]
+template <typename T>
+__global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int cop, int K) {
+  const T* __restrict__ dy = (const T*)mg.dy[blockIdx.y];
+  const T* __restrict__ wc = (const T*)mg.wcorner[blockIdx.y];
+  const int b = blockIdx.x, H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2;
+  for (int it = threadIdx.x; it < 4 * Cin; it += 256) {
+    const int ci = it % Cin, c = it / Cin, cr = c >> 1, cc = c & 1;
+    const int nqr = cr ? K - pad : pad + 1, nqs = cc ? K - pad : pad + 1;
+    float v = 0.f;
+    for (int qr = 0; qr < nqr; ++qr)
+      for (int qs = 0; qs < nqs; ++qs) {
+        const T* dp = dy + (((int64_t)b * H2 + (cr ? H2 - 1 - qr : qr)) * W2 + (cc ? W2 - 1 - qs : qs)) * gdy;
+        const T* wp = wc + ((int64_t)((c * 4 + qr) * 4 + qs) * cop) * Cin + ci;
+        for (int co = 0; co < gdy; ++co) v += to_f32(wp[(int64_t)co * Cin]) * to_f32(dp[co]);
+      }
+    mg.erow[blockIdx.y][(((int64_t)b * 2 + cr) * w + (cc ? w - 1 : 0)) * Cin + ci] += v;
+  }
+}
+
+template <typename T, int NT, int NGRP>
+static int launch_edge(const PolydEdgeMulti& m, int n, int B, int h, int w, int Cin, int gdy, int K, hipStream_t st) {
+  constexpr int NB = 2;
+  const int big = h > w ? h : w, SW = 2 * big + NT - 1, npf = big >> 4;
+  const size_t lds = (size_t)NB * 4 * SW * (NGRP * FixMma<T>::CPG * sizeof(T) + 16) + (size_t)4 * NB * (npf < 1 ? 1 : npf) * 256 * 4;
+  if (lds > 150 * 1024 || (h & 15) || (w & 15)) return SV_E_UNSUPPORTED;
+  int groups = (B + 7) / 8;                                 // ~8 images per workgroup
+  if (groups < 1) groups = 1;
+  sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NB>, lds);
+  hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NB>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
+  SV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(polyd_corner_kernel<T>, dim3(B, n), dim3(256), 0, st, m, B, h, w, Cin, gdy, NGRP * FixMma<T>::CPG, K);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
+}
+
+}  // namespace
+
+// n <= 2 twin layers: edge + corner terms into edgews[i] (svg_polyd_ws_bytes), then the main stride-2 conv whose epilogue adds them and applies the ReLU
+// gate of the low-res activation mask_lo[i] (may be null).  w_polyd[i]: the main / edge / corner images (svg_prep_job_polyd 0, 1, 2 back to back).
+int svk_polyd_dgrad_multi(const sv_conv_desc* d, int n, const void* const* dy, const void* const* w_polyd, const void* const* mask_lo, void* const* dx_lo,
+                          void* const* edgews, hipStream_t st) {
+  if (!svg_polyd(d) || n < 1 || n > 2) return SV_E_UNSUPPORTED;
+  const size_t esz = d->dtype == SV_BF16 ? 2 : 4;
+  const int h = d->H / 2, w = d->W / 2, cin = svg_cin_pad(d), gdy = svg_gdy(d), cop = svg_polyd_cop(d), K = d->KH;
+  const int64_t o1 = svg_polyd_elems(d, 0), o2 = o1 + svg_polyd_elems(d, 1);
+  PolydEdgeMulti m;
+  TapGemmArgs a[2];
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    m.dy[i] = dy[k];
+    m.wedge[i] = (const char*)w_polyd[k] + o1 * esz; m.wcorner[i] = (const char*)w_polyd[k] + o2 * esz;
+    m.erow[i] = (float*)edgews[k]; m.ecol[i] = m.erow[i] + (int64_t)d->B * 2 * w * cin;
+  }
+  int rc = SV_E_UNSUPPORTED;
+  if (d->dtype == SV_F32 && K == 6 && cop == 32) rc = launch_edge<float, 9, 2>(m, n, d->B, h, w, cin, gdy, K, st);
+  else if (d->dtype == SV_F32 && K == 6 && cop == 16) rc = launch_edge<float, 9, 1>(m, n, d->B, h, w, cin, gdy, K, st);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    svg_polyd_args(d, &a[i]);
+    a[i].A = dy[i]; a[i].Wt = w_polyd[i]; a[i].out = dx_lo[i]; a[i].mask = mask_lo ? mask_lo[i] : nullptr;
+    a[i].fix = m.erow[i]; a[i].fix2 = m.ecol[i];
+  }
+  return svk_conv_dispatch_multi(a, n, d->dtype, svg_pick_cfg(d->Cin), st);
+}

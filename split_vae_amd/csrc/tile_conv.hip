@@ -497,7 +497,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s && ((t.N != 16 && !(t.N == 32 && t.d2s_y)) || !t.out_f32)) return false;
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
-  if (t.fix_nc && !t.d2s_y && (!t.fix || !t.fix2 || (t.N & 15) || t.OS != 2 || t.out_f32)) return false;
+  if (t.fix_nc && !t.d2s_y && (!t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path

@@ -327,7 +327,14 @@ class Conv2D:
         mask); None when the geometry has no fused kernel (then: upsample2x_bwd(dgrad(dy), mask))."""
         d = self.desc
         dx = torch.empty((d.B, d.H // 2, d.W // 2, d.ldx), dtype=self.dtype, device=dy.device)
-        rc = _lib.load().sv_conv2d_nhwc_dgrad_lowres(C.byref(d), _p(dy), _p(self.w_dgrad), _p(relu_mask_lo), _p(dx), _stream())
+        lib = _lib.load()
+        n = lib.sv_conv2d_dgrad_lowres_workspace_bytes(C.byref(d))          # > 0: the polyphase form (fp32 d4 / d5), edge terms through a workspace
+        if n > 0:
+            if getattr(self, "_dws", None) is None or self._dws.numel() < n or self._dws.device != dy.device:
+                self._dws = torch.empty((n,), dtype=torch.uint8, device=dy.device)
+            rc = lib.sv_conv2d_nhwc_dgrad_lowres_ws(C.byref(d), _p(dy), _p(self.w_dgrad), _p(relu_mask_lo), _p(dx), _p(self._dws), n, _stream())
+        else:
+            rc = lib.sv_conv2d_nhwc_dgrad_lowres(C.byref(d), _p(dy), _p(self.w_dgrad), _p(relu_mask_lo), _p(dx), _stream())
         if rc == _lib.STATUS_UNSUPPORTED:
             return None
         check(rc, "sv_conv2d_nhwc_dgrad_lowres")

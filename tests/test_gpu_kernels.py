@@ -876,12 +876,14 @@ def test_fp32_fused_upsample_forward_and_weight_gradient(ops, layer):
 @pytest.mark.parametrize("B", [1, 5])
 @pytest.mark.parametrize("layer", [("d3_64", 16, 128, 64, 4, "relu", False), ("d4", 16, 64, 32, 6, "relu", False), ("d4_64", 32, 64, 32, 6, "relu", False),
                                    ("d4_128", 64, 64, 32, 6, "relu", False), ("d5", 32, 32, 6, 6, None, True), ("d5_64", 64, 32, 6, 6, None, True)], ids=lambda l: l[0])
-def test_fp32_polyphase_forward_against_fp64(ops, layer, B):
+def test_fp32_polyphase_forward_against_fp64(ops, layer, B, monkeypatch):
     """UpSampling2D(bilinear) -> Conv2D(padding='same') (vae/model.py:154-156,:163-167) at the reference's precision in POLYPHASE form: the head as one 5 x 5 conv over
     the low-res tensor (svg_poly), d4 / d3 as four per-parity-class convs (svg_polyc; 81 of 144 / 49 of 64 tap products), border rows / columns
     corrected by poly_fix.hip.  Against the fp64 composition resize -> zero-padded conv from the same fp32 operands: every pixel at the fp32 bar, the
     border ring (whose taps leave the image) on its own, bias and ReLU included; bitwise run to run."""
     name, H, Cin, Cout, k, act, yf32 = layer
+    if k == 4:
+        monkeypatch.setenv("SV_POLYC_K", "64")               # k = 4 (d3) keeps the direct form by default (no gain measured): the form itself is still pinned here
     rng = np.random.default_rng(H * 100 + Cin + B)
     x_lo = torch.from_numpy(rng.standard_normal((B, H // 2, H // 2, Cin)).astype(np.float32))
     w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
@@ -934,6 +936,50 @@ def test_fp32_polyphase_weight_gradient_against_fp64(ops, layer, B):
     conv.wgrad(x_lo.cuda(), dy.cuda(), workspace=True, dw=dw2, db=db2)
     torch.testing.assert_close(dw2, 2 * dw, rtol=1e-5, atol=0)
     torch.testing.assert_close(db2, 2 * db, rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5, 19])
+@pytest.mark.parametrize("layer", [("d4_64", 32, 64, 32, 6, False), ("d4_128", 64, 64, 32, 6, False), ("d5", 32, 32, 6, 6, True), ("d5_64", 64, 32, 6, 6, True)],
+                         ids=lambda l: l[0])
+def test_fp32_polyphase_input_gradient_against_fp64(ops, layer, B):
+    """Conv2DBackpropInput + ResizeBilinearGrad + ReluGrad of UpSampling2D(bilinear) -> Conv2D (vae/model.py:155-156 behind :165 / :167) at the reference's precision
+    as ONE stride-2 conv with 9 x 9 taps over the hi-res dy (polyd_dgrad.hip), edge rows / columns and corners corrected through the workspace, delivered at the
+    LOW-RES tensor with the ReLU gate: against fp64 autograd of resize -> conv from the same fp32 operands -- all pixels, the border ring and the four corners on
+    their own -- and bitwise run to run."""
+    name, H, Cin, Cout, k, yf32 = layer
+    rng = np.random.default_rng(H * 13 + Cin + B)
+    h = H // 2
+    c8 = (Cout + 7) // 8 * 8
+    x_lo = torch.from_numpy(rng.standard_normal((B, h, h, Cin)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    dy = torch.from_numpy(rng.standard_normal((B, H, H, c8)).astype(np.float32))
+    dy[..., Cout:] = 0
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.float32, y_f32=yf32, ups_in=True)
+    conv.prep(w.cuda())
+    dx = conv.dgrad_lowres(dy.cuda(), relu_mask_lo=x_lo.cuda())
+    assert dx is not None
+    xt = x_lo.double().requires_grad_(True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(xt), w.double(), torch.zeros(Cout, dtype=torch.float64), 1, None)
+    (y * dy[..., :Cout].double()).sum().backward()
+    want = xt.grad * (x_lo.double() > 0)
+    got = dx[..., :Cin].double().cpu()
+    scale = float(xt.grad.abs().max())
+    torch.testing.assert_close(got, want, rtol=F32_RTOL, atol=F32_ATOL * scale)
+    ring = torch.ones(h, h, dtype=torch.bool)
+    ring[1:h - 1, 1:h - 1] = False
+    torch.testing.assert_close(got[:, ring], want[:, ring], rtol=F32_RTOL, atol=F32_ATOL * scale)
+    for i in (0, h - 1):
+        for j in (0, h - 1):
+            torch.testing.assert_close(got[:, i, j], want[:, i, j], rtol=F32_RTOL, atol=F32_ATOL * scale)
+    # without the gate: the raw gradient
+    dx_raw = conv.dgrad_lowres(dy.cuda())
+    torch.testing.assert_close(dx_raw[..., :Cin].double().cpu(), xt.grad, rtol=F32_RTOL, atol=F32_ATOL * scale)
+    dx2 = conv.dgrad_lowres(dy.cuda(), relu_mask_lo=x_lo.cuda())
+    assert torch.equal(dx, dx2)
+    # the two-launch form of the same build (conv-transpose at hi-res, then the stand-alone resize adjoint)
+    two = ops.upsample2x_bwd(conv.dgrad(dy.cuda()), x_lo.cuda())
+    torch.testing.assert_close(dx[..., :Cin], two[..., :Cin], rtol=F32_RTOL, atol=F32_ATOL * scale)
 
 
 SPAIR_OBJECT_LAYERS = [  # name, H, Cin, Cout, k, stride: the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses

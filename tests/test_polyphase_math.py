@@ -282,3 +282,71 @@ def test_per_class_polyphase_weight_gradient_identity(K):
                             dW[k, tap] -= np.outer(rv, dy[b, edge, pos])
                             dW[tap, k] -= np.outer(cv, dy[b, pos, edge])
     np.testing.assert_allclose(dW, want, rtol=1e-9, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# POLYPHASE INPUT GRADIENT (csrc/conv_geom.h: svg_polyd; csrc/polyd_dgrad.hip): Conv2DBackpropInput + ResizeBilinearGrad as ONE stride-2 conv with (2R+1)^2
+# taps over the hi-res dy, plus corrections of the first / last low-res row and column (zero padding of the upsampled image, edge clamp of the resize) and of
+# the four corner pixels.  Written with the device code's index maps (svg_polyd_hitap, svg_polyd_kpm).
+
+def _hi_taps(K):
+    """hi-res offset dh = p - 2 t  ->  (parity p, low-res offset t)"""
+    return {p - 2 * t: (p, t) for p in range(2) for t in _polyc_taps(K, p)}
+
+
+def _kpm(K, hi_edge, q):
+    pad = (K - 1) // 2
+    a, b = (pad + q, pad + 1 + q) if hi_edge else (pad - q, pad - 1 - q)
+    return (a if 0 <= a < K else -1), (b if 0 <= b < K else -1)
+
+
+@pytest.mark.parametrize("K", [6, 4])
+def test_polyphase_input_gradient_identity(K):
+    pad = (K - 1) // 2
+    rng = np.random.default_rng(3 + K)
+    B, h, C, Co = 2, 8, 4, 3
+    H = 2 * h
+    x = rng.standard_normal((B, h, h, C))
+    w = rng.standard_normal((K, K, C, Co)) * 0.2
+    dy = rng.standard_normal((B, H, H, Co))
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y = torch_ref.conv2d_same(torch_ref.resize_bilinear_2x(xt), torch.from_numpy(w), torch.zeros(Co, dtype=torch.float64), 1, None)
+    (y * torch.from_numpy(dy)).sum().backward()
+    want = xt.grad.numpy()
+    ht = _hi_taps(K)
+    R = max(max(ht), -min(ht))
+    assert sorted(ht) == list(range(-R, R + 1)) and R == (4 if K == 6 else 3)        # every hi-res offset belongs to exactly one (parity, offset)
+    E = R + 1
+    dyp = np.pad(dy, ((0, 0), (E, E), (E, E), (0, 0)))
+    at = lambda r, c: dyp[:, r + E, c + E]                                                # dy[:, r, c], zero outside the image
+    wz = lambda ky, kx: w[ky, kx] if ky >= 0 and kx >= 0 else np.zeros((C, Co))
+    got = np.zeros((B, h, h, C))
+    for dyh, (py, ty) in ht.items():                                                      # main term: stride-2 conv over the hi-res dy
+        for dxh, (px, tx) in ht.items():
+            V = sum(_pcoef(py, ky, ty, pad) * _pcoef(px, kx, tx, pad) * w[ky, kx] for ky in range(K) for kx in range(K))
+            for i in range(h):
+                for j in range(h):
+                    got[:, i, j] += at(2 * i + dyh, 2 * j + dxh) @ V.T
+    main_only = np.abs(got - want).max()
+    for hi_edge in (0, 1):                                                                # edges: rows 0 / h-1 and columns 0 / h-1
+        nq = K - pad if hi_edge else pad + 1
+        edge_lo = h - 1 if hi_edge else 0
+        for q in range(nq):
+            kp, km = _kpm(K, hi_edge, q)
+            across = H - 1 - q if hi_edge else q
+            for d, (pp, tt) in ht.items():
+                Vr = 0.25 * sum(_pcoef(pp, k, tt, pad) * (wz(kp, k) - wz(km, k)) for k in range(K))       # row edge: x-composite of the kernel-row difference
+                Vc = 0.25 * sum(_pcoef(pp, k, tt, pad) * (wz(k, kp) - wz(k, km)) for k in range(K))       # column edge
+                for pos in range(h):
+                    got[:, edge_lo, pos] += at(across, 2 * pos + d) @ Vr.T
+                    got[:, pos, edge_lo] += at(2 * pos + d, across) @ Vc.T
+    for cr in (0, 1):                                                                     # corners
+        for cc in (0, 1):
+            for qr in range(K - pad if cr else pad + 1):
+                for qs in range(K - pad if cc else pad + 1):
+                    kpr, kmr = _kpm(K, cr, qr)
+                    kps, kms = _kpm(K, cc, qs)
+                    Wc = 0.0625 * (wz(kpr, kps) - wz(kpr, kms) - wz(kmr, kps) + wz(kmr, kms))
+                    got[:, h - 1 if cr else 0, h - 1 if cc else 0] += dy[:, H - 1 - qr if cr else qr, H - 1 - qs if cc else qs] @ Wc.T
+    assert main_only > 0.1                                                                # the corrections matter
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
