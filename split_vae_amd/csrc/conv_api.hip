@@ -52,8 +52,8 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
           v += 0.25f * c * (e < 2 ? W(kp, k, ci, co) - W(km, k, ci, co) : W(k, kp, ci, co) - W(k, km, ci, co));
         }
     } else {
-      // [corner: TL, TR, BL, BR][qr][qs][co][ci] = .0625 (w[k+r][k+s] - w[k+r][k-s] - w[k-r][k+s] + w[k-r][k-s])
-      const int ci = idx % j.rows, co = (idx / j.rows) % j.inner, qs = (idx / (j.rows * j.inner)) & 3, qr = (idx / (j.rows * j.inner * 4)) & 3, c = idx / (j.rows * j.inner * 16);
+      // [corner: TL, TR, BL, BR][qr][qs][ci][co] = .0625 (w[k+r][k+s] - w[k+r][k-s] - w[k-r][k+s] + w[k-r][k-s])
+      const int co = idx % j.inner, ci = (idx / j.inner) % j.rows, qs = (idx / (j.rows * j.inner)) & 3, qr = (idx / (j.rows * j.inner * 4)) & 3, c = idx / (j.rows * j.inner * 16);
       int kpr, kmr, kps, kms;
       svg_polyd_kpm(K, c >> 1, qr, &kpr, &kmr);
       svg_polyd_kpm(K, c & 1, qs, &kps, &kms);

@@ -242,7 +242,7 @@ struct PrepJob {
                        // 3: per-class polyphase image [rows][nty*ntx (x-major)][Cin] of class pcls of a pk x pk kernel (conv_geom.h: svg_polyc)
                        // 4: its border-class image [2*(pk-1) classes][pk taps][rows][Cin] = -(sum over the taps that leave the image)
                        // 5: main image of the polyphase INPUT gradient [rows = ci][(2R+1)^2 hi-res taps (x-major)][co]; 6: its edge images
-                       // [4 edges: top, bottom, left, right][4 rows from the edge][2R+1][ci][co]; 7: its corner images [4 corners][4][4][co][ci] (conv_geom.h: svg_polyd)
+                       // [4 edges: top, bottom, left, right][4 rows from the edge][2R+1][ci][co]; 7: its corner images [4 corners][4][4][ci][co] (conv_geom.h: svg_polyd)
   int32_t pk, pcls;    // poly 3 .. 7: kernel size; poly 3: parity class py*2 + px
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;

@@ -89,24 +89,37 @@ __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg
   }
 }
 
-// corner (cr, cc) = (bottom?, right?): dx[row edge][column edge][ci] += sum_{qr, qs, co} Wc[corner][qr][qs][co][ci] dy[row qr from the edge][column qs from the edge][co]
-template <typename T>
-__global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int cop, int K) {
-  const T* __restrict__ dy = (const T*)mg.dy[blockIdx.y];
-  const T* __restrict__ wc = (const T*)mg.wcorner[blockIdx.y];
-  const int b = blockIdx.x, H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2;
-  for (int it = threadIdx.x; it < 4 * Cin; it += 256) {
-    const int ci = it % Cin, c = it / Cin, cr = c >> 1, cc = c & 1;
-    const int nqr = cr ? K - pad : pad + 1, nqs = cc ? K - pad : pad + 1;
-    float v = 0.f;
-    for (int qr = 0; qr < nqr; ++qr)
-      for (int qs = 0; qs < nqs; ++qs) {
-        const T* dp = dy + (((int64_t)b * H2 + (cr ? H2 - 1 - qr : qr)) * W2 + (cc ? W2 - 1 - qs : qs)) * gdy;
-        const T* wp = wc + ((int64_t)((c * 4 + qr) * 4 + qs) * cop) * Cin + ci;
-        for (int co = 0; co < gdy; ++co) v += to_f32(wp[(int64_t)co * Cin]) * to_f32(dp[co]);
+// corner (cr, cc) = (bottom?, right?): dx[row edge][column edge][ci] += sum_{qr, qs, co} Wc[corner][qr][qs][ci][co] dy[row qr from the edge][column qs from the edge][co]
+// -- a [16 channels] x [16 images] GEMM tile per wave with K = (qr, qs, co): weights and dY pixels straight from memory (both 16-B pieces), added into the row terms.
+// (The first version -- one thread per (corner, channel), every workgroup re-reading the 0.5 MB of corner weights -- took 113 us per launch.)
+template <typename T, int NGRP>
+__global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int K) {
+  constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG, COP = NGRP * CPG;
+  const T* __restrict__ dy = (const T*)mg.dy[blockIdx.z];
+  const T* __restrict__ wc = (const T*)mg.wcorner[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int ncif = Cin >> 4, c = (int)blockIdx.x / ncif, cif = (int)blockIdx.x % ncif, cr = c >> 1, cc = c & 1;
+  const int H2 = 2 * h, W2 = 2 * w, pad = (K - 1) / 2;
+  const int nqr = cr ? K - pad : pad + 1, nqs = cc ? K - pad : pad + 1;
+  const int b = ((int)blockIdx.y * 4 + wave) * 16 + lr;                        // this lane's image (B operand column)
+  const bool bok = b < B;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qr = 0; qr < nqr; ++qr)
+    for (int qs = 0; qs < nqs; ++qs) {
+      const T* wp = wc + (((int64_t)((c * 4 + qr) * 4 + qs)) * Cin + cif * 16 + lr) * COP + lg * EPP;
+      const T* dp = dy + (((int64_t)(bok ? b : 0) * H2 + (cr ? H2 - 1 - qr : qr)) * W2 + (cc ? W2 - 1 - qs : qs)) * gdy + lg * EPP;
+#pragma unroll
+      for (int gq = 0; gq < NGRP; ++gq) {
+        const uint4 av = *(const uint4*)(wp + gq * CPG);
+        const uint4 bv = (bok && gq * CPG + lg * EPP < gdy) ? *(const uint4*)(dp + gq * CPG) : make_uint4(0, 0, 0, 0);
+        FixMma<T>::run(av, bv, acc);                                            // D rows = channels 4 lg .., columns = images
       }
-    mg.erow[blockIdx.y][(((int64_t)b * 2 + cr) * w + (cc ? w - 1 : 0)) * Cin + ci] += v;
-  }
+    }
+  if (!bok) return;
+  float4* p = (float4*)(mg.erow[blockIdx.z] + (((int64_t)b * 2 + cr) * w + (cc ? w - 1 : 0)) * Cin + cif * 16 + lg * 4);
+  float4 v = *p;
+  v.x += acc[0]; v.y += acc[1]; v.z += acc[2]; v.w += acc[3];
+  *p = v;
 }
 
 template <typename T, int NT, int NGRP>
@@ -120,7 +133,7 @@ static int launch_edge(const PolydEdgeMulti& m, int n, int B, int h, int w, int 
   sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NB>, lds);
   hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NB>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
   SV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(polyd_corner_kernel<T>, dim3(B, n), dim3(256), 0, st, m, B, h, w, Cin, gdy, NGRP * FixMma<T>::CPG, K);
+  hipLaunchKernelGGL((polyd_corner_kernel<T, NGRP>), dim3(4 * (Cin >> 4), (B + 63) / 64, n), dim3(256), 0, st, m, B, h, w, Cin, gdy, K);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

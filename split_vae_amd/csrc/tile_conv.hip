@@ -606,6 +606,10 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     const int wslots = (wres_on && !yr && dtype == SV_BF16 && BN == 32 && MF == 4 && t.S == 1 && lnph == 0 && nks > 2 && nks <= 6 && nks * BN * tile_pps(BN) * 16 <= 24 * 1024) ? nks : 2;
     const int64_t lds = (int64_t)wslots * BN * tile_pps(BN, yr) * 16 + off_bytes + in_bytes;
     if (lds > 78 * 1024 && MF == 4 && BN >= 64) continue;   // prefer 2 workgroups per CU: retry with 128 rows
+    // (the stride-2 9 x 9-tap polyphase input gradient, conv_geom.h svg_polyd: its 39 x 39-pixel hi-res tile leaves ONE workgroup per CU -- no overlap
+    //  of one tile's staging with another's MFMAs; SV_TC_S2_MF4=1: the 256-row tile for A/B)
+    static const bool s2_mf4 = getenv("SV_TC_S2_MF4") != nullptr;
+    if (lds > 78 * 1024 && MF == 4 && t.S == 2 && t.fix_nc && !s2_mf4) continue;
     if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
     memset(a, 0, sizeof(*a));
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
