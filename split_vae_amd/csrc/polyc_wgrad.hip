@@ -21,15 +21,16 @@
 
 namespace {
 
-// image groups per border class (workgroups = 2 (K-1) x groups x networks) and images staged per barrier pair.  Measured (2 x 512 images, d4 / d5 frame kernel + projection):
-// 16 groups, 1 image: 177 / 131 + 30 us; 32 groups, 4 images (72-86 KB of LDS: one workgroup per CU): 160 / 165 + 52 us
+// image groups per border class (workgroups = 2 (K-1) x groups x networks).  Measured (2 x 512 images, d4 / d5 frame kernel + projection): 16 groups, one image per
+// barrier pair: 177 / 131 + 30 us; 32 groups, 4 images (72-86 KB of LDS: one workgroup per CU): 160 / 165 + 52 us; the loop is all latency (global loads -> lerp ->
+// LDS -> barrier -> 8-16 short K steps), so the next image's loads are issued BEFORE the current image's MFMAs and land in LDS after them (register prefetch).
 constexpr int FRAME_GROUPS = 16;
-constexpr int FRAME_NB = 2;
 
 struct PolycFrameMulti { const float* x[2]; const float* dy[2]; float* slab[2]; };
 
-// CIF / COF: 16-channel fragments of the input / of dY (the head's 6 -> 8 channels fill half a fragment); NFW = fragments per wave = ceil(K CIF COF / 4)
-template <int K, int CIF, int COF, int NB>
+// CIF / COF: 16-channel fragments of the input / of dY (the head's 6 -> 8 channels fill half a fragment); NFW = fragments per wave = ceil(K CIF COF / 4);
+// NLI / NDI: line / dY 16-B items per thread and image (host-checked upper bounds)
+template <int K, int CIF, int COF, int NLI, int NDI>
 __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrameMulti mg, int B, int h, int w, int ldy) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CIN = 16 * CIF, NFRAG = K * CIF * COF, NFW = (NFRAG + 3) / 4, NC = K - 1, PAD = (K - 1) / 2;
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
   const int npos = rows ? W2 : H2, m2 = rows ? H2 : W2;
   const int edge = c < PAD ? c : m2 - (K - 1 - PAD) + (c - PAD);
   const int line = (rows ? 0 : 2) + (c >= PAD ? 1 : 0), n = rows ? w : h;
-  char* sLine = smem;                    // [NB][LW] pixels of PSL bytes
-  char* sDy = smem + NB * LW * PSL;      // [NB][L] pixels of YSL bytes
+  char* sLine = smem;                    // [LW] pixels of PSL bytes
+  char* sDy = smem + LW * PSL;           // [L] pixels of YSL bytes
   f32x4 acc[NFW];
   int aoff[NFW];
 #pragma unroll
@@ -56,48 +57,76 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
     aoff[q] = (tap + kq) * PSL + (cif * 16 + lr) * 4;
   }
   const int boff = kq * YSL + ((wave % COF) * 16 + lr) * 4;
-  // NB images per barrier pair (one image at a time the loop was all latency: 177 us per launch for 4 GFLOP)
-  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
-  for (int b0 = b_lo; b0 < b_hi; b0 += NB) {
-    __syncthreads();                     // the previous batch is consumed
-    for (int it = tid; it < NB * LW * (CIN / 4); it += 256) {
-      const int ch = it % (CIN / 4), li = (it / (CIN / 4)) % LW, ib = it / ((CIN / 4) * LW), b = b0 + ib;
+  // ---- this thread's items (the same for every image): line pieces (two source pixels + blend weight -> one LDS slot), dY pieces
+  int l_o0[NLI], l_o1[NLI], l_dst[NLI], d_src[NDI], d_dst[NDI];
+  float l_f[NLI];
+#pragma unroll
+  for (int s = 0; s < NLI; ++s) {
+    const int it = tid + s * 256;
+    l_dst[s] = -1; l_o0[s] = l_o1[s] = -1; l_f[s] = 0.f;
+    if (it < LW * (CIN / 4)) {
+      const int ch = it % (CIN / 4), li = it / (CIN / 4);
       int u = li - PAD;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < b_hi && li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
+      l_dst[s] = li * PSL + ch * 16;
+      if (li < 2 * n + K - 1 && (rows || (u >= 0 && u < 2 * n))) {
         u = min(max(u, 0), 2 * n - 1);
         const int m = u >> 1;
         const int i0 = (u & 1) ? m : max(m - 1, 0), i1 = (u & 1) ? min(m + 1, n - 1) : m;
-        const float fw = (u & 1) ? 0.25f : 0.75f;
-        const float* xb = x + (int64_t)b * h * w * CIN;
-        const int64_t o0 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i0) * CIN : ((int64_t)i0 * w + (line == 2 ? 0 : w - 1)) * CIN;
-        const int64_t o1 = rows ? ((int64_t)(line == 0 ? 0 : h - 1) * w + i1) * CIN : ((int64_t)i1 * w + (line == 2 ? 0 : w - 1)) * CIN;
-        const uint4 a0 = *(const uint4*)(xb + o0 + ch * 4), a1 = *(const uint4*)(xb + o1 + ch * 4);
-        f32x2 p0[2], p1[2], r[2];
-        Piece<float>::unpack(a0, p0); Piece<float>::unpack(a1, p1);
-        r[0] = lerp2(p0[0], p1[0], fw); r[1] = lerp2(p0[1], p1[1], fw);          // the arithmetic of the forward's lines (poly_fix.hip)
-        v = __builtin_bit_cast(float4, Piece<float>::pack(r));
+        l_f[s] = (u & 1) ? 0.25f : 0.75f;
+        l_o0[s] = (rows ? ((line == 0 ? 0 : h - 1) * w + i0) : (i0 * w + (line == 2 ? 0 : w - 1))) * CIN + ch * 4;
+        l_o1[s] = (rows ? ((line == 0 ? 0 : h - 1) * w + i1) : (i1 * w + (line == 2 ? 0 : w - 1))) * CIN + ch * 4;
       }
-      *(float4*)(sLine + (ib * LW + li) * PSL + ch * 16) = v;
     }
-    for (int it = tid; it < NB * L * (COF * 4); it += 256) {
-      const int ch = it % (COF * 4), pos = (it / (COF * 4)) % L, ib = it / (COF * 4 * L), b = b0 + ib;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < b_hi && pos < npos && ch * 4 < ldy)
-        v = *(const float4*)(dy + (int64_t)b * H2 * W2 * ldy + ((int64_t)(rows ? edge : pos) * W2 + (rows ? pos : edge)) * ldy + ch * 4);
-      *(float4*)(sDy + (ib * L + pos) * YSL + ch * 16) = v;
-    }
-    __syncthreads();
-    for (int ib = 0; ib < NB; ++ib)      // (images past the group's end were staged as zeros)
-#pragma unroll 4
-      for (int p0 = 0; p0 < npos; p0 += 4) {
-        const float bv = *(const float*)(sDy + (ib * L + p0) * YSL + boff);
+  }
 #pragma unroll
-        for (int q = 0; q < NFW; ++q) {
-          const float av = *(const float*)(sLine + (ib * LW + p0) * PSL + aoff[q]);
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);     // D rows = input channels, columns = dY channels
-        }
+  for (int s = 0; s < NDI; ++s) {
+    const int it = tid + s * 256;
+    d_dst[s] = -1; d_src[s] = -1;
+    if (it < L * (COF * 4)) {
+      const int ch = it % (COF * 4), pos = it / (COF * 4);
+      d_dst[s] = pos * YSL + ch * 16;
+      if (pos < npos && ch * 4 < ldy) d_src[s] = ((rows ? edge : pos) * W2 + (rows ? pos : edge)) * ldy + ch * 4;
+    }
+  }
+  uint4 ra0[NLI], ra1[NLI];
+  float4 rd[NDI];
+  auto fetch = [&](int b) {
+    const float* xb = x + (int64_t)b * h * w * CIN;
+    const float* dyb = dy + (int64_t)b * H2 * W2 * ldy;
+#pragma unroll
+    for (int s = 0; s < NLI; ++s) {
+      ra0[s] = ra1[s] = make_uint4(0, 0, 0, 0);
+      if (l_o0[s] >= 0) { ra0[s] = *(const uint4*)(xb + l_o0[s]); ra1[s] = *(const uint4*)(xb + l_o1[s]); }
+    }
+#pragma unroll
+    for (int s = 0; s < NDI; ++s) rd[s] = d_src[s] >= 0 ? *(const float4*)(dyb + d_src[s]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
+  if (b_lo < b_hi) fetch(b_lo);
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();                     // the previous image is consumed
+#pragma unroll
+    for (int s = 0; s < NLI; ++s) {
+      if (l_dst[s] < 0) continue;
+      f32x2 p0[2], p1[2], r[2];
+      Piece<float>::unpack(ra0[s], p0); Piece<float>::unpack(ra1[s], p1);
+      r[0] = lerp2(p0[0], p1[0], l_f[s]); r[1] = lerp2(p0[1], p1[1], l_f[s]);          // the arithmetic of the forward's lines (poly_fix.hip); unsourced slots: 0
+      *(uint4*)(sLine + l_dst[s]) = Piece<float>::pack(r);
+    }
+#pragma unroll
+    for (int s = 0; s < NDI; ++s)
+      if (d_dst[s] >= 0) *(float4*)(sDy + d_dst[s]) = rd[s];
+    __syncthreads();
+    if (b + 1 < b_hi) fetch(b + 1);      // in flight during this image's MFMAs
+#pragma unroll 4
+    for (int p0 = 0; p0 < npos; p0 += 4) {
+      const float bv = *(const float*)(sDy + p0 * YSL + boff);
+#pragma unroll
+      for (int q = 0; q < NFW; ++q) {
+        const float av = *(const float*)(sLine + p0 * PSL + aoff[q]);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[q], 0, 0, 0);     // D rows = input channels, columns = dY channels
       }
+    }
   }
   // slab[group][class][fragment f = (tap * CIF + cif) * COF + cof][register][lane]
   float* sl = mg.slab[blockIdx.z] + ((int64_t)blockIdx.y * (2 * NC) + cls) * (NFRAG * 256) + lane;
@@ -108,6 +137,18 @@ __global__ __launch_bounds__(256) void polyc_wgrad_frame_kernel(const PolycFrame
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) sl[(f * 4 + r4) * 64] = acc[q][r4];
   }
+}
+
+template <int K, int CIF, int COF>
+static int launch_frame(const PolycFrameMulti& m, dim3 grid, int B, int h, int w, int ldy, hipStream_t st) {
+  constexpr int NLI = CIF == 4 ? 5 : 3, NDI = 2;           // up to 64-pixel lines (69 line slots x CIN / 4 pieces; 64 x COF x 4 dY pieces)
+  const int L = 2 * (h > w ? h : w), LW = L + K - 1;
+  if (LW * (CIF * 4) > NLI * 256 || L * (COF * 4) > NDI * 256) return SV_E_UNSUPPORTED;
+  const size_t lds = (size_t)LW * (CIF * 64 + 64) + (size_t)L * (COF * 64 + 64);
+  sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<K, CIF, COF, NLI, NDI>, lds);
+  hipLaunchKernelGGL((polyc_wgrad_frame_kernel<K, CIF, COF, NLI, NDI>), grid, dim3(256), lds, st, m, B, h, w, ldy);
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
 
 struct PolycProject {
@@ -188,8 +229,8 @@ int svg_polyc_wgrad_form(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_POLYC_WGRAD") != nullptr;
   if (off || d->dtype != SV_F32) return 0;
   const int cin = svg_cin_pad(d);
-  if (svg_polyc(d) && d->KH == 6 && d->Cout == 32 && (cin == 64 || cin == 32) && d->H / 2 >= 8 && d->W / 2 >= 8) return 1;    // (instantiations: d4)
-  if (svg_poly(d) && cin == 32 && d->H / 2 >= 8 && d->W / 2 >= 8) return 2;
+  if (svg_polyc(d) && d->KH == 6 && d->Cout == 32 && (cin == 64 || cin == 32) && d->H / 2 >= 8 && d->W / 2 >= 8 && d->H <= 64 && d->W <= 64) return 1;    // (instantiations: d4)
+  if (svg_poly(d) && cin == 32 && d->H / 2 >= 8 && d->W / 2 >= 8 && d->H <= 64 && d->W <= 64) return 2;      // (frame kernel: lines of up to 64 pixels)
   return 0;
 }
 
@@ -247,23 +288,14 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
     pj.dWp[i] = pw[k]; pj.dbp[i] = pw[k] + ndwp; pj.slab[i] = m.slab[i]; pj.dW[i] = dW[k]; pj.dbias[i] = dbias ? dbias[k] : nullptr;
   }
   pj.K = K; pj.Cin = cin; pj.Cout = d->Cout; pj.merged = merged; pj.groups = FRAME_GROUPS;
-  const int L = 2 * (h > w ? h : w), LW = L + K - 1;
   const dim3 grid(2 * (K - 1), FRAME_GROUPS, n);
   const int ldy = svg_gdy(d);
-  if (cin == 64 && d->Cout == 32) {
-    const size_t lds = FRAME_NB * ((size_t)LW * (64 * 4 + 64) + (size_t)L * (2 * 64 + 64));
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 4, 2, FRAME_NB>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 4, 2, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
-  } else if (cin == 32 && d->Cout == 32) {
-    const size_t lds = FRAME_NB * ((size_t)LW * (32 * 4 + 64) + (size_t)L * (2 * 64 + 64));
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 2, FRAME_NB>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 2, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
-  } else if (cin == 32 && d->Cout <= 16) {
-    const size_t lds = FRAME_NB * ((size_t)LW * (32 * 4 + 64) + (size_t)L * (64 + 64));
-    sv_ensure_dynamic_lds((const void*)polyc_wgrad_frame_kernel<6, 2, 1, FRAME_NB>, lds);
-    hipLaunchKernelGGL((polyc_wgrad_frame_kernel<6, 2, 1, FRAME_NB>), grid, dim3(256), lds, st, m, d->B, h, w, ldy);
-  } else return SV_E_STATE;                                                       // (svg_polyc_wgrad_form admits only these)
-  SV_LAUNCH_CHECK();
+  int rcf;
+  if (cin == 64 && d->Cout == 32) rcf = launch_frame<6, 4, 2>(m, grid, d->B, h, w, ldy, st);
+  else if (cin == 32 && d->Cout == 32) rcf = launch_frame<6, 2, 2>(m, grid, d->B, h, w, ldy, st);
+  else if (cin == 32 && d->Cout <= 16) rcf = launch_frame<6, 2, 1>(m, grid, d->B, h, w, ldy, st);
+  else rcf = SV_E_STATE;                                                            // (svg_polyc_wgrad_form admits only these)
+  if (rcf) return rcf == SV_E_UNSUPPORTED ? SV_E_STATE : rcf;                       // (the main terms are already enqueued: the form check below keeps this unreachable)
   hipLaunchKernelGGL(polyc_wgrad_project_kernel, dim3((K * K * cin * d->Cout + 255) / 256, n), dim3(256), 0, st, pj);
   SV_LAUNCH_CHECK();
   return SV_OK;

@@ -514,7 +514,9 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   // runs on 64-column tiles instead -- twice the workgroups, half the weight streaming each (SV_TC_SMALL_WGS: the threshold)
   static const int small_wgs = getenv("SV_TC_SMALL_WGS") ? atoi(getenv("SV_TC_SMALL_WGS")) : 200;   // (per problem) measured: helps at 128 such workgroups per network (B = 256: -1.6 %; 128: -3.6 %, 64: -3.4 %), hurts at 256 (B = 512: +1.8 %)
   const int64_t wgs128 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 128);
-  const bool small = t.N % 128 == 0 && wgs128 < small_wgs && dtype == SV_BF16 && !t.cls_n;
+  // (fp32 too since round 5: at 64 images per network d2 / e3 -- 8 x 8 grids, 128 columns -- ran 64 workgroups on 256 CUs, 14 % of the fp32 matrix peak; SV_TC_SMALL_F32=0: off)
+  static const bool small_f32 = !(getenv("SV_TC_SMALL_F32") && atoi(getenv("SV_TC_SMALL_F32")) == 0);
+  const bool small = t.N % 128 == 0 && wgs128 < small_wgs && (dtype == SV_BF16 || small_f32) && !t.cls_n;
   static const int tiny_wgs = getenv("SV_TC_TINY_WGS") ? atoi(getenv("SV_TC_TINY_WGS")) : 100;   // ... and on 32-column tiles below this (64-image shards: -1.3 .. -1.9 %)
   const bool tiny = small && wgs128 < tiny_wgs;
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
