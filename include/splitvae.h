@@ -397,6 +397,11 @@ enum { SV_PHASE_PREP = 1,           /* fp32 master weights -> MFMA-ready images 
                                        are not stored (100 MB of HBM writes per 512-image step).  Losses and gradients are unchanged. */
        SV_PHASE_INPUTS_STAGED = 512, /* modifier: the plan buffers in8_x / in8_xh already hold this call's images6 as padded 8-channel
                                        tensors in the plan's dtype (written by sv_scramble_gather_staged): the split / pad pass is skipped */
+       SV_PHASE_BUCKET_EVENTS = 1024, /* modifier (data parallelism): the plan records an event set when each gradient bucket is complete -- 0: both decoders
+                                       (after SV_PHASE_BWD_DECODERS), 1: the encoder heads (e4_mean / e4_sd, after SV_PHASE_BWD_ENC_HEADS), 2: the encoder convs --
+                                       on the compute stream AND on its weight-gradient side streams, so ONE call can run the whole backward with the
+                                       single-GPU stream overlap while the caller's communication stream picks every bucket up as it completes
+                                       (sv_lgvae_bucket_wait); no phase-split host round trips */
        SV_PHASE_FORWARD = 6, SV_PHASE_BACKWARD = 112, SV_PHASE_ALL = 255 };
 
 typedef struct {
@@ -428,6 +433,10 @@ int sv_lgvae_step(sv_lgvae_plan* plan, const sv_lgvae_step_args* a, void* stream
  * B=512): replay == eager to 1 %: the kernels already run back to back, the small configurations are bound by the
  * ~10 us dependent-kernel latency of an in-order stream, which a graph of the same chain keeps. */
 int sv_lgvae_graph_enable(sv_lgvae_plan* plan, int32_t enable);
+/* Make `stream` wait (hipStreamWaitEvent, no host sync) until gradient bucket `bucket` of the most recent sv_lgvae_step call that carried
+ * SV_PHASE_BUCKET_EVENTS is complete: 0 decoders, 1 encoder heads, 2 encoder convs, 3 = 1 and 2 (the whole encoders' range).  The gradient
+ * all-reduce of that bucket (RCCL over xGMI) is then enqueued on `stream`.  SV_E_STATE: no such events were recorded. */
+int sv_lgvae_bucket_wait(sv_lgvae_plan* plan, int32_t bucket, void* stream);
 /* number of captured (instantiated) step graphs, or a negative SV_E_* */
 int sv_lgvae_graph_count(const sv_lgvae_plan* plan);
 

@@ -16,6 +16,7 @@ PHASE_BWD_DECODERS, PHASE_BWD_ENC_HEADS, PHASE_BWD_ENC_CONVS, PHASE_ADAM = 16, 3
 PHASE_FORWARD, PHASE_BACKWARD, PHASE_ALL = 6, 112, 255
 PHASE_INPUTS_STAGED = 512  # modifier: in8_x / in8_xh were written by sv_scramble_gather_staged (include/splitvae.h)
 PHASE_NO_RECON = 256      # modifier: the fused-loss training step does not store out6_x / out6_xh (include/splitvae.h)
+PHASE_BUCKET_EVENTS = 1024  # modifier: record the gradient-bucket events of the data-parallel step (include/splitvae.h)
 PHASE_INFER = PHASE_PREP | PHASE_FORWARD
 
 STATUS = {0: "SV_OK", -1: "SV_E_BADARG", -2: "SV_E_UNSUPPORTED", -3: "SV_E_WORKSPACE", -4: "SV_E_STATE"}
@@ -183,6 +184,7 @@ SYMBOLS = {
     "sv_lgvae_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i64), C.POINTER(_i64)]),
     "sv_lgvae_step": (C.c_int, [_vp, C.POINTER(StepArgs), _vp]),
     "sv_lgvae_graph_enable": (C.c_int, [_vp, _i32]),
+    "sv_lgvae_bucket_wait": (C.c_int, [_vp, _i32, _vp]),
     "sv_lgvae_graph_count": (C.c_int, [_vp]),
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),

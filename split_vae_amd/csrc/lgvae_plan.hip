@@ -17,6 +17,12 @@
 #include "kernels.h"
 #include "conv_geom.h"
 
+__global__ void sv_plan_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static void sv_plan_spin(hipStream_t st, int us) { hipLaunchKernelGGL(sv_plan_spin_kernel, dim3(1), dim3(64), 0, st, (long long)us * 100); }   // wall_clock64: 100 MHz
+
 namespace {
 
 struct Buf { std::string name; int64_t off, bytes; };
@@ -150,6 +156,11 @@ struct sv_lgvae_plan {
     if (order && order[0]) { const int c = order[side_count % (int)strlen(order)] - '0'; if (c >= 0 && c < use) slot = c; }
     ++side_count;
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
+    {   // TEST KNOB (tests/test_gpu_dist.py): hold the side stream back at its first use of a step, so that a consumer of the gradients that does
+        // not wait for the side stream's part (a missing bucket dependency) reads them before they exist
+      static const int delay_us = getenv("SV_TEST_SIDE_DELAY_US") ? atoi(getenv("SV_TEST_SIDE_DELAY_US")) : 0;
+      if (delay_us > 0 && side_count == 1) sv_plan_spin(side[slot], delay_us);
+    }
     side_next = slot + 1;
     side_slot = slot;
     side_pending = true;
@@ -162,6 +173,20 @@ struct sv_lgvae_plan {
     side_count = 0;
     for (int i = 0; i < nside; ++i)
       if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return (int)hipGetLastError();
+    return SV_OK;
+  }
+  // gradient-bucket events (SV_PHASE_BUCKET_EVENTS): [bucket][0 = compute stream, 1 + i = side stream i]
+  hipEvent_t ev_bucket[3][1 + SIDE_MAX] = {};
+  bool bucket_rec[3][1 + SIDE_MAX] = {};
+  int record_bucket(int k, hipStream_t st) {
+    for (int i = 0; i <= SIDE_MAX; ++i) bucket_rec[k][i] = false;
+    for (int i = 0; i <= nside; ++i) {                    // every stream that may hold work of this bucket, in its own order
+      hipStream_t s = i == 0 ? st : side[i - 1];
+      if (i > 0 && !s) continue;
+      if (!ev_bucket[k][i] && hipEventCreateWithFlags(&ev_bucket[k][i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+      if (hipEventRecord(ev_bucket[k][i], s) != hipSuccess) return (int)hipGetLastError();
+      bucket_rec[k][i] = true;
+    }
     return SV_OK;
   }
   // captured steps (sv_lgvae_graph_enable): one executable graph per distinct (phase mask, buffers, baked scalars)
@@ -1127,7 +1152,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
   return SV_OK;
 }
 
-static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_heads, bool do_convs, hipStream_t st) {
+static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_heads, bool do_convs, hipStream_t st, bool buckets = false) {
   const sv_lgvae_desc& d = p->d;
   const int B = d.B, dt = d.dtype;
   const int Lg = d.global_latent, Ll = d.local_latent, Lc = Lg + Ll;
@@ -1229,6 +1254,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       else if (rc != SV_E_UNSUPPORTED) return rc;
     }
     if (!done) SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gh + e0, a3 + e0, ga3 + e0, false, st));
+    if (buckets) SV_TRY(p->record_bucket(1, st));       // the heads' weight gradients are enqueued (main or side stream)
   }
   if (do_convs) {
     auto both = [&](const char* n, const void** out) { out[0] = p->bp(std::string(n) + "x"); out[1] = p->bp(std::string(n) + "xh"); };
@@ -1243,6 +1269,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
       both(g_name[l - 1], gx);
       SV_TRY(run_dgrad_layers(p, 2 - e0, Ls + e0, gy + e0, x + e0, (void* const*)gx + e0, false, st));
     }
+    if (buckets) SV_TRY(p->record_bucket(2, st));
   }
   return SV_OK;
 }
@@ -1301,6 +1328,9 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
     (void)hipEventDestroy(p->ev_join[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  for (auto& row : p->ev_bucket)
+    for (auto e : row)
+      if (e) (void)hipEventDestroy(e);
   if (!p->graphs.empty()) (void)hipDeviceSynchronize();   // a replay may still be in flight
   for (auto& kv : p->graphs)
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -1363,9 +1393,13 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
     }
     SV_TRY(phase_loss(p, s, s->grads != nullptr, st));
   }
-  if (ph & SV_PHASE_BWD_DECODERS) SV_TRY(phase_bwd_decoders(p, s, st));
+  const bool buckets = (ph & SV_PHASE_BUCKET_EVENTS) && !p->graph_on && !p->dyn;      // (not in captured steps: the events belong to eager launches)
+  if (ph & SV_PHASE_BWD_DECODERS) {
+    SV_TRY(phase_bwd_decoders(p, s, st));
+    if (buckets) SV_TRY(p->record_bucket(0, st));
+  }
   if (ph & (SV_PHASE_BWD_ENC_HEADS | SV_PHASE_BWD_ENC_CONVS))
-    SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st));
+    SV_TRY(phase_bwd_encoders(p, s, ph & SV_PHASE_BWD_ENC_HEADS, ph & SV_PHASE_BWD_ENC_CONVS, st, buckets));
   SV_TRY(p->join_side(st));
   if (p->n_pending) {                    // every layer's partial sums -> dW / dbias, one launch (fixed order: deterministic)
     Scope sc(p, st, "wgrad.all.reduce", 0, 0);
@@ -1444,6 +1478,21 @@ extern "C" int sv_lgvae_graph_enable(sv_lgvae_plan* p, int32_t enable) {
     p->graphs.clear();
   }
   return SV_OK;
+}
+
+extern "C" int sv_lgvae_bucket_wait(sv_lgvae_plan* p, int32_t bucket, void* stream) {
+  if (!p || bucket < 0 || bucket > 3) return SV_E_BADARG;
+  int n = 0;
+  for (int k = (bucket == 3 ? 1 : bucket); k <= (bucket == 3 ? 2 : bucket); ++k)
+    for (int i = 0; i <= sv_lgvae_plan::SIDE_MAX; ++i)
+      if (p->bucket_rec[k][i]) {
+        // TEST KNOB (negative control of tests/test_gpu_dist.py::test_buckets_wait_for_the_side_stream): drop the side streams' events
+        static const bool skip_side = getenv("SV_TEST_BUCKET_SKIP_SIDE") != nullptr;
+        if (skip_side && i > 0) continue;
+        if (hipStreamWaitEvent((hipStream_t)stream, p->ev_bucket[k][i], 0) != hipSuccess) return (int)hipGetLastError();
+        ++n;
+      }
+  return n ? SV_OK : SV_E_STATE;
 }
 
 extern "C" int sv_lgvae_graph_count(const sv_lgvae_plan* p) {

@@ -18,8 +18,10 @@ namespace {
 
 struct PolydEdgeMulti { const void* dy[2]; const void* wedge[2]; const void* wcorner[2]; float* erow[2]; float* ecol[2]; };
 
-// NT = 2R+1 taps along the strip, NGRP = MFMA groups over the (padded) dY channels, NB images per barrier pair
-template <typename T, int NT, int NGRP, int NB>
+// NT = 2R+1 taps along the strip, NGRP = MFMA groups over the (padded) dY channels, NLI = strip pieces per thread and image (host-checked bound).
+// One image per barrier pair; the NEXT image's strip is fetched into registers before the current image's MFMAs and written to LDS after them (the loop is
+// latency otherwise: 174 us per launch at 2 x 512 images for 8 GFLOP).
+template <typename T, int NT, int NGRP, int NLI>
 __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG, COP = NGRP * CPG, NPC = COP / EPP, R = (NT - 1) / 2;
@@ -42,49 +44,63 @@ __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg
 #pragma unroll
       for (int gq = 0; gq < NGRP; ++gq) wv[d][gq] = *(const uint4*)(wp + (int64_t)d * Cin * COP + gq * CPG);
   }
-  char* sStrip = smem;                                         // [NB][4][SW] pixels of PSB bytes
-  float* sRed = (float*)(smem + NB * 4 * SW * PSB);           // [4 waves][NB * npf][256] partial sums
+  char* sStrip = smem;                                         // [4][SW] pixels of PSB bytes
   const int npf = n >> 4;
-  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
-  for (int b0 = b_lo; b0 < b_hi; b0 += NB) {
-    __syncthreads();                                           // the previous batch is consumed
-    for (int it = tid; it < NB * 4 * SW * NPC; it += 256) {
-      const int ch = it % NPC, a = (it / NPC) % SW - R, q = (it / (NPC * SW)) & 3, ib = it / (NPC * SW * 4), b = b0 + ib;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (b < b_hi && q < nq && a >= 0 && a < L2 && ch * EPP < gdy) {
+  float* sRed = (float*)(smem + 4 * SW * PSB);                // [4 waves][npf][256] partial sums
+  // ---- this thread's strip pieces (the same for every image): source element offset inside the image (-1: zero) and LDS slot
+  int s_src[NLI], s_dst[NLI];
+#pragma unroll
+  for (int s = 0; s < NLI; ++s) {
+    const int it = tid + s * 256;
+    s_src[s] = -1; s_dst[s] = -1;
+    if (it < 4 * SW * NPC) {
+      const int ch = it % NPC, a = (it / NPC) % SW - R, q = it / (NPC * SW);
+      s_dst[s] = (q * SW + a + R) * PSB + ch * 16;
+      if (q < nq && a >= 0 && a < L2 && ch * EPP < gdy) {
         const int across = hi_edge ? (rows ? H2 : W2) - 1 - q : q;
-        const int64_t pix = rows ? (int64_t)across * W2 + a : (int64_t)a * W2 + across;
-        v = *(const uint4*)(dy + ((int64_t)b * H2 * W2 + pix) * gdy + ch * EPP);
+        s_src[s] = (rows ? across * W2 + a : a * W2 + across) * gdy + ch * EPP;
       }
-      *(uint4*)(sStrip + ((ib * 4 + q) * SW + a + R) * PSB + ch * 16) = v;
     }
+  }
+  uint4 rs[NLI];
+  auto fetch = [&](int b) {
+    const T* dyb = dy + (int64_t)b * H2 * W2 * gdy;
+#pragma unroll
+    for (int s = 0; s < NLI; ++s) rs[s] = s_src[s] >= 0 ? *(const uint4*)(dyb + s_src[s]) : make_uint4(0, 0, 0, 0);
+  };
+  const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
+  if (b_lo < b_hi) fetch(b_lo);
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();                                           // the previous image's strip and partial sums are consumed
+#pragma unroll
+    for (int s = 0; s < NLI; ++s)
+      if (s_dst[s] >= 0) *(uint4*)(sStrip + s_dst[s]) = rs[s];
     __syncthreads();
-    for (int u = 0; u < NB * npf; ++u) {                       // (image of the batch, pixel fragment): every wave its strip row
-      const int ib = u / npf, pf = u - ib * npf;
+    if (b + 1 < b_hi) fetch(b + 1);                            // in flight during this image's MFMAs
+    for (int pf = 0; pf < npf; ++pf) {                         // every wave its strip row
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (wave < nq) {
-        const char* sp = sStrip + ((ib * 4 + wave) * SW + 2 * (16 * pf + lr)) * PSB + lg * 16;      // pixel 2 pos + d (d = 0 .. 2R: the halo shifts it by R)
+        const char* sp = sStrip + (wave * SW + 2 * (16 * pf + lr)) * PSB + lg * 16;      // pixel 2 pos + d (d = 0 .. 2R: the halo shifts it by R)
 #pragma unroll
         for (int d = 0; d < NT; ++d)
 #pragma unroll
           for (int gq = 0; gq < NGRP; ++gq) FixMma<T>::run(wv[d][gq], *(const uint4*)(sp + d * PSB + gq * (CPG * (int)sizeof(T))), acc);
       }
-      *(float4*)(sRed + ((wave * NB * npf + u) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *(float4*)(sRed + ((wave * npf + pf) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
-    for (int it = tid; it < NB * npf * 64; it += 256) {        // sum the four strip rows in wave order; lane (lr = position, lg -> channels 4 lg ..)
-      const int ln = it & 63, u = it >> 6, ib = u / npf, pf = u - ib * npf, b = b0 + ib;
-      if (b >= b_hi) continue;
-      float4 s = *(const float4*)(sRed + ((0 * NB * npf + u) * 64 + ln) * 4);
+    for (int it = tid; it < npf * 64; it += 256) {             // sum the four strip rows in wave order; lane (lr = position, lg -> channels 4 lg ..)
+      const int ln = it & 63, pf = it >> 6;
+      float4 sm = *(const float4*)(sRed + ((0 * npf + pf) * 64 + ln) * 4);
 #pragma unroll
       for (int q = 1; q < 4; ++q) {
-        const float4 v = *(const float4*)(sRed + ((q * NB * npf + u) * 64 + ln) * 4);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        const float4 v = *(const float4*)(sRed + ((q * npf + pf) * 64 + ln) * 4);
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
       }
       const int pos = 16 * pf + (ln & 15), ci = cif * 16 + (ln >> 4) * 4;
       float* p = rows ? mg.erow[blockIdx.z] + (((int64_t)b * 2 + (e & 1)) * w + pos) * Cin + ci
                       : mg.ecol[blockIdx.z] + (((int64_t)b * h + pos) * 2 + (e & 1)) * Cin + ci;
-      *(float4*)p = s;
+      *(float4*)p = sm;
     }
   }
 }
@@ -122,20 +138,27 @@ __global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti 
   *p = v;
 }
 
-template <typename T, int NT, int NGRP>
-static int launch_edge(const PolydEdgeMulti& m, int n, int B, int h, int w, int Cin, int gdy, int K, hipStream_t st) {
-  constexpr int NB = 2;
-  const int big = h > w ? h : w, SW = 2 * big + NT - 1, npf = big >> 4;
-  const size_t lds = (size_t)NB * 4 * SW * (NGRP * FixMma<T>::CPG * sizeof(T) + 16) + (size_t)4 * NB * (npf < 1 ? 1 : npf) * 256 * 4;
-  if (lds > 150 * 1024 || (h & 15) || (w & 15)) return SV_E_UNSUPPORTED;
+template <typename T, int NT, int NGRP, int NLI>
+static int launch_edge_n(const PolydEdgeMulti& m, int n, int B, int h, int w, int Cin, int gdy, int K, size_t lds, hipStream_t st) {
   int groups = (B + 7) / 8;                                 // ~8 images per workgroup
   if (groups < 1) groups = 1;
-  sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NB>, lds);
-  hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NB>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
+  sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NLI>, lds);
+  hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NLI>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
   SV_LAUNCH_CHECK();
   hipLaunchKernelGGL((polyd_corner_kernel<T, NGRP>), dim3(4 * (Cin >> 4), (B + 63) / 64, n), dim3(256), 0, st, m, B, h, w, Cin, gdy, K);
   SV_LAUNCH_CHECK();
   return SV_OK;
+}
+template <typename T, int NT, int NGRP>
+static int launch_edge(const PolydEdgeMulti& m, int n, int B, int h, int w, int Cin, int gdy, int K, hipStream_t st) {
+  constexpr int NPC = NGRP * FixMma<T>::CPG / ElemTraits<T>::EPP;
+  const int big = h > w ? h : w, SW = 2 * big + NT - 1, npf = big >> 4;
+  const size_t lds = (size_t)4 * SW * (NGRP * FixMma<T>::CPG * sizeof(T) + 16) + (size_t)4 * (npf < 1 ? 1 : npf) * 256 * 4;
+  if (lds > 150 * 1024 || (h & 15) || (w & 15)) return SV_E_UNSUPPORTED;
+  const int items = 4 * SW * NPC;                          // strip pieces per image: 16-pixel low-res lines 1280 (d4) / 32-pixel lines 1152 (the head), 2304 (d4 at 128 x 128)
+  if (items <= 5 * 256) return launch_edge_n<T, NT, NGRP, 5>(m, n, B, h, w, Cin, gdy, K, lds, st);
+  if (items <= 9 * 256) return launch_edge_n<T, NT, NGRP, 9>(m, n, B, h, w, Cin, gdy, K, lds, st);
+  return SV_E_UNSUPPORTED;
 }
 
 }  // namespace

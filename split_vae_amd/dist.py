@@ -110,15 +110,20 @@ class NativeGradReducer:
             self._ranges[k] = ((C.c_int64 * n)(*[b for b, _ in spans]), (C.c_int64 * n)(*[e for _, e in spans]), n)
         self._dirty = False
         self.force = True
-        self.mode = os.environ.get("SV_DP_MODE", "overlap")             # 'overlap' (bucketed, behind the backward) | 'single'
+        self.mode = os.environ.get("SV_DP_MODE", "events")              # 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
-    def launch(self, flat, bucket):
+    def launch(self, flat, bucket, after=None):
+        """after=(plan, k): the communication stream waits for the plan's bucket-k events (sv_lgvae_bucket_wait) instead of for everything
+        enqueued on the compute stream so far -- the whole backward is one call and the bucket starts as soon as ITS kernels are done."""
         from . import _lib
-        self.stream.wait_stream(torch.cuda.current_stream())           # the phase that filled the bucket
+        if after is not None:
+            after[0].bucket_wait(after[1], self.stream)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())       # the phase that filled the bucket
         b, e, n = self._ranges[bucket]
         _lib.check(self.lib.sv_comm_allreduce_ranges(self.handle, self.C.c_void_p(flat.data_ptr()), b, e, n,
                                                      self.C.c_void_p(self.stream.cuda_stream)), "sv_comm_allreduce_ranges")
@@ -156,7 +161,7 @@ class GradReducer:
         self.group = group
         self.buckets = param_buckets(param_table, n_params)
         self._pending = []
-        self.mode = os.environ.get("SV_DP_MODE", "overlap")             # 'overlap' (bucketed, behind the backward) | 'single'
+        self.mode = os.environ.get("SV_DP_MODE", "events")              # 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
 
     def launch_all(self, flat):
         """mode 'single': the whole flat buffer as one all-reduce."""
@@ -168,12 +173,22 @@ class GradReducer:
     def grad_scale(self):
         return 1.0 / self.world
 
-    def launch(self, flat, bucket):
-        """Enqueue the all-reduce of one bucket (call right after the phase that produced it)."""
+    def launch(self, flat, bucket, after=None):
+        """Enqueue the all-reduce of one bucket (call right after the phase that produced it).  after=(plan, k): the collective is ordered
+        behind the plan's bucket-k events only (sv_lgvae_bucket_wait on an auxiliary stream that is `current` while the collective is enqueued:
+        torch's process groups order a collective after the current stream), not behind the rest of the backward the compute stream already holds."""
         if self.world == 1 and not self.force:
             return
-        for b, e in self.buckets[bucket]:
-            self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if after is None:
+            for b, e in self.buckets[bucket]:
+                self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        if getattr(self, "_aux", None) is None:
+            self._aux = torch.cuda.Stream()
+        after[0].bucket_wait(after[1], self._aux)
+        with torch.cuda.stream(self._aux):
+            for b, e in self.buckets[bucket]:
+                self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
         """Make the compute stream wait for every outstanding bucket (no host sync on nccl)."""

@@ -432,6 +432,11 @@ class LGVaePlan:
             self.in8_gen += 1                                  # this step's split / pad pass overwrites in8_x / in8_xh
         check(self.lib.sv_lgvae_step(self.handle, C.byref(a), _stream()), "sv_lgvae_step")
 
+    def bucket_wait(self, bucket, stream):
+        """Make `stream` (a torch.cuda.Stream) wait for gradient bucket 0 (decoders) / 1 (encoder heads) / 2 (encoder convs) / 3 (1 and 2) of the last
+        step that carried PHASE_BUCKET_EVENTS (sv_lgvae_bucket_wait)."""
+        check(self.lib.sv_lgvae_bucket_wait(self.handle, int(bucket), C.c_void_p(stream.cuda_stream)), "sv_lgvae_bucket_wait")
+
     def graph_enable(self, on=True):
         """hipGraph replay of `step` (include/splitvae.h: sv_lgvae_graph_enable); effective on a non-default stream."""
         check(self.lib.sv_lgvae_graph_enable(self.handle, 1 if on else 0), "sv_lgvae_graph_enable")

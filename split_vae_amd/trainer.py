@@ -12,7 +12,7 @@ from datetime import datetime
 import torch
 
 from . import dist as svdist
-from ._lib import (PHASE_ADAM, PHASE_ALL, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS,
+from ._lib import (PHASE_ADAM, PHASE_ALL, PHASE_BUCKET_EVENTS, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS,
                    PHASE_FORWARD, PHASE_INPUTS_STAGED, PHASE_LOSS, PHASE_NO_RECON, PHASE_PREP)
 from .model import LGVae
 
@@ -103,7 +103,22 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
         reducer.wait()
         plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
         return plan
-    # data parallel: launch each bucket's all-reduce as soon as the phase that fills it is enqueued
+    if getattr(reducer, "mode", "events") == "events":
+        # data parallel, default: ONE call for forward + loss + the whole backward (the single-GPU stream placement: weight gradients on the side
+        # stream(s) beside the input-gradient chain, no join between the decoders' and the encoders' backward); the library records an event set as each
+        # gradient bucket completes and the all-reduces are ordered behind THOSE (sv_lgvae_bucket_wait), so the decoders' bucket travels while the
+        # encoders' backward runs.  Two host calls into the library per step instead of four or five.
+        plan.step((PHASE_ALL & ~PHASE_ADAM) | PHASE_BUCKET_EVENTS | nr, **kw)
+        reducer.launch(model.grad_flat, "decoders", after=(plan, 0))
+        if B <= _DP_TWO_BUCKETS_MAX:
+            reducer.launch(model.grad_flat, "encoders", after=(plan, 3))
+        else:
+            reducer.launch(model.grad_flat, "enc_heads", after=(plan, 1))
+            reducer.launch(model.grad_flat, "enc_convs", after=(plan, 2))
+        reducer.wait()
+        plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
+        return plan
+    # SV_DP_MODE=overlap (rounds 1-4): the step split at the phase boundaries, each bucket's all-reduce launched as soon as the phase that fills it is enqueued
     plan.step(PHASE_PREP | PHASE_FORWARD | PHASE_LOSS | PHASE_BWD_DECODERS | nr, **kw)
     reducer.launch(model.grad_flat, "decoders")
     if B <= _DP_TWO_BUCKETS_MAX:

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32_f32", deterministic=False, buckets=None):
+def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32_f32", deterministic=False, buckets=None, mode=None, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -37,6 +37,9 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32
             env["SV_DP_TWO_BUCKETS_MAX"] = "0"    # the three-bucket schedule of shards above 256 images (trainer.train_step) at this small shard
         elif buckets == 2:
             env["SV_DP_TWO_BUCKETS_MAX"] = "1024"
+        if mode:
+            env["SV_DP_MODE"] = mode              # 'events' (default: one backward call + bucket events) | 'overlap' (the phase split of rounds 1-4) | 'single'
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps), config],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -45,10 +48,11 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32
     return np.load(out)
 
 
+@pytest.mark.parametrize("mode", ["events", "overlap"])
 @pytest.mark.parametrize("buckets", [2, 3])
-def test_two_ranks_equal_one(lib_built, tmp_path, buckets):
+def test_two_ranks_equal_one(lib_built, tmp_path, buckets, mode):
     one = _run(1, str(tmp_path / "one.npz"))
-    two = _run(2, str(tmp_path / "two.npz"), buckets=buckets)
+    two = _run(2, str(tmp_path / "two.npz"), buckets=buckets, mode=mode)
     # rank 0's loss scalars are its SHARD means; gradients and weights are global
     g1, g2 = one["grads"], two["grads"] / 2.0                 # all-reduce(sum); 1/world lives in the Adam kernel
     assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)          # (bounds: see test_one_rank_through_the_rccl_path_equals_the_plain_step)
@@ -68,6 +72,37 @@ def test_two_ranks_equal_one_at_config_4s_shard(lib_built, tmp_path):
     g1, g2 = one["grads"], two["grads"] / 2.0
     assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
     assert np.all(np.isfinite(two["losses"]))
+
+
+def _bucket_probe(extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bucket_probe.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("BUCKET_SNAPSHOT_ERR")][-1]
+    return [float(v) for v in line.split()[1:]]
+
+
+def test_buckets_wait_for_the_side_stream(lib_built):
+    """The event path's dependency, made observable on ONE GPU (a world-1 all-reduce is the identity on a buffer that is final by the time anyone
+    reads it, so the one-rank RCCL tests cannot see a missing dependency): the weight-gradient side stream is held back for 5 ms at its first use of
+    the step (SV_TEST_SIDE_DELAY_US), and a fresh stream ordered ONLY by sv_lgvae_bucket_wait snapshots each bucket's gradient range.  The snapshot
+    must equal the final gradients bit for bit -- the stream waited for the side stream's part of the bucket -- and with the side streams' events
+    dropped on purpose (SV_TEST_BUCKET_SKIP_SIDE: negative control) the decoders' snapshot must NOT (measured: taken 1.2 ms into a 6.2 ms step, all of
+    the side stream's weight gradients missing): the probe can see the failure it guards against.  (The library's default of three hardware queues; a
+    probe stream that happens to share a queue with the held-back side stream inherits its order, which is why only the first bucket is asserted on.)"""
+    knobs = {"SV_TEST_SIDE_DELAY_US": "5000"}
+    good = _bucket_probe(knobs)
+    assert good == [0.0, 0.0, 0.0], good
+    bad = _bucket_probe(dict(knobs, SV_TEST_BUCKET_SKIP_SIDE="1"))
+    assert bad[0] > 0.1, bad
+
+
+def test_two_ranks_equal_one_with_a_late_side_stream(lib_built, tmp_path):
+    """... and end to end: two ranks over gloo with the side stream held back, against the single-process step."""
+    one = _run(1, str(tmp_path / "one.npz"), steps=1)
+    two = _run(2, str(tmp_path / "two.npz"), steps=1, mode="events", extra_env={"SV_TEST_SIDE_DELAY_US": "5000"})
+    g1, g2 = one["grads"], two["grads"] / 2.0
+    assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
 
 
 @pytest.mark.parametrize("backend", ["nccl", "sv_comm"])
