@@ -62,6 +62,8 @@ def compute(config=None):
     o32 = R.forward(p32, cfg, img, {k: v.float() for k, v in noise.items()}, training=True)
     g32 = torch.autograd.grad(R.losses(cfg, img, o32, STEP)[0], list(p32.values()))
     out["grad_norms_f32"] = np.array([float(g.double().norm()) for g in g32])
+    # ... and each gradient's relative L2 distance from the fp64 one (the same noise scale tests/test_gpu_spair_model.py::test_spair_step_matches_oracle uses)
+    out["grad_err_f32"] = np.array([float((a.double() - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(g32, grads)])
     out["grad_samples"] = np.stack([g.detach().numpy().reshape(-1)[sample_idx(g.numel(), 8)] if g.numel() >= 8 else
                                     np.resize(g.detach().numpy().reshape(-1), 8) for g in grads])
     return out

@@ -259,8 +259,9 @@ def test_spair_step_matches_the_golden_fixture(lib_built, fixture):
         s = f[mk.sample_idx(f.size)]
         assert np.linalg.norm(s - G["sample/" + k]) <= 5e-4 * max(np.linalg.norm(G["sample/" + k]), 1e-12), k
     gn = np.array([float(g.norm()) for g in grads])
-    # bound per variable: 5e-3, or 3x what fp32 rounding alone does to this norm on the CPU (the fixture's grad_norms_f32: the same graph in fp32)
-    tol = np.maximum(5e-3, 3.0 * np.abs(G["grad_norms_f32"] - G["grad_norms"]) / np.maximum(G["grad_norms"], 1e-30))
+    # bound per variable: 5e-3, or 3x what fp32 rounding alone does to this gradient on the CPU (the fixture's grad_err_f32: relative L2 distance of the same
+    # graph evaluated in fp32 from the fp64 gradient; a norm cannot move further than the vector does)
+    tol = np.maximum(5e-3, 3.0 * G["grad_err_f32"])
     bad = np.abs(gn - G["grad_norms"]) > tol * np.abs(G["grad_norms"])
     assert not bad.any(), (np.nonzero(bad)[0], gn[bad], G["grad_norms"][bad], tol[bad])
 

@@ -128,4 +128,10 @@ def test_oracle_reproduces_the_committed_spair_fixture(fixture):
     with np.load(os.path.join(here, "golden", fixture)) as G:
         assert set(G.files) == set(got)
         for k in G.files:
+            if k == "grad_err_f32":          # (a noise scale of this host's fp32 evaluation: order of magnitude only)
+                assert got[k].shape == G[k].shape and np.all(got[k] <= 10 * G[k] + 1e-6), k
+                continue
+            if k == "grad_norms_f32":        # the fp32 evaluation of the graph on THIS host's CPU (thread count / vector width reorder its sums): a noise scale, not a pinned value
+                np.testing.assert_allclose(got[k], G[k], rtol=2e-2, err_msg=k)
+                continue
             np.testing.assert_allclose(got[k], G[k], rtol=1e-9, atol=1e-12, err_msg=k)
