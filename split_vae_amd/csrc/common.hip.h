@@ -190,7 +190,13 @@ inline bool sv_deterministic() {
 
 // (wgrad_tile.hip, wgrad_tile_f32.hip) index of (tap, ci, co) in the HWIO gradient; the x-packed conv (fold_kw > 0) has taps (ky, tx) of
 // KH x (KW+1) and columns co = px*8 + c, which fold onto tap (ky, tx - px), channel c.  -1: padding.
-__device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_real, int N, int fold_kw, int fold_c) {
+// s2d3: the space-to-depth form of a 6 x 6 stride-2 conv over 3 channels (conv_geom.h: svg_s2d3): tap = ty * 3 + tx of the 3 x 3 kernel, ci = (py * 2 + px) * 3 + c
+// -> kernel position (2 ty + py, 2 tx + px), channel c of the [6][6][3][N] gradient.
+__device__ __forceinline__ int64_t dw_index(int tap, int ci, int co, int Cin_real, int N, int fold_kw, int fold_c, int s2d3 = 0) {
+  if (s2d3) {
+    const int ty = tap / 3, tx = tap - ty * 3, p = ci / 3, c = ci - p * 3;
+    return ((int64_t)(((2 * ty + (p >> 1)) * 6 + 2 * tx + (p & 1)) * 3 + c)) * N + co;
+  }
   if (!fold_kw) return ((int64_t)(tap * Cin_real + ci)) * N + co;
   const int ky = tap / (fold_kw + 1), tx = tap - ky * (fold_kw + 1), px = co >> 3, c = co & 7, kx = tx - px;
   if ((unsigned)kx >= (unsigned)fold_kw || c >= fold_c) return -1;

@@ -137,6 +137,17 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
     arena[j.dst_off + idx] = from_f32<T>(v);
     return;
   }
+  if (j.s2d3) {
+    // [co][t = tx * 3 + ty][ci16]: channel ci16 = (py*2+px)*3 + c of the space-to-depth view <- kernel position (2 ty + py, 2 tx + px), channel c (conv_geom.h: svg_s2d3)
+    const int total = j.rows * 9 * 16;
+    const int idx = block_in_job * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ci = idx & 15, t = (idx >> 4) % 9, co = idx / 144, tx = t / 3, ty = t - tx * 3, pq = ci / 3, c = ci - pq * 3;
+    float v = 0.f;
+    if (ci < 12 && co < j.Cout) v = params[j.src_off + ((int64_t)((2 * ty + (pq >> 1)) * 6 + 2 * tx + (pq & 1)) * 3 + c) * j.Cout + co];
+    arena[j.dst_off + idx] = from_f32<T>(v);
+    return;
+  }
   if (j.packx_kw) {
     const int total = j.rows * j.ntaps * j.inner;
     const int idx = block_in_job * 256 + threadIdx.x;
@@ -321,6 +332,14 @@ void svg_fwd_args(const sv_conv_desc* d, TapGemmArgs* a) {
   a->N = d->Cout;
   a->OHF = OH; a->OWF = OW; a->OS = 1; a->ooy = 0; a->oox = 0; a->ldo = d->ldy;
   a->act = d->act; a->out_f32 = d->y_f32; a->splitk = 1; a->ups = d->ups_in;
+  if (svg_s2d3(d)) {
+    // the 3 x 3 stride-1 conv over the space-to-depth view [B, H/2, W/2, 16] of the padded RGB tensor; taps x-major like every stride-1 forward
+    a->IH = OH; a->IW = OW; a->lda = 16; a->cl2 = 2;
+    a->ntaps = 9; a->Ktot = 144; a->P = 36; a->S = 1; a->SX = 1; a->s2d3 = 1;
+    for (int tx = 0; tx < 3; ++tx)
+      for (int ty = 0; ty < 3; ++ty) { a->dy[tx * 3 + ty] = (int8_t)(ty - 1); a->dx[tx * 3 + ty] = (int8_t)(tx - 1); }
+    return;
+  }
   if (svg_poly(d)) {
     // rows = LOW-RES pixels (i, j) of the [B, H/2, W/2, Cin] tensor; tap (ty, tx) in -2..2, x-major; 32 columns (py, px, co)
     const int h = d->H / 2, w = d->W / 2;
@@ -438,6 +457,15 @@ void svg_wgrad_args(const sv_conv_desc* d, WgradArgs* a) {
   a->Cin_pad = cpad; a->Cin_real = d->Cin; a->N = d->Cout; a->ups = d->ups_in;
   a->ntaps = d->KH * d->KW;
   a->Nrows = a->ntaps * cpad;
+  if (svg_s2d3(d)) {
+    // space-to-depth form: 3 x 3 taps (y-major) over the 16-channel view; the reduce maps (tap, (py,px,c)) back to the [6][6][3][N] gradient (dw_index)
+    a->IH = OH; a->IW = OW; a->lda = 16; a->S = 1; a->SX = 1; a->cl2 = 2;
+    a->Cin_pad = 16; a->Cin_real = 12; a->ntaps = 9; a->Nrows = 144; a->s2d3 = 1;
+    for (int ty = 0; ty < 3; ++ty)
+      for (int tx = 0; tx < 3; ++tx) { a->dy[ty * 3 + tx] = (int8_t)(ty - 1); a->dx[ty * 3 + tx] = (int8_t)(tx - 1); }
+    a->msplit = a->M;
+    return;
+  }
   if (svg_packx(d)) {
     // the x-packed conv's weight gradient: rows = pixel pairs, dY = the [B,H,W,8] gradient viewed as
     // [B,H,W/2,16]; the tile kernel folds dW' back into the HWIO gradient (the im2col kernel cannot)
@@ -486,6 +514,11 @@ void svg_prep_job_fwd(const sv_conv_desc* d, PrepJob* j) {
   j->inner = svg_cin_pad(d);
   j->inner_ld = j->inner; j->inner_off = 0;
   j->transpose = 0;
+  if (svg_s2d3(d)) {
+    j->ntaps = 9; j->inner = 16; j->inner_ld = 16; j->s2d3 = 1;
+    j->nblocks = (j->rows * 144 + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);
+    return;
+  }
   if (svg_poly(d)) {
     j->ntaps = 25; j->rows = 32; j->poly = 1;
     j->nblocks = (j->rows * j->ntaps * j->inner + 256 * SV_PREP_UNITS - 1) / (256 * SV_PREP_UNITS);

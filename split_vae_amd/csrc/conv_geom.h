@@ -95,6 +95,15 @@ static inline __host__ __device__ bool svg_polyc_excl(int K, int c, int k) {
   return k > below - 1 + pad;                                         // Y + k - pad > 2h - 1  <=>  k > (2h - 1 - Y) + pad, 2h - 1 - Y = below - 1
 }
 #define SV_POLY_FIX_ELEMS(cin) (10 * 6 * 16 * (cin))                 // [10 border classes][6 taps][16 columns][Cin]
+// SPACE-TO-DEPTH form of the first encoder layer at fp32 (e1: Conv2D(32, 6, strides 2) over RGB, vae/model.py:36).  The padded 8-channel pixels make 62 % of every
+// fp32 MFMA zeros (3 of 8 channels: K = 36 x 8 = 288 for 108 real products).  Input row 2 oy + ky - 2 = 2 (oy + t) + py with t in {-1, 0, 1}: over the space-to-depth view
+// [B, H/2, W/2, (py, px, c)] the layer is a 3 x 3 stride-1 SAME conv with 12 (padded to 16) channels: K = 9 x 16 = 144, half the MFMAs, and the stride-1 tile path.  The
+// view is formed while the tile is staged (tile_stage.hip.h: stage_tile_s2d3) from the unchanged 8-channel tensor; weights / gradients map by dw_index's s2d3 rule.
+static inline int svg_s2d3(const sv_conv_desc* d) {
+  static const bool off = getenv("SV_NO_S2D3") != nullptr;
+  return !off && d->dtype == SV_F32 && d->Cin == 3 && d->ldx == 8 && d->KH == 6 && d->KW == 6 && d->stride == 2 && !d->ups_in && !d->y_f32 &&
+         d->H >= 16 && d->W >= 16 && !(d->H & (d->H - 1)) && !(d->W & (d->W - 1)) && d->Cout % 16 == 0;
+}
 // N tile selection of the tap GEMM: 0: 128, 1: 64, 2: 32, 3: 16 columns
 static inline int svg_pick_cfg(int N) {
   if (N % 128 == 0) return 0;

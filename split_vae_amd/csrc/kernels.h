@@ -34,6 +34,8 @@ struct TapGemmArgs {
                         // form of (2x bilinear upsample -> conv): a plain conv over the LOW-RES tensor whose four output
                         // parities are four column classes (conv_api.hip: svg_poly)
   int clampin;          // input coordinates outside the image clamp to the edge (replicate) instead of reading zero
+  int s2d3;             // A is the 8-channel padded RGB tensor [B, 2 IH, 2 IW, 8]; the conv sees its space-to-depth view [B, IH, IW, 16] (channel (py*2+px)*3 + c,
+                        // 12 real + 4 zero): the 6 x 6 stride-2 first encoder layer as a 3 x 3 stride-1 conv with K = 144 instead of 288 (conv_geom.h: svg_s2d3)
   // FUSED LOSS (with d2s_y, training step): the epilogue evaluates the discretised-logistic NLL of its pixels against
   // nll_img (images6 [B,OHF,OWF,6], channels nll_ch..nll_ch+2), writes the gradient nll_gscale * d nll / d out6 to nll_grad
   // ([B,OHF,OWF,8] bf16, what dlogistic_kernel would write) and one partial sum per (image, tile) to nll_part[b * tiles + tile];
@@ -90,6 +92,7 @@ struct TileConvArgs {
   int d2s;                    // depth-to-space (x) epilogue of the pixel-packed conv: real channels per sub-pixel
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
+  int s2d3;                   // TapGemmArgs::s2d3
   const float* fix;           // TapGemmArgs::fix
   const float* fix2; int fix_nc, fix_pad;   // TapGemmArgs::fix2 / fix_nc / fix_pad (per-class polyphase)
   const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale; int nll_noout;   // TapGemmArgs: fused loss
@@ -126,6 +129,7 @@ struct WgradArgs {
   int dy_os, dy_oy, dy_ox;   // dy_os = 2: dY is the hi-res gradient [B, 2*OY, 2*OX, ldy] and iteration pixel (oy, ox) reads its pixel (2 oy + dy_oy, 2 ox + dy_ox):
                              // one parity class of the per-class polyphase weight gradient (conv_geom.h: svg_polyc; wgrad_tile_f32.hip only)
   int assign;         // slab path: the reduce WRITES dW (every element has one owner) instead of adding to it
+  int s2d3;           // TapGemmArgs::s2d3 (A = the padded RGB tensor read through its space-to-depth view; dW lands in the [6][6][3][N] layout)
   float* ws;          // optional partial-sum workspace for the two-stage (deterministic) flush of the tile kernel
   int64_t ws_bytes;
   hipEvent_t ev_mid[2];   // profiling: when set, both are recorded after the main kernel, before the slab reduce
@@ -165,6 +169,7 @@ struct WgradTileArgs {
   int ups;                  // fused 2x bilinear upsample of the input
   int clampin, dy_s2d, assign;   // WgradArgs::clampin / dy_s2d / assign
   int dy_os, dy_oy, dy_ox;       // WgradArgs::dy_os / dy_oy / dy_ox
+  int s2d3;                      // WgradArgs::s2d3
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];
@@ -174,6 +179,7 @@ struct WgradTileArgs {
 struct WgradReduceDesc {
   const float* slab; float* dW; const float* bslab; float* dbias;
   int msplit, groups, ncg, CW, Cin_real, N, ntaps, fold_kw, fold_c, pairx, assign, TPW, CIF, COF;
+  int s2d3;           // dw_index's space-to-depth map (last member: the positional initialisers of the other kernels leave it 0)
 };
 #define SV_WGRAD_DEFER_MAX 16
 struct WgradReduceAll { WgradReduceDesc d[SV_WGRAD_DEFER_MAX]; int first[SV_WGRAD_DEFER_MAX + 1]; int n; };   // first: block ranges of the flat grid
@@ -244,6 +250,7 @@ struct PrepJob {
                        // 5: main image of the polyphase INPUT gradient [rows = ci][(2R+1)^2 hi-res taps (x-major)][co]; 6: its edge images
                        // [4 edges: top, bottom, left, right][4 rows from the edge][2R+1][ci][co]; 7: its corner images [4 corners][4][4][ci][co] (conv_geom.h: svg_polyd)
   int32_t pk, pcls;    // poly 3 .. 7: kernel size; poly 3: parity class py*2 + px
+  int32_t s2d3;        // forward image of the space-to-depth form (svg_s2d3): [co][t = tx*3 + ty][16] <- the 6 x 6 x 3 master
   int32_t first_block; // first block of this job in the launch
   int32_t nblocks;
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap

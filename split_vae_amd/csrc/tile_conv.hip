@@ -161,6 +161,9 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, lcH, g.TIW, g.TIH, g.PS, NB, g.plane_bytes};
     const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
     const T* Ap = (const T*)g.A + ((phase << lcH) * EPP);
+    if constexpr (sizeof(T) == 4) {
+      if (g.s2d3) { stage_tile_s2d3<NT>((const float*)g.A, sg, b0, iy_base, ix_base, sIn, tid); return; }     // the padded RGB tensor through its space-to-depth view
+    }
     if (g.ups) stage_tile_upsampled<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
     else if (g.clampin) stage_tile_plain<T, NT, true>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
     else stage_tile_plain<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
@@ -497,6 +500,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s && ((t.N != 16 && !(t.N == 32 && t.d2s_y)) || !t.out_f32)) return false;
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
+  if (t.s2d3 && (dtype != SV_F32 || t.S != 1 || t.SX != 1 || t.ups || t.clampin || t.cl2 != 2)) return false;
   if (t.fix_nc && !t.d2s_y && (!t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
@@ -598,7 +602,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
       static const int ph_kb = getenv("SV_TC_PH_KB") ? atoi(getenv("SV_TC_PH_KB")) : 53;   // LDS per workgroup the split aims below (3 workgroups per CU)
       static const bool s2_phases = getenv("SV_TC_NPH_NO_S2") == nullptr;               // A/B: phases for the padded stride-2 layouts too
       static const int ph_wgs = getenv("SV_TC_PH_WGS") ? atoi(getenv("SV_TC_PH_WGS")) : 256;   // launches smaller than this keep one pass
-      if (yr || !(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
+      if (yr || t.s2d3 || !(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
                   in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
     }
     // whole K resident in LDS (kernel comment): one phase, <= 6 K steps, <= 24 KB of weights
@@ -617,7 +621,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
     a->cl2 = t.cl2; a->P = t.P; a->Ktot = t.Ktot; a->S = t.S; a->SX = t.SX; a->d2s = t.d2s; a->cls_n = t.cls_n; a->d2s_y = t.d2s_y; a->clampin = t.clampin; a->fix = t.fix;
-    a->fix2 = t.fix2; a->fix_nc = t.d2s_y ? 0 : t.fix_nc; a->fix_pad = t.fix_pad;
+    a->fix2 = t.fix2; a->fix_nc = t.d2s_y ? 0 : t.fix_nc; a->fix_pad = t.fix_pad; a->s2d3 = t.s2d3;
     a->nll_img = t.nll_img; a->nll_grad = t.nll_grad; a->nll_part = t.nll_part; a->nll_ch = t.nll_ch; a->nll_gscale = t.nll_gscale; a->nll_noout = t.nll_noout;
     a->lTW = lTW; a->lTH = lTH; a->lNB = lNB;
     a->OY = OY; a->OX = OX;
@@ -719,7 +723,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
   for (int i = 0; i < n && none_tile; ++i) {
     TileConvArgs b;
     int c;
-    none_tile = !(t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
+    none_tile = !(t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc || t[i].s2d3) && (force_tap || !svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c));
   }
   if (none_tile) {
     for (int i = 0; i < n; i += SV_TAP_MAX_MULTI) {
@@ -735,7 +739,7 @@ int svk_conv_dispatch_multi(const TapGemmArgs* t, int n, int dtype, int tap_cfg,
     if (!force_tap && svk_tile_conv_plan(t[i], dtype, t[i].M / (t[i].OY * t[i].OX), &b, &c)) {
       b.dbg = dbg;
       rc = svk_tile_conv(b, dtype, c, st);
-    } else if (t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc) {
+    } else if (t[i].ups || t[i].d2s || t[i].cls_n || t[i].clampin || t[i].fix_nc || t[i].s2d3) {
       rc = SV_E_UNSUPPORTED;               // the im2col kernel needs the materialised hi-res tensor / has no depth-to-space store
     } else {
       rc = svk_tap_gemm(t[i], dtype, tap_cfg, st);

@@ -59,6 +59,31 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
   }
 }
 
+// Space-to-depth view of the padded RGB tensor (conv_geom.h: svg_s2d3): Ab = [B, 2 IH, 2 IW, 8] fp32 (channels 0..2 real), the tile pixel (i, j) of the
+// [B, IH, IW, 16] view holds channel (py*2+px)*3 + c = pixel (2i+py, 2j+px) channel c; zero outside the image (SAME padding) and in channels 12..15.
+// One item = one source pixel: a 16-B load (its first four floats), three 4-B LDS stores.
+template <int NT = 256>
+__device__ __forceinline__ void stage_tile_s2d3(const float* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base, int ix_base, char* sIn, int tid) {
+  const int total = s.NB * s.TIH * s.TIW * 4;
+  const float inv_row = 1.0f / (float)(s.TIW * 4), inv_h = 1.0f / (float)s.TIH;
+  for (int it = tid; it < total; it += NT) {
+    const int row = (int)(((float)it + 0.5f) * inv_row), r = it - row * (s.TIW * 4);      // (image, tile row); (tile column, parity)
+    const int bl = (int)(((float)row + 0.5f) * inv_h), iyl = row - bl * s.TIH;
+    const int ixl = r >> 2, p = r & 3, iy = iy_base + iyl, ix = ix_base + ixl, b = b0 + bl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < s.B && (unsigned)iy < (unsigned)s.IH && (unsigned)ix < (unsigned)s.IW)
+      v = *(const float4*)(Ab + (((int64_t)b * (2 * s.IH) + 2 * iy + (p >> 1)) * (2 * s.IW) + 2 * ix + (p & 1)) * 8);
+    const int pixel = row * s.TIW + ixl;
+    const float f[3] = {v.x, v.y, v.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int ch = p * 3 + c;
+      *(float*)(sIn + tile_piece_off(s, pixel, ch >> 2) + (ch & 3) * 4) = f[c];
+    }
+    if (p == 0) *(float4*)(sIn + tile_piece_off(s, pixel, 3)) = make_float4(0.f, 0.f, 0.f, 0.f);     // channels 12..15
+  }
+}
+
 // the 2x2 hi-res block {2i+1, 2i+2} x {2j+1, 2j+2} from the low-res 2x2 neighbourhood: horizontal
 // interpolation first (shared by the two rows), packed fp32 math (56 v_pk ops per 16-B piece quad
 // instead of ~200 scalar ones: the blend, not the MFMAs, was the busiest user of the issue slots)

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const WgradReduce
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (co + k >= N) continue;
-    const int64_t di = dw_index(otap, ci, co + k, g.Cin_real, N, fold_kw, g.fold_c);
+    const int64_t di = dw_index(otap, ci, co + k, g.Cin_real, N, fold_kw, g.fold_c, g.s2d3);
     if (di < 0) continue;
     if (fold_kw) atomicAdd(g.dW + di, sv[k]); else if (g.assign) g.dW[di] = sv[k]; else g.dW[di] += sv[k];
   }
@@ -920,6 +920,8 @@ int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipS
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
   // im2col kernel (no tile instantiation for this shape, or fp32): all of them in one launch
+  for (int i = 0; i < n; ++i)
+    if (w[i].s2d3 || w[i].clampin || w[i].dy_os || w[i].dy_s2d) return SV_E_UNSUPPORTED;      // views only the tile kernels form
   const bool any_tile = no_multi || n > SV_WGRAD_IM2COL_MAX_MULTI;
   int rc = SV_OK;
   if (!any_tile) {
@@ -951,6 +953,6 @@ int svk_wgrad_dispatch(const WgradArgs& w, int dtype, int cfg, hipStream_t st) {
     const int rc = svk_wgrad_tile_f32_multi(&w, 1, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
-  if (w.ups || w.fold_kw) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor / cannot fold
+  if (w.ups || w.fold_kw || w.s2d3 || w.clampin || w.dy_os || w.dy_s2d) return SV_E_UNSUPPORTED;    // the im2col kernel needs the materialised hi-res tensor / cannot fold / reads no views
   return svk_wgrad(w, dtype, cfg, st);
 }

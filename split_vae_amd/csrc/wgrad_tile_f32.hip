@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
     {
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       // (ups: the layer's input is the 2x bilinear resize of the LOW-RES tensor A, blended on the fly with upsample2x_fwd's own arithmetic)
-      if (g.ups) stage_tile_upsampled<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
+      if (g.s2d3) stage_tile_s2d3<256>((const float*)g.A, sg, b0, ty0 + g.y_lo, tx0 + g.x_lo, sIn, tid);      // e1: the padded RGB tensor through its space-to-depth view
+      else if (g.ups) stage_tile_upsampled<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
       else if (g.clampin) stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);   // polyphase forms: the edge-clamped low-res tensor
       else stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
     }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
 #pragma unroll
         for (int j = 0; j < COF; ++j) {
           const int co = j * 16 + lr;
-          const int64_t di = co < g.N ? dw_index(otap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c) : -1;
+          const int64_t di = co < g.N ? dw_index(otap, ci, co, g.Cin_real, g.N, g.fold_kw, g.fold_c, g.s2d3) : -1;
           if (di >= 0) atomicAdd(g.dW + di, acc[t2][j][r4]);
         }
       }
@@ -197,6 +198,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const bool polyf = w.clampin != 0;
   if (polyf && (w.S != 1 || w.ups || w.fold_kw || !(w.dy_s2d == 8 ? w.ldy == 32 : w.dy_os == 2))) F32_REJ("polyphase form");
   if (!polyf && (w.dy_s2d || w.dy_os)) F32_REJ("dY view");
+  if (w.s2d3 && (w.S != 1 || w.ups || polyf || w.fold_kw || w.Cin_pad != 16 || w.ntaps != 9)) F32_REJ("space-to-depth form");
   const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, ldy = w.ldy, nt = w.ntaps;
   if (OX < 4 || OY * OX < 16 || ldy > 128 || (ldy & 7) || (nt != 36 && nt != 16 && nt != 9 && !(nt == 42 && w.fold_kw) && !(polyf && (nt == 25 || nt == 20 || nt == 12 || nt == 9)))) {
     if (trace) fprintf(stderr, "wgrad_tile_f32: OY %d OX %d ldy %d taps %d cin %d\n", OY, OX, ldy, nt, cin);
@@ -245,7 +247,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const int B = w.M >> (w.lOY + w.lOX);
   a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = w.S; a.SX = w.SX; a.assign = w.assign; a.ups = w.ups;
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
-  a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.dy_os = w.dy_os; a.dy_oy = w.dy_oy; a.dy_ox = w.dy_ox;
+  a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.dy_os = w.dy_os; a.dy_oy = w.dy_oy; a.dy_ox = w.dy_ox; a.s2d3 = w.s2d3;
   a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
   a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
   a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
@@ -263,7 +265,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   const int64_t need = (int64_t)msplit * groups * PER * 4 + (int64_t)msplit * 128 * 4;
   bool slab = true;                      // no (or a small) workspace: fp32 atomics straight into dW -- kept for the x-packed head and the layers behind
   for (int i = 0; i < n; ++i) slab = slab && wv[i].ws && wv[i].ws_bytes >= need;          // a fused resize, which the im2col kernel cannot do; every other shape falls back to it
-  if (!slab && !w.fold_kw && !w.ups) F32_REJ("workspace");
+  if (!slab && !w.fold_kw && !w.ups && !w.s2d3) F32_REJ("workspace");        // (s2d3: the im2col kernel cannot form the space-to-depth view: fp32 atomics flush)
   WgradTileArgs av[SV_WGRAD_MAX_MULTI];
   WgradReduceDesc rd[SV_WGRAD_MAX_MULTI];
   for (int i = 0; i < n; ++i) {
@@ -271,7 +273,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
     av[i].A = wv[i].A; av[i].dY = wv[i].dY; av[i].dW = wv[i].dW; av[i].dbias = wv[i].dbias;
     av[i].slab = slab ? wv[i].ws : nullptr;
     av[i].bslab = slab && wv[i].dbias ? wv[i].ws + (int64_t)msplit * groups * PER : nullptr;
-    rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, ntk, w.fold_kw, w.fold_c, a.pairx, a.assign, TPW, 1, COF};
+    rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, ntk, w.fold_kw, w.fold_c, a.pairx, a.assign, TPW, 1, COF, w.s2d3};
   }
   const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
   // <taps per wave, column fragments, dY floats per pixel, slice channels, x stride, pixel groups per tile row>: the layers of the model
