@@ -24,7 +24,11 @@ namespace {
 // image groups per border class (workgroups = 2 (K-1) x groups x networks).  Measured (2 x 512 images, d4 / d5 frame kernel + projection): 16 groups, one image per
 // barrier pair: 177 / 131 + 30 us; 32 groups, 4 images (72-86 KB of LDS: one workgroup per CU): 160 / 165 + 52 us; the loop is all latency (global loads -> lerp ->
 // LDS -> barrier -> 8-16 short K steps), so the next image's loads are issued BEFORE the current image's MFMAs and land in LDS after them (register prefetch).
-constexpr int FRAME_GROUPS = 16;
+constexpr int FRAME_GROUPS_MAX = 64; // (round 5, with the group sum as its own streaming pass: more, shorter workgroups hide each other's load latency)
+static int frame_groups() {
+  static const int g = getenv("SV_POLYC_FRAME_GROUPS") ? atoi(getenv("SV_POLYC_FRAME_GROUPS")) : 32;      // in the step (2 x 512 images): 16 groups 9.80-9.84 ms, 32: 9.795, 64: 9.86-9.89 (serial: 137 / 101 / 101 us for d4)
+  return g < 1 ? 1 : g > FRAME_GROUPS_MAX ? FRAME_GROUPS_MAX : g;
+}
 
 struct PolycFrameMulti { const float* x[2]; const float* dy[2]; float* slab[2]; };
 
@@ -151,6 +155,21 @@ static int launch_frame(const PolycFrameMulti& m, dim3 grid, int B, int h, int w
   return SV_OK;
 }
 
+// frame slabs of all image groups -> one slab, groups added in group order (deterministic): 16-B streaming reads, the projection then reads one value per term
+struct PolycFrameSum { const float* slab[2]; float* sum[2]; };
+__global__ __launch_bounds__(256) void polyc_frame_sum_kernel(const PolycFrameSum f, int groups, int per) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= per) return;
+  const float* p = f.slab[blockIdx.y] + e;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int g = 0; g < groups; ++g) {
+    const float4 v = *(const float4*)(p + (int64_t)g * per);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *(float4*)(f.sum[blockIdx.y] + e) = s;
+}
+
 struct PolycProject {
   const float* dWp[2]; float* dbp[2]; const float* slab[2]; float* dW[2]; float* dbias[2];
   int K, Cin, Cout, merged, groups, coff[4];      // coff: float offsets of the class buffers in dWp (per-class form)
@@ -201,12 +220,10 @@ __global__ __launch_bounds__(256) void polyc_wgrad_project_kernel(const PolycPro
     }
     f.dW[z][idx] += v;
   }
-  if (f.merged) {                       // the head's dbias' has the four parities side by side; the class problems of the per-class form add into dbias themselves
-    if (blockIdx.x == 0 && threadIdx.x < Cout && f.dbias[z]) {
-      float s = 0.f;
-      for (int p = 0; p < 4; ++p) s += f.dbp[z][p * 8 + threadIdx.x];
-      f.dbias[z][threadIdx.x] += s;
-    }
+  if (blockIdx.x == 0 && threadIdx.x < Cout && f.dbias[z]) {       // dbias' blocks: four parities x 8 columns (merged head) / four classes x 32
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += f.dbp[z][p * (f.merged ? 8 : 32) + threadIdx.x];
+    f.dbias[z][threadIdx.x] += s;
   }
 }
 
@@ -234,11 +251,11 @@ int svg_polyc_wgrad_form(const sv_conv_desc* d) {
   return 0;
 }
 
-// floats of the per-problem workspace: [dW' of every class | the merged dW'] [dbias' 32] [frame slabs]
+// floats of the per-problem workspace: [dW' of every class | the merged dW'] [dbias' 128: four parities x 8 (merged) / four classes x 32] [frame slabs + their sum]
 int64_t svk_polyc_wgrad_ws_floats(const sv_conv_desc* d) {
   const int form = svg_polyc_wgrad_form(d);
   if (!form) return 0;
-  return dwp_floats(d, form == 2, nullptr) + 32 + (int64_t)FRAME_GROUPS * 2 * (d->KH - 1) * frame_per(d->KH, svg_cin_pad(d), d->Cout);
+  return dwp_floats(d, form == 2, nullptr) + 128 + (int64_t)(FRAME_GROUPS_MAX + 1) * 2 * (d->KH - 1) * frame_per(d->KH, svg_cin_pad(d), d->Cout);   // (+ 1: the groups' sum)
 }
 
 void svg_polyc_wgrad_args(const sv_conv_desc* d, int cls, WgradArgs* a) {
@@ -267,28 +284,39 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
   memset(&pj, 0, sizeof(pj));
   const int64_t ndwp = dwp_floats(d, merged, pj.coff);
   WgradArgs a[2];
-  if (merged)                          // the head's dbias' (four parities side by side): the main term's reduce ADDS its bias partials
-    for (int i = 0; i < n; ++i)
-      if (hipMemsetAsync(pw[i] + ndwp, 0, 32 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+  // the class launches leave their slabs in their own quarter of the partial-sum workspace; ONE reduce launch sums them all (four 10-us launches less)
+  WgradReduceDesc pend[8];
+  int npend = 0;
+  const int nparts = merged ? 1 : 4;
+  const int64_t part = (slab_bytes / nparts) & ~(int64_t)255;
+  // dbias': the head's four parities side by side / one 32-column block per class (the class reduces run in ONE launch: they must not add into the same
+  // dbias); the main terms' reduce ADDS its bias partials, the projection sums the blocks in a fixed order
+  for (int i = 0; i < n; ++i)
+    if (hipMemsetAsync(pw[i] + ndwp, 0, 128 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
   for (int c = 0; c < (merged ? 1 : 4); ++c) {
     for (int i = 0; i < n; ++i) {
       if (merged) svg_poly_wgrad_args(d, &a[i]); else svg_polyc_wgrad_args(d, c, &a[i]);
       a[i].A = x_lo[i]; a[i].dY = dy[i];
       a[i].dW = pw[i] + (merged ? 0 : pj.coff[c]);
-      a[i].dbias = merged ? pw[i] + ndwp : (dbias ? dbias[i] : nullptr);
-      a[i].ws = slab_ws[i]; a[i].ws_bytes = slab_bytes;
+      a[i].dbias = (dbias && dbias[i]) ? pw[i] + ndwp + (merged ? 0 : c * 32) : nullptr;
+      a[i].ws = (float*)((char*)slab_ws[i] + c * part); a[i].ws_bytes = part;
+      a[i].defer = pend; a[i].n_defer = &npend;
     }
     const int rc = svk_wgrad_tile_f32_multi(a, n, st);
     if (rc) return c == 0 ? rc : (rc == SV_E_UNSUPPORTED ? SV_E_STATE : rc);    // (a later class cannot fail where class 0 passed: same geometry)
   }
+  if (npend) {
+    const int rc = svk_wgrad_reduce_all(pend, npend, st);
+    if (rc) return rc;
+  }
   PolycFrameMulti m;
   for (int i = 0; i < 2; ++i) {
     const int k = i < n ? i : 0;
-    m.x[i] = (const float*)x_lo[k]; m.dy[i] = (const float*)dy[k]; m.slab[i] = pw[k] + ndwp + 32;
+    m.x[i] = (const float*)x_lo[k]; m.dy[i] = (const float*)dy[k]; m.slab[i] = pw[k] + ndwp + 128;
     pj.dWp[i] = pw[k]; pj.dbp[i] = pw[k] + ndwp; pj.slab[i] = m.slab[i]; pj.dW[i] = dW[k]; pj.dbias[i] = dbias ? dbias[k] : nullptr;
   }
-  pj.K = K; pj.Cin = cin; pj.Cout = d->Cout; pj.merged = merged; pj.groups = FRAME_GROUPS;
-  const dim3 grid(2 * (K - 1), FRAME_GROUPS, n);
+  pj.K = K; pj.Cin = cin; pj.Cout = d->Cout; pj.merged = merged; pj.groups = 1;
+  const dim3 grid(2 * (K - 1), frame_groups(), n);
   const int ldy = svg_gdy(d);
   int rcf;
   if (cin == 64 && d->Cout == 32) rcf = launch_frame<6, 4, 2>(m, grid, d->B, h, w, ldy, st);
@@ -296,6 +324,17 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
   else if (cin == 32 && d->Cout <= 16) rcf = launch_frame<6, 2, 1>(m, grid, d->B, h, w, ldy, st);
   else rcf = SV_E_STATE;                                                            // (svg_polyc_wgrad_form admits only these)
   if (rcf) return rcf == SV_E_UNSUPPORTED ? SV_E_STATE : rcf;                       // (the main terms are already enqueued: the form check below keeps this unreachable)
+  {
+    const int per = (int)(2 * (K - 1) * frame_per(K, cin, d->Cout));
+    PolycFrameSum fs;
+    for (int i = 0; i < 2; ++i) {
+      fs.slab[i] = m.slab[i]; fs.sum[i] = m.slab[i] + (int64_t)FRAME_GROUPS_MAX * per;
+      pj.slab[i] = fs.sum[i];
+    }
+    pj.groups = 1;
+    hipLaunchKernelGGL(polyc_frame_sum_kernel, dim3((per / 4 + 255) / 256, n), dim3(256), 0, st, fs, frame_groups(), per);
+    SV_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(polyc_wgrad_project_kernel, dim3((K * K * cin * d->Cout + 255) / 256, n), dim3(256), 0, st, pj);
   SV_LAUNCH_CHECK();
   return SV_OK;

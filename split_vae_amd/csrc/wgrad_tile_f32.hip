@@ -296,7 +296,8 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   // the 3 x 3 layers of LG-SPAIR's object encoder / decoder on 32 x 32 glimpses (9 taps on 12 slots: three per wave, the reduce drops the padding)
   F32_LAYER(3, 4, 64, 16, 2);       // object encoder conv2
   F32_LAYER(3, 4, 64, 16, 1);       // object decoder d2
-  F32_LAYER(3, 2, 32, 16, 1);       // object decoder d3
+  F32_LAYER(3, 2, 32, 16, 1);       // object decoder d3; e1 in space-to-depth form (svg_s2d3)
+  F32_LAYER(3, 8, 128, 16, 1);      // SPLIT-GMVAE's first encoder layer (3 -> 128, vae/model.py:50) in space-to-depth form
   F32_LAYER(3, 1, 8, 16, 1);        // object decoder d5 (RGB + alpha)
   F32_LAYER(3, 2, 32, 8, 2);        // object encoder conv1 (RGB padded to 8 channels, no tap pairs: half of every fragment is dropped)
 #undef F32_LAYER
