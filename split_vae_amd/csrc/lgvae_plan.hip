@@ -118,6 +118,7 @@ struct sv_lgvae_plan {
   bool dz_slabs = false;
   bool dz_valid = false;        // the decoders' backward has run since the last encoder forward (dz is what reparam_kl_bwd may read)
   bool gz_zero_skipped = false; // that forward did not zero dz (slab path): an encoder backward WITHOUT the decoders' (KL terms only) zeroes it first
+  unsigned polycw_bad = 0;      // decoder layers (bit = index in dec[]) whose polyphase weight gradient was refused once: not tried again (one profile scope per launch)
   bool lat_head_ok = false, lat_d1_ok = false;     // the heads' forward / d1's input gradient of this plan run on latent_gemm.hip (shapes are fixed per plan)
   int dz_S[2] = {0, 0};
   int64_t dz_stride[2] = {0, 0};
@@ -778,7 +779,8 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   }
   // fp32: the polyphase weight gradient of the upsample -> conv layers (polyc_wgrad.hip: d4 per parity class, the head merged)
   static const int pcw_min = getenv("SV_POLYC_WGRAD_MIN") ? atoi(getenv("SV_POLYC_WGRAD_MIN")) : 0;
-  if (L[0]->d.dtype == SV_F32 && n <= 2 && n * L[0]->d.B >= pcw_min && svg_polyc_wgrad_form(&L[0]->d) && p->bufidx.count("polycw" + std::to_string(ln[1] - '0' - 1) + "_x")) {
+  if (L[0]->d.dtype == SV_F32 && n <= 2 && n * L[0]->d.B >= pcw_min && svg_polyc_wgrad_form(&L[0]->d) && !(p->polycw_bad >> (ln[1] - '0' - 1) & 1) &&
+      p->bufidx.count("polycw" + std::to_string(ln[1] - '0' - 1) + "_x")) {
     const std::string base = "polycw" + std::to_string(ln[1] - '0' - 1);          // layer name d<k>: index k - 1 in dec[]
     float *dwv[2], *dbv[2], *slab[2], *pw[2];
     for (int i = 0; i < n; ++i) {
@@ -790,6 +792,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     Scope sc(p, st, nm, fl, by);
     const int rc = svk_polyc_wgrad_multi(&L[0]->d, n, x, dy, dwv, dbv, slab, wsb, pw, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
+    p->polycw_bad |= 1u << (ln[1] - '0' - 1);
     fl = 0;
   }
   // measured (profiles/r03_f_defer.txt): one launch instead of seven saves 20-26 us of SERIAL time, but the slabs (~250 MB a step) are then read

@@ -224,7 +224,10 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   WgradTileArgs a;
   static const int bm_max = getenv("SV_WTF32_BM") ? atoi(getenv("SV_WTF32_BM")) : 256;      // A/B knobs
   static const int wgs = getenv("SV_WTF32_WGS") ? atoi(getenv("SV_WTF32_WGS")) : 512;
-  static const int lds_max = getenv("SV_WTF32_LDS") ? atoi(getenv("SV_WTF32_LDS")) : 78 * 1024;
+  // LDS per workgroup the tile may take.  78 KB (two workgroups per CU) gives the best launch ALONE on the chip; in the step the weight gradients run on the side
+  // stream beside the input-gradient chain, and 52 KB tiles (three to five workgroups per CU fit beside the other stream's) make the 512-image fp32 step 2.3 %
+  // shorter: 9.82-9.90 -> 9.60-9.62 ms (40 KB: 9.68; 128-pixel tiles at 78 KB: 9.77; profiles/r05_wtf32_lds_ab.txt), the serial rows 0-3 % longer
+  static const int lds_max = getenv("SV_WTF32_LDS") ? atoi(getenv("SV_WTF32_LDS")) : 52000;
   int BM = bm_max;
   for (;; BM >>= 1) {
     if (BM < 32) F32_REJ("tile");
