@@ -1381,7 +1381,9 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
     // on GPU_MAX_HW_QUEUES = 3): one.  SV_SIDE_STREAMS forces a count.
     static const int forced = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 0;
     const bool whole = (ph & SV_PHASE_ALL) == SV_PHASE_ALL;
-    p->side_use = forced > 0 ? forced : (whole && p->d.dtype == SV_BF16 && 2 * p->d.B >= 768) ? 2 : 1;
+    // fp32 (round 5, polyphase decoder layers + 52-KB weight-gradient tiles): two side streams 9.60-9.62 -> 9.37-9.39 ms at B = 512 (profiles/r05_f32_streams.txt)
+    // (fp32, 256 images per network: 5.14 -> 5.09 ms; 128: 2.84 -> 2.87: from 256)
+    p->side_use = forced > 0 ? forced : (whole && 2 * p->d.B >= (p->d.dtype == SV_F32 ? 512 : 768)) ? 2 : 1;
   }
   if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
   static const bool no_fused_nll = getenv("SV_NO_FUSED_NLL") != nullptr;    // A/B: dlogistic_kernel after the forward
