@@ -59,14 +59,23 @@ def _traffic_file(dtype="bf16"):
 
 
 def measured_traffic(kernel_stems, dtype="bf16"):
-    """(HBM bytes per launch, kernel symbol, file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE in separate runs, gfx950 x2 read correction) for the first stem that matches exactly one kernel; the
-    value is CACHED evidence of that profile run, not measured by this process: None when no symbol matches."""
+    """(HBM bytes per launch, kernel symbol(s), file) from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 x2 read
+    correction).  kernel_stems: strings -- the first stem that matches exactly one kernel -- or (stem, launches) pairs -- a scope made of several kernels: the
+    sum over those found.  The value is CACHED evidence of that profile run, not measured by this process: None when no symbol matches."""
     path = _traffic_file(dtype)
     try:
         kernels = json.load(open(path))["kernels"]
     except (OSError, ValueError, KeyError):
         return None, None, path
+    if kernel_stems and isinstance(kernel_stems[0], tuple):
+        total, names = 0, []
+        for stem, count in kernel_stems:
+            hits = [(n, k) for n, k in kernels.items() if stem in n]
+            if len(hits) != 1:
+                return None, None, path                      # a kernel of the scope is missing from the profile: no figure rather than a partial one
+            total += count * hits[0][1]["hbm_bytes_per_launch"]
+            names.append("%d x %s" % (count, hits[0][0].split("(")[0][-60:]))
+        return total, " + ".join(names), path
     for stem in kernel_stems:
         hits = [(n, k) for n, k in kernels.items() if stem and stem in n]
         if len(hits) == 1:
@@ -264,11 +273,18 @@ SCOPE_KERNEL = {"fwd.d5": ["tile_conv_kernelIDF16bLi32ELi4ELi4ELi0E"],   # polyp
                 "dgrad.e2": ["RowCfg<3, 3, 64, 128, 16, 4, 2, "]}
 
 
-# the fp32 step's weight gradients: wgrad_tile_f32_kernel<TPW, COF, LDY, CW, SX, G4> (profiles/*_f32_traffic.json; the forward / input-gradient tile kernels
-# serve several layers per symbol and are not mapped)
-SCOPE_KERNEL_F32 = {"wgrad.d5": ["wgrad_tile_f32_kernel<11, 1, 16, 16, 2, "], "wgrad.d4": ["wgrad_tile_f32_kernel<9, 2, 32, 16, 1, "],
-                    "wgrad.d3": ["wgrad_tile_f32_kernel<4, 4, 64, 16, 1, "], "wgrad.e2": ["wgrad_tile_f32_kernel<9, 4, 64, 16, 2, "],
-                    "wgrad.e1": ["wgrad_tile_f32_kernel<5, 2, 32, 8, 2, "]}
+# the fp32 step: a plan scope may be SEVERAL kernels (the polyphase forms: class launches + border kernels); (symbol stem, launches per scope) -- the scope's
+# traffic is the sum.  wgrad_tile_f32_kernel<TPW, COF, LDY, CW, SX, G4>; <7, 2, 32, 16, 1, .> serves d4's class (0, 0) AND the head's merged 25-tap form (one symbol:
+# the per-launch figure in profiles/*_f32_traffic.json is the mean of the two uses)
+SCOPE_KERNEL_F32 = {
+    "wgrad.d4": [("wgrad_tile_f32_kernel<7, 2, 32, 16, 1, ", 1), ("wgrad_tile_f32_kernel<5, 2, 32, 16, 1, ", 2), ("wgrad_tile_f32_kernel<4, 2, 32, 16, 1, ", 1),
+                 ("polyc_wgrad_frame_kernel<6, 4, 2", 1), ("polyc_frame_sum_kernel", 1), ("polyc_wgrad_project_kernel", 1)],
+    "wgrad.d5": [("wgrad_tile_f32_kernel<7, 2, 32, 16, 1, ", 1), ("polyc_wgrad_frame_kernel<6, 2, 1", 1), ("polyc_frame_sum_kernel", 1), ("polyc_wgrad_project_kernel", 1)],
+    "wgrad.d3": [("wgrad_tile_f32_kernel<4, 4, 64, 16, 1, ", 1)], "wgrad.e2": [("wgrad_tile_f32_kernel<9, 4, 64, 16, 2, ", 1)],
+    "wgrad.e1": [("wgrad_tile_f32_kernel<3, 2, 32, 16, 1, ", 1)],
+    "dgrad.d4": [("polyd_edge_kernel<float, 9, 2", 1), ("polyd_corner_kernel<float, 2", 1), ("tile_conv_kernel<float, 64, 2, ", 1)],
+    "fwd.d4": [("polyc_fix_kernel<float, 6, 4, 2", 1), ("tile_conv_kernel<float, 32, 4, ", 1)],
+}
 
 
 def wgrad_main_layers(images_per_launch, dtype, world=1):
