@@ -74,7 +74,7 @@ def measured_traffic(kernel_stems, dtype="bf16"):
             if len(hits) != 1:
                 return None, None, path                      # a kernel of the scope is missing from the profile: no figure rather than a partial one
             total += count * hits[0][1]["hbm_bytes_per_launch"]
-            names.append("%d x %s" % (count, hits[0][0].split("(")[0][-60:]))
+            names.append("%d x %s" % (count, hits[0][0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]))
         return total, " + ".join(names), path
     for stem in kernel_stems:
         hits = [(n, k) for n, k in kernels.items() if stem and stem in n]
@@ -399,9 +399,9 @@ def roofline_block(table, dom, worst, prof, dtype, B, world):
           "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
                     prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, dtype, world) else
                     "main (the weight-gradient side stream runs other layers' launches beside it)",
-          "live_note": "achieved / frac are LIVE: hipEvents around the launch on its stream inside the timed region, where up to three "
-                       "launches share the chip (two weight-gradient side streams beside the input-gradient chain from 768 images per "
-                       "launch: DESIGN.md 4g); `serial` is the same launch alone on the chip",
+          "live_note": "achieved / frac are LIVE: hipEvents around the scope on its stream inside the timed region, where up to three launches share the "
+                       "chip (two weight-gradient side streams beside the input-gradient chain: DESIGN.md section 5) -- the scope's wall time there counts "
+                       "what runs beside it; `serial` is the same scope alone on the chip, what the per-launch table and `decoder_stack` are built from",
           "decoder_stack": decoder_stack(table, dtype, TABLE_PASSES)}
     gs = grade(dom, dtype)
     rl["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
