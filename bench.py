@@ -376,8 +376,14 @@ def gm_row(dev, B=64, steps=100, warmup=10):
         train_step_lg_gm_vae(m, aug.augment(x), opt)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / steps
+    # 135.0 M forward MACs per image for the whole LGGMVae at SVHN-32 [derived]; train FLOP = 6 MACs_fwd - 4 MACs of the two first convs
+    # (gmvae encoder 16 x 16 x 128 x 108 = 3.54 M, local encoder 0.88 M: no input gradient).  A 64-image step is launch-bound: the fraction says so.
+    fl = 6 * 135.0e6 - 4 * (3.54e6 + 0.88e6)
     return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "steps": steps, "batch": B, "dtype": "bf16",
-            "workload": "SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4"}
+            "workload": "SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4",
+            "roofline": {"bound": "mfma", "flops_per_image": fl, "achieved": round(B / t * fl / 1e12, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                         "frac": round(B / t * fl / 1e12 / PEAK_TFLOPS["bf16"], 4),
+                         "note": "64 images per step: ~100 launches of a few microseconds each; the step is launch- and latency-bound, not matrix-pipe-bound"}}
 
 
 def roofline_block(table, dom, worst, prof, dtype, B, world):
