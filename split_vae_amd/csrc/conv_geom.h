@@ -62,8 +62,7 @@ static inline int svg_polyc(const sv_conv_desc* d) {
   // kernel sizes that take the form.  Measured (fp32, 2 x 512 images): d4 (k 6) forward 1.182 -> 0.88 ms; d3 (k 4: 49 of 64 tap products, four launches' worth of
   // staging and a border pass) 0.549 -> 0.567 ms: k 4 stays on the fused-resize direct form (SV_POLYC_K=64 enables it)
   const char* ks = getenv("SV_POLYC_K") ? getenv("SV_POLYC_K") : "6";       // (read per call: tests/test_gpu_kernels.py switches it for the k = 4 case)
-  static const bool bf = getenv("SV_POLYC_BF16") != nullptr;
-  if (off || !(d->dtype == SV_F32 || bf) || !d->ups_in || d->stride != 1 || d->KH != d->KW || (d->KH != 6 && d->KH != 4)) return 0;
+  if (off || d->dtype != SV_F32 || !d->ups_in || d->stride != 1 || d->KH != d->KW || (d->KH != 6 && d->KH != 4)) return 0;
   if (!strchr(ks, d->KH == 6 ? '6' : '4')) return 0;
   if (d->y_f32 || d->ldy != d->Cout || d->ldx != d->Cin) return 0;
   // (the border kernel's instantiations, poly_fix.hip)

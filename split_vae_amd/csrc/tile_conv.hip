@@ -294,8 +294,10 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     const int r = wave * WM + i * 16 + lr;
     // PER-CLASS POLYPHASE (conv_geom.h: svg_polyc): the out-of-image taps of the hi-res border rows / columns (poly_fix.hip: polyc_fix_kernel wrote them)
     // are added before the activation; only the lanes of border pixels load anything
+    // (fp32 instantiations only: the extra address registers cost the bf16 head's fused-loss epilogue 24 us per launch -- 0.127 -> 0.150 ms -- when compiled in)
+    constexpr bool FIXC = sizeof(T) == 4;
     const float *frp = nullptr, *fcp = nullptr;
-    if (g.fix_nc) {
+    if (FIXC && g.fix_nc) {
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl, R = (ty0 + ty) * g.OS + g.ooy, Cc = (tx0 + tx) * g.OS + g.oox, nbot = g.fix_nc - g.fix_pad;
       const int rc = R < g.fix_pad ? R : R >= g.OHF - nbot ? g.fix_pad + R - (g.OHF - nbot) : -1;
@@ -308,14 +310,17 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
       const int nl = j * 16 + lg * 4;
       if (nl >= ncols) continue;
       float v[4];
-      float4 fr = make_float4(0.f, 0.f, 0.f, 0.f), fc = fr;
-      if (frp) fr = *(const float4*)(frp + nl);
-      if (fcp) fc = *(const float4*)(fcp + nl);
-      const float fv[4] = {fr.x + fc.x, fr.y + fc.y, fr.z + fc.z, fr.w + fc.w};
+      float fv[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (FIXC) {
+        float4 fr = make_float4(0.f, 0.f, 0.f, 0.f), fc = fr;
+        if (frp) fr = *(const float4*)(frp + nl);
+        if (fcp) fc = *(const float4*)(fcp + nl);
+        fv[0] = fr.x + fc.x; fv[1] = fr.y + fc.y; fv[2] = fr.z + fc.z; fv[3] = fr.w + fc.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + bv[j][e];
-        if (g.fix_nc) v[e] += fv[e];
+        if (FIXC && g.fix_nc) v[e] += fv[e];
         if (relu) v[e] = fmaxf(v[e], 0.f);
       }
       if (g.d2s) {                                      // n = px*8 + co -> column px*C + co (co < C)
@@ -501,7 +506,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
   if (t.s2d3 && (dtype != SV_F32 || t.S != 1 || t.SX != 1 || t.ups || t.clampin || t.cl2 != 2)) return false;
-  if (t.fix_nc && !t.d2s_y && (!t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;
+  if (t.fix_nc && !t.d2s_y && (dtype != SV_F32 || !t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;     // (the epilogue's border-term path is compiled into the fp32 kernels only)
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
