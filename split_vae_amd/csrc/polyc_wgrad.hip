@@ -293,7 +293,22 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
   // dbias); the main terms' reduce ADDS its bias partials, the projection sums the blocks in a fixed order
   for (int i = 0; i < n; ++i)
     if (hipMemsetAsync(pw[i] + ndwp, 0, 128 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
-  for (int c = 0; c < (merged ? 1 : 4); ++c) {
+  bool fused = false;
+  if (!merged) {                       // all four classes in one launch: the input tile staged once (wgrad_tile_f32.hip: wgrad_polyc_f32_kernel)
+    WgradArgs cls[8];
+    for (int c = 0; c < 4; ++c)
+      for (int i = 0; i < n; ++i) {
+        WgradArgs& q = cls[c * n + i];
+        svg_polyc_wgrad_args(d, c, &q);
+        q.A = x_lo[i]; q.dY = dy[i]; q.dW = pw[i] + pj.coff[c];
+        q.dbias = (c == 0 && dbias && dbias[i]) ? pw[i] + ndwp : nullptr;          // ONE bias partial for all classes (their dY tiles cover every pixel once): block 0 of dbias'
+        q.ws = (float*)((char*)slab_ws[i] + c * part); q.ws_bytes = part;
+      }
+    const int rc = svk_wgrad_polyc_f32_multi(cls, n, pend, &npend, st);
+    if (rc == SV_OK) fused = true;
+    else if (rc != SV_E_UNSUPPORTED) return rc;
+  }
+  for (int c = 0; c < (merged ? 1 : 4) && !fused; ++c) {
     for (int i = 0; i < n; ++i) {
       if (merged) svg_poly_wgrad_args(d, &a[i]); else svg_polyc_wgrad_args(d, c, &a[i]);
       a[i].A = x_lo[i]; a[i].dY = dy[i];

@@ -27,10 +27,13 @@
 #ifndef SV_TC_PPS32
 #define SV_TC_PPS32 8     // K-step pieces of the 32-column kernel (build-time A/B knob)
 #endif
+#ifndef SV_TC_PPS64
+#define SV_TC_PPS64 8     // ... of the 64-column kernel
+#endif
 // with row-window reuse (YR = KH) the 16-column kernel steps one whole filter column (KH taps x 4 pieces), the wider
 // ones two taps (their weight tiles are BN x PPS x 16 B x 2 buffers of LDS)
 static __host__ __device__ constexpr int tile_pps(int BN, int YR = 0) {
-  return YR ? (BN == 16 || YR == 5 ? YR * 4 : 8) : BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : 8;   // (KH = 5: a step = one filter column, 20 pieces)
+  return YR ? (BN == 16 || YR == 5 ? YR * 4 : 8) : BN == 16 ? SV_TC_PPS16 : BN == 32 ? SV_TC_PPS32 : BN == 64 ? SV_TC_PPS64 : 8;   // (KH = 5: a step = one filter column, 20 pieces)
 }
 
 // position of weight piece q of row n inside its LDS row: XOR swizzle within each 8-piece group (a trailing group of 4 pieces,

@@ -173,6 +173,140 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
   }
 }
 
+// ---- the four parity classes of a per-class polyphase layer (conv_geom.h: svg_polyc; polyc_wgrad.hip) in ONE launch: the clamped low-res input tile is staged ONCE
+// per tile and serves the 25 + 20 + 20 + 16 taps of the four classes; only dY -- each class reads its own sub-pixel of the hi-res gradient -- is re-staged per class.
+// As four launches the input moved four times (PMC: 713 MB per d4 weight gradient against 201 MB algorithmic).  Accumulators of all four classes live in registers
+// (42 fragments x 4 = 168); slabs leave per class in the single-class kernel's layout, so the reduce and the projection are unchanged.
+struct WgradPolycArgs {
+  WgradTileArgs g;                 // geometry (taps unused), A, bslab, dbias
+  const float* dY; float* slab[4];
+  int ntaps[4];
+  int8_t cdy[4][28], cdx[4][28];
+};
+struct WgradPolycMulti { WgradPolycArgs a[SV_WGRAD_MAX_MULTI]; };
+
+template <int TPW, int COF, int G4, int YS, int SXPS>
+__device__ __forceinline__ void polyc_rows(f32x4 (&acc)[TPW][COF], f32x4 (&bacc)[(COF + 3) / 4], const int (&tapoff)[TPW], const char* sIn, const char* sDy,
+                                           int dy_lane, int nrow, int TH, int lTH, int TIH, int TIW, int PS, bool do_bias, int wave) {
+  for (int row = 0; row < nrow; ++row) {
+    const int ty = row & (TH - 1), bl = row >> lTH;
+    const char* pin = sIn + ((bl * TIH + ty) * TIW) * PS;
+    const char* pdy = sDy + dy_lane + row * (4 * G4 * YS);
+    float bfr[G4][COF], afr[G4][TPW];
+#pragma unroll
+    for (int q = 0; q < G4; ++q)
+#pragma unroll
+      for (int j = 0; j < COF; ++j) bfr[q][j] = *(const float*)(pdy + q * 4 * YS + j * 64);
+#pragma unroll
+    for (int t2 = 0; t2 < TPW; ++t2) {
+      const char* pa = pin + tapoff[t2];
+#pragma unroll
+      for (int q = 0; q < G4; ++q) afr[q][t2] = *(const float*)(pa + q * SXPS);
+    }
+#pragma unroll
+    for (int q = 0; q < G4; ++q) {
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < COF; ++j)
+          if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[q][j], bacc[j >> 2], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+        for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q][t2], bfr[q][j], acc[t2][j], 0, 0, 0);
+    }
+  }
+}
+
+template <int T0, int T1, int T2, int T3, int COF, int LDY, int CW, int G4>
+__global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPolycMulti mg) {
+  constexpr int PS = 4 * CW, YS = 4 * LDY;
+  const WgradPolycArgs& pa = mg.a[blockIdx.z];
+  const WgradTileArgs& g = pa.g;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sIn = smem;
+  char* sDy = smem + g.in_bytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  const int ci0 = (int)blockIdx.y * g.CW;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB, BM = TW * TH * NB;
+  const int in_lane = kq * PS + lr * 4, dy_lane = kq * YS + lr * 4;
+  int off0[T0], off1[T1], off2[T2], off3[T3];
+  auto taps = [&](int c, int TPWc, int* out) {
+    for (int t = 0; t < TPWc; ++t) {
+      const int tap = min(wave * TPWc + t, pa.ntaps[c] - 1);
+      out[t] = (((int)pa.cdy[c][tap] - g.y_lo) * g.TIW + ((int)pa.cdx[c][tap] - g.x_lo)) * PS + in_lane;
+    }
+  };
+  taps(0, T0, off0); taps(1, T1, off1); taps(2, T2, off2); taps(3, T3, off3);
+  f32x4 a0[T0][COF], a1[T1][COF], a2[T2][COF], a3[T3][COF];
+#pragma unroll
+  for (int j = 0; j < COF; ++j) {
+#pragma unroll
+    for (int t = 0; t < T0; ++t) a0[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T1; ++t) a1[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T2; ++t) a2[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < T3; ++t) a3[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int BJ = (COF + 3) / 4;
+  f32x4 bacc[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) bacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = g.dbias != nullptr && blockIdx.y == 0;
+  const float* __restrict__ Ab = (const float*)g.A + ci0;
+  const float* __restrict__ Yb = pa.dY;
+  const int lycp = g.lycp, dy_total = BM << lycp;
+  const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_lo = (int)blockIdx.x * per_wg, tile_hi = min(g.ntiles, tile_lo + per_wg);
+  const int nrow = BM / (4 * G4);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    int t = tile;
+    const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
+    const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
+    const int b0 = t << g.lNB;
+    __syncthreads();                      // the previous tile (its last class) is consumed
+    {
+      const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
+      stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 + g.y_lo, tx0 + g.x_lo, sIn, tid);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c) __syncthreads();             // the previous class's dY tile is consumed
+      for (int q = tid; q < dy_total; q += 256) {
+        const int r = q >> lycp, cc = q & ((1 << lycp) - 1);
+        const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+        const int b = b0 + bl;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b < g.B) v = *(const uint4*)(Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 1)) * (2 * g.OX) + 2 * (tx0 + tx) + (c & 1)) * g.ldy + cc * 4);
+        *(uint4*)(sDy + r * YS + cc * 16) = v;
+      }
+      __syncthreads();
+      if (c == 0) polyc_rows<T0, COF, G4, YS, 4 * PS>(a0, bacc, off0, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      else if (c == 1) polyc_rows<T1, COF, G4, YS, 4 * PS>(a1, bacc, off1, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      else if (c == 2) polyc_rows<T2, COF, G4, YS, 4 * PS>(a2, bacc, off2, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      else polyc_rows<T3, COF, G4, YS, 4 * PS>(a3, bacc, off3, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+    }
+  }
+  auto flush = [&](int c, int TPWc, auto& acc) {
+    float* sl = pa.slab[c] + ((((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (TPWc * COF)) * 256 + lane;
+#pragma unroll
+    for (int t2 = 0; t2 < (int)(sizeof(acc) / sizeof(acc[0])); ++t2)
+#pragma unroll
+      for (int j = 0; j < COF; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) sl[((t2 * COF + j) * 4 + r4) * 64] = acc[t2][j][r4];
+  };
+  flush(0, T0, a0); flush(1, T1, a1); flush(2, T2, a2); flush(3, T3, a3);
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < COF; ++j)
+      if ((j & 3) == wave && j * 16 + lane < g.N) g.bslab[(int64_t)blockIdx.x * 128 + j * 16 + lane] = bacc[j >> 2][0];
+  }
+}
+
 template <int TPW, int COF, int LDY, int CW, int SX, int G4>
 int launch_f32(const WgradTileArgs* a, int n, int msplit, int groups, size_t lds, hipStream_t st) {
   WgradTileMulti m;
@@ -314,4 +448,83 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
     return SV_OK;
   }
   return svk_wgrad_reduce_all(rd, n, st);
+}
+
+
+// The four class problems of n <= 2 per-class polyphase layers as ONE launch (see wgrad_polyc_f32_kernel).  cls[c * n + i]: class c of network i (svg_polyc_wgrad_args
+// + pointers; ws = the class's slab region); descriptors of the 4 n slab reduces are appended to rd.  SV_E_UNSUPPORTED: no instantiation / small workspace (nothing launched).
+int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, WgradReduceDesc* rd, int* nrd, hipStream_t st) {
+  static const bool trace = getenv("SV_TRACE_DISPATCH") != nullptr;
+  // OPT-IN (SV_WGRAD_POLYC_FUSED=1).  Measured (2 x 512 images, profiles/r05_polyc_fused_ab.txt): alone on the chip the d4 weight gradient goes 1.078 -> 0.949 ms (the input
+  // tile moves once), but the 512-image STEP goes 9.355 -> 9.54 ms: at 239 VGPRs the kernel leaves no room beside it for the other streams' workgroups, and the step lives
+  // on that co-residency (same finding as the 52-KB tiles).  The default keeps the four class launches.
+  static const bool off = !(getenv("SV_WGRAD_POLYC_FUSED") && atoi(getenv("SV_WGRAD_POLYC_FUSED")) != 0);
+  if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) F32_REJ("off / problems");
+  const WgradArgs& w = cls[0];
+  if (w.lOY < 0 || w.lOX < 0 || w.S != 1 || !w.clampin || w.dy_os != 2 || w.ldy != 32 || w.ycols != 32 || w.N != 32) F32_REJ("form");
+  const int ntc[4] = {cls[0].ntaps, cls[n].ntaps, cls[2 * n].ntaps, cls[3 * n].ntaps};
+  if (ntc[0] != 25 || ntc[1] != 20 || ntc[2] != 20 || ntc[3] != 16) F32_REJ("taps");
+  const int OY = 1 << w.lOY, OX = 1 << w.lOX, cin = w.Cin_pad, CW = 16;
+  if (OX < 4 || OY * OX < 16 || cin % CW) F32_REJ("grid / channels");
+  static const int bm_max = getenv("SV_WTF32_BM") ? atoi(getenv("SV_WTF32_BM")) : 256;
+  static const int wgs = getenv("SV_WTF32_WGS") ? atoi(getenv("SV_WTF32_WGS")) : 512;
+  static const int lds_max = getenv("SV_WTF32_LDS") ? atoi(getenv("SV_WTF32_LDS")) : 52000;
+  WgradTileArgs a;
+  int BM = bm_max;
+  for (;; BM >>= 1) {
+    if (BM < 32) F32_REJ("tile");
+    if (OY * OX < BM && (BM % (OY * OX))) continue;
+    const int lTW = OX >= 16 ? 4 : w.lOX;
+    int lTH = 0;
+    while ((1 << (lTW + lTH)) < BM && (1 << lTH) < OY) ++lTH;
+    int lNB = 0;
+    while ((1 << (lTW + lTH + lNB)) < BM) ++lNB;
+    const int TW = 1 << lTW, TH = 1 << lTH, NB = 1 << lNB;
+    memset(&a, 0, sizeof(a));
+    a.lTW = lTW; a.lTH = lTH; a.lNB = lNB;
+    a.TIW = TW + 4; a.TIH = TH + 4;                          // the union of the classes' windows: offsets -2 .. 2
+    a.PS = CW * 4; a.YS = 32 * 4;
+    a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;
+    a.dy_bytes = BM * a.YS + 64;
+    if (a.in_bytes + a.dy_bytes <= lds_max) break;
+  }
+  const int TW = 1 << a.lTW, TH = 1 << a.lTH, NB = 1 << a.lNB, G4 = TW / 4;
+  const int B = w.M >> (w.lOY + w.lOX);
+  a.B = B; a.IH = w.IH; a.IW = w.IW; a.lda = w.lda; a.S = 1; a.SX = 1; a.assign = 1; a.clampin = 1;
+  a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = 2;
+  a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
+  a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
+  a.y_lo = -2; a.x_lo = -2; a.ldy = 32; a.lycp = 3; a.Cin_real = w.Cin_real; a.N = 32;
+  const int groups = a.ncg;
+  int msplit = (wgs + groups * n - 1) / (groups * n);
+  if (msplit > a.ntiles) msplit = a.ntiles;
+  if (msplit < 1) msplit = 1;
+  static const int tpw[4] = {7, 5, 5, 4};
+  WgradPolycMulti m;
+  for (int i = 0; i < n; ++i) {
+    WgradPolycArgs& p = m.a[i];
+    p.g = a;
+    p.g.A = cls[i].A; p.dY = (const float*)cls[i].dY; p.g.dbias = cls[i].dbias;
+    for (int c = 0; c < 4; ++c) {
+      const WgradArgs& wc = cls[c * n + i];
+      const int64_t PER = 4LL * tpw[c] * 2 * 256;
+      const int64_t need = (int64_t)msplit * groups * PER * 4 + (c == 0 ? (int64_t)msplit * 128 * 4 : 0);
+      if (!wc.ws || wc.ws_bytes < need) F32_REJ("workspace");
+      p.slab[c] = wc.ws;
+      p.ntaps[c] = wc.ntaps;
+      for (int t = 0; t < wc.ntaps; ++t) { p.cdy[c][t] = wc.dy[t]; p.cdx[c][t] = wc.dx[t]; }
+      if (c == 0) p.g.bslab = cls[i].dbias ? wc.ws + (int64_t)msplit * groups * PER : nullptr;
+      rd[(*nrd)++] = WgradReduceDesc{p.slab[c], wc.dW, c == 0 ? p.g.bslab : nullptr, c == 0 ? cls[i].dbias : nullptr, msplit, groups, a.ncg, CW, a.Cin_real, 32,
+                                     wc.ntaps, 0, 0, 0, 1, tpw[c], 1, 2, 0};
+    }
+    if (!p.g.bslab) p.g.dbias = nullptr;
+  }
+  const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+  const dim3 grid(msplit, groups, n);
+#define POLYC_CASE(G) if (G4 == G) { sv_ensure_dynamic_lds((const void*)wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>, lds); \
+    hipLaunchKernelGGL((wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>), grid, dim3(256), lds, st, m); }
+  POLYC_CASE(4) else POLYC_CASE(2) else POLYC_CASE(1) else { *nrd -= 4 * n; F32_REJ("tile row"); }
+#undef POLYC_CASE
+  SV_LAUNCH_CHECK();
+  return SV_OK;
 }
