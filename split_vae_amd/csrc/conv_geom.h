@@ -193,7 +193,8 @@ int64_t svg_polyc_fix_ws_bytes(const sv_conv_desc* d);
 // The main term runs on the tile kernel (S = 2); the edge terms come from polyd_edge_kernel through the epilogue's border-term path (TapGemmArgs::fix).
 static inline int svg_polyd(const sv_conv_desc* d) {
   static const bool off = getenv("SV_NO_POLYD") != nullptr;
-  if (off || d->dtype != SV_F32 || !d->ups_in || d->stride != 1 || d->KH != 6 || d->KW != 6 || d->ldx != d->Cin) return 0;
+  static const bool bf = getenv("SV_POLYD_BF16") && atoi(getenv("SV_POLYD_BF16")) != 0;     // bf16: opt-in (A/B against the row-ring kernel's fused adjoint)
+  if (off || (d->dtype != SV_F32 && !bf) || !d->ups_in || d->stride != 1 || d->KH != 6 || d->KW != 6 || d->ldx != d->Cin) return 0;
   if (d->H < 32 || d->W < 32 || (d->H & (d->H - 1)) || (d->W & (d->W - 1))) return 0;      // (the edge kernel works on 16-pixel fragments of the low-res lines)
   // (the edge kernel's instantiations: d4 = 64 -> 32, its 32-channel variant, the head 32 -> 6)
   return (d->Cout == 32 && (d->Cin == 64 || d->Cin == 32)) || (d->Cout <= 8 && d->Cin == 32);

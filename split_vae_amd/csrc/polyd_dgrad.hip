@@ -182,6 +182,7 @@ int svk_polyd_dgrad_multi(const sv_conv_desc* d, int n, const void* const* dy, c
   int rc = SV_E_UNSUPPORTED;
   if (d->dtype == SV_F32 && K == 6 && cop == 32) rc = launch_edge<float, 9, 2>(m, n, d->B, h, w, cin, gdy, K, st);
   else if (d->dtype == SV_F32 && K == 6 && cop == 16) rc = launch_edge<float, 9, 1>(m, n, d->B, h, w, cin, gdy, K, st);
+  else if (d->dtype == SV_BF16 && K == 6 && cop == 32) rc = launch_edge<bf16_t, 9, 1>(m, n, d->B, h, w, cin, gdy, K, st);      // (32 dY channels = one bf16 MFMA group: d4 exactly, the head padded)
   if (rc) return rc;
   for (int i = 0; i < n; ++i) {
     svg_polyd_args(d, &a[i]);

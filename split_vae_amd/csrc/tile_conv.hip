@@ -71,7 +71,9 @@ template <> struct MmaOpT<float> {
 // waves per SIMD the row-window kernels are compiled for (left alone, hipcc spreads the window over AGPR copies and
 // drops a wave: 92 + 120 registers for <64,4,4,YR=4>)
 static constexpr int tile_min_waves(int BN, int NW, int YR, bool WR = false) { return (YR || WR) && NW == 4 ? (BN == 64 ? 3 : 4) : 1; }
-template <typename T, int BN, int MF, int NW, int YR, bool WR>
+// FX: the epilogue's per-class border-term path (TileConvArgs::fix_nc) is compiled in: always at fp32; at bf16 only in the instantiations the polyphase input
+// gradient uses (the extra address registers cost the bf16 head's fused-loss epilogue 24 us per launch when every bf16 kernel carried them)
+template <typename T, int BN, int MF, int NW, int YR, bool WR, bool FX = false>
 __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_conv_kernel(const TileConvMulti mg) {
   // blockIdx.z picks one of up to 8 problems of identical geometry (the x / x_hat twin networks and
   // the four parity classes of a stride-2 dgrad) so that they share one launch and one wave of
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     // PER-CLASS POLYPHASE (conv_geom.h: svg_polyc): the out-of-image taps of the hi-res border rows / columns (poly_fix.hip: polyc_fix_kernel wrote them)
     // are added before the activation; only the lanes of border pixels load anything
     // (fp32 instantiations only: the extra address registers cost the bf16 head's fused-loss epilogue 24 us per launch -- 0.127 -> 0.150 ms -- when compiled in)
-    constexpr bool FIXC = sizeof(T) == 4;
+    constexpr bool FIXC = FX || sizeof(T) == 4;
     const float *frp = nullptr, *fcp = nullptr;
     if (FIXC && g.fix_nc) {
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
@@ -480,7 +482,7 @@ static inline size_t tile_lds_bytes(int BN, int BM, const TileConvArgs& a, size_
   return lds < epi ? epi : lds;
 }
 
-template <typename T, int BN, int MF, int NW = 4, int YR = 0, bool WR = false>
+template <typename T, int BN, int MF, int NW = 4, int YR = 0, bool WR = false, bool FX = false>
 static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
   const int Npad = round_up(a[0].N, BN);
   dim3 grid(a[0].ntiles, Npad / BN, n), block(64 * NW);
@@ -491,8 +493,8 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
     const size_t l = tile_lds_bytes(BN, NW * 16 * MF, a[i], sizeof(T), YR);
     if (l > lds) lds = l;
   }
-  sv_ensure_dynamic_lds((const void*)tile_conv_kernel<T, BN, MF, NW, YR, WR>, lds);
-  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR, WR>), grid, block, lds, st, m);
+  sv_ensure_dynamic_lds((const void*)tile_conv_kernel<T, BN, MF, NW, YR, WR, FX>, lds);
+  hipLaunchKernelGGL((tile_conv_kernel<T, BN, MF, NW, YR, WR, FX>), grid, block, lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -509,7 +511,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   if (t.d2s_y && (!t.d2s || t.N != 32 || ((2 * t.d2s * 4) & 7))) return false;
   if (t.clampin && (t.ups || t.S != 1)) return false;
   if (t.s2d3 && (dtype != SV_F32 || t.S != 1 || t.SX != 1 || t.ups || t.clampin || t.cl2 != 2)) return false;
-  if (t.fix_nc && !t.d2s_y && (dtype != SV_F32 || !t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;     // (the epilogue's border-term path is compiled into the fp32 kernels only)
+  if (t.fix_nc && !t.d2s_y && ((dtype != SV_F32 && t.S != 2) || !t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;     // (bf16: only the stride-2 polyphase input gradient has instantiations with the border-term epilogue)
   if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
@@ -663,6 +665,15 @@ int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStr
   // wait also waited for that step's HBM slice loads, and the second buffer halved the resident
   // workgroups.  Overlap needs producer waves with their own load queue, not in-loop slices.)
   if (n < 1 || n > SV_MAX_MULTI) return SV_E_BADARG;
+  if (dtype == SV_BF16 && a[0].fix_nc) {              // the polyphase input gradient at bf16 (SV_POLYD_BF16=1): the border-term epilogue compiled in
+    switch (cfg) {
+      case 2: return launch_tile<bf16_t, 64, 4, 4, 0, false, true>(a, n, st);
+      case 3: return launch_tile<bf16_t, 64, 2, 4, 0, false, true>(a, n, st);
+      case 4: return launch_tile<bf16_t, 32, 4, 4, 0, false, true>(a, n, st);
+      case 5: return launch_tile<bf16_t, 32, 2, 4, 0, false, true>(a, n, st);
+    }
+    return SV_E_UNSUPPORTED;
+  }
   if (dtype == SV_BF16) {
     switch (cfg) {
       case 0: return launch_tile<bf16_t, 128, 4>(a, n, st);
