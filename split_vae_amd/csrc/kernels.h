@@ -218,6 +218,7 @@ struct NtGemmProb {
   const float* bias;              // [N] or null (bf16 output only)
   const void* mask;               // bf16 [M][ldo] or null: out = mask > 0 ? out : 0
   int M, N, K, act, splitk, out_f32;
+  int f32;                        // operands / output / mask are float instead of bf16
   int64_t slab_stride;            // floats between K slices
   int zbase;                      // first blockIdx.z of this problem (filled by svk_nt_gemm_multi)
 };
@@ -229,7 +230,7 @@ int svk_nt_gemm_multi(NtGemmProb* p, int n, int bm, hipStream_t st);
 int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_t st);
 
 // dW [Kw, N] = X^T . dY, dbias [N] = colsum(dY): X [M, ldx] (columns [0, Kw) used; Kw_real <= Kw rows of dW are stored), dY [M, ldy]
-struct TnWgradProb { const void* X; int ldx; const void* dY; int ldy; float* dW; float* dbias; int M, Kw, Kw_real, N; };
+struct TnWgradProb { const void* X; int ldx; const void* dY; int ldy; float* dW; float* dbias; int M, Kw, Kw_real, N; int f32; };
 struct TnWgradMulti { TnWgradProb p[4]; };
 bool svk_tn_wgrad_supported(const TnWgradProb& p);
 int svk_tn_wgrad_multi(const TnWgradProb* p, int n, hipStream_t st);

@@ -10,14 +10,19 @@
 // p ^ (r & 15): the DMA writes linearly and each lane FETCHES the piece that belongs in its slot; fragment reads un-swizzle.
 // Big-K layers (heads forward, d1 input gradient: K = H/8 * W/8 * 128) split K over blockIdx.z into fp32 slabs [S][M][N] that
 // nt_slab_reduce_kernel sums in slice order -- no atomics, no zero fill, run-to-run identical.
+//
+// fp32 (the reference's precision, vae/model.py:12): the same kernels over float operands.  An LDS row is still 256 B, so a phase is 64
+// deep and a 16-B piece holds 4 floats; a lane's piece pair feeds FOUR v_mfma_f32_16x16x4_f32 (instruction e contracts element e of both
+// pieces: the same permutation of K on both operands, fix_mma.hip.h), exact fp32 products and sums.
 #include "common.hip.h"
+#include "fix_mma.hip.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int BN = 128, BK = 128, RB = 256;        // tile columns, K per phase, bytes per LDS row
+constexpr int BN = 128, BK = 128, RB = 256;        // tile columns, K per phase (bf16; fp32: RB / 4 = 64), bytes per LDS row
 
-template <int BM>
+template <typename T, int BM>
 __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int inst = (mg.n > 1 && (int)blockIdx.z >= mg.p[1].zbase) ? 1 : 0;
@@ -28,7 +33,8 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
   char* sA = smem;
   char* sW = smem + BM * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BK;
+  constexpr int PE = 16 / (int)sizeof(T), BKT = RB / (int)sizeof(T);      // elements per 16-B piece, K per phase
+  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BKT;
   const int lr = lane & 15, lg = lane >> 4;
   constexpr int FM = BM / 32;                      // 16-row fragments per wave along M (waves 2 x 2: (BM / 2) x 64 each)
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
@@ -38,22 +44,22 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bf16_t* __restrict__ Ab = (const bf16_t*)g.A;
-  const bf16_t* __restrict__ Wb = (const bf16_t*)g.W;
+  const T* __restrict__ Ab = (const T*)g.A;
+  const T* __restrict__ Wb = (const T*)g.W;
   auto issue = [&](int ph) {
-    const int kk = kbeg + ph * BK;
+    const int kk = kbeg + ph * BKT;
     // one wave-instruction = 64 x 16 B = 4 LDS rows; lane -> (row 4q + lane / 16, slot lane % 16) fetches piece slot ^ (row & 15)
 #pragma unroll
     for (int q = wave; q < BM / 4; q += 4) {
       const int r = 4 * q + lg, gm = min(m0 + r, g.M - 1);           // rows past M re-read the last row (discarded in the epilogue)
-      const bf16_t* src = Ab + (int64_t)gm * g.lda + kk + ((lr ^ (r & 15)) << 3);
+      const T* src = Ab + (int64_t)gm * g.lda + kk + (lr ^ (r & 15)) * PE;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sA + q * (4 * RB)),
                                        16, 0, 0);
     }
 #pragma unroll
     for (int q = wave; q < BN / 4; q += 4) {
       const int r = 4 * q + lg;
-      const bf16_t* src = Wb + (int64_t)(n0 + r) * g.ldw + kk + ((lr ^ (r & 15)) << 3);
+      const T* src = Wb + (int64_t)(n0 + r) * g.ldw + kk + (lr ^ (r & 15)) * PE;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(sW + q * (4 * RB)),
                                        16, 0, 0);
     }
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMAs have landed ...
     __syncthreads();                                        // ... and everybody else's
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {                  // 16 pieces per row, 4 lane groups
       const int p = ks * 4 + lg;
       uint4 af[FM], wf[4];
 #pragma unroll
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          FixMma<T>::run(wf[j], af[i], acc[i][j]);
     }
     if (ph + 1 < nph) {
       __syncthreads();                                      // the tile is consumed: the next phase may overwrite it
@@ -110,8 +116,15 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
       const int64_t o = (int64_t)m * g.ldo + n;
+      if constexpr (sizeof(T) == 4) {
+        if (g.mask) {                                       // ReLU gate of the tensor this gradient lands on
+          const float4 mk = *(const float4*)((const float*)g.mask + o);
+          v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f; v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
+        }
+        *(float4*)((float*)g.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+      bf16_t pk[4] = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
       if (g.mask) {                                         // ReLU gate of the tensor this gradient lands on
         bf16_t mk[4];
         *(uint2*)mk = *(const uint2*)((const bf16_t*)g.mask + o);
@@ -119,6 +132,7 @@ __global__ __launch_bounds__(256) void nt_gemm_kernel(const NtGemmMulti mg) {
         for (int e = 0; e < 4; ++e) pk[e] = (float)mk[e] > 0.f ? pk[e] : (bf16_t)0.f;
       }
       *(uint2*)((bf16_t*)g.out + o) = *(uint2*)pk;
+      }
     }
   }
 }
@@ -133,7 +147,7 @@ __device__ __forceinline__ void nt_dma16(const void* base, uint32_t off, const c
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
 }
 
-template <int BM, int NS>
+template <typename T, int BM, int NS>
 __global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int inst = (mg.n > 1 && (int)blockIdx.z >= mg.p[1].zbase) ? 1 : 0;
@@ -144,7 +158,8 @@ __global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg)
   constexpr int SLOTB = (BM + BN) * RB;
   constexpr int PER = (BM + BN) / 16;               // DMA instructions per wave and phase
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BK;
+  constexpr int PE = 16 / (int)sizeof(T), BKT = RB / (int)sizeof(T);
+  const int kper = g.K / g.splitk, kbeg = zi * kper, nph = kper / BKT;
   const int lr = lane & 15, lg = lane >> 4;
   constexpr int FM = BM / 32;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
@@ -159,17 +174,17 @@ __global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg)
 #pragma unroll
   for (int i = 0; i < BM / 16; ++i) {
     const int r = 4 * (wave + 4 * i) + lg, gm = min(m0 + r, g.M - 1);
-    offA[i] = (uint32_t)(((int64_t)gm * g.lda + kbeg + ((lr ^ (r & 15)) << 3)) * 2);
+    offA[i] = (uint32_t)(((int64_t)gm * g.lda + kbeg + (lr ^ (r & 15)) * PE) * (int)sizeof(T));
   }
 #pragma unroll
   for (int i = 0; i < BN / 16; ++i) {
     const int r = 4 * (wave + 4 * i) + lg;
-    offW[i] = (uint32_t)(((int64_t)(n0 + r) * g.ldw + kbeg + ((lr ^ (r & 15)) << 3)) * 2);
+    offW[i] = (uint32_t)(((int64_t)(n0 + r) * g.ldw + kbeg + (lr ^ (r & 15)) * PE) * (int)sizeof(T));
   }
   auto issue = [&](int ph, int slot) {
     char* sA = smem + slot * SLOTB;
     char* sW = sA + BM * RB;
-    const uint32_t kb = (uint32_t)ph * (BK * 2);
+    const uint32_t kb = (uint32_t)ph * RB;
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) nt_dma16(g.A, offA[i] + kb, sA + (wave + 4 * i) * (4 * RB));
 #pragma unroll
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg)
     const char* sA = smem + slot * SLOTB;
     const char* sW = sA + BM * RB;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {                  // 16 pieces per row, 4 lane groups
       const int p = ks * 4 + lg;
       uint4 af[FM], wf[4];
 #pragma unroll
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256) void nt_gemm_ring_kernel(const NtGemmMulti mg)
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+          FixMma<T>::run(wf[j], af[i], acc[i][j]);
     }
     if (++slot == NS) slot = 0;
   }
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void nt_slab_reduce_kernel(const NtReduceMulti
   *(float4*)(r.out[z] + i) = a;
 }
 
-template <int BM>
+template <typename T, int BM>
 int launch_nt(const NtGemmMulti& m, hipStream_t st) {
   int gx = 0, gy = 0;
   bool ring = BM == 64;                 // slab launches whose slices span several phases: the ring form
@@ -250,22 +265,22 @@ int launch_nt(const NtGemmMulti& m, hipStream_t st) {
   for (int i = 0; i < m.n; ++i) {
     gx = max(gx, (m.p[i].M + BM - 1) / BM);
     gy = max(gy, m.p[i].N / BN);
-    ring = ring && m.p[i].out_f32 && m.p[i].K / m.p[i].splitk >= 2 * BK;
+    ring = ring && m.p[i].out_f32 && m.p[i].K / m.p[i].splitk >= 2 * (RB / (int)sizeof(T));
   }
   const int gz = m.p[m.n - 1].zbase + m.p[m.n - 1].splitk;
   if constexpr (BM == 64) {
     if (ring && !no_ring) {
       constexpr int NS = 3;
       const size_t lds = (size_t)NS * (BM + BN) * RB;
-      sv_ensure_dynamic_lds((const void*)nt_gemm_ring_kernel<BM, NS>, lds);
-      hipLaunchKernelGGL((nt_gemm_ring_kernel<BM, NS>), dim3(gx, gy, gz), dim3(256), lds, st, m);
+      sv_ensure_dynamic_lds((const void*)nt_gemm_ring_kernel<T, BM, NS>, lds);
+      hipLaunchKernelGGL((nt_gemm_ring_kernel<T, BM, NS>), dim3(gx, gy, gz), dim3(256), lds, st, m);
       SV_LAUNCH_CHECK();
       return SV_OK;
     }
   }
   const size_t lds = (size_t)(BM + BN) * RB;
-  sv_ensure_dynamic_lds((const void*)nt_gemm_kernel<BM>, lds);
-  hipLaunchKernelGGL((nt_gemm_kernel<BM>), dim3(gx, gy, gz), dim3(256), lds, st, m);
+  sv_ensure_dynamic_lds((const void*)nt_gemm_kernel<T, BM>, lds);
+  hipLaunchKernelGGL((nt_gemm_kernel<T, BM>), dim3(gx, gy, gz), dim3(256), lds, st, m);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -273,8 +288,9 @@ int launch_nt(const NtGemmMulti& m, hipStream_t st) {
 }  // namespace
 
 bool svk_nt_gemm_supported(const NtGemmProb& p) {
-  if (p.M < 1 || p.N < BN || (p.N % BN) || p.K < BK || (p.K % BK) || p.splitk < 1 || (p.K % p.splitk) || ((p.K / p.splitk) % BK)) return false;
-  if ((p.lda & 7) || (p.ldw & 7) || (p.ldo & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.out & 15)) return false;
+  const int bk = p.f32 ? RB / 4 : BK, pe = p.f32 ? 3 : 7;         // K per phase, elements per 16-B piece - 1
+  if (p.M < 1 || p.N < BN || (p.N % BN) || p.K < bk || (p.K % bk) || p.splitk < 1 || (p.K % p.splitk) || ((p.K / p.splitk) % bk)) return false;
+  if ((p.lda & pe) || (p.ldw & pe) || (p.ldo & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || ((uintptr_t)p.out & 15)) return false;
   if (p.bias && ((uintptr_t)p.bias & 15)) return false;
   return true;
 }
@@ -285,7 +301,9 @@ int svk_nt_gemm_pick_splitk(int M, int N, int K, int nprob) {
   const int bm = 64;
   const int tiles = ((M + bm - 1) / bm) * (N / BN) * (nprob < 1 ? 1 : nprob);
   int s = (256 + tiles - 1) / tiles;
-  const int maxs = K / BK;
+  int maxs = K / BK;
+  static const int cap = getenv("SV_NT_MAXS") ? atoi(getenv("SV_NT_MAXS")) : 0;       // (experiments)
+  if (cap > 0 && maxs > cap) maxs = cap;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   while (s > 1 && ((K % s) || ((K / s) % BK))) --s;       // slices of whole phases
@@ -299,13 +317,16 @@ int svk_nt_gemm_multi(NtGemmProb* p, int n, int bm, hipStream_t st) {
   m.n = n;
   int z = 0;
   for (int i = 0; i < n; ++i) {
-    if (!svk_nt_gemm_supported(p[i])) return SV_E_UNSUPPORTED;
+    if (!svk_nt_gemm_supported(p[i]) || p[i].f32 != p[0].f32) return SV_E_UNSUPPORTED;
     p[i].zbase = z;
     z += p[i].splitk;
     m.p[i] = p[i];
   }
   if (n == 1) m.p[1] = m.p[0];
-  return bm == 64 ? launch_nt<64>(m, st) : launch_nt<128>(m, st);
+  static const int bm32 = getenv("SV_NT_F32_BM") ? atoi(getenv("SV_NT_F32_BM")) : 0;
+  if (p[0].f32 && bm32) bm = bm32;
+  if (p[0].f32) return bm == 64 ? launch_nt<float, 64>(m, st) : launch_nt<float, 128>(m, st);
+  return bm == 64 ? launch_nt<bf16_t, 64>(m, st) : launch_nt<bf16_t, 128>(m, st);
 }
 
 int svk_nt_slab_reduce(const NtGemmProb* p, float* const* out, int n, hipStream_t st) {
@@ -427,10 +448,92 @@ __global__ __launch_bounds__(256) void tn_wgrad_kernel(const TnWgradMulti mg) {
   }
 }
 
+// fp32: the same 128 x 128 tile of dW over the whole batch in exact fp32 (v_mfma_f32_16x16x4_f32 wants ONE float per lane and operand: A [i = lane & 15]
+// [k = lane >> 4], B [k][j = lane & 15], so the k-major operands are plain ds_read_b32 of 16 consecutive columns of 4 consecutive batch rows).
+// LDS rows are 512 B (128 floats); piece p of row r sits in slot p ^ 4 (r & 3): the four rows of a read land on four different 64-B bank groups.
+// Phases are 32 batch rows (32 KB for both operands), two slots: phase ph + 1 is in flight beside the MFMAs of phase ph (inline-assembly
+// transfers with counted waits, as nt_gemm_ring_kernel).
+__global__ __launch_bounds__(256) void tn_wgrad_f32_kernel(const TnWgradMulti mg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TnWgradProb g = mg.p[blockIdx.z];
+  const int w0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+  if (w0 >= g.Kw || n0 >= g.N) return;
+  constexpr int PR = 32, ROWB = 512, OPB = PR * ROWB, SLOTB = 2 * OPB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = g.dbias != nullptr && blockIdx.x == 0 && wm == 0;
+  // one wave-instruction = 64 x 16 B = 2 LDS rows; lane -> (row 2 q + lane / 32, slot lane % 32) fetches piece slot ^ 4 (row & 3)
+  uint32_t offX[4], offY[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * (wave + 4 * i) + (lane >> 5), piece = (lane & 31) ^ ((r & 3) << 2);
+    offX[i] = (uint32_t)(((int64_t)r * g.ldx + w0 + piece * 4) * 4);
+    offY[i] = (uint32_t)(((int64_t)r * g.ldy + n0 + piece * 4) * 4);
+  }
+  const uint32_t phX = (uint32_t)PR * g.ldx * 4, phY = (uint32_t)PR * g.ldy * 4;
+  auto issue = [&](int ph, int slot) {
+    char* sX = smem + slot * SLOTB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nt_dma16(g.X, offX[i] + (uint32_t)ph * phX, sX + (wave + 4 * i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nt_dma16(g.dY, offY[i] + (uint32_t)ph * phY, sX + OPB + (wave + 4 * i) * 1024);
+  };
+  const int nph = g.M / PR;                          // (M is a multiple of 32: svk_tn_wgrad_supported)
+  issue(0, 0);
+  int slot = 0;
+  for (int ph = 0; ph < nph; ++ph) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // phase ph is complete; phase ph - 1 is consumed by every wave
+    if (ph + 1 < nph) issue(ph + 1, slot ^ 1);
+    const char* sX = smem + slot * SLOTB + lg * ROWB + (lr & 3) * 4;
+    const char* sY = sX + OPB;
+    const int sw = lg << 2;                          // (row & 3 == lane group: rows 4 kk + lg)
+#pragma unroll
+    for (int kk = 0; kk < PR / 4; ++kk) {
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const float*)(sX + kk * (4 * ROWB) + (((((wm + i * 16) >> 2) + (lr >> 2)) ^ sw) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *(const float*)(sY + kk * (4 * ROWB) + (((((wn + j * 16) >> 2) + (lr >> 2)) ^ sw) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[j], bacc[j], 0, 0, 0);
+      }
+    }
+    slot ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = w0 + wm + i * 16 + lg * 4 + r;
+      if (w >= g.Kw_real) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g.dW[(int64_t)w * g.N + n0 + wn + j * 16 + lr] = acc[i][j][r];
+    }
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.dbias[n0 + wn + j * 16 + lane] = bacc[j][0];
+  }
+}
+
 }  // namespace
 
 bool svk_tn_wgrad_supported(const TnWgradProb& p) {
-  return p.M >= 32 && !(p.M & 31) && p.Kw >= 128 && !(p.Kw & 127) && p.N >= 128 && !(p.N & 127) && !(p.ldx & 7) && !(p.ldy & 7) &&
+  const int pe = p.f32 ? 3 : 7;
+  return p.M >= 32 && !(p.M & 31) && p.Kw >= 128 && !(p.Kw & 127) && p.N >= 128 && !(p.N & 127) && !(p.ldx & pe) && !(p.ldy & pe) &&
          !((uintptr_t)p.X & 15) && !((uintptr_t)p.dY & 15) && p.Kw_real <= p.Kw && p.Kw_real > 0;
 }
 
@@ -440,12 +543,19 @@ int svk_tn_wgrad_multi(const TnWgradProb* p, int n, hipStream_t st) {
   TnWgradMulti m;
   int gx = 0, gy = 0;
   for (int i = 0; i < n; ++i) {
-    if (!svk_tn_wgrad_supported(p[i])) return SV_E_UNSUPPORTED;
+    if (!svk_tn_wgrad_supported(p[i]) || p[i].f32 != p[0].f32) return SV_E_UNSUPPORTED;
     m.p[i] = p[i];
     gx = max(gx, p[i].Kw / 128);
     gy = max(gy, p[i].N / 128);
   }
   for (int i = n; i < 4; ++i) m.p[i] = p[0];
+  if (p[0].f32) {
+    const size_t lds32 = 2 * 2 * 32 * 512;
+    sv_ensure_dynamic_lds((const void*)tn_wgrad_f32_kernel, lds32);
+    hipLaunchKernelGGL(tn_wgrad_f32_kernel, dim3(gx, gy, n), dim3(256), lds32, st, m);
+    SV_LAUNCH_CHECK();
+    return SV_OK;
+  }
   const size_t lds = 2 * 128 * 256;
   sv_ensure_dynamic_lds((const void*)tn_wgrad_kernel, lds);
   hipLaunchKernelGGL(tn_wgrad_kernel, dim3(gx, gy, n), dim3(256), lds, st, m);

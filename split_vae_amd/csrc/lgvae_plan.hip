@@ -551,7 +551,8 @@ static bool latent_fuse_on() {
 }
 static bool latent_gemm_on(const sv_lgvae_plan* p) {
   static const bool off = getenv("SV_NO_LATENT_GEMM") != nullptr;
-  return !off && p->d.dtype == SV_BF16;
+  static const bool off32 = getenv("SV_NO_LATENT_GEMM_F32") != nullptr;       // (A/B: the fp32 forms of latent_gemm.hip)
+  return !off && (p->d.dtype == SV_BF16 || !off32);
 }
 
 static double conv_flops(const sv_conv_desc& d) {
@@ -603,6 +604,7 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
       const sv_conv_desc& d = L[i]->d;
       NtGemmProb& g = q[i];
       memset(&g, 0, sizeof(g));
+        g.f32 = p->d.dtype == SV_F32;
       g.A = x[i]; g.lda = d.ldx;
       g.W = a[i].Wt; g.ldw = svg_cin_pad(&d);
       g.out = y[i]; g.ldo = d.ldy;
@@ -741,7 +743,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     for (int i = 0; i < n; ++i) {
       const sv_conv_desc& d = L[i]->d;
       q[i] = TnWgradProb{x[i], d.ldx, dy[i], d.ldy, grads + p->params[L[i]->kparam].off, grads + p->params[L[i]->bparam].off, d.B, svg_cin_pad(&d),
-                         d.Cin, d.Cout};
+                         d.Cin, d.Cout, p->d.dtype == SV_F32};
       fl += conv_flops(d);
     }
     bool ok = true;
@@ -898,6 +900,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
         Layer& Lh = p->enc[e][3];
         NtGemmProb& g = q[nq];
         memset(&g, 0, sizeof(g));
+        g.f32 = p->d.dtype == SV_F32;
         g.A = p->bp(std::string("a3_") + en[e]); g.lda = Lh.d.Cin;
         g.W = (char*)p->bp("warena") + Lh.wf_off * p->esz(); g.ldw = Lh.d.Cin;
         g.out = p->bp(std::string("lat_ws_") + en[e]); g.ldo = Lh.d.Cout;
@@ -1128,6 +1131,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
         const sv_conv_desc& dd = Ld[k].d;
         NtGemmProb& g = q[k];
         memset(&g, 0, sizeof(g));
+        g.f32 = p->d.dtype == SV_F32;
         g.A = g1[k]; g.lda = dd.ldy;
         g.W = (char*)p->bp("warena") + Ld[k].wd_off[0] * p->esz(); g.ldw = svg_gdy(&dd);
         g.out = p->bp(k == 0 ? "lat_ws_x" : "lat_ws_xh"); g.ldo = dd.Cin;
@@ -1225,7 +1229,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
         TnWgradProb q[4];
         bool ok = true;
         for (int i = 0; i < n; ++i) {
-          q[i] = TnWgradProb{a[i].A, a[i].lda, a[i].dY, a[i].ldy, a[i].dW, a[i].dbias, B, a[i].Cin_pad, a[i].Cin_real, a[i].N};
+          q[i] = TnWgradProb{a[i].A, a[i].lda, a[i].dY, a[i].ldy, a[i].dW, a[i].dbias, B, a[i].Cin_pad, a[i].Cin_real, a[i].N, dt == SV_F32};
           ok = ok && svk_tn_wgrad_supported(q[i]);
         }
         if (ok) { SV_TRY(svk_tn_wgrad_multi(q, n, ws)); done = true; }
@@ -1245,6 +1249,7 @@ static int phase_bwd_encoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, boo
         Layer& Lh = p->enc[e][3];
         NtGemmProb& g = q[nq];
         memset(&g, 0, sizeof(g));
+        g.f32 = p->d.dtype == SV_F32;
         g.A = gh[e]; g.lda = Lh.d.Cout;
         g.W = (char*)p->bp("warena") + Lh.wd_off[0] * p->esz(); g.ldw = Lh.d.Cout;
         g.out = ga3[e]; g.ldo = Lh.d.Cin; g.mask = a3[e];
