@@ -612,8 +612,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
       static const int ph_kb = getenv("SV_TC_PH_KB") ? atoi(getenv("SV_TC_PH_KB")) : 53;   // LDS per workgroup the split aims below (3 workgroups per CU)
       static const bool s2_phases = getenv("SV_TC_NPH_NO_S2") == nullptr;               // A/B: phases for the padded stride-2 layouts too
       static const int ph_wgs = getenv("SV_TC_PH_WGS") ? atoi(getenv("SV_TC_PH_WGS")) : 256;   // launches smaller than this keep one pass
-      if (yr || t.s2d3 || !(wgs >= ph_wgs && (2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
-                  in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes > ph_kb * 1024)) break;
+      // (a tile that does not fit the CU at all is split whatever the launch size: e3's stride-2 forward at fp32 -- 2 x 18 x 18 pixels of 528 B -- fell to the
+      //  im2col kernel below 256 workgroups: 0.102 ms for 64 images per network against 0.198 ms for 512)
+      const int64_t tot = in_bytes + 2 * BN * tile_pps(BN) * 16 + off_bytes;
+      if (yr || t.s2d3 || !((2 << lnph) <= nph_max && (pbh >> 1) >= 32 && (planar || s2_phases) &&
+                            ((wgs >= ph_wgs && tot > ph_kb * 1024) || tot > 150 * 1024))) break;
     }
     // whole K resident in LDS (kernel comment): one phase, <= 6 K steps, <= 24 KB of weights
     static const bool wres_on = getenv("SV_TC_NO_WRES") == nullptr;
@@ -626,7 +629,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     //  of one tile's staging with another's MFMAs; SV_TC_S2_MF4=1: the 256-row tile for A/B)
     static const bool s2_mf4 = getenv("SV_TC_S2_MF4") != nullptr;
     if (lds > 78 * 1024 && MF == 4 && t.S == 2 && t.fix_nc && !s2_mf4) continue;
-    if (lds > 150 * 1024) { if (MF == 4) continue; return false; }
+    if (lds > 150 * 1024) {
+      if (MF == 4) continue;
+      if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: REFUSED (LDS %lld) N=%d cin=%d S=%d ntaps=%d\n", (long long)lds, t.N, cin, t.S, t.ntaps);
+      return false;
+    }
     memset(a, 0, sizeof(*a));
     a->A = t.A; a->Wt = t.Wt; a->bias = t.bias; a->out = t.out; a->mask = t.mask;
     a->B = B; a->IH = t.IH; a->IW = t.IW; a->lda = t.lda;
