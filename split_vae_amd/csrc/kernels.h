@@ -93,6 +93,7 @@ struct TileConvArgs {
   int cls_n;                  // merged parity classes (TapGemmArgs::cls_n): channels per class
   int d2s_y, clampin;         // TapGemmArgs::d2s_y / clampin
   int s2d3;                   // TapGemmArgs::s2d3
+  int dma;                    // the input tile is staged by LDS-DMA (tile_stage.hip.h: stage_tile_plain_dma; fp32, plain / clamped input, planar or unpadded tiles)
   const float* fix;           // TapGemmArgs::fix
   const float* fix2; int fix_nc, fix_pad;   // TapGemmArgs::fix2 / fix_nc / fix_pad (per-class polyphase)
   const float* nll_img; void* nll_grad; float* nll_part; int nll_ch; float nll_gscale; int nll_noout;   // TapGemmArgs: fused loss
@@ -170,6 +171,7 @@ struct WgradTileArgs {
   int clampin, dy_s2d, assign;   // WgradArgs::clampin / dy_s2d / assign
   int dy_os, dy_oy, dy_ox;       // WgradArgs::dy_os / dy_oy / dy_ox
   int s2d3;                      // WgradArgs::s2d3
+  int dma;                       // fp32 kernel: tiles staged by LDS-DMA (wgrad_tile_f32.hip)
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];

@@ -170,6 +170,11 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
       if (g.s2d3) { stage_tile_s2d3<NT>((const float*)g.A, sg, b0, iy_base, ix_base, sIn, tid); return; }     // the padded RGB tensor through its space-to-depth view
     }
     if (g.ups) stage_tile_upsampled<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
+    else if (g.dma) {                                 // LDS-DMA: every transfer of the tile in flight at once, no staging registers
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      if (g.clampin) stage_tile_plain_dma<T, NW, true>(Ap, sg, b0, iy_base, ix_base, sIn, lane, wv);
+      else stage_tile_plain_dma<T, NW, false>(Ap, sg, b0, iy_base, ix_base, sIn, lane, wv);
+    }
     else if (g.clampin) stage_tile_plain<T, NT, true>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
     else stage_tile_plain<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
   };
@@ -646,6 +651,11 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     a->ntiles = a->tilesX * a->tilesY * ((B + NB - 1) / NB);
     a->TIW = TIW; a->TIH = TIH; a->y_lo = y_lo; a->x_lo = x_lo; a->PS = PS; a->plane_bytes = plane_bytes;
     a->nph = 1 << lnph; a->lnph = lnph; a->wslots = wslots;
+    {
+      // (fp32: the register staging keeps four loads per lane in flight and waits -- three to four dependent L2 round trips per tile; SV_TC_NO_DMA: A/B)
+      static const bool no_dma = getenv("SV_TC_NO_DMA") != nullptr;
+      a->dma = (!no_dma && dtype == SV_F32 && !t.ups && !t.s2d3 && (planar || PS == (pb >> lnph))) ? 1 : 0;
+    }
     if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: yr=%d wslots=%d N=%d BN=%d MF=%d cin=%d pb=%d planar=%d nph=%d tile=%dx%dx%d PS=%d in_bytes=%lld lds=%lld ntiles=%d S=%d SX=%d\n", yr, wslots, t.N, BN, MF, cin, pb, (int)planar, 1 << lnph, NB, TIH, TIW, PS, (long long)in_bytes, (long long)lds, a->ntiles, t.S, t.SX);
     {
       static const bool xcd = getenv("SV_TC_NO_XCD") == nullptr;

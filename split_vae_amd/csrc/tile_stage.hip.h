@@ -59,6 +59,54 @@ __device__ __forceinline__ void stage_tile_plain(const T* __restrict__ Ab, const
   }
 }
 
+// The same tile by LDS-DMA (global_load_lds_dwordx4: no staging registers, every transfer of the tile in flight at once; the register form above keeps four
+// 16-B loads per lane in flight and waits -- a 20 x 20 x 64-B tile is three dependent L2 round trips per workgroup, which two workgroups per CU do not hide).
+// Tiles without padding bytes only: LINEAR (PS == 16 << cl2: piece L = pixel * cpp + c lives at byte 16 L) or PLANAR; one wave-instruction fills 64
+// consecutive 16-B slots and each lane fetches the piece of its slot.  Lanes whose pixel is outside the image (zero padding) or past the batch store zeros instead
+// (masked-off lanes of the DMA instruction write nothing).  `wave` must be wave-uniform.
+__device__ __forceinline__ void stage_dma16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <typename T, int NW = 4, bool CLAMP = false>
+__device__ __forceinline__ void stage_tile_plain_dma(const T* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base, int ix_base, char* sIn, int lane, int wave) {
+  constexpr int EPP = ElemTraits<T>::EPP;
+  const float inv_h = 1.0f / (float)s.TIH;
+  auto piece = [&](int row, int ixl, int c, char* lds_wave_base, char* lds_lane) {       // row = image * TIH + tile row
+    const int bl = (int)(((float)row + 0.5f) * inv_h), iyl = row - bl * s.TIH, b = b0 + bl;
+    int iy = iy_base + iyl, ix = ix_base + ixl;
+    bool ok = b < s.B;
+    if (CLAMP) { iy = min(max(iy, 0), s.IH - 1); ix = min(max(ix, 0), s.IW - 1); }
+    else ok = ok && (unsigned)iy < (unsigned)s.IH && (unsigned)ix < (unsigned)s.IW;
+    if (ok) stage_dma16(Ab + ((int64_t)(b * s.IH + iy) * s.IW + ix) * s.lda + c * EPP, lds_wave_base);
+    else *(uint4*)lds_lane = make_uint4(0, 0, 0, 0);
+  };
+  if (s.plane_bytes) {
+    // PLANAR tiles: plane k holds chunks 2k, 2k + 1 of every pixel as 32-B records -- slot = pixel * 2 + (c & 1) is linear inside a plane
+    const int slots = s.NB * s.TIH * s.TIW * 2, ipp = (slots + 63) >> 6, nplanes = 1 << (s.cl2 - 1);
+    const float inv_w = 1.0f / (float)s.TIW;
+    int plane = 0, k = wave;
+    while (k >= ipp) { k -= ipp; ++plane; }
+    while (plane < nplanes) {
+      const int slot = k * 64 + lane;
+      if (slot < slots) {
+        const int p = slot >> 1, row = (int)(((float)p + 0.5f) * inv_w);
+        piece(row, p - row * s.TIW, plane * 2 + (slot & 1), sIn + plane * s.plane_bytes + k * 1024, sIn + plane * s.plane_bytes + slot * 16);
+      }
+      k += NW;
+      while (k >= ipp) { k -= ipp; ++plane; }
+    }
+    return;
+  }
+  const int cpp = 1 << s.cl2, ppr = s.TIW << s.cl2, total = s.NB * s.TIH * ppr;
+  const float inv_row = 1.0f / (float)ppr;
+  for (int base = wave * 64; base < total; base += NW * 64) {
+    const int L = base + lane;
+    if (L >= total) continue;
+    const int row = (int)(((float)L + 0.5f) * inv_row), r = L - row * ppr;            // (image, tile row); (tile column, chunk)
+    piece(row, r >> s.cl2, r & (cpp - 1), sIn + base * 16, sIn + L * 16);
+  }
+}
+
 // Space-to-depth view of the padded RGB tensor (conv_geom.h: svg_s2d3): Ab = [B, 2 IH, 2 IW, 8] fp32 (channels 0..2 real), the tile pixel (i, j) of the
 // [B, IH, IW, 16] view holds channel (py*2+px)*3 + c = pixel (2i+py, 2j+px) channel c; zero outside the image (SAME padding) and in channels 12..15.
 // One item = one source pixel: a 16-B load (its first four floats), three 4-B LDS stores.

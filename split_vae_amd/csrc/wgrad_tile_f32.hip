@@ -68,37 +68,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
   const int lycp = g.lycp, dy_total = BM << lycp;
   const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int tile_lo = (int)blockIdx.x * per_wg, tile_hi = min(g.ntiles, tile_lo + per_wg);
+  const bool dma = g.dma != 0;
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     int t = tile;
     const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
     const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
     const int b0 = t << g.lNB;
     __syncthreads();                      // the previous tile is consumed
-    {
+    if (!(SV_DBG(g.dbg) & 4)) {           // (ablation builds: bit 4 skips the staging, bit 2 the MFMA rows)
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       // (ups: the layer's input is the 2x bilinear resize of the LOW-RES tensor A, blended on the fly with upsample2x_fwd's own arithmetic)
       if (g.s2d3) stage_tile_s2d3<256>((const float*)g.A, sg, b0, ty0 + g.y_lo, tx0 + g.x_lo, sIn, tid);      // e1: the padded RGB tensor through its space-to-depth view
       else if (g.ups) stage_tile_upsampled<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
-      else if (g.clampin) stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);   // polyphase forms: the edge-clamped low-res tensor
+      else if (dma) {                     // LDS-DMA: the whole tile in flight at once (tile_stage.hip.h)
+        if (g.clampin) stage_tile_plain_dma<float, 4, true>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, lane, wave);   // polyphase forms: the edge-clamped low-res tensor
+        else stage_tile_plain_dma<float, 4, false>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, lane, wave);
+      }
+      else if (g.clampin) stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
       else stage_tile_plain<float>(Ab, sg, b0, ty0 * g.S + g.y_lo, tx0 * g.SX + g.x_lo, sIn, tid);
     }
-    for (int q = tid; q < dy_total; q += 256) {
+    // dY tile: piece q = pixel * (ldy / 4) + c lives at byte 16 q (YS = 4 ldy): by LDS-DMA too (the register form was ONE load in flight per lane: eight dependent round trips per tile)
+    for (int base = dma ? wave * 64 : tid; base < ((SV_DBG(g.dbg) & 4) ? 0 : dy_total); base += 256) {
+      const int q = dma ? base + lane : base;
+      if (q >= dy_total) continue;
       const int r = q >> lycp, c = q & ((1 << lycp) - 1);
       const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
       const int b = b0 + bl;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (b < g.B) {
-        if (g.dy_s2d)          // merged polyphase head: column c * 4 = (py * 2 + px) * 8 + co of low-res pixel (i, j) is channel co of hi-res pixel (2i + py, 2j + px)
-          v = *(const uint4*)(Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 2)) * (2 * g.OX) + 2 * (tx0 + tx) + ((c >> 1) & 1)) * 8 + (c & 1) * 4);
-        else if (g.dy_os)      // one parity class of the per-class polyphase form: hi-res pixel (2i + dy_oy, 2j + dy_ox)
-          v = *(const uint4*)(Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + g.dy_oy) * (2 * g.OX) + 2 * (tx0 + tx) + g.dy_ox) * g.ldy + c * 4);
-        else v = *(const uint4*)(Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4);
-      }
-      *(uint4*)(sDy + r * YS + c * 16) = v;
+      const float* src;
+      if (g.dy_s2d)          // merged polyphase head: column c * 4 = (py * 2 + px) * 8 + co of low-res pixel (i, j) is channel co of hi-res pixel (2i + py, 2j + px)
+        src = Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 2)) * (2 * g.OX) + 2 * (tx0 + tx) + ((c >> 1) & 1)) * 8 + (c & 1) * 4;
+      else if (g.dy_os)      // one parity class of the per-class polyphase form: hi-res pixel (2i + dy_oy, 2j + dy_ox)
+        src = Yb + ((int64_t)(b * 2 * g.OY + 2 * (ty0 + ty) + g.dy_oy) * (2 * g.OX) + 2 * (tx0 + tx) + g.dy_ox) * g.ldy + c * 4;
+      else src = Yb + ((int64_t)(b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4;
+      if (dma && b < g.B) stage_dma16(src, sDy + base * 16);
+      else *(uint4*)(sDy + q * 16) = b < g.B ? *(const uint4*)src : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     // ---- MFMA: K = pixels, four per instruction; one tile row (G4 groups of four pixels) at a time
-    const int nrow = BM / (4 * G4);
+    const int nrow = (SV_DBG(g.dbg) & 2) ? 0 : BM / (4 * G4);
     for (int row = 0; row < nrow; ++row) {
       const int ty = row & (TH - 1), bl = row >> g.lTH;                                   // wave-uniform
       const char* pin = sIn + ((bl * g.TIH + ty * g.S) * g.TIW) * PS;
@@ -386,6 +393,10 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
   a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.dy_os = w.dy_os; a.dy_oy = w.dy_oy; a.dy_ox = w.dy_ox; a.s2d3 = w.s2d3;
   a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
+  static const bool no_dma = getenv("SV_WT32_NO_DMA") != nullptr;          // A/B: the register staging
+  a.dma = no_dma ? 0 : 1;
+  static const int dbg = getenv("SV_WT32_DBG") ? atoi(getenv("SV_WT32_DBG")) : 0;       // (read by SV_DEBUG_KNOBS builds only)
+  a.dbg = dbg;
   a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
   a.ntiles = a.tilesX * a.tilesY * ((B + NB - 1) / NB);
   a.y_lo = y_lo; a.x_lo = x_lo;
