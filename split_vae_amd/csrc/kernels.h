@@ -172,6 +172,7 @@ struct WgradTileArgs {
   int dy_os, dy_oy, dy_ox;       // WgradArgs::dy_os / dy_oy / dy_ox
   int s2d3;                      // WgradArgs::s2d3
   int dma;                       // fp32 kernel: tiles staged by LDS-DMA (wgrad_tile_f32.hip)
+  int db;                        // ... into two LDS buffers: tile t + 1 in flight beside the MFMAs of tile t
   int CW, ncg;              // input-channel slice width per workgroup and number of slices (cl2 = log2(CW/8))
   int Cin_real, N, ntaps;
   int8_t dy[SV_MAX_TAPS];

@@ -20,6 +20,13 @@
 
 namespace {
 
+// one LDS-DMA wave-instruction as inline assembly (base: wave-uniform tensor pointer, off: this lane's byte offset): the compiler orders every LDS access behind
+// the builtin's vmcnt(0); with the assembly form the double-buffered loop waits where IT wants to (latent_gemm.hip: nt_dma16)
+__device__ __forceinline__ void dma16_asm(const void* base, uint32_t off, const char* lds) {
+  const uint32_t l = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory", "m0");
+}
+
 // TPW taps per wave (4 waves: 4 * TPW taps per workgroup = all of them), COF 16-column fragments of dY.  A workgroup owns a 16-channel (8 for
 // an 8-channel input) slice of the input, blockIdx.y, and walks a contiguous run of tiles, blockIdx.x.
 // LDY (dY floats per pixel), CW (channels of the slice), SX (x stride) and G4 (pixel groups of four per tile row) are compile-time: inside a tile row
@@ -69,6 +76,93 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
   const int per_wg = (g.ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int tile_lo = (int)blockIdx.x * per_wg, tile_hi = min(g.ntiles, tile_lo + per_wg);
   const bool dma = g.dma != 0;
+  // the MFMA rows of one staged tile
+  auto rows = [&](const char* sIn, const char* sDy) {
+      // ---- MFMA: K = pixels, four per instruction; one tile row (G4 groups of four pixels) at a time
+      const int nrow = (SV_DBG(g.dbg) & 2) ? 0 : BM / (4 * G4);
+      for (int row = 0; row < nrow; ++row) {
+        const int ty = row & (TH - 1), bl = row >> g.lTH;                                   // wave-uniform
+        const char* pin = sIn + ((bl * g.TIH + ty * g.S) * g.TIW) * PS;
+        const char* pdy = sDy + dy_lane + row * (4 * G4 * YS);
+        float bfr[G4][COF], afr[G4][TPW];
+#pragma unroll
+        for (int q = 0; q < G4; ++q)
+#pragma unroll
+          for (int j = 0; j < COF; ++j) {
+            const float v = *(const float*)(pdy + q * 4 * YS + j * 64);
+            bfr[q][j] = (MASKB && j * 16 + lr >= LDY) ? 0.f : v;
+          }
+#pragma unroll
+        for (int t2 = 0; t2 < TPW; ++t2) {
+          const char* pa = pin + tapoff[t2];
+#pragma unroll
+          for (int q = 0; q < G4; ++q) afr[q][t2] = *(const float*)(pa + q * 4 * SX * PS);
+        }
+#pragma unroll
+        for (int q = 0; q < G4; ++q) {
+          if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < COF; ++j)
+              if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[q][j], bacc[j >> 2], 0, 0, 0);
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < TPW; ++t2)
+#pragma unroll
+            for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q][t2], bfr[q][j], acc[t2][j], 0, 0, 0);
+        }
+      }
+  };
+  if (g.db) {
+    // DOUBLE-BUFFERED (plain / clamped inputs): the transfers of tile t + 1 -- inline-assembly LDS-DMA, which the compiler does not order the LDS reads behind --
+    // are in flight beside the MFMAs of tile t; one barrier per tile.  (Single-buffered, the staging of a tile was exposed unless the CU's other workgroup
+    // happened to be in its MFMA rows: 0.12 of the d4 weight gradient's 1.03 ms.)
+    const int bufb = g.in_bytes + g.dy_bytes;
+    const float inv_row = 1.0f / (float)(g.TIW << g.cl2), inv_h = 1.0f / (float)g.TIH;
+    auto stage_db = [&](int tile, char* sI) {
+      int t = tile;
+      const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
+      const int ty0 = (t % g.tilesY) << g.lTH; t /= g.tilesY;
+      const int b0 = t << g.lNB;
+      const int iy_base = ty0 * g.S + g.y_lo, ix_base = tx0 * g.SX + g.x_lo;
+      const int cpp = 1 << g.cl2, ppr = g.TIW << g.cl2, total = NB * g.TIH * ppr;
+      for (int base = wave * 64; base < total; base += 256) {
+        const int L = base + lane;
+        if (L >= total) continue;
+        const int row = (int)(((float)L + 0.5f) * inv_row), r = L - row * ppr;
+        const int bl = (int)(((float)row + 0.5f) * inv_h), iyl = row - bl * g.TIH;
+        const int ixl = r >> g.cl2, c = r & (cpp - 1), b = b0 + bl;
+        int iy = iy_base + iyl, ix = ix_base + ixl;
+        bool ok = b < g.B;
+        if (g.clampin) { iy = min(max(iy, 0), g.IH - 1); ix = min(max(ix, 0), g.IW - 1); }
+        else ok = ok && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+        if (ok) dma16_asm(Ab, (uint32_t)((((b * g.IH + iy) * g.IW + ix) * g.lda + c * 4) * 4), sI + base * 16);
+        else *(uint4*)(sI + L * 16) = make_uint4(0, 0, 0, 0);
+      }
+      char* sY = sI + g.in_bytes;
+      for (int base = wave * 64; base < dy_total; base += 256) {
+        const int q = base + lane;
+        if (q >= dy_total) continue;
+        const int r = q >> lycp, c = q & ((1 << lycp) - 1);
+        const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
+        const int b = b0 + bl;
+        uint32_t off;
+        if (g.dy_s2d) off = (uint32_t)((((b * 2 * g.OY + 2 * (ty0 + ty) + (c >> 2)) * (2 * g.OX) + 2 * (tx0 + tx) + ((c >> 1) & 1)) * 8 + (c & 1) * 4) * 4);
+        else if (g.dy_os) off = (uint32_t)((((b * 2 * g.OY + 2 * (ty0 + ty) + g.dy_oy) * (2 * g.OX) + 2 * (tx0 + tx) + g.dy_ox) * g.ldy + c * 4) * 4);
+        else off = (uint32_t)((((b * g.OY + ty0 + ty) * g.OX + tx0 + tx) * g.ldy + c * 4) * 4);
+        if (b < g.B) dma16_asm(Yb, off, sY + base * 16);
+        else *(uint4*)(sY + q * 16) = make_uint4(0, 0, 0, 0);
+      }
+    };
+    int cur = 0;
+    if (tile_lo < tile_hi) stage_db(tile_lo, smem);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                    // tile `tile` has landed for every wave; tile - 1 is consumed: the other buffer is free
+      if (tile + 1 < tile_hi) stage_db(tile + 1, smem + (cur ^ 1) * bufb);
+      rows(smem + cur * bufb, smem + cur * bufb + g.in_bytes);
+      cur ^= 1;
+    }
+  } else
   for (int tile = tile_lo; tile < tile_hi; ++tile) {
     int t = tile;
     const int tx0 = (t % g.tilesX) << g.lTW; t /= g.tilesX;
@@ -104,39 +198,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_f32_kernel(const WgradTileM
       else *(uint4*)(sDy + q * 16) = b < g.B ? *(const uint4*)src : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    // ---- MFMA: K = pixels, four per instruction; one tile row (G4 groups of four pixels) at a time
-    const int nrow = (SV_DBG(g.dbg) & 2) ? 0 : BM / (4 * G4);
-    for (int row = 0; row < nrow; ++row) {
-      const int ty = row & (TH - 1), bl = row >> g.lTH;                                   // wave-uniform
-      const char* pin = sIn + ((bl * g.TIH + ty * g.S) * g.TIW) * PS;
-      const char* pdy = sDy + dy_lane + row * (4 * G4 * YS);
-      float bfr[G4][COF], afr[G4][TPW];
-#pragma unroll
-      for (int q = 0; q < G4; ++q)
-#pragma unroll
-        for (int j = 0; j < COF; ++j) {
-          const float v = *(const float*)(pdy + q * 4 * YS + j * 64);
-          bfr[q][j] = (MASKB && j * 16 + lr >= LDY) ? 0.f : v;
-        }
-#pragma unroll
-      for (int t2 = 0; t2 < TPW; ++t2) {
-        const char* pa = pin + tapoff[t2];
-#pragma unroll
-        for (int q = 0; q < G4; ++q) afr[q][t2] = *(const float*)(pa + q * 4 * SX * PS);
-      }
-#pragma unroll
-      for (int q = 0; q < G4; ++q) {
-        if (do_bias) {
-#pragma unroll
-          for (int j = 0; j < COF; ++j)
-            if ((j & 3) == wave) bacc[j >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[q][j], bacc[j >> 2], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t2 = 0; t2 < TPW; ++t2)
-#pragma unroll
-          for (int j = 0; j < COF; ++j) acc[t2][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[q][t2], bfr[q][j], acc[t2][j], 0, 0, 0);
-      }
-    }
+    rows(sIn, sDy);
   }
 
   // ---- flush: one slab per workgroup in the fragment order of wgrad_reduce <TPW, 1, COF>; without a workspace, fp32 atomics into dW
@@ -369,6 +431,12 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   // stream beside the input-gradient chain, and 52 KB tiles (three to five workgroups per CU fit beside the other stream's) make the 512-image fp32 step 2.3 %
   // shorter: 9.82-9.90 -> 9.60-9.62 ms (40 KB: 9.68; 128-pixel tiles at 78 KB: 9.77; profiles/r05_wtf32_lds_ab.txt), the serial rows 0-3 % longer
   static const int lds_max = getenv("SV_WTF32_LDS") ? atoi(getenv("SV_WTF32_LDS")) : 52000;
+  // double-buffered staging (plain / clamped inputs; the kernel's g.db loop): both buffers inside SV_WTF32_DB_LDS bytes.  OPT-IN (default 0 = single buffer).  Measured
+  // (2 x 512 images): alone on the chip the d4 weight gradient goes 1.020 -> 0.990 ms and d5's 0.605 -> 0.590 at 64 KB (e2: 0.335 -> 0.359, its stride-2 tile halves),
+  // but the STEP goes 9.19 -> 9.35 ms (48 KB: 9.32, 78 KB: 9.38, 120 KB: 9.60): the second buffer takes the LDS that the other streams' workgroups lived in
+  static const int db_lds = getenv("SV_WTF32_DB_LDS") ? atoi(getenv("SV_WTF32_DB_LDS")) : 0;
+  static const bool no_dma = getenv("SV_WT32_NO_DMA") != nullptr;          // A/B: the register staging
+  const bool db = db_lds > 0 && !no_dma && !w.ups && !w.s2d3;
   int BM = bm_max;
   for (;; BM >>= 1) {
     if (BM < 32) F32_REJ("tile");
@@ -385,7 +453,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
     a.PS = CW * 4; a.YS = ldy * 4;
     a.in_bytes = (NB * a.TIH * a.TIW * a.PS + 64 + 15) / 16 * 16;      // slack: the masked lanes of a half-filled fragment read past the last pixel
     a.dy_bytes = BM * a.YS + 64;
-    if (a.in_bytes + a.dy_bytes <= lds_max) break;
+    if (db ? 2 * (a.in_bytes + a.dy_bytes) <= db_lds : a.in_bytes + a.dy_bytes <= lds_max) break;
   }
   const int TW = 1 << a.lTW, TH = 1 << a.lTH, NB = 1 << a.lNB;
   const int B = w.M >> (w.lOY + w.lOX);
@@ -393,8 +461,8 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
   a.fold_kw = w.fold_kw; a.fold_c = w.fold_c;
   a.clampin = w.clampin; a.dy_s2d = w.dy_s2d; a.dy_os = w.dy_os; a.dy_oy = w.dy_oy; a.dy_ox = w.dy_ox; a.s2d3 = w.s2d3;
   a.contig = 1; a.CW = CW; a.ncg = cin / CW; a.cl2 = ilog2_exact(CW / 4);
-  static const bool no_dma = getenv("SV_WT32_NO_DMA") != nullptr;          // A/B: the register staging
   a.dma = no_dma ? 0 : 1;
+  a.db = db ? 1 : 0;
   static const int dbg = getenv("SV_WT32_DBG") ? atoi(getenv("SV_WT32_DBG")) : 0;       // (read by SV_DEBUG_KNOBS builds only)
   a.dbg = dbg;
   a.OY = OY; a.OX = OX; a.tilesX = OX / TW; a.tilesY = OY / TH;
@@ -423,7 +491,7 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
     av[i].bslab = slab && wv[i].dbias ? wv[i].ws + (int64_t)msplit * groups * PER : nullptr;
     rd[i] = WgradReduceDesc{av[i].slab, wv[i].dW, av[i].bslab, wv[i].dbias, msplit, groups, a.ncg, CW, a.Cin_real, a.N, ntk, w.fold_kw, w.fold_c, a.pairx, a.assign, TPW, 1, COF, w.s2d3};
   }
-  const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+  const size_t lds = ((size_t)a.in_bytes + a.dy_bytes) * (a.db ? 2 : 1);
   // <taps per wave, column fragments, dY floats per pixel, slice channels, x stride, pixel groups per tile row>: the layers of the model
   const int G4 = TW / 4, SXv = w.SX;
   int rc = SV_E_UNSUPPORTED;
@@ -530,7 +598,7 @@ int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, WgradReduceDesc* rd, 
     }
     if (!p.g.bslab) p.g.dbias = nullptr;
   }
-  const size_t lds = (size_t)a.in_bytes + a.dy_bytes;
+  const size_t lds = ((size_t)a.in_bytes + a.dy_bytes) * (a.db ? 2 : 1);
   const dim3 grid(msplit, groups, n);
 #define POLYC_CASE(G) if (G4 == G) { sv_ensure_dynamic_lds((const void*)wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>, lds); \
     hipLaunchKernelGGL((wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>), grid, dim3(256), lds, st, m); }
