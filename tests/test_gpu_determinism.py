@@ -105,3 +105,19 @@ def test_latent_block_fused_slab_sums_and_ring_kernel_keep_the_bits(lib_built):
     ref = out[()]
     for k, v in out.items():
         assert v == ref, (k, v, ref)
+
+
+def test_default_fp32_step_is_run_to_run_identical(lib_built):
+    """WITHOUT SV_DETERMINISTIC: since round 5 the fp32 SPLIT-VAE step has no fp32 atomics left on its default path -- the latent block (heads, d1:
+    vae/model.py:41-42, :111-112, :152, :160 and their gradients) runs on latent_gemm.hip (K slices summed in slice order, whole-batch weight-gradient
+    tiles), every conv weight gradient leaves through slabs summed in workgroup order.  Five training steps hash identically twice in one process and
+    in a fresh process (scripts/r05_f32_step_hash.py: CelebA-64 B = 64 / 512, SVHN-32 B = 64)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("SV_DETERMINISTIC", "SV_TEST_STRICT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "r05_f32_step_hash.py")], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("f32 ")]
+    twice = [l for l in lines if len(l) == 5]
+    fresh = [l for l in lines if len(l) == 4]
+    assert len(twice) == 3 and len(fresh) == 3, r.stdout
+    for t, f in zip(twice, fresh):
+        assert t[3] == t[4] == f[3], (t, f)
