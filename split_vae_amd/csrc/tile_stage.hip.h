@@ -114,21 +114,33 @@ template <int NT = 256>
 __device__ __forceinline__ void stage_tile_s2d3(const float* __restrict__ Ab, const TileStageGeom& s, int b0, int iy_base, int ix_base, char* sIn, int tid) {
   const int total = s.NB * s.TIH * s.TIW * 4;
   const float inv_row = 1.0f / (float)(s.TIW * 4), inv_h = 1.0f / (float)s.TIH;
-  for (int it = tid; it < total; it += NT) {
-    const int row = (int)(((float)it + 0.5f) * inv_row), r = it - row * (s.TIW * 4);      // (image, tile row); (tile column, parity)
-    const int bl = (int)(((float)row + 0.5f) * inv_h), iyl = row - bl * s.TIH;
-    const int ixl = r >> 2, p = r & 3, iy = iy_base + iyl, ix = ix_base + ixl, b = b0 + bl;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (b < s.B && (unsigned)iy < (unsigned)s.IH && (unsigned)ix < (unsigned)s.IW)
-      v = *(const float4*)(Ab + (((int64_t)b * (2 * s.IH) + 2 * iy + (p >> 1)) * (2 * s.IW) + 2 * ix + (p & 1)) * 8);
-    const int pixel = row * s.TIW + ixl;
-    const float f[3] = {v.x, v.y, v.z};
+  constexpr int U = 4;                                   // loads in flight per lane (one per pass left every item's L2 round trip in line: five passes for an 18 x 18 tile)
+  for (int it0 = tid; it0 < total; it0 += NT * U) {
+    float4 v[U];
+    int pix[U], par[U];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int ch = p * 3 + c;
-      *(float*)(sIn + tile_piece_off(s, pixel, ch >> 2) + (ch & 3) * 4) = f[c];
+    for (int u = 0; u < U; ++u) {
+      const int it = it0 + u * NT;
+      const int row = (int)(((float)it + 0.5f) * inv_row), r = it - row * (s.TIW * 4);      // (image, tile row); (tile column, parity)
+      const int bl = (int)(((float)row + 0.5f) * inv_h), iyl = row - bl * s.TIH;
+      const int ixl = r >> 2, p = r & 3, iy = iy_base + iyl, ix = ix_base + ixl, b = b0 + bl;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < total && b < s.B && (unsigned)iy < (unsigned)s.IH && (unsigned)ix < (unsigned)s.IW)
+        v[u] = *(const float4*)(Ab + (((int64_t)b * (2 * s.IH) + 2 * iy + (p >> 1)) * (2 * s.IW) + 2 * ix + (p & 1)) * 8);
+      pix[u] = it < total ? row * s.TIW + ixl : -1;
+      par[u] = p;
     }
-    if (p == 0) *(float4*)(sIn + tile_piece_off(s, pixel, 3)) = make_float4(0.f, 0.f, 0.f, 0.f);     // channels 12..15
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (pix[u] < 0) continue;
+      const float f[3] = {v[u].x, v[u].y, v[u].z};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int ch = par[u] * 3 + c;
+        *(float*)(sIn + tile_piece_off(s, pix[u], ch >> 2) + (ch & 3) * 4) = f[c];
+      }
+      if (par[u] == 0) *(float4*)(sIn + tile_piece_off(s, pix[u], 3)) = make_float4(0.f, 0.f, 0.f, 0.f);     // channels 12..15
+    }
   }
 }
 
