@@ -170,7 +170,8 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
       if (g.s2d3) { stage_tile_s2d3<NT>((const float*)g.A, sg, b0, iy_base, ix_base, sIn, tid); return; }     // the padded RGB tensor through its space-to-depth view
     }
     if (g.ups) stage_tile_upsampled<T, NT>(Ap, sg, b0, iy_base, ix_base, sIn, tid);
-    else if (g.dma) {                                 // LDS-DMA: every transfer of the tile in flight at once, no staging registers
+    else if (sizeof(T) == 4 && g.dma) {               // LDS-DMA: every transfer of the tile in flight at once, no staging registers
+      // (fp32 instantiations only -- the constant folds the branch away at bf16: compiled into the bf16 kernels it cost the head's fused-loss forward 0.125 -> 0.150 ms)
       const int wv = __builtin_amdgcn_readfirstlane(wave);
       if (g.clampin) stage_tile_plain_dma<T, NW, true>(Ap, sg, b0, iy_base, ix_base, sIn, lane, wv);
       else stage_tile_plain_dma<T, NW, false>(Ap, sg, b0, iy_base, ix_base, sIn, lane, wv);
