@@ -129,6 +129,57 @@ def _fp32_step_vs_oracle(ops, H, patch, beta, B, strict):
                 pr.copy_(pg.double())
 
 
+@pytest.mark.parametrize("B,Lg,Ll", [(32, 128, 128), (96, 128, 128), (32, 64, 64), (64, 256, 256)])
+def test_step_fp32_latent_block_kernels_match_oracle(ops, deterministic, B, Lg, Ll):
+    """The fp32 latent block on latent_gemm.hip (round 5; vae/model.py:41-42, :111-112 heads, :152, :160 d1 and their gradients, tape.gradient
+    vae/trainer.py:137): nt_gemm_kernel<float> / nt_gemm_ring_kernel<float> (K-slice slabs summed inside Sampling + KL) and the whole-batch
+    weight-gradient tile tn_wgrad_f32_kernel need batches of whole 32-row phases, which the 3- / 4-image strict tests above never reach.
+    SVHN-32 shapes, one gradient evaluation against the fp64 oracle at the strict bounds (outputs rtol 1e-4 / atol 1e-5, every gradient within
+    2e-3 of its tensor's max |g|; beyond that only what the default-order twin above allows: a ReLU unit within fp32 noise of zero taking the other
+    gate than the fp64 oracle -- at 96 images one such unit shows in e1's kernel gradient, on the im2col launches (SV_NO_LATENT_GEMM_F32=1) as well).
+    (64, 64): the heads take the kernels, d1's input gradient of decoder_x-hat (N = 64 < one column tile) does not -- the mixed state of the plan's
+    slab bookkeeping; (256, 256): wider tiles, other split-K slice counts.  (The plan takes equal power-of-two latent widths only: check_desc.)"""
+    H, patch, beta = 32, 1, 40.0
+    rng0 = np.random.Generator(np.random.PCG64(5))
+    x = (rng0.integers(0, 256, size=(B, H, H, 3)) / 255.0 * 2 - 1).astype(np.float32)
+    perm = np.stack([np.random.Generator(np.random.PCG64(6 + b)).permutation((H // patch) ** 2) for b in range(B)]).astype(np.int32)
+    eps_x = np.random.Generator(np.random.PCG64(7)).standard_normal((B, Lg)).astype(np.float32)
+    eps_h = np.random.Generator(np.random.PCG64(8)).standard_normal((B, Ll)).astype(np.float32)
+    images = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), patch)
+    params_np = np_ref.glorot_init(H, H, seed=3, global_latent=Lg, local_latent=Ll)
+    rng = np.random.default_rng(9)
+    for i in range(1, len(params_np), 2):
+        params_np[i] = (rng.standard_normal(params_np[i].shape) * 0.05).astype(np.float32)
+    ref = torch_ref.RefTrainer(params_np, beta, dtype=torch.float64)
+    plan = ops.LGVaePlan(B, H, H, global_latent=Lg, local_latent=Ll, beta=beta, dtype=torch.float32)
+    P = flat_params(plan, params_np)
+    G = torch.zeros_like(P)
+    from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM
+    fwd_ref, loss_ref, g_ref = ref.grads(images.cpu().double(), eps_x, eps_h)
+    for _ in range(2):                                  # twice: the second call starts from the first one's host-side slab state
+        plan.step(PHASE_ALL & ~PHASE_ADAM, params=P, grads=G, images6=images, eps_x=torch.from_numpy(eps_x).cuda(), eps_x_hat=torch.from_numpy(eps_h).cuda(), t=1)
+        torch.cuda.synchronize()
+        got = {"z_x": plan.buffer("z_x", torch.float32, (B, Lg)), "z_mean_x": plan.buffer("z_mean_x", torch.float32, (B, Lg)),
+               "z_sig_x": plan.buffer("z_sig_x", torch.float32, (B, Lg)), "z_x_hat": plan.buffer("z_xh", torch.float32, (B, Ll)),
+               "z_mean_x_hat": plan.buffer("z_mean_xh", torch.float32, (B, Ll)), "z_sig_x_hat": plan.buffer("z_sig_xh", torch.float32, (B, Ll))}
+        for name, r in zip(NAMES10, fwd_ref):
+            if name in got:
+                torch.testing.assert_close(got[name].cpu().double(), r.detach(), rtol=1e-4, atol=1e-5, msg=lambda m: name + ": " + m)
+        losses = plan.buffer("losses", torch.float32, (8,)).cpu().double()
+        for i, k in enumerate(LOSS_KEYS):
+            assert abs(float(losses[i]) - float(loss_ref[k])) <= 1e-4 * abs(float(loss_ref[k])) + 1e-5, k
+        for (name, off, shape), gr, gg in zip(plan.param_table, g_ref, unflat(plan, G)):
+            tol = 2e-3 * float(gr.abs().max()) + 1e-7
+            dlt = (gg.double() - gr).abs()
+            err = float(dlt.max())
+            if err > tol:
+                # (96 images: decoder_x-hat's d4 output has two units whose fp64 pre-activations are 1.2e-7 and -2.4e-8 -- images 2 and 14 -- and the fp32 step takes the
+                #  other gate at both; scripts/f32_latent_probe.py prints them, scripts/f32_gateflip_probe.py shows the gradients they reach: 13 of e1's 3456 kernel
+                #  elements leave the 2e-3 band, relative L2 2.6e-3)
+                frac, rel = float((dlt > tol).double().mean()), float(dlt.norm() / gr.norm().clamp_min(1e-30))
+                assert frac <= 1e-2 and rel <= 5e-3, "grad %s: err %g tol %g (%.2e of the elements, relative L2 %.2e)" % (name, err, tol, frac, rel)
+
+
 def test_step_bf16_close_to_oracle(ops):
     """bf16 MFMA path (config 2's compute type): operands rounded to 8 significant bits, fp32
     accumulate, fp32 ELBO/KL/Adam.  Stated tolerance vs the fp64 oracle at B=8:
