@@ -7,7 +7,7 @@ from oracle import np_ref, torch_ref as R
 from split_vae_amd import ops
 from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-H, patch, beta, L = 32, 1, 40.0, 128
+H, patch, beta, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), (int(sys.argv[3]) if len(sys.argv) > 3 else 1), 40.0, 128
 rng0 = np.random.Generator(np.random.PCG64(5))
 x = (rng0.integers(0, 256, size=(B, H, H, 3)) / 255.0 * 2 - 1).astype(np.float32)
 perm = np.stack([np.random.Generator(np.random.PCG64(6 + b)).permutation((H // patch) ** 2) for b in range(B)]).astype(np.int32)
@@ -49,7 +49,7 @@ def cmp(tag, got, ref):
     rows = sorted(set(bad.nonzero()[:, 0].tolist()))[:16] if bad.any() else []
     print("  %-10s %.3e  bad %d  rows %s" % (tag, float(d.max()) / m, int(bad.sum()), rows))
 for sfx in ("x", "xh"):
-    cmp("ga3_" + sfx, plan.buffer("ga3_" + sfx, torch.float32, (B, 4, 4, 128)).cpu().double(), keep["a3_" + sfx].grad * (keep["a3_" + sfx] > 0))
+    cmp("ga3_" + sfx, plan.buffer("ga3_" + sfx, torch.float32, (B, H // 8, H // 8, 128)).cpu().double(), keep["a3_" + sfx].grad * (keep["a3_" + sfx] > 0))
     gh = plan.buffer("ghead_" + sfx, torch.float32, (B, 256)).cpu().double()
     cmp("ghead.m_" + sfx, gh[:, :128], keep["zm_" + sfx].grad)
 gz_x = plan.buffer("gz_x", torch.float32, (B, 256)).cpu().double(); gz_xh = plan.buffer("gz_xh", torch.float32, (B, 128)).cpu().double()
@@ -69,9 +69,32 @@ def dec_pre(z, pp):
 with torch.no_grad():
     for tag, z, pp, sfx in (("x", torch.cat([zx, zh], 1), p[20:30], "x"), ("x_hat", zh, p[30:40], "xh")):
         pres = dec_pre(z.detach(), [q.detach() for q in pp])
-        for name, pre, shp in zip(("h1_", "h2_", "h3_", "h4_"), pres, ((B, 4, 4, 128), (B, 4, 4, 128), (B, 8, 8, 64), (B, 16, 16, 32))):
+        for name, pre, shp in zip(("h1_", "h2_", "h3_", "h4_"), pres, ((B, H // 8, H // 8, 128), (B, H // 8, H // 8, 128), (B, H // 4, H // 4, 64), (B, H // 2, H // 2, 32))):
             got = plan.buffer(name + sfx, torch.float32, shp).cpu().double()
             mism = (got > 0) != (pre > 0)
             idx = mism.nonzero()
             print("  decoder_%s %s: %d gate mismatches %s" % (tag, name, int(mism.sum()),
                   [(int(i[0]), "pre64 %.2e" % float(pre[tuple(i)]), "dev %.2e" % float(got[tuple(i)])) for i in idx[:6]]))
+
+# ---- the encoders: ReLU gates against fp64 pre-activations, and each input gradient against an fp64 recomputation from the plan's own upstream buffers
+print("== encoders: gates, then ga2 / ga1 recomputed in fp64 from the device's ga3 / ga2 (max |got - ref| / max |ref|, elements beyond 1e-4)")
+with torch.no_grad():
+    P64 = {name: torch.from_numpy(q).double() for (name, off, shape), q in zip(plan.param_table, params_np)}
+for net, sfx, ch0 in (("encoder_x", "x", 0), ("encoder_x_hat", "xh", 3)):
+    xin = im[..., ch0:ch0 + 3]
+    shp = {"a1_": (B, H // 2, H // 2, 32), "a2_": (B, H // 4, H // 4, 64), "a3_": (B, H // 8, H // 8, 128)}
+    dev = {k: plan.buffer(k + sfx, torch.float32, v).cpu().double() for k, v in shp.items()}
+    pre1 = R.conv2d_same(xin, P64[net + "/e1/kernel"], P64[net + "/e1/bias"], 2, None)
+    pre2 = R.conv2d_same(F.relu(pre1), P64[net + "/e2/kernel"], P64[net + "/e2/bias"], 2, None)
+    pre3 = R.conv2d_same(F.relu(pre2), P64[net + "/e3/kernel"], P64[net + "/e3/bias"], 2, None)
+    for k, pre in (("a1_", pre1), ("a2_", pre2), ("a3_", pre3)):
+        mism = (dev[k] > 0) != (pre > 0)
+        idx = mism.nonzero()
+        print("  %s %s: %d gate mismatches %s" % (net, k, int(mism.sum()), [(int(i[0]), "pre64 %.2e" % float(pre[tuple(i)]), "dev %.2e" % float(dev[k][tuple(i)])) for i in idx[:4]]))
+    ga3 = plan.buffer("ga3_" + sfx, torch.float32, shp["a3_"]).cpu().double()
+    a2v = dev["a2_"].clone().requires_grad_(True)
+    (g2,) = torch.autograd.grad((R.conv2d_same(a2v, P64[net + "/e3/kernel"], P64[net + "/e3/bias"], 2, None) * ga3).sum(), a2v)
+    ga2 = plan.buffer("ga2_" + sfx, torch.float32, shp["a2_"]).cpu().double(); cmp(sfx + " ga2", ga2, g2 * (dev["a2_"] > 0))
+    a1v = dev["a1_"].clone().requires_grad_(True)
+    (g1,) = torch.autograd.grad((R.conv2d_same(a1v, P64[net + "/e2/kernel"], P64[net + "/e2/bias"], 2, None) * ga2).sum(), a1v)
+    ga1 = plan.buffer("ga1_" + sfx, torch.float32, shp["a1_"]).cpu().double(); cmp(sfx + " ga1", ga1, g1 * (dev["a1_"] > 0))
