@@ -508,7 +508,22 @@ static int launch_tile(const TileConvArgs* a, int n, hipStream_t st) {
 // Plans the tiling for a tap-GEMM problem; returns false when the problem does not fit the
 // direct kernel (dense layers, huge channel counts, K-split needed) and the caller should use
 // the im2col kernel instead.
+static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out, bool narrow, int64_t* lds_out);
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out) {
+  int64_t lds = 0;
+  if (!tile_conv_plan_impl(t, dtype, B, a, cfg_out, false, &lds)) return false;
+  // fp32: a 128-column tile that leaves ONE workgroup per CU (> 78 KB of LDS: e3's stride-2 forward, 2 x 18 x 18 padded pixels + 32 KB of weight slots) runs on
+  // 64-column tiles if those fit twice -- nothing overlaps a lone workgroup's staging and epilogue (fwd.e3 0.201 -> 0.181 ms at 2 x 512 images; SV_TC_NO_LDS_NARROW=1: off)
+  static const bool no_narrow = getenv("SV_TC_NO_LDS_NARROW") != nullptr;
+  if (!no_narrow && dtype == SV_F32 && t.N % 128 == 0 && !t.cls_n && lds > 78 * 1024) {
+    TileConvArgs b;
+    int c = 0;
+    int64_t l2 = 0;
+    if (tile_conv_plan_impl(t, dtype, B, &b, &c, true, &l2) && l2 <= 78 * 1024) { *a = b; *cfg_out = c; }
+  }
+  return true;
+}
+static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out, bool narrow, int64_t* lds_out) {
   if (t.splitk != 1 || t.accum) return false;   // (accumulating fp32 targets: the im2col kernel's epilogue adds)
   if (t.lOY < 0 || t.lOX < 0 || t.S > 2) return false;    // power-of-two grids, stride <= 2 (the tile maps shift and mask)
   const int OY = 1 << t.lOY, OX = 1 << t.lOX;
@@ -536,7 +551,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
   const int64_t wgs128 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 128);
   // (fp32 too since round 5: at 64 images per network d2 / e3 -- 8 x 8 grids, 128 columns -- ran 64 workgroups on 256 CUs, 14 % of the fp32 matrix peak; SV_TC_SMALL_F32=0: off)
   static const bool small_f32 = !(getenv("SV_TC_SMALL_F32") && atoi(getenv("SV_TC_SMALL_F32")) == 0);
-  const bool small = t.N % 128 == 0 && wgs128 < small_wgs && (dtype == SV_BF16 || small_f32) && !t.cls_n;
+  const bool small = t.N % 128 == 0 && (wgs128 < small_wgs || narrow) && (dtype == SV_BF16 || small_f32) && !t.cls_n;
   static const int tiny_wgs = getenv("SV_TC_TINY_WGS") ? atoi(getenv("SV_TC_TINY_WGS")) : 100;   // ... and on 32-column tiles below this (64-image shards: -1.3 .. -1.9 %)
   const bool tiny = small && wgs128 < tiny_wgs;
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
@@ -635,6 +650,7 @@ bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a,
     //  of one tile's staging with another's MFMAs; SV_TC_S2_MF4=1: the 256-row tile for A/B)
     static const bool s2_mf4 = getenv("SV_TC_S2_MF4") != nullptr;
     if (lds > 78 * 1024 && MF == 4 && t.S == 2 && t.fix_nc && !s2_mf4) continue;
+    *lds_out = lds;
     if (lds > 150 * 1024) {
       if (MF == 4) continue;
       if (getenv("SV_TC_VERBOSE")) fprintf(stderr, "tile_conv plan: REFUSED (LDS %lld) N=%d cin=%d S=%d ntaps=%d\n", (long long)lds, t.N, cin, t.S, t.ntaps);
