@@ -21,3 +21,9 @@ template <> struct FixMma<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
   }
 };
+
+// hipcc 7.2 pads the wait states between an MFMA and a read of its result inside a basic block (10 for the 8-pass v_mfma_f32_16x16x4_f32, 6 for 16x16x32_bf16) but lost them across
+// the s_branch that leaves a loop / branch around an MFMA chain (polyd_dgrad.hip: `ds_write_b128 v, a[0:3]` two instructions behind the last v_mfma; the -O1 build of the corner
+// kernel: v_accvgpr_read one instruction behind it).  Kernels whose accumulator leaves such a region and is consumed at once spell the wait states out on the accumulator itself:
+// a read-write operand in its AGPRs, so every later use depends on the asm and the asm on the last MFMA.  scripts/mfma_hazard_scan.py + tests/test_mfma_hazards.py check the assembly.
+__device__ __forceinline__ void mfma_result_fence(f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 7" : "+a"(acc)); }

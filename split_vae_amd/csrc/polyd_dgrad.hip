@@ -85,12 +85,7 @@ __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg
         for (int d = 0; d < NT; ++d)
 #pragma unroll
           for (int gq = 0; gq < NGRP; ++gq) FixMma<T>::run(wv[d][gq], *(const uint4*)(sp + d * PSB + gq * (CPG * (int)sizeof(T))), acc);
-        // HAZARD (found round 5, scripts/mfma_hazard_scan.py): hipcc 7.2 reads the accumulator -- `ds_write_b128 v, a[0:3]`, or v_accvgpr_read -- in the block this
-        // MFMA chain BRANCHES to, two instructions behind the last v_mfma that writes a[0:3]; an XDL result needs 10 wait states (8-pass MFMA) before an LDS / VALU
-        // read and the compiler's hazard pass did not carry them across the s_branch.  Builds whose code alignment differed returned a stale third accumulator
-        // component, differently from run to run.  The wait states are spelled out here, on the accumulator itself (read-write operand in its AGPRs: every later
-        // use depends on the asm, and the asm on the last MFMA).
-        asm volatile("s_nop 7\n\ts_nop 7" : "+a"(acc));
+        mfma_result_fence(acc);                                  // (fix_mma.hip.h: the store below sat two instructions behind the last v_mfma, across an s_branch)
       }
       *(float4*)(sRed + ((wave * npf + pf) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
@@ -137,6 +132,7 @@ __global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti 
         FixMma<T>::run(av, bv, acc);                                            // D rows = channels 4 lg .., columns = images
       }
     }
+  mfma_result_fence(acc);                                        // (fix_mma.hip.h: at -O1 the accumulator was read one instruction behind the loop's last v_mfma)
   if (!bok) return;
   float4* p = (float4*)(mg.erow[blockIdx.z] + (((int64_t)b * 2 + cr) * w + (cc ? w - 1 : 0)) * Cin + cif * 16 + lg * 4);
   float4 v = *p;
