@@ -342,7 +342,7 @@ int sv_gm_param_info(const sv_gm_desc* d, int32_t index, int64_t* offset, int32_
 int sv_gm_encoder_create(const sv_gm_desc* d, sv_gm_encoder** enc);
 void sv_gm_encoder_destroy(sv_gm_encoder* enc);
 int64_t sv_gm_encoder_workspace_bytes(const sv_gm_encoder* enc);
-int sv_gm_encoder_bind(sv_gm_encoder* enc, void* workspace, int64_t bytes, void* stream);
+int sv_gm_encoder_bind(sv_gm_encoder* enc, void* workspace, int64_t bytes, void* stream);   /* zero-fills the workspace, uploads the job table (as sv_lgvae_plan_bind) */
 /* named activation / gradient buffers inside the workspace (z, zm, zs, pm, ps, y, logits, kl2, ykl, keep1, ...) */
 int sv_gm_encoder_buffer(const sv_gm_encoder* enc, const char* name, int64_t* offset, int64_t* bytes);
 /* fp32 masters -> MFMA-ready weight images of the twelve layers (after every parameter update) */
@@ -378,7 +378,8 @@ int sv_lgvae_param_info(const sv_lgvae_desc* d, int32_t index, int64_t* offset, 
 int sv_lgvae_plan_create(const sv_lgvae_desc* d, sv_lgvae_plan** plan);
 void sv_lgvae_plan_destroy(sv_lgvae_plan* plan);
 int64_t sv_lgvae_workspace_bytes(const sv_lgvae_plan* plan);
-/* carve the caller-owned workspace; uploads the (tiny) weight-prep job table on `stream`. */
+/* carve the caller-owned workspace: ZERO-FILLS it (pad channels / rows that no kernel writes are read as zeros; a few accumulators count up from zero) and uploads the
+ * (tiny) weight-prep job table, both on `stream`; returns after the upload has finished.  The workspace must not be written by anything else while the plan is bound. */
 int sv_lgvae_plan_bind(sv_lgvae_plan* plan, void* workspace, int64_t bytes, void* stream);
 /* byte offset/size of a named workspace buffer (for zero-copy views of outputs); <0 if unknown */
 int sv_lgvae_buffer(const sv_lgvae_plan* plan, const char* name, int64_t* offset, int64_t* bytes);

@@ -220,6 +220,7 @@ extern "C" int sv_gm_encoder_bind(sv_gm_encoder* e, void* workspace, int64_t byt
   if ((uintptr_t)workspace & 255) return SV_E_BADARG;
   e->ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, (size_t)e->ws_bytes, st) != hipSuccess) return (int)hipGetLastError();     // pad channels and accumulation targets start from zero (as sv_lgvae_plan_bind)
   if (hipMemcpyAsync(e->bp("jobs"), e->jobs.data(), e->jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st) != hipSuccess)
     return (int)hipGetLastError();
   if (hipStreamSynchronize(st) != hipSuccess) return (int)hipGetLastError();   // the host vector may go away

@@ -1353,13 +1353,12 @@ extern "C" int sv_lgvae_plan_bind(sv_lgvae_plan* p, void* workspace, int64_t byt
   if ((uintptr_t)workspace & 255) return SV_E_BADARG;
   p->ws = (char*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemcpyAsync(p->bp("jobs"), p->jobs.data(), p->jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st);
+  // The whole workspace starts from ZERO: pad channels / pad rows of the activation, gradient and weight-image buffers that no kernel ever writes are read as
+  // zeros by the MFMA kernels, and a few accumulators (metric_acc, the polyphase head's dbias') count up from zero.  The Python mirror used to hand in a zeroed
+  // tensor; a C caller's hipMalloc'd block is garbage (scripts/ws_poison_probe.py: with 0xFF bytes every loss was NaN), so the bind does it itself.
+  hipError_t e = hipMemsetAsync(workspace, 0, (size_t)p->ws_bytes, st);
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(p->bp("metric_acc"), 0, 32, st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(p->bp("polyw_x"), 0, (size_t)p->bbytes("polyw_x"), st);   // dbias' accumulates from zero
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(p->bp("polyw_xh"), 0, (size_t)p->bbytes("polyw_xh"), st);
+  e = hipMemcpyAsync(p->bp("jobs"), p->jobs.data(), p->jobs.size() * sizeof(PrepJob), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
   e = hipStreamSynchronize(st);   // the job table lives in plan-owned host memory: finish the copy now
   if (e != hipSuccess) return (int)e;
