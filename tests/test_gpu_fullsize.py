@@ -277,3 +277,14 @@ def test_celeba128_step_at_a_polyphase_sized_launch(ops):
         a, b = G16[off:off + n].double(), G32[off:off + n].double()
         nb = float(b.norm())
         assert float((a - b).norm()) <= 8e-2 * nb + 1e-8, name
+
+
+def test_large_batches_against_their_quarters(lib_built):
+    """32-bit offsets: a 2048-image fp32 and a 4096-image bf16 gradient evaluation (activation tensors past 2^31 bytes / 2^30 elements) against the 512-image quarters of the
+    same global batch -- per-image ELBO terms to 2e-4, the gradient to 2e-3 of its norm (scripts/big_batch_probe.py; measured 2e-7 / 2e-6)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "big_batch_probe.py")], capture_output=True, text=True, cwd=root, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if " B=" in l]
+    assert r.returncode == 0 and len(lines) == 10 and all(l.endswith("ok") for l in lines), r.stdout[-2000:] + r.stderr[-1000:]
