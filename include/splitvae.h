@@ -209,7 +209,11 @@ int sv_conv2d_nhwc_fwd(const sv_conv_desc* d, const void* x, const void* w_fwd, 
  * (UpSampling2D(bilinear) -> Conv2D(6, 6x6, 'same'), vae/model.py:163-167 + d5) runs in POLYPHASE form: one 5x5 conv over
  * the low-res tensor whose four output parities are four column classes, plus 1-D border terms for the taps that leave the
  * zero-padded hi-res image; with a workspace those terms are computed first and added by the conv's epilogue, without one
- * they are added to y with atomics afterwards (same result, slower). */
+ * they are added to y with atomics afterwards (same result, slower).  The fp32 upsample -> 6 x 6 conv layers with 32 output channels (d4) run per output-parity
+ * class over the low-res tensor and need the workspace for their border terms; WITHOUT one the call runs the direct fused-resize form on a second
+ * weight image that sv_conv2d_prep_weights keeps behind the class images (sv_conv2d_wprep_elems counts it) -- same result to fp32 rounding, 1.4x the time.
+ * Form selection is a pure function of the descriptor (and of the SV_NO_POLY* / SV_POLYC_K tuning variables, which must not change between
+ * sv_conv2d_prep_weights and the calls that consume its images). */
 int64_t sv_conv2d_fwd_workspace_bytes(const sv_conv_desc* d);
 int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const void* w_fwd, const float* bias, void* y,
                           void* workspace, int64_t workspace_bytes, void* stream);
@@ -436,8 +440,17 @@ int sv_lgvae_step(sv_lgvae_plan* plan, const sv_lgvae_step_args* a, void* stream
 int sv_lgvae_graph_enable(sv_lgvae_plan* plan, int32_t enable);
 /* Make `stream` wait (hipStreamWaitEvent, no host sync) until gradient bucket `bucket` of the most recent sv_lgvae_step call that carried
  * SV_PHASE_BUCKET_EVENTS is complete: 0 decoders, 1 encoder heads, 2 encoder convs, 3 = 1 and 2 (the whole encoders' range).  The gradient
- * all-reduce of that bucket (RCCL over xGMI) is then enqueued on `stream`.  SV_E_STATE: no such events were recorded. */
+ * all-reduce of that bucket (RCCL over xGMI) is then enqueued on `stream`.  SV_E_STATE: no such events were recorded.
+ * Every call that runs a backward phase invalidates the events of the steps before it; a captured (hipGraph) step records none -- callers then order the
+ * collective behind the compute stream instead (split_vae_amd/trainer.py falls back to one all-reduce after the backward).  Weight-gradient slab reduces
+ * are never deferred past the events of a call that records them (SV_DEFER_REDUCE is ignored for that call). */
 int sv_lgvae_bucket_wait(sv_lgvae_plan* plan, int32_t bucket, void* stream);
+/* Test hooks of ONE plan (tests/test_gpu_dist.py); an explicit call, never an environment variable, so nothing a training job inherits can switch them on:
+ *   "side_delay_us" = n    the first weight-gradient side-stream launch of every step is held back n microseconds (a consumer that misses the side
+ *                          stream's part of a bucket then reads gradients that do not exist yet);
+ *   "bucket_skip_side" = 1 sv_lgvae_bucket_wait drops the side streams' events (the negative control of the dependency test).
+ * SV_E_BADARG: unknown key / value out of range. */
+int sv_lgvae_plan_debug(sv_lgvae_plan* plan, const char* key, int64_t value);
 /* number of captured (instantiated) step graphs, or a negative SV_E_* */
 int sv_lgvae_graph_count(const sv_lgvae_plan* plan);
 

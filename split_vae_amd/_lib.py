@@ -185,6 +185,7 @@ SYMBOLS = {
     "sv_lgvae_step": (C.c_int, [_vp, C.POINTER(StepArgs), _vp]),
     "sv_lgvae_graph_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_bucket_wait": (C.c_int, [_vp, _i32, _vp]),
+    "sv_lgvae_plan_debug": (C.c_int, [_vp, C.c_char_p, _i64]),
     "sv_lgvae_graph_count": (C.c_int, [_vp]),
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),

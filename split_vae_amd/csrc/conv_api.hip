@@ -641,12 +641,18 @@ void svg_prep_job_dgrad(const sv_conv_desc* d, int cls, PrepJob* j) {
   j->nblocks = svg_prep_nblocks(j);
 }
 
+// stand-alone forward image of a per-class polyphase layer: the four class images, the border-class image, and -- 128-element aligned behind them -- the DIRECT
+// (fused-resize) image, which the forward falls back to when the caller brings no workspace for the border terms (the plan's arena keeps the class images only)
+static int64_t svg_polyc_direct_off(const sv_conv_desc* d) {
+  int64_t n = svg_polyc_fix_elems(d);
+  for (int c = 0; c < 4; ++c) n += svg_polyc_class_elems(d, c);
+  return (n + 127) / 128 * 128;
+}
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls) {
   PrepJob j;
-  if (!for_dgrad && svg_polyc(d)) {          // the four class images, then the border-class image
-    int64_t n = svg_polyc_fix_elems(d);
-    for (int c = 0; c < 4; ++c) n += svg_polyc_class_elems(d, c);
-    return n;
+  if (!for_dgrad && svg_polyc(d)) {
+    svg_prep_job_fwd(d, &j);
+    return svg_polyc_direct_off(d) + (int64_t)j.rows * j.ntaps * j.inner;
   }
   if (for_dgrad) svg_prep_job_dgrad(d, cls, &j); else svg_prep_job_fwd(d, &j);
   return (int64_t)j.rows * j.ntaps * j.inner + (!for_dgrad && svg_poly(d) ? SV_POLY_FIX_ELEMS(svg_cin_pad(d)) : 0);
@@ -686,6 +692,10 @@ extern "C" int sv_conv2d_prep_weights(const sv_conv_desc* d, const float* w_hwio
     }
     svg_prep_job_polyc_fix(d, &j);
     j.dst_off = off;
+    rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
+    if (rc) return rc;
+    svg_prep_job_fwd(d, &j);                             // the direct image (no-workspace forward)
+    j.dst_off = svg_polyc_direct_off(d);
     rc = prep_single(w_hwio, w_fwd, d->dtype, j, st);
     if (rc) return rc;
   } else if (w_fwd) {
@@ -778,13 +788,14 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
   int rc = svg_check(d);
   if (rc != SV_OK) return rc;
   if (!x || !w_fwd || !y) return SV_E_BADARG;
-  if (svg_polyc(d)) {
-    if (!ws || ws_bytes < svg_polyc_fix_ws_bytes(d)) return SV_E_WORKSPACE;    // the border terms travel through the workspace
+  const bool polyc = svg_polyc(d);
+  if (polyc && ws && ws_bytes >= svg_polyc_fix_ws_bytes(d))                    // the border terms travel through the workspace
     return svk_polyc_fwd_multi(d, 1, &x, &w_fwd, &bias, &y, &ws, (hipStream_t)stream);
-  }
   TapGemmArgs a;
   svg_fwd_args(d, &a);
   a.A = x; a.Wt = w_fwd; a.bias = bias; a.out = y;
+  // (per-class polyphase layer without a workspace: the direct fused-resize form on the direct image sv_conv2d_prep_weights keeps behind the class images)
+  if (polyc) a.Wt = (const char*)w_fwd + svg_polyc_direct_off(d) * (int64_t)(d->dtype == SV_BF16 ? 2 : 4);
   if (!svg_poly(d)) {
     // dense layers (1x1 on a 1x1 grid) with an fp32 pre-activation output: a [B, Cin] x [Cin, Cout] GEMM whose tile grid is a
     // handful of workgroups (SPLIT-GMVAE's y_block / prior / posterior layers, vae/model.py:54-75) -- split K into the zeroed output

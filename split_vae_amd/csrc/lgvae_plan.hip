@@ -17,13 +17,14 @@
 #include "kernels.h"
 #include "conv_geom.h"
 
+namespace {
+
+// test hook only (sv_lgvae_plan_debug "side_delay_us"): holds a stream back for a while
 __global__ void sv_plan_spin_kernel(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 static void sv_plan_spin(hipStream_t st, int us) { hipLaunchKernelGGL(sv_plan_spin_kernel, dim3(1), dim3(64), 0, st, (long long)us * 100); }   // wall_clock64: 100 MHz
-
-namespace {
 
 struct Buf { std::string name; int64_t off, bytes; };
 
@@ -157,11 +158,9 @@ struct sv_lgvae_plan {
     if (order && order[0]) { const int c = order[side_count % (int)strlen(order)] - '0'; if (c >= 0 && c < use) slot = c; }
     ++side_count;
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
-    {   // TEST KNOB (tests/test_gpu_dist.py): hold the side stream back at its first use of a step, so that a consumer of the gradients that does
-        // not wait for the side stream's part (a missing bucket dependency) reads them before they exist
-      static const int delay_us = getenv("SV_TEST_SIDE_DELAY_US") ? atoi(getenv("SV_TEST_SIDE_DELAY_US")) : 0;
-      if (delay_us > 0 && side_count == 1) sv_plan_spin(side[slot], delay_us);
-    }
+    // test hook (sv_lgvae_plan_debug "side_delay_us", tests/test_gpu_dist.py): hold the side stream back at its first use of a step, so that a consumer
+    // of the gradients that does not wait for the side stream's part (a missing bucket dependency) reads them before they exist
+    if (dbg_side_delay_us > 0 && side_count == 1) sv_plan_spin(side[slot], dbg_side_delay_us);
     side_next = slot + 1;
     side_slot = slot;
     side_pending = true;
@@ -176,9 +175,17 @@ struct sv_lgvae_plan {
       if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return (int)hipGetLastError();
     return SV_OK;
   }
+  // per-plan test hooks (sv_lgvae_plan_debug): never read from the environment, so nothing a job inherits can switch them on
+  int dbg_side_delay_us = 0;
+  bool dbg_bucket_skip_side = false;
   // gradient-bucket events (SV_PHASE_BUCKET_EVENTS): [bucket][0 = compute stream, 1 + i = side stream i]
   hipEvent_t ev_bucket[3][1 + SIDE_MAX] = {};
   bool bucket_rec[3][1 + SIDE_MAX] = {};
+  bool buckets_now = false;   // the running call records bucket events: weight-gradient reduces must not be deferred past them
+  void clear_buckets() {
+    for (auto& row : bucket_rec)
+      for (auto& b : row) b = false;
+  }
   int record_bucket(int k, hipStream_t st) {
     for (int i = 0; i <= SIDE_MAX; ++i) bucket_rec[k][i] = false;
     for (int i = 0; i <= nside; ++i) {                    // every stream that may hold work of this bucket, in its own order
@@ -803,7 +810,8 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
   static const char* slots[7] = {"e1", "e2", "e3", "d2", "d3", "d4", "d5"};
   int slot = -1;
   for (int k = 0; k < 7; ++k) if (ln == slots[k]) slot = k;
-  const bool defer = !no_defer && slot >= 0 && L[0]->d.dtype == SV_BF16 && n <= SV_WGRAD_MAX_MULTI;
+  // (not while gradient-bucket events are recorded: a deferred reduce writes dW / dbias AFTER the events the all-reduce waits on)
+  const bool defer = !no_defer && !p->buckets_now && slot >= 0 && L[0]->d.dtype == SV_BF16 && n <= SV_WGRAD_MAX_MULTI;
   for (int i = 0; i < n; ++i) {
     svg_wgrad_args(&L[i]->d, &a[i]);
     a[i].A = x[i]; a[i].dY = dy[i];
@@ -1403,6 +1411,10 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
     SV_TRY(phase_loss(p, s, s->grads != nullptr, st));
   }
   const bool buckets = (ph & SV_PHASE_BUCKET_EVENTS) && !p->graph_on && !p->dyn;      // (not in captured steps: the events belong to eager launches)
+  // a backward phase invalidates the events of every earlier step: sv_lgvae_bucket_wait must never succeed against events that belong to gradients
+  // of a previous step (it returns SV_E_STATE instead, and the trainer falls back to ordering the collective behind the compute stream)
+  if (ph & SV_PHASE_BACKWARD) p->clear_buckets();
+  p->buckets_now = buckets;
   if (ph & SV_PHASE_BWD_DECODERS) {
     SV_TRY(phase_bwd_decoders(p, s, st));
     if (buckets) SV_TRY(p->record_bucket(0, st));
@@ -1495,13 +1507,22 @@ extern "C" int sv_lgvae_bucket_wait(sv_lgvae_plan* p, int32_t bucket, void* stre
   for (int k = (bucket == 3 ? 1 : bucket); k <= (bucket == 3 ? 2 : bucket); ++k)
     for (int i = 0; i <= sv_lgvae_plan::SIDE_MAX; ++i)
       if (p->bucket_rec[k][i]) {
-        // TEST KNOB (negative control of tests/test_gpu_dist.py::test_buckets_wait_for_the_side_stream): drop the side streams' events
-        static const bool skip_side = getenv("SV_TEST_BUCKET_SKIP_SIDE") != nullptr;
-        if (skip_side && i > 0) continue;
+        // test hook (negative control of tests/test_gpu_dist.py::test_buckets_wait_for_the_side_stream): drop the side streams' events
+        if (p->dbg_bucket_skip_side && i > 0) continue;
         if (hipStreamWaitEvent((hipStream_t)stream, p->ev_bucket[k][i], 0) != hipSuccess) return (int)hipGetLastError();
         ++n;
       }
   return n ? SV_OK : SV_E_STATE;
+}
+
+// per-plan test hooks: "side_delay_us" (hold the first side-stream launch of every step back by that long), "bucket_skip_side" (sv_lgvae_bucket_wait
+// drops the side streams' events: the negative control of the bucket-dependency test).  Deliberately an explicit call on one plan, not an environment
+// variable: nothing a training job inherits can switch them on.
+extern "C" int sv_lgvae_plan_debug(sv_lgvae_plan* p, const char* key, int64_t value) {
+  if (!p || !key) return SV_E_BADARG;
+  if (!strcmp(key, "side_delay_us")) { if (value < 0 || value > 1000000) return SV_E_BADARG; p->dbg_side_delay_us = (int)value; return SV_OK; }
+  if (!strcmp(key, "bucket_skip_side")) { p->dbg_bucket_skip_side = value != 0; return SV_OK; }
+  return SV_E_BADARG;
 }
 
 extern "C" int sv_lgvae_graph_count(const sv_lgvae_plan* p) {

@@ -110,7 +110,7 @@ class NativeGradReducer:
             self._ranges[k] = ((C.c_int64 * n)(*[b for b, _ in spans]), (C.c_int64 * n)(*[e for _, e in spans]), n)
         self._dirty = False
         self.force = True
-        self.mode = os.environ.get("SV_DP_MODE", "events")              # 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
+        self.mode = os.environ.get("SV_DP_MODE", "auto")                # 'auto' (default: 'events' with peers, 'single' on one rank) | 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
 
     @property
     def grad_scale(self):
@@ -161,7 +161,7 @@ class GradReducer:
         self.group = group
         self.buckets = param_buckets(param_table, n_params)
         self._pending = []
-        self.mode = os.environ.get("SV_DP_MODE", "events")              # 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
+        self.mode = os.environ.get("SV_DP_MODE", "auto")                # 'auto' (default: 'events' with peers, 'single' on one rank) | 'events' (one backward call, buckets picked up by their events) | 'overlap' (phase split) | 'single'
 
     def launch_all(self, flat):
         """mode 'single': the whole flat buffer as one all-reduce."""

@@ -404,6 +404,7 @@ class LGVaePlan:
         # generation of the shared input buffers in8_x / in8_xh: bumped by every writer (a staged augmentation, the split / pad
         # pass of any step that runs the encoders' forward); a staged batch is only valid while its generation is the current one
         self.in8_gen = 0
+        self.graph_on = False
 
     def __del__(self):
         try:
@@ -437,9 +438,14 @@ class LGVaePlan:
         step that carried PHASE_BUCKET_EVENTS (sv_lgvae_bucket_wait)."""
         check(self.lib.sv_lgvae_bucket_wait(self.handle, int(bucket), C.c_void_p(stream.cuda_stream)), "sv_lgvae_bucket_wait")
 
+    def debug(self, key, value):
+        """Test hooks of this plan (include/splitvae.h: sv_lgvae_plan_debug)."""
+        check(self.lib.sv_lgvae_plan_debug(self.handle, key.encode(), int(value)), "sv_lgvae_plan_debug")
+
     def graph_enable(self, on=True):
         """hipGraph replay of `step` (include/splitvae.h: sv_lgvae_graph_enable); effective on a non-default stream."""
         check(self.lib.sv_lgvae_graph_enable(self.handle, 1 if on else 0), "sv_lgvae_graph_enable")
+        self.graph_on = bool(on)
 
     def graph_count(self):
         return int(self.lib.sv_lgvae_graph_count(self.handle))

@@ -95,7 +95,14 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
     if reducer is None or (reducer.world == 1 and not getattr(reducer, "force", False)):
         plan.step(PHASE_ALL | nr, **kw)
         return plan
-    if getattr(reducer, "mode", "overlap") == "single":
+    mode = getattr(reducer, "mode", "events")
+    if mode == "auto":
+        # one rank (SV_DIST_FORCE: the data-parallel path on a single device) has no link time to hide and one all-reduce is the cheapest hand-over
+        # (profiles/r05_dp_ab.txt); with real peers the decoders' 16.4 MB travel beside the encoders' backward
+        mode = "single" if reducer.world == 1 else "events"
+    if mode == "events" and getattr(plan, "graph_on", False):
+        mode = "single"          # captured steps record no bucket events (sv_lgvae_bucket_wait would return SV_E_STATE): one all-reduce behind the compute stream
+    if mode == "single":
         # one all-reduce of the whole gradient buffer between the backward and Adam: nothing overlaps, but there is one
         # cross-stream hand-over instead of four and the backward runs as in the single-GPU step
         plan.step((PHASE_ALL & ~PHASE_ADAM) | nr, **kw)
@@ -103,7 +110,7 @@ def train_step(model, images, optimizer, eps=None, reducer=None, sample_offset=0
         reducer.wait()
         plan.step(PHASE_ADAM, grad_scale=reducer.grad_scale, **kw)
         return plan
-    if getattr(reducer, "mode", "events") == "events":
+    if mode == "events":
         # data parallel, default: ONE call for forward + loss + the whole backward (the single-GPU stream placement: weight gradients on the side
         # stream(s) beside the input-gradient chain, no join between the decoders' and the encoders' backward); the library records an event set as each
         # gradient bucket completes and the all-reduces are ordered behind THOSE (sv_lgvae_bucket_wait), so the decoders' bucket travels while the

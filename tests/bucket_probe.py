@@ -24,6 +24,9 @@ def main():
     x = data.synthetic_images(B, H, H, seed=0, device="cuda")
     img = Augmentator("scramble", size=4, seed=1).augment(x)
     plan = model.plan(B)
+    # the plan's own test hooks (include/splitvae.h: sv_lgvae_plan_debug); the library itself reads no environment variable for them
+    plan.debug("side_delay_us", int(os.environ.get("SV_PYTEST_SIDE_DELAY_US", "0")))
+    plan.debug("bucket_skip_side", int(os.environ.get("SV_PYTEST_BUCKET_SKIP_SIDE", "0")))
     m, v = opt.slots(model.flat)
     buckets = svdist.param_buckets(model.param_table, model.n_params)
     names = {0: "decoders", 1: "enc_heads", 2: "enc_convs"}

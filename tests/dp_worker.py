@@ -29,6 +29,8 @@ def main():
     aug = Augmentator("scramble", size=patch, seed=1)
     x = data.synthetic_images(hi - lo, H, H, seed=0, device="cuda", sample_offset=lo)
     reducer = svdist.make_reducer(model.param_table, model.n_params) if (world > 1 or os.environ.get("SV_DIST_FORCE")) else None
+    if os.environ.get("SV_PYTEST_SIDE_DELAY_US"):       # the plan's own test hook (include/splitvae.h: sv_lgvae_plan_debug); the library reads no such variable
+        model.plan(hi - lo).debug("side_delay_us", int(os.environ["SV_PYTEST_SIDE_DELAY_US"]))
     losses = []
     for _ in range(steps):
         img = aug.augment(x, sample_offset=lo)

@@ -38,7 +38,7 @@ def _run(world, out, gb=32, steps=3, backend="gloo", force=False, config="svhn32
         elif buckets == 2:
             env["SV_DP_TWO_BUCKETS_MAX"] = "1024"
         if mode:
-            env["SV_DP_MODE"] = mode              # 'events' (default: one backward call + bucket events) | 'overlap' (the phase split of rounds 1-4) | 'single'
+            env["SV_DP_MODE"] = mode              # 'auto' (default: events with peers, single on one rank) | 'events' (one backward call + bucket events) | 'overlap' (the phase split of rounds 1-4) | 'single'
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, str(gb), str(steps), config],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -85,22 +85,22 @@ def _bucket_probe(extra_env):
 def test_buckets_wait_for_the_side_stream(lib_built):
     """The event path's dependency, made observable on ONE GPU (a world-1 all-reduce is the identity on a buffer that is final by the time anyone
     reads it, so the one-rank RCCL tests cannot see a missing dependency): the weight-gradient side stream is held back for 5 ms at its first use of
-    the step (SV_TEST_SIDE_DELAY_US), and a fresh stream ordered ONLY by sv_lgvae_bucket_wait snapshots each bucket's gradient range.  The snapshot
+    the step (SV_PYTEST_SIDE_DELAY_US), and a fresh stream ordered ONLY by sv_lgvae_bucket_wait snapshots each bucket's gradient range.  The snapshot
     must equal the final gradients bit for bit -- the stream waited for the side stream's part of the bucket -- and with the side streams' events
-    dropped on purpose (SV_TEST_BUCKET_SKIP_SIDE: negative control) the decoders' snapshot must NOT (measured: taken 1.2 ms into a 6.2 ms step, all of
+    dropped on purpose (SV_PYTEST_BUCKET_SKIP_SIDE: negative control) the decoders' snapshot must NOT (measured: taken 1.2 ms into a 6.2 ms step, all of
     the side stream's weight gradients missing): the probe can see the failure it guards against.  (The library's default of three hardware queues; a
     probe stream that happens to share a queue with the held-back side stream inherits its order, which is why only the first bucket is asserted on.)"""
-    knobs = {"SV_TEST_SIDE_DELAY_US": "5000"}
+    knobs = {"SV_PYTEST_SIDE_DELAY_US": "5000"}
     good = _bucket_probe(knobs)
     assert good == [0.0, 0.0, 0.0], good
-    bad = _bucket_probe(dict(knobs, SV_TEST_BUCKET_SKIP_SIDE="1"))
+    bad = _bucket_probe(dict(knobs, SV_PYTEST_BUCKET_SKIP_SIDE="1"))
     assert bad[0] > 0.1, bad
 
 
 def test_two_ranks_equal_one_with_a_late_side_stream(lib_built, tmp_path):
     """... and end to end: two ranks over gloo with the side stream held back, against the single-process step."""
     one = _run(1, str(tmp_path / "one.npz"), steps=1)
-    two = _run(2, str(tmp_path / "two.npz"), steps=1, mode="events", extra_env={"SV_TEST_SIDE_DELAY_US": "5000"})
+    two = _run(2, str(tmp_path / "two.npz"), steps=1, mode="events", extra_env={"SV_PYTEST_SIDE_DELAY_US": "5000"})
     g1, g2 = one["grads"], two["grads"] / 2.0
     assert np.linalg.norm(g1 - g2) <= 1e-2 * np.linalg.norm(g1)
 
