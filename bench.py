@@ -201,6 +201,7 @@ class Workload:
         if world > 1:
             tdist.barrier()
         dt = time.perf_counter() - t0
+        self.last_rank_dt = dt                       # this rank's own time (the reported one is the MAX over ranks)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
             tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
@@ -236,8 +237,12 @@ def grade(r, dtype):
     t_mfma = r["flops"] / (PEAK_TFLOPS[dtype] * 1e12) if r["flops"] else 0.0
     t_hbm = r["bytes"] / (PEAK_HBM_GBS * 1e9) if r["bytes"] else 0.0
     bound = "mfma" if t_mfma >= t_hbm and t_mfma > 0 else ("hbm" if t_hbm > 0 else "none")
+    iss = r.get("issued", r["flops"])
     return {"avg_ms": avg * 1e3, "tflops": r["flops"] / avg / 1e12 if r["flops"] else 0.0, "gbs": r["bytes"] / avg / 1e9 if r["bytes"] else 0.0,
-            "bound": bound, "frac": max(t_mfma, t_hbm) / avg if avg else 0.0}
+            "bound": bound, "frac": max(t_mfma, t_hbm) / avg if avg else 0.0,
+            # MFMA-bound rows: the same launch at the FLOPs its algorithm really multiplies (polyphase forms: < the direct count) = matrix-pipe utilisation
+            "tflops_issued": iss / avg / 1e12 if iss else 0.0,
+            "frac_issued": (iss / (PEAK_TFLOPS[dtype] * 1e12) / avg if (avg and bound == "mfma") else (max(t_mfma, t_hbm) / avg if avg else 0.0))}
 
 
 DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "wgrad.all.reduce", "upsample_bwd", "upsample_fwd")   # (the one slab reduce of ALL layers is booked here whole: conservative)   # d2..d5 convs + everything that exists only for them
@@ -246,17 +251,26 @@ DECODER_STACK = ("fwd.d", "dgrad.d", "wgrad.d", "wgrad.all.reduce", "upsample_bw
 def decoder_stack(table, dtype, passes):
     """FLOPs and time of both decoders' conv stacks (d2..d5: forward, input and weight gradients incl. their slab reduces,
     the bilinear-resize adjoints) from the serial per-launch table -- the sub-target north_star quotes against the MFMA peak."""
-    fl = ms = 0.0
+    fl = ms = iss = 0.0
     for r in table:
         n = r["name"]
         if not n.startswith(DECODER_STACK) or any(p.startswith("d1") for p in n.split(".")[1:]):
             continue
         ms += r["total_ms"] / passes
         fl += r["flops"] * r["launches"] / passes
+        iss += r.get("issued", r["flops"]) * r["launches"] / passes
     ach = fl / (ms * 1e-3) / 1e12 if ms else 0.0
-    return {"flops_per_step": fl, "ms_per_step": round(ms, 4), "achieved": round(ach, 1), "unit": "TFLOP/s",
-            "peak": PEAK_TFLOPS[dtype], "frac": round(ach / PEAK_TFLOPS[dtype], 4),
+    achi = iss / (ms * 1e-3) / 1e12 if ms else 0.0
+    return {"flops_per_step": fl, "issued_flops_per_step": iss, "ms_per_step": round(ms, 4), "achieved": round(ach, 1), "achieved_issued": round(achi, 1), "unit": "TFLOP/s",
+            "peak": PEAK_TFLOPS[dtype], "frac": round(ach / PEAK_TFLOPS[dtype], 4), "frac_issued": round(achi / PEAK_TFLOPS[dtype], 4),
             "scope": "d2-d5 of both decoders: fwd + dgrad + wgrad (+ slab reduce) + resize adjoint, serial launches"}
+
+
+def step_flops(table, passes):
+    """(direct, issued) FLOPs of one step summed over the serial per-launch table's scopes."""
+    fl = sum(r["flops"] * r["launches"] for r in table) / passes
+    iss = sum(r.get("issued", r["flops"]) * r["launches"] for r in table) / passes
+    return fl, iss
 
 
 # plan scope -> substrings of its HIP kernel symbol as rocprofv3 prints it (profiles/*_traffic.json keys)
@@ -355,9 +369,9 @@ def spair_row(dev, which="hard", B=32, steps=60, warmup=5):
     return out
 
 
-def gm_row(dev, B=64, steps=100, warmup=10):
+def gm_row(dev, B=64, steps=100, warmup=10, dtype="bf16"):
     """SPLIT-GMVAE (config 3, README.md:62: --model lggmvae --beta 40 --alpha 40 --y_size 30 --patch_size 4 on SVHN-32, batch 64 =
-    vae/main.py:23's default) train step: scramble + forward + losses + backward + Keras-Adam, bf16 contractions."""
+    vae/main.py:23's default) train step: scramble + forward + losses + backward + Keras-Adam; dtype f32 = the reference's precision, bf16 = bf16 contractions."""
     import torch
     from split_vae_amd import data
     from split_vae_amd.augmentation import Augmentator
@@ -365,7 +379,7 @@ def gm_row(dev, B=64, steps=100, warmup=10):
     from split_vae_amd.optimizer import Adam
     x = data.synthetic_images(B, 32, 32, seed=0, device=dev)
     aug = Augmentator("scramble", size=4, seed=1)
-    m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype="bf16", device=dev, seed=3)
+    m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype=dtype, device=dev, seed=3)
     m.beta, m.alpha = 40.0, 40.0
     opt = Adam(learning_rate=1e-4)
     for _ in range(warmup):
@@ -379,47 +393,59 @@ def gm_row(dev, B=64, steps=100, warmup=10):
     # 135.0 M forward MACs per image for the whole LGGMVae at SVHN-32 [derived]; train FLOP = 6 MACs_fwd - 4 MACs of the two first convs
     # (gmvae encoder 16 x 16 x 128 x 108 = 3.54 M, local encoder 0.88 M: no input gradient).  A 64-image step is launch-bound: the fraction says so.
     fl = 6 * 135.0e6 - 4 * (3.54e6 + 0.88e6)
-    return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "steps": steps, "batch": B, "dtype": "bf16",
-            "workload": "SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4",
-            "roofline": {"bound": "mfma", "flops_per_image": fl, "achieved": round(B / t * fl / 1e12, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                         "frac": round(B / t * fl / 1e12 / PEAK_TFLOPS["bf16"], 4),
+    return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "steps": steps, "batch": B, "dtype": dtype,
+            "workload": "BASELINE configs[2]: SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4" + (" at the reference's precision" if dtype == "f32" else ""),
+            "roofline": {"bound": "mfma", "flops_per_image": fl, "achieved": round(B / t * fl / 1e12, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": round(B / t * fl / 1e12 / PEAK_TFLOPS[dtype], 4),
                          "note": "64 images per step: ~100 launches of a few microseconds each; the step is launch- and latency-bound, not matrix-pipe-bound"}}
 
 
-def roofline_block(table, dom, worst, prof, dtype, B, world):
-    """The `roofline` object of one precision: the dominant kernel live (hipEvents on its stream inside the timed region) and serial, the decoder
-    conv stack, the worst large launch, the top-12 table and the HBM-bound entry."""
-    if not (prof and prof[0]["launches"]):
-        return None
-    avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
-    ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[dtype]
-    traffic, symbol, tfile = measured_traffic((SCOPE_KERNEL if dtype == "bf16" else SCOPE_KERNEL_F32).get(prof[0]["name"], []), dtype)
-    rl = {"bound": "mfma", "kernel": prof[0]["name"], "achieved": round(ach, 2), "peak": peak,
-          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-          "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                            "bench, bytes per launch; null when the kernel symbol of this build is not in it)" % os.path.basename(tfile),
-          "hip_kernel": symbol,
-          "avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"],
-          "flops_per_launch": prof[0]["flops"],
-          "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)" if prof[0]["name"].startswith("wgrad.") and
-                    prof[0]["name"].split(".")[1] not in wgrad_main_layers(2 * B, dtype, world) else
-                    "main (the weight-gradient side stream runs other layers' launches beside it)",
-          "live_note": "achieved / frac are LIVE: hipEvents around the scope on its stream inside the timed region, where up to three launches share the "
-                       "chip (two weight-gradient side streams beside the input-gradient chain: DESIGN.md section 5) -- the scope's wall time there counts "
-                       "what runs beside it; `serial` is the same scope alone on the chip, what the per-launch table and `decoder_stack` are built from",
-          "decoder_stack": decoder_stack(table, dtype, TABLE_PASSES)}
+def roofline_block(table, dom, worst, prof, dtype, B, world, step_ms=None, passes=TABLE_PASSES):
+    """The `roofline` object of one precision.  Top level = the dominant scope of the serial per-launch table ALONE ON THE CHIP (hipEvents on its launch
+    stream, measured by this process outside the timed region); flat scalars give serial scope / decoder stack / whole step against the MFMA peak at BOTH
+    FLOP counts -- `*_direct` (SURVEY 8d's count, 2 B OH OW Cout KH KW Cin: the polyphase forms multiply fewer, so a row may exceed 1) and `*_issued` (what
+    the chosen algorithm really multiplies: matrix-pipe utilisation).  `live` = the same scope inside the timed region, where up to three queues share the
+    chip (a co-scheduling figure, not a kernel figure)."""
     gs = grade(dom, dtype)
-    rl["serial"] = {"avg_launch_ms": round(gs["avg_ms"], 4), "achieved": round(gs["tflops"], 2), "frac": round(gs["frac"], 4),
-                    "note": "the same launch alone on the chip (per-launch table, side stream off)"}
+    peak = PEAK_TFLOPS[dtype]
+    traffic, symbol, tfile = measured_traffic((SCOPE_KERNEL if dtype == "bf16" else SCOPE_KERNEL_F32).get(dom["name"], []), dtype)
+    ds = decoder_stack(table, dtype, passes)
+    fl_step, iss_step = step_flops(table, passes)
+    rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(gs["tflops"], 2), "peak": peak, "unit": "TFLOP/s", "frac": round(gs["frac"], 4),
+          "traffic": traffic,
+          "traffic_source": "cached: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                            "bench, bytes per launch set; null when a kernel symbol of this build is not in it)" % os.path.basename(tfile),
+          "algorithmic_bytes": dom["bytes"],
+          "hip_kernel": symbol,
+          "avg_launch_ms": round(gs["avg_ms"], 4), "launches": dom["launches"], "flops_per_launch": dom["flops"], "issued_flops_per_launch": dom.get("issued", dom["flops"]),
+          "measured": "serial: the scope alone on the chip, hipEvents on its launch stream, this process (per-launch table passes outside the timed region)",
+          "serial_frac_direct": round(gs["frac"], 4), "serial_frac_issued": round(gs["frac_issued"], 4),
+          "decoder_stack_frac_direct": ds["frac"], "decoder_stack_frac_issued": ds["frac_issued"],
+          "count_note": "direct = SURVEY 8d's FLOP count of the layer as the reference computes it; issued = the FLOPs the chosen algorithm really multiplies on the "
+                        "matrix pipe (polyphase forms of the upsample->conv layers: 81 or 100 of 144 tap products per low-res pixel + border terms; include/splitvae.h: "
+                        "sv_lgvae_profile_read_issued) -- only the issued figure is a matrix-pipe utilisation",
+          "decoder_stack": ds}
+    if step_ms:
+        rl["step_frac_direct"] = round(fl_step / (step_ms * 1e-3) / 1e12 / peak, 4)
+        rl["step_frac_issued"] = round(iss_step / (step_ms * 1e-3) / 1e12 / peak, 4)
+        rl["step_flops_direct"], rl["step_flops_issued"] = fl_step, iss_step
+    if prof and prof[0]["launches"]:
+        avg_ms = prof[0]["total_ms"] / prof[0]["launches"]
+        ach = prof[0]["flops"] / (avg_ms * 1e-3) / 1e12
+        rl["live"] = {"avg_launch_ms": round(avg_ms, 4), "launches": prof[0]["launches"], "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                      "stream": "a weight-gradient side stream (co-runs with the input-gradient chain and, in whole steps at this size, a second side stream)"
+                                if dom["name"].startswith("wgrad.") and dom["name"].split(".")[1] not in wgrad_main_layers(2 * B, dtype, world) else
+                                "main (the weight-gradient side stream runs other layers' launches beside it)",
+                      "note": "hipEvents around the scope on its stream INSIDE the timed region, where up to three launches share the chip: the wall time counts what "
+                              "runs beside it -- a co-scheduling figure, not the kernel's"}
     if worst is not None:
         gw = grade(worst, dtype)
         rl["worst_large"] = {"kernel": worst["name"], "bound": gw["bound"], "avg_launch_ms": round(gw["avg_ms"], 4),
                              "achieved": round(gw["tflops"] if gw["bound"] == "mfma" else gw["gbs"], 2),
-                             "unit": "TFLOP/s" if gw["bound"] == "mfma" else "GB/s", "frac": round(gw["frac"], 4),
-                             "note": "the launch >= 0.1 ms with the lowest fraction of its roofline (serial table)"}
+                             "unit": "TFLOP/s" if gw["bound"] == "mfma" else "GB/s", "frac": round(gw["frac"], 4), "frac_issued": round(gw["frac_issued"], 4),
+                             "note": "the launch >= 0.1 ms with the lowest fraction of its roofline (serial table, direct count)"}
     rl["table"] = [{"kernel": r["name"], "ms": round(grade(r, dtype)["avg_ms"], 4), "bound": grade(r, dtype)["bound"],
-                    "frac": round(grade(r, dtype)["frac"], 4)} for r in table[:12]]
+                    "frac": round(grade(r, dtype)["frac"], 4), "frac_issued": round(grade(r, dtype)["frac_issued"], 4)} for r in table[:12]]
     # the HBM-bound entry: the ELBO kernel when the step runs it, else (training steps evaluate the loss in the decoder
     # head's epilogue) the Adam update -- 28 algorithmic bytes per parameter
     elbo = next((r for r in table if r["name"].startswith("dlogistic")), None) or \
@@ -447,8 +473,8 @@ def print_table(table, dtype, H, B):
     sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (dtype, H, H, B))
     for r in table:
         g = grade(r, dtype)
-        sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline\n" %
-                         (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"]))
+        sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline (direct count)  %5.1f%% issued\n" %
+                         (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"], 100 * g["frac_issued"]))
 
 
 DTYPE_NOTE = {"f32": "f32 operands, f32 accumulate (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the reference's precision (vae/model.py:12)",
@@ -477,7 +503,7 @@ def precision_block(dev, H, B, dtype, steps=40, warmup=5):
            "dtype": DTYPE_NOTE[dtype], "per_gpu_batch": B,
            "step_tflops": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12, 2),
            "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[dtype], 4),
-           "roofline": roofline_block(table, dom, worst, prof, dtype, B, 1)}
+           "roofline": roofline_block(table, dom, worst, prof, dtype, B, 1, step_ms=1e3 * dt / steps)}
     del w
     return out
 
@@ -570,6 +596,22 @@ def main():
                 w.reducer.wait()
             e1.record(); torch.cuda.synchronize()
             ar[name] = round(e0.elapsed_time(e1) / 5, 4)
+        # self-diagnosis of a multi-GPU run: every rank's own ms/step of the timed region, and the time the compute stream really waits for the
+        # collectives (hipEvent pair around reducer.wait(), 20 extra untimed steps): ~0 when the all-reduce hides behind the encoders' backward
+        if world > 1:
+            mine = torch.tensor([w.last_rank_dt / args.steps * 1e3], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            extra["per_rank_ms_per_step"] = [round(float(t_.item()), 4) for t_ in allr]
+        w.reducer.wait_events = []
+        for _ in range(20):
+            w.step()
+        torch.cuda.synchronize()
+        ev = w.reducer.wait_events
+        w.reducer.wait_events = None
+        if ev:
+            extra["exposed_allreduce_ms"] = round(sum(a_.elapsed_time(b_) for a_, b_ in ev) / len(ev), 4)
+        extra["dp_mode"] = getattr(w.reducer, "mode", None) if getattr(w.reducer, "mode", None) != "auto" else ("single" if world == 1 else "events")
         native = os.environ.get("SV_DIST_BACKEND") == "sv_comm"
         extra["rccl_ranks"] = world if (backend == "nccl" or native) else 0
         extra["dist_backend"] = "sv_comm (RCCL through the C ABI)" if native else backend
@@ -611,10 +653,11 @@ def main():
         rows["celeba64_b256_f32"] = row(64, 256, "f32", 60)
         rows["svhn32_b64"] = row(32, 64, "bf16", 200)          # config C1's shape on the GPU
         rows["svhn32_b64_f32"] = row(32, 64, "f32", 200, workload="BASELINE configs[0]'s shape (SVHN-32 beta=40 patch_size=1 bs64) at the reference's precision")
-        try:
-            rows["lggmvae_svhn32_b64"] = gm_row(dev)             # config 3 (SPLIT-GMVAE)
-        except Exception as e:
-            rows["lggmvae_svhn32_b64"] = {"error": repr(e)[:200]}
+        for key, dt_ in (("lggmvae_svhn32_b64", "bf16"), ("lggmvae_svhn32_b64_f32", "f32")):      # config 3 (SPLIT-GMVAE), both precisions
+            try:
+                rows[key] = gm_row(dev, dtype=dt_)
+            except Exception as e:
+                rows[key] = {"error": repr(e)[:200]}
         # config 4's per-GPU shards (global 512 over 8 / 4 GPUs), both precisions: what bounds strong scaling before any link time
         rows["celeba64_b64"] = row(64, 64, "bf16", 200)
         rows["celeba64_b128"] = row(64, 128, "bf16", 200)
@@ -642,6 +685,28 @@ def main():
             except Exception as e:
                 rows["dp_path_b64"][k] = {"error": repr(e)[:200]}
 
+        # a `--gpus 2`-shaped dry run on the ONE device: two rank processes over gloo sharing the GPU, global batch 512 = 256 images per rank, fp32.  Not a
+        # scaling number (the ranks take turns on one chip): it exercises the whole N > 1 host path -- process group, sharding, bucket events, all-reduce
+        # hand-over, 1/world in Adam -- so that a regression there shows in the driver's one-GPU line.  Reference for the ratio: two plain 256-image steps.
+        try:
+            port = _free_port()
+            procs = []
+            for r_ in range(2):
+                env = dict(os.environ, RANK=str(r_), LOCAL_RANK="0", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                           SV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpus", "2", "--dtype", "f32", "--steps", "40", "--warmup", "5",
+                                               "--no-rows", "--no-other-precision", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            outs = [p_.communicate(timeout=400)[0] for p_ in procs]
+            c = [json.loads(ln) for ln in outs[0].splitlines() if ln.startswith("{")][-1]
+            base = 2 * rows["celeba64_b256_f32"]["ms_per_step"]
+            rows["dp2_shared_gpu_b256_f32"] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "steps": c["steps"], "n_ranks": 2,
+                                               "backend": c.get("dist_backend"), "dp_mode": c.get("dp_mode"), "per_rank_ms_per_step": c.get("per_rank_ms_per_step"),
+                                               "exposed_allreduce_ms": c.get("exposed_allreduce_ms"),
+                                               "vs_two_plain_b256_steps": round(c["ms_per_step"] / base, 4),
+                                               "workload": "two ranks x 256 images (global 512) over gloo SHARING the one GPU: the N > 1 host path, not a scaling number"}
+        except Exception as e:
+            rows["dp2_shared_gpu_b256_f32"] = {"error": repr(e)[:200]}
+
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
@@ -666,10 +731,10 @@ def main():
         # untimed steps run before the clock starts: the W requested, the serial per-launch table passes, and the steady-state top-up
         "untimed_steps_before_timing": max(args.warmup, 1) + TABLE_PASSES + 1 + max(max(0, 30 - args.warmup), 1),
         "step_tflops": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12, 2),
-        "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[args.dtype] / world, 4),
+        "step_frac_of_peak": round(value * TRAIN_FLOP_PER_IMAGE[H] / 1e12 / PEAK_TFLOPS[args.dtype] / world, 4),     # direct FLOP count; issued: roofline.step_frac_issued
     }
     out.update(extra)
-    rl = roofline_block(table, dom, worst, prof, args.dtype, B, world)
+    rl = roofline_block(table, dom, worst, prof, args.dtype, B, world, step_ms=1e3 * dt / args.steps)
     if rl:
         out["roofline"] = rl
     if other is not None:

@@ -461,6 +461,11 @@ int sv_lgvae_profile_filter(sv_lgvae_plan* plan, const char* name);
 int sv_lgvae_profile_read(sv_lgvae_plan* plan, int32_t max_entries, char names[][64],
                           double* total_ms, int32_t* launches, double* flops_per_launch,
                           double* bytes_per_launch);
+/* FLOPs per launch the scope's algorithm really multiplies on the matrix pipe, entry i = entry i of sv_lgvae_profile_read.  flops_per_launch above is the DIRECT
+ * form's count (2 B OH OW Cout KH KW Cin: SURVEY 8d); the polyphase forms of the upsample -> conv layers multiply 81 (per-class forms, the
+ * stride-2 input gradient) or 100 (the head's merged 25-tap form) of the direct form's 144 tap products per low-res pixel, plus their border terms: a scope's
+ * rate against the MFMA peak is a utilisation figure only at THIS count.  Equal to flops_per_launch for every direct-form scope. */
+int sv_lgvae_profile_read_issued(sv_lgvae_plan* plan, int32_t max_entries, double* issued_flops_per_launch);
 
 /* ---------------------------------------------------------------- SPLIT-SPAIR: Dense layers, exact fp32 on the matrix cores
  * tf.keras.layers.Dense (spair/spair.py:135-154, :185-202, :246-273, :341-366, :424-467) for ANY fan-in / fan-out, reading the Keras

@@ -190,6 +190,7 @@ SYMBOLS = {
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),
     "sv_lgvae_profile_read": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sv_lgvae_profile_read_issued": (C.c_int, [_vp, _i32, _vp]),
 }
 
 _lib = None

@@ -254,16 +254,17 @@ __device__ __forceinline__ void prep_block(const PrepJob& j, const float* __rest
 
 template <typename T>
 __global__ __launch_bounds__(256) void prep_table_kernel(const float* __restrict__ params, T* __restrict__ arena,
-                                                         const PrepJob* __restrict__ jobs, int njobs) {
-  // binary search the job owning this block (first_block is ascending)
+                                                         const PrepJob* __restrict__ jobs, int njobs, int block0) {
+  // binary search the job owning this block (first_block is ascending); block0: the launch covers the table's blocks from there (a sub-range of the jobs)
+  const int blk = (int)blockIdx.x + block0;
   int lo = 0, hi = njobs - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (jobs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
   }
   const PrepJob& j = jobs[lo];   // by reference: uniform (scalar) loads, srctap[] indexed in memory
   // SV_PREP_UNITS units of 256 threads' work per block amortise the job lookup (dependent global loads)
-  for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, ((int)blockIdx.x - j.first_block) * SV_PREP_UNITS + u);
+  for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, (blk - j.first_block) * SV_PREP_UNITS + u);
 }
 
 template <typename T>
@@ -272,14 +273,16 @@ __global__ __launch_bounds__(256) void prep_single_kernel(const float* __restric
   for (int u = 0; u < SV_PREP_UNITS; ++u) prep_block<T>(j, params, arena, (int)blockIdx.x * SV_PREP_UNITS + u);
 }
 
+// blocks [block0, block0 + nblocks) of the job table (the whole table: 0, total)
 int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
-                     int total_blocks, hipStream_t st) {
+                     int nblocks, hipStream_t st, int block0) {
+  if (nblocks < 1) return SV_OK;
   if (dtype == SV_BF16)
-    hipLaunchKernelGGL((prep_table_kernel<bf16_t>), dim3(total_blocks), dim3(256), 0, st, params,
-                       (bf16_t*)arena, jobs_dev, njobs);
+    hipLaunchKernelGGL((prep_table_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, params,
+                       (bf16_t*)arena, jobs_dev, njobs, block0);
   else
-    hipLaunchKernelGGL((prep_table_kernel<float>), dim3(total_blocks), dim3(256), 0, st, params,
-                       (float*)arena, jobs_dev, njobs);
+    hipLaunchKernelGGL((prep_table_kernel<float>), dim3(nblocks), dim3(256), 0, st, params,
+                       (float*)arena, jobs_dev, njobs, block0);
   SV_LAUNCH_CHECK();
   return SV_OK;
 }
@@ -771,6 +774,21 @@ int svk_polyc_fwd_multi(const sv_conv_desc* d, int n, const void* const* x, cons
       t.fix = frow[i]; t.fix2 = fcol[i];
     }
   return svk_conv_dispatch_multi(a, 4 * n, d->dtype, svg_pick_cfg(d->Cout), st);
+}
+
+// do the four class problems of a per-class polyphase layer plan on the tile kernel?  Asked when a plan chooses the layer's form (lgvae_plan.hip), so that a
+// refusal (LDS, shape) selects the direct form at creation instead of failing the step after the border kernel has run
+bool svk_polyc_fwd_plannable(const sv_conv_desc* d) {
+  static float dummy[4];
+  for (int c = 0; c < 4; ++c) {
+    TapGemmArgs t;
+    svg_polyc_fwd_args(d, c, &t);
+    t.A = dummy; t.Wt = dummy; t.out = dummy; t.fix = dummy; t.fix2 = dummy;     // (the planner only tests them for presence)
+    TileConvArgs a;
+    int cfg = 0;
+    if (!svk_tile_conv_plan(t, d->dtype, d->B, &a, &cfg)) return false;
+  }
+  return true;
 }
 
 // im2col tile for a layer the tile kernel does not plan (non-power-of-two grids, stride 3: SPAIR's backbone): when the

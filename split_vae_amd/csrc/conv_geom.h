@@ -239,6 +239,7 @@ void svg_polyc_wgrad_args(const sv_conv_desc* d, int cls, WgradArgs* a);
 int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo, const void* const* dy, float* const* dW, float* const* dbias,
                           float* const* slab_ws, int64_t slab_bytes, float* const* pw, hipStream_t st);
 // n <= 2 svg_polyc layers of one geometry (the twin networks): border kernel + all class problems in one launch (conv_api.hip)
+bool svk_polyc_fwd_plannable(const sv_conv_desc* d);
 int svk_polyc_fwd_multi(const sv_conv_desc* d, int n, const void* const* x, const void* const* w_fwd, const float* const* bias, void* const* y,
                         void* const* fixws, hipStream_t st);
 int64_t svg_wprep_elems_class(const sv_conv_desc* d, int for_dgrad, int cls);

@@ -262,7 +262,7 @@ struct PrepJob {
   uint8_t srctap[SV_MAX_TAPS];  // destination tap -> source (kh*KW+kw) tap
 };
 int svk_prep_weights(const float* params, void* arena, int dtype, const PrepJob* jobs_dev, int njobs,
-                     int total_blocks, hipStream_t st);
+                     int nblocks, hipStream_t st, int block0 = 0);
 
 // border correction of the polyphase forward (poly_fix.hip): the out-of-image taps of the 5 hi-res border rows / columns.
 // fixbuf[i] != null: written to the workspace BEFORE the conv, whose epilogue adds it (TapGemmArgs::fix); else added to out6[i]

@@ -78,7 +78,7 @@ static int check_desc(const sv_lgvae_desc* d) {
   return SV_OK;
 }
 
-struct ProfEntry { std::string name; double flops, bytes, total_ms; int launches; };
+struct ProfEntry { std::string name; double flops, bytes, total_ms; int launches; double issued; };   // issued: see issued_flops() below
 struct ProfPending { int entry; hipEvent_t a, b; };
 
 // one conv-like layer instance with everything needed for fwd / dgrad / wgrad
@@ -90,6 +90,8 @@ struct Layer {
   int64_t wd_off[4];            // prepared dgrad weights per parity class
   int64_t wdp_off;              // polyphase input gradient (svg_polyd): main / edge / corner images, or -1
   bool need_dgrad;
+  bool polyc;                   // forward in per-class polyphase form (conv_geom.h: svg_polyc), LATCHED when the plan is created: the arena then holds the class images
+                                // only, and a later change of the tuning environment must not send the direct kernel to them
 };
 
 }  // namespace
@@ -108,6 +110,7 @@ struct sv_lgvae_plan {
   Layer dec[2][5];
   std::vector<PrepJob> jobs;
   int prep_blocks;
+  int dec_block0 = 0;           // first block of the decoders' jobs in the table (the encoders' jobs come first): the step prepares the two halves on two streams
   int64_t arena_elems;
   // slab reduces of the tile weight gradients, deferred: every layer keeps its partial sums in its own workspace region and ONE launch
   // sums them all after the backward pass (after the side stream has joined).  Opt-in (SV_DEFER_REDUCE=1): see run_wgrad_layers for the measurement
@@ -133,25 +136,53 @@ struct sv_lgvae_plan {
   int side_count = 0;      // layers forked since the last join
   int nside = 0, side_next = 0, side_slot = 0;   // side_slot: which stream (and which slab workspace) the last wgrad_stream() gave out
   bool side_pending = false;
-  hipStream_t wgrad_stream(hipStream_t st) {
+  // EARLY SIDE WORK (round 6): what the step's first launches do not need runs on side stream 0 beside them -- the decoders' weight images (the encoders' forward
+  // reads only its own) and the zero fill of the gradient buffer (first written by the backward).  Both are HBM-bound, the encoder convs beside them matrix-bound;
+  // batch-independent time off the critical path of every shard size.  ev_early is waited for before the decoders' forward / the backward / the end of the call.
+  hipEvent_t ev_early = nullptr;
+  bool early_pending = false;
+  bool side_allowed() const {
     static const bool off = getenv("SV_NO_SIDE") != nullptr;
-    side_slot = 0;
-    if (off || (prof_on && prof_filter.empty())) return st;     // the full per-kernel table wants serial launches
-    if (graph_on) return st;   // a captured fork/join replayed wrongly on ROCm 7.2 (corrupt gradients, then a crash): keep captures single-stream
-    if (!nside) {
+    return !(off || (prof_on && prof_filter.empty()) || graph_on || dyn);
+  }
+  hipStream_t early_stream(hipStream_t st) {          // side stream 0, ordered behind everything `st` holds now; nullptr: no side streams (serial modes)
+    static const bool off = getenv("SV_NO_EARLY_SIDE") != nullptr;
+    if (off || !side_allowed() || !ensure_side()) return nullptr;
+    if (!ev_early && hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[0], ev_fork, 0) != hipSuccess) return nullptr;
+    return side[0];
+  }
+  int early_done(hipStream_t side0) {                 // the early work is enqueued: mark it
+    if (hipEventRecord(ev_early, side0) != hipSuccess) return (int)hipGetLastError();
+    early_pending = true;
+    return SV_OK;
+  }
+  int early_wait(hipStream_t st) {
+    if (!early_pending) return SV_OK;
+    early_pending = false;
+    return hipStreamWaitEvent(st, ev_early, 0) == hipSuccess ? SV_OK : (int)hipGetLastError();
+  }
+  bool ensure_side() {
+    if (nside) return true;
+    {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
       static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 2;      // created; `side_use` of them are used per call
       const int k = want < 1 ? 1 : want > SIDE_MAX - 1 ? SIDE_MAX - 1 : want;   // the last workspace slot belongs to the main stream
-      if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return st;
+      if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
       for (int i = 0; i < k; ++i) {
         if (hipStreamCreateWithPriority(&side[i], hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side[i] = nullptr; break; }
         (void)hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
         ++nside;
       }
-      if (!nside) return st;
     }
+    return nside > 0;
+  }
+  hipStream_t wgrad_stream(hipStream_t st) {
+    side_slot = 0;
+    if (!side_allowed()) return st;     // the full per-kernel table wants serial launches; a captured fork/join replayed wrongly on ROCm 7.2 (corrupt gradients, then a crash): captures stay single-stream
+    if (!ensure_side()) return st;
     const int use = side_use < nside ? side_use : nside;
     static const char* order = getenv("SV_SIDE_ORDER");        // experiment: stream per forked layer in launch order, e.g. "0110" (repeats)
     int slot = side_next % use;
@@ -268,10 +299,11 @@ struct Scope {   // hipEvent bracket around one launch when profiling is on
     if (it != p->profidx.end()) return it->second;
     const int e = (int)p->prof.size();
     p->profidx[name] = e;
-    p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0});
+    p->prof.push_back(ProfEntry{name, flops, bytes, 0.0, 0, flops});
     return e;
   }
   bool marked = false;
+  void issued(double fl) { if (entry >= 0) p->prof[entry].issued = fl; }      // the launch set runs a strength-reduced form: FLOPs it really multiplies
   Scope(sv_lgvae_plan* p_, hipStream_t st_, const std::string& name, double flops, double bytes) : p(p_), st(st_), on(p_->prof_on) {
     if (roctx().push) { roctx().push(name.c_str()); marked = true; }
     if (on && !p->prof_filter.empty() && p->prof_filter != name) on = false;
@@ -313,7 +345,7 @@ static void build_layers(sv_lgvae_plan* p) {
     L.name = name;
     L.d = sv_conv_desc{B, h, w, cin, cout, k, k, s, act, d.dtype, ldx, ldy, yf32, 0};
     L.kparam = kparam; L.bparam = kparam + 1; L.need_dgrad = need_dgrad;
-    L.wf_off = 0; L.wdp_off = -1;
+    L.wf_off = 0; L.wdp_off = -1; L.polyc = false;
     for (int i = 0; i < 4; ++i) L.wd_off[i] = 0;
     return L;
   };
@@ -366,7 +398,8 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
     }
   };
   auto do_layer = [&](Layer& L, bool is_head) {
-    if (!is_head && svg_polyc(&L.d)) {
+    L.polyc = !is_head && svg_polyc(&L.d) && svk_polyc_fwd_plannable(&L.d);     // (the class problems must plan on the tile kernel: else the direct form is prepared)
+    if (L.polyc) {
       // per-class polyphase forward (conv_geom.h: svg_polyc): four class images + the border-class image, contiguous from wf_off in the
       // order svk_polyc_fwd_multi expects; the input / weight gradients keep their own forms
       align(); L.wf_off = arena;
@@ -449,6 +482,7 @@ static void build_prep_jobs(sv_lgvae_plan* p) {
   };
   for (int e = 0; e < 2; ++e)
     for (int l = 0; l < 4; ++l) do_layer(p->enc[e][l], l == 3);
+  p->dec_block0 = blocks;
   for (int k = 0; k < 2; ++k)
     for (int l = 0; l < 5; ++l) do_layer(p->dec[k][l], false);
   p->arena_elems = arena + 128;
@@ -470,7 +504,7 @@ static void build_buffers(sv_lgvae_plan* p) {
   {   // border terms of the per-class polyphase layers (d3, d4): one region per network, sized for the largest layer (the layers run one after the other)
     int64_t need = 256;
     for (int l = 2; l <= 4; ++l)
-      if (svg_polyc(&p->dec[0][l].d)) need = std::max<int64_t>(need, svg_polyc_fix_ws_bytes(&p->dec[0][l].d));
+      if (p->dec[0][l].polyc) need = std::max<int64_t>(need, svg_polyc_fix_ws_bytes(&p->dec[0][l].d));
     p->add_buf("polycfix_x", need);
     p->add_buf("polycfix_xh", need);
     int64_t needd = 256;                                  // edge terms of the polyphase input gradients (d4, d5): one region per network
@@ -566,6 +600,17 @@ static double conv_flops(const sv_conv_desc& d) {
   return 2.0 * d.B * svg_oh(&d) * svg_ow(&d) * (double)d.Cout * d.KH * d.KW * d.Cin;
 }
 
+// FLOPs a POLYPHASE form of an upsample -> K x K conv layer really multiplies on the matrix pipe (real channels only; DESIGN.md section 5 "issued"):
+//   main term: `taps` tap products per LOW-RES pixel where the direct form has 4 K^2 (per-class forms and the stride-2 input gradient: (5+4)^2 = 81 of 144 for
+//   K = 6; the head's merged 25-tap form multiplies all 4 x 25 = 100 -- 19 of them structural zeros of the composite image -- of 144);
+//   border terms: forward / weight gradient 2 (K-1) edge lines of H (W) hi-res pixels x K taps (poly_fix.hip, polyc_wgrad.hip's frame kernel); input gradient
+//   four low-res edge lines x 4 strip rows x 9 taps (polyd_dgrad.hip).  Corner terms, the projection and the frame sum (< 1 % of a layer) are not counted.
+static double poly_issued(const sv_conv_desc& d, int taps, bool dgrad) {
+  const double main_ = conv_flops(d) * taps / (4.0 * d.KH * d.KW);
+  const double border = 2.0 * d.B * (double)(d.H + d.W) * d.Cin * d.Cout * (dgrad ? 36.0 : (double)(d.KH - 1) * d.KH);
+  return main_ + border;
+}
+
 // algorithmic HBM bytes of one conv-like launch (what a perfect kernel must move once): kind 0 forward (input [low-res when the
 // resize is fused] + output + weights), 1 input gradient (dY + mask + dX), 2 weight gradient (input + dY + fp32 dW)
 static double conv_bytes(const sv_conv_desc& d, int kind, size_t es) {
@@ -621,7 +666,8 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     const int rc = svk_nt_gemm_multi(q, n, L[0]->d.B >= 256 ? 128 : 64, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
   }
-  if (svg_polyc(&L[0]->d) && !nll && n <= 2) {
+  if (L[0]->polyc && !nll && n <= 2) {
+    { double is = 0; for (int i = 0; i < n; ++i) is += poly_issued(L[i]->d, L[i]->d.KH == 6 ? 81 : 49, false); sc.issued(is); }
     // per-class polyphase (d4, d3): border kernel, then the four class problems of both networks in one launch
     const void* wf[2];
     const float* bs[2];
@@ -630,6 +676,7 @@ static int run_fwd_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void* 
     return svk_polyc_fwd_multi(&L[0]->d, n, x, wf, bs, y, fws, st);
   }
   if (svg_poly(&L[0]->d)) {
+    { double is = 0; for (int i = 0; i < n; ++i) is += poly_issued(L[i]->d, 100, false); sc.issued(is); }
     // polyphase head: the out-of-image taps of the border rows / columns go to a workspace first; the conv's epilogue adds them
     const void* wfix[2];
     float* fixbuf[2];
@@ -782,6 +829,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       fl += conv_flops(L[i]->d);
     }
     Scope sc(p, st, nm, fl, by);
+    { double is = 0; for (int i = 0; i < n; ++i) is += poly_issued(L[i]->d, 100, false); sc.issued(is); }
     SV_TRY(svk_wgrad_tile_multi(a, n, st));
     const sv_conv_desc& d = L[0]->d;
     return svk_poly_wgrad_finish(n, x, dy, pw, dwv, dbv, d.B, d.H / 2, d.W / 2, d.ldx, Cin, d.Cout, SV_POLY_WGRAD_NWG, st);
@@ -799,6 +847,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
       fl += conv_flops(L[i]->d);
     }
     Scope sc(p, st, nm, fl, by);
+    { double is = 0; for (int i = 0; i < n; ++i) is += poly_issued(L[i]->d, svg_polyc_wgrad_form(&L[i]->d) == 2 ? 100 : 81, false); sc.issued(is); }
     const int rc = svk_polyc_wgrad_multi(&L[0]->d, n, x, dy, dwv, dbv, slab, wsb, pw, st);
     if (rc != SV_E_UNSUPPORTED) return rc;
     p->polycw_bad |= 1u << (ln[1] - '0' - 1);
@@ -825,6 +874,7 @@ static int run_wgrad_layers(sv_lgvae_plan* p, int n, Layer* const* L, const void
     fl += conv_flops(L[i]->d);
   }
   Scope sc(p, st, nm, fl, by);
+  sc.issued(fl);                        // (a polyphase form above may have been refused after booking its count)
   if (!defer) sc.split(nm + ".reduce", 0, a[0].ev_mid);
   return svk_wgrad_dispatch_multi(a, n, L[0]->d.dtype, svg_pick_cfg(L[0]->d.Cout), st);
 }
@@ -833,10 +883,13 @@ static int run_wgrad_layer(sv_lgvae_plan* p, Layer& L, const void* x, const void
   return run_wgrad_layers(p, 1, &Lp, &x, &dy, grads, st);
 }
 
-static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
+// early: side stream 0 (sv_lgvae_plan::early_stream) or nullptr -- the decoders' half of the job table goes there, the encoders' half stays in front of their forward
+static int phase_prep(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st, hipStream_t early) {
   Scope sc(p, st, "prep_weights", 0, (double)p->nparams * (4 + 2.0 * p->esz()));
-  return svk_prep_weights(s->params, p->bp("warena"), p->d.dtype, (const PrepJob*)p->bp("jobs"),
-                          (int)p->jobs.size(), p->prep_blocks, st);
+  const PrepJob* jobs = (const PrepJob*)p->bp("jobs");
+  if (!early) return svk_prep_weights(s->params, p->bp("warena"), p->d.dtype, jobs, (int)p->jobs.size(), p->prep_blocks, st);
+  SV_TRY(svk_prep_weights(s->params, p->bp("warena"), p->d.dtype, jobs, (int)p->jobs.size(), p->prep_blocks - p->dec_block0, early, p->dec_block0));
+  return svk_prep_weights(s->params, p->bp("warena"), p->d.dtype, jobs, (int)p->jobs.size(), p->dec_block0, st);
 }
 
 static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_enc, bool do_dec, hipStream_t st,
@@ -968,6 +1021,7 @@ static int phase_forward(sv_lgvae_plan* p, const sv_lgvae_step_args* s, bool do_
     }
   }
   if (do_dec) {
+    SV_TRY(p->early_wait(st));               // the decoders' weight images (and the zeroed gradient buffer) of this call's early side work
     const void* zin[2] = {p->bp("zcat"), (const char*)p->bp("zcat") + (size_t)Lg * p->esz()};
     {   // d1 differs between the twins (zcat vs local-only input): two shapes, one launch
       Layer* Ls[2] = {&p->dec[0][0], &p->dec[1][0]};
@@ -1092,6 +1146,7 @@ static int phase_bwd_decoders(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hip
         fl += conv_flops(Ls[k]->d); by += conv_bytes(Ls[k]->d, 1, p->esz());
       }
       Scope sc(p, st, "dgrad." + Ls[0]->name.substr(Ls[0]->name.find('.') + 1), fl, by);
+      { double is = 0; for (int k = 0; k < 2; ++k) is += poly_issued(Ls[k]->d, 81, true); sc.issued(is); }
       frc = svk_polyd_dgrad_multi(&Ls[0]->d, 2, gy, wp, lo, (void* const*)gl, ews, st);
     }
     if (frc == SV_E_UNSUPPORTED && Ls[0]->d.ups_in && Ls[1]->d.ups_in && !no_adj && 2 * B >= adj_min) frc = run_dgrad_layers(p, 2, Ls, gy, lo, (void* const*)gl, false, st, true);
@@ -1344,6 +1399,7 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
     (void)hipEventDestroy(p->ev_join[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_early) (void)hipEventDestroy(p->ev_early);
   for (auto& row : p->ev_bucket)
     for (auto e : row)
       if (e) (void)hipEventDestroy(e);
@@ -1397,19 +1453,28 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
     // (fp32, 256 images per network: 5.14 -> 5.09 ms; 128: 2.84 -> 2.87: from 256)
     p->side_use = forced > 0 ? forced : (whole && 2 * p->d.B >= (p->d.dtype == SV_F32 ? 512 : 768)) ? 2 : 1;
   }
-  if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st));
+  // early side work: the decoders' weight images and the gradient buffer's zero fill on side stream 0 beside the encoders' forward (see early_stream)
+  const bool zero_here = (ph & SV_PHASE_LOSS) && s->grads;
+  hipStream_t early = ((ph & SV_PHASE_PREP) && (ph & SV_PHASE_FWD_ENCODERS)) ? p->early_stream(st) : nullptr;
+  if (early && zero_here) {
+    if (hipMemsetAsync(s->grads, 0, (size_t)p->nparams * 4, early) != hipSuccess) return (int)hipGetLastError();
+  }
+  if (ph & SV_PHASE_PREP) SV_TRY(phase_prep(p, s, st, early));
+  if (early) SV_TRY(p->early_done(early));
   static const bool no_fused_nll = getenv("SV_NO_FUSED_NLL") != nullptr;    // A/B: dlogistic_kernel after the forward
+  static const bool no_fused_nll_f32 = getenv("SV_NO_FUSED_NLL_F32") != nullptr;    // (fp32 since round 6; A/B)
   const bool want_nll = !no_fused_nll && (ph & SV_PHASE_FWD_DECODERS) && (ph & SV_PHASE_LOSS) && s->grads && s->images6 &&
-                        p->d.dtype == SV_BF16;
+                        (p->d.dtype == SV_BF16 || !no_fused_nll_f32);
   if (!(ph & SV_PHASE_FORWARD)) p->nll_fused = false;
   if (ph & SV_PHASE_FORWARD) SV_TRY(phase_forward(p, s, ph & SV_PHASE_FWD_ENCODERS, ph & SV_PHASE_FWD_DECODERS, st, want_nll));
   if (ph & SV_PHASE_LOSS) {
-    if (s->grads) {
+    if (s->grads && !early) {
       Scope sc(p, st, "zero_grads", 0, (double)p->nparams * 4);
       if (hipMemsetAsync(s->grads, 0, (size_t)p->nparams * 4, st) != hipSuccess) return (int)hipGetLastError();
     }
     SV_TRY(phase_loss(p, s, s->grads != nullptr, st));
   }
+  SV_TRY(p->early_wait(st));                 // (a call without the decoders' forward: before any gradient is written, at the latest here)
   const bool buckets = (ph & SV_PHASE_BUCKET_EVENTS) && !p->graph_on && !p->dyn;      // (not in captured steps: the events belong to eager launches)
   // a backward phase invalidates the events of every earlier step: sv_lgvae_bucket_wait must never succeed against events that belong to gradients
   // of a previous step (it returns SV_E_STATE instead, and the trainer falls back to ordering the collective behind the compute stream)
@@ -1573,6 +1638,15 @@ extern "C" int sv_lgvae_profile_read(sv_lgvae_plan* p, int32_t max_entries, char
     if (flops_per_launch) flops_per_launch[i] = p->prof[i].flops;
     if (bytes_per_launch) bytes_per_launch[i] = p->prof[i].bytes;
   }
+  return n;
+}
+
+// FLOPs per launch the scope's chosen algorithm really multiplies (polyphase forms: fewer than the direct count flops_per_launch), same order as sv_lgvae_profile_read
+extern "C" int sv_lgvae_profile_read_issued(sv_lgvae_plan* p, int32_t max_entries, double* issued_flops_per_launch) {
+  if (!p || !issued_flops_per_launch) return SV_E_BADARG;
+  int n = (int)p->prof.size();
+  if (n > max_entries) n = max_entries;
+  for (int i = 0; i < n; ++i) issued_flops_per_launch[i] = p->prof[i].issued;
   return n;
 }
 

@@ -232,6 +232,10 @@ static int launch_polyc_fix(const PolycFixMulti& m, int n, int B, int h, int w, 
   const size_t lds = (size_t)NB * LW * (NGRP * FixMma<T>::CPG * sizeof(T) + 16);
   if (lds > 150 * 1024) return SV_E_UNSUPPORTED;
   int groups = (B + 15) / 16;                               // ~16 images per workgroup: four batches of NB
+  // small shards (config 4: 64 images per network): 16 images per workgroup left 80 workgroups on 256 CUs (53 us of the 64-image fp32 step for 0.5 GFLOP);
+  // one batch of NB images per workgroup until the launch holds ~2 workgroups per CU (the class weights are 24-48 registers per lane: cheap to re-load)
+  const int want = (512 + 2 * (K - 1) * n - 1) / (2 * (K - 1) * n), most = (B + NB - 1) / NB;
+  if (groups < want) groups = want < most ? want : most;
   if (groups < 1) groups = 1;
   sv_ensure_dynamic_lds((const void*)polyc_fix_kernel<T, K, NGRP, NCF, NB>, lds);
   hipLaunchKernelGGL((polyc_fix_kernel<T, K, NGRP, NCF, NB>), dim3(2 * (K - 1), groups, n), dim3(256), lds, st, m, B, h, w);

@@ -121,17 +121,29 @@ __global__ __launch_bounds__(256) void polyd_corner_kernel(const PolydEdgeMulti 
   const int b = ((int)blockIdx.y * 4 + wave) * 16 + lr;                        // this lane's image (B operand column)
   const bool bok = b < B;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int qr = 0; qr < nqr; ++qr)
-    for (int qs = 0; qs < nqs; ++qs) {
-      const T* wp = wc + (((int64_t)((c * 4 + qr) * 4 + qs)) * Cin + cif * 16 + lr) * COP + lg * EPP;
-      const T* dp = dy + (((int64_t)(bok ? b : 0) * H2 + (cr ? H2 - 1 - qr : qr)) * W2 + (cc ? W2 - 1 - qs : qs)) * gdy + lg * EPP;
+  // one strip row (up to four corner pixels x NGRP operand pairs) per round: every load of the round is issued before its first MFMA.  (As a plain (qr, qs) loop
+  // with run-time bounds each pair was load -> wait -> multiply: up to 16 x NGRP dependent round trips, 20-28 us per launch at 2 x 64 images for 0.03 GFLOP.)
+  // The (qr, qs, gq) order of the multiplies -- the accumulation order -- is unchanged.
+  for (int qr = 0; qr < nqr; ++qr) {
+    uint4 av[4][NGRP], bv[4][NGRP];
+#pragma unroll
+    for (int qs = 0; qs < 4; ++qs) {
+      const bool on = qs < nqs;                                                 // (block-uniform)
+      const T* wp = wc + (((int64_t)((c * 4 + qr) * 4 + (on ? qs : 0))) * Cin + cif * 16 + lr) * COP + lg * EPP;
+      const T* dp = dy + (((int64_t)(bok ? b : 0) * H2 + (cr ? H2 - 1 - qr : qr)) * W2 + (cc ? W2 - 1 - (on ? qs : 0) : (on ? qs : 0))) * gdy + lg * EPP;
 #pragma unroll
       for (int gq = 0; gq < NGRP; ++gq) {
-        const uint4 av = *(const uint4*)(wp + gq * CPG);
-        const uint4 bv = (bok && gq * CPG + lg * EPP < gdy) ? *(const uint4*)(dp + gq * CPG) : make_uint4(0, 0, 0, 0);
-        FixMma<T>::run(av, bv, acc);                                            // D rows = channels 4 lg .., columns = images
+        av[qs][gq] = on ? *(const uint4*)(wp + gq * CPG) : make_uint4(0, 0, 0, 0);
+        bv[qs][gq] = (on && bok && gq * CPG + lg * EPP < gdy) ? *(const uint4*)(dp + gq * CPG) : make_uint4(0, 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int qs = 0; qs < 4; ++qs) {
+      if (qs >= nqs) break;
+#pragma unroll
+      for (int gq = 0; gq < NGRP; ++gq) FixMma<T>::run(av[qs][gq], bv[qs][gq], acc);        // D rows = channels 4 lg .., columns = images
+    }
+  }
   mfma_result_fence(acc);                                        // (fix_mma.hip.h: at -O1 the accumulator was read one instruction behind the loop's last v_mfma)
   if (!bok) return;
   float4* p = (float4*)(mg.erow[blockIdx.z] + (((int64_t)b * 2 + cr) * w + (cc ? w - 1 : 0)) * Cin + cif * 16 + lg * 4);

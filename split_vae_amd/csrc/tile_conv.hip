@@ -355,14 +355,14 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
     // 2*oy, the rest to 2*oy + 1.  Border rows / columns add their out-of-image terms, which poly_fix.hip wrote in this
     // tensor's own layout (one aligned 16-B piece each); the loads of four pieces are issued before any is used.
     const int C = g.d2s, pps = ppr_o >> 1, total = BM * ppr_o;
-    if constexpr (sizeof(T) == 2) {
+    {
       if (g.nll_part) {
         // FUSED LOSS: one thread per hi-res pixel (4 per tile row): its 6 outputs + border terms -> out6, the NLL of its three
         // colour channels against the target image (vae/trainer.py:21-38, :127) and the bf16 gradient record; the tile's
         // NLL sum goes to nll_part[image][tile] (summed per image in a fixed order by svk_nll_rowsum: deterministic).
         const float* __restrict__ img = g.nll_img;
         float* __restrict__ outp = (float*)g.out;
-        bf16_t* __restrict__ gp = (bf16_t*)g.nll_grad;
+        T* __restrict__ gp = (T*)g.nll_grad;                 // the gradient record in the step's dtype: [pixel][dm0 dm1 dm2 dl0 dl1 dl2 0 0]
         float nacc = 0.f;
 #pragma unroll 2
         for (int hp = tid; hp < BM * 4; hp += NT) {
@@ -398,11 +398,17 @@ __global__ __launch_bounds__(64 * NW, tile_min_waves(BN, NW, YR, WR)) void tile_
           dll_elem(x2, o23[0], o45[1], n2, dm2, dl2);
           nacc += (n0 + n1) + n2;
           const float gs = g.nll_gscale;
-          bf16x8 v;
-          v[0] = (bf16_t)(dm0 * gs); v[1] = (bf16_t)(dm1 * gs); v[2] = (bf16_t)(dm2 * gs);
-          v[3] = (bf16_t)(dl0 * gs); v[4] = (bf16_t)(dl1 * gs); v[5] = (bf16_t)(dl2 * gs);
-          v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
-          *(bf16x8*)(gp + pix * 8) = v;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 v;
+            v[0] = (bf16_t)(dm0 * gs); v[1] = (bf16_t)(dm1 * gs); v[2] = (bf16_t)(dm2 * gs);
+            v[3] = (bf16_t)(dl0 * gs); v[4] = (bf16_t)(dl1 * gs); v[5] = (bf16_t)(dl2 * gs);
+            v[6] = (bf16_t)0.f; v[7] = (bf16_t)0.f;
+            *(bf16x8*)(gp + pix * 8) = v;
+          } else {                                            // fp32 step (round 6): the same record in floats, exactly dlogistic_kernel's values (dm * gscale, dl * gscale)
+            float4* gq = (float4*)(gp + pix * 8);
+            gq[0] = make_float4(dm0 * gs, dm1 * gs, dm2 * gs, dl0 * gs);
+            gq[1] = make_float4(dl1 * gs, dl2 * gs, 0.f, 0.f);
+          }
         }
         nacc = wave_sum(nacc);
         __syncthreads();                                    // every read of the transposed tile is done: reuse its head
@@ -533,7 +539,7 @@ static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConv
   if (t.clampin && (t.ups || t.S != 1)) return false;
   if (t.s2d3 && (dtype != SV_F32 || t.S != 1 || t.SX != 1 || t.ups || t.clampin || t.cl2 != 2)) return false;
   if (t.fix_nc && !t.d2s_y && ((dtype != SV_F32 && t.S != 2) || !t.fix || !t.fix2 || (t.N & 15) || t.out_f32)) return false;     // (bf16: only the stride-2 polyphase input gradient has instantiations with the border-term epilogue)
-  if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || dtype != SV_BF16 || !t.nll_img || !t.nll_grad)) return false;
+  if (t.nll_part && (!t.d2s_y || t.d2s != 6 || OY * OX < 256 || !t.nll_img || !t.nll_grad)) return false;
   if (t.cls_n && (t.OS != 2 || t.N != 4 * t.cls_n || (t.cls_n & 7) || t.out_f32 || t.bias)) return false;
   if (OY * OX < 16) return false;                       // dense / tiny spatial: im2col path
   if (!t.d2s && !t.cls_n) {                             // the epilogue stores 8- / 16-byte pieces (see Nst in the kernel)

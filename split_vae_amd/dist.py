@@ -138,9 +138,14 @@ class NativeGradReducer:
         self._dirty = True
 
     def wait(self):
+        ev = getattr(self, "wait_events", None)      # bench.py's diagnosis: (before, after) event pairs on the compute stream = the time it really waits
+        if ev is not None:
+            a = torch.cuda.Event(enable_timing=True); a.record()
         if self._dirty:
             torch.cuda.current_stream().wait_stream(self.stream)        # no host sync
             self._dirty = False
+        if ev is not None:
+            b = torch.cuda.Event(enable_timing=True); b.record(); ev.append((a, b))
 
     def __del__(self):
         try:
@@ -192,6 +197,11 @@ class GradReducer:
 
     def wait(self):
         """Make the compute stream wait for every outstanding bucket (no host sync on nccl)."""
+        ev = getattr(self, "wait_events", None)      # bench.py's diagnosis: (before, after) event pairs on the compute stream = the time it really waits
+        if ev is not None:
+            a = torch.cuda.Event(enable_timing=True); a.record()
         for w in self._pending:
             w.wait()
         self._pending = []
+        if ev is not None:
+            b = torch.cuda.Event(enable_timing=True); b.record(); ev.append((a, b))

@@ -465,7 +465,12 @@ class LGVaePlan:
         n = self.lib.sv_lgvae_profile_read(self.handle, max_entries, names, ms, n_l, fl, by)
         if n < 0:
             check(n, "sv_lgvae_profile_read")
-        return [dict(name=names[i].value.decode(), total_ms=ms[i], launches=n_l[i], flops=fl[i], bytes=by[i])
+        iss = (C.c_double * max_entries)()
+        ni = self.lib.sv_lgvae_profile_read_issued(self.handle, max_entries, iss)
+        if ni < 0:
+            check(ni, "sv_lgvae_profile_read_issued")
+        # flops: the direct form's count; issued: what the scope's algorithm really multiplies (polyphase forms: fewer)
+        return [dict(name=names[i].value.decode(), total_ms=ms[i], launches=n_l[i], flops=fl[i], bytes=by[i], issued=iss[i] if i < ni else fl[i])
                 for i in range(n)]
 
 

@@ -215,16 +215,18 @@ def test_step_bf16_close_to_oracle(ops):
         assert cos > 0.995 and rel < 0.12, "grad %s: cosine %g relfro %g" % (name, cos, rel)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("H,patch,B", [(32, 1, 5), (64, 8, 3)])
-def test_loss_fused_into_the_head_equals_the_separate_kernel(ops, H, patch, B):
+def test_loss_fused_into_the_head_equals_the_separate_kernel(ops, H, patch, B, dtype):
     """A training step evaluates the discretised-logistic loss in the decoder head's epilogue (tile_conv.hip: nll_part); the
     same phases issued as two calls (forward, then loss + backward) run dlogistic_kernel on out6 instead.  Same element
     function on the same fp32 outputs: the gradient records g5 are bitwise equal, the per-image NLL sums differ by fp32
-    summation order only, and so do the weight gradients (split-K atomics in the encoder)."""
+    summation order only, and so do the weight gradients (split-K atomics in the encoder).  Both precisions: the fp32 step (the reference's precision,
+    vae/trainer.py:21-38 behind vae/model.py:169) takes the fused form since round 6, its gradient record in floats."""
     from split_vae_amd._lib import PHASE_ALL, PHASE_ADAM, PHASE_PREP, PHASE_FORWARD
     x, perm, eps = make_inputs(B, H, patch, seed=11)
     images = ops.scramble_gather(torch.from_numpy(x).cuda(), torch.from_numpy(perm).cuda(), patch)
-    plan = ops.LGVaePlan(B, H, H, beta=40.0, dtype=torch.bfloat16)
+    plan = ops.LGVaePlan(B, H, H, beta=40.0, dtype=dtype)
     P = flat_params(plan, np_ref.glorot_init(H, H, seed=3))
     ex, eh = torch.from_numpy(eps[0]).cuda(), torch.from_numpy(eps[1]).cuda()
     res = []
@@ -236,8 +238,8 @@ def test_loss_fused_into_the_head_equals_the_separate_kernel(ops, H, patch, B):
             rest &= ~(PHASE_PREP | PHASE_FORWARD)
         plan.step(rest, params=P, grads=G, images6=images, eps_x=ex, eps_x_hat=eh)
         torch.cuda.synchronize()
-        res.append({"g5x": plan.buffer("g5_x", torch.bfloat16, (B, H, H, 8)).clone(),
-                    "g5h": plan.buffer("g5_xh", torch.bfloat16, (B, H, H, 8)).clone(),
+        res.append({"g5x": plan.buffer("g5_x", dtype, (B, H, H, 8)).clone(),
+                    "g5h": plan.buffer("g5_xh", dtype, (B, H, H, 8)).clone(),
                     "o6x": plan.buffer("out6_x", torch.float32, (B, H, H, 6)).clone(),
                     "nll": plan.buffer("nll_x", torch.float32, (B,)).clone(),
                     "losses": plan.buffer("losses", torch.float32, (8,)).clone(), "G": G})
