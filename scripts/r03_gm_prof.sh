@@ -15,7 +15,7 @@ from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae
 from split_vae_amd.optimizer import Adam
 x = data.synthetic_images(64, 32, 32, seed=0, device="cuda")
 aug = Augmentator("scramble", size=4, seed=1)
-m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype="bf16", device="cuda", seed=3)
+m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype=__import__("os").environ.get("GM_DTYPE", "bf16"), device="cuda", seed=3)
 m.beta, m.alpha = 40.0, 40.0
 opt = Adam(learning_rate=1e-4)
 for _ in range(10): train_step_lg_gm_vae(m, aug.augment(x), opt)
@@ -25,7 +25,7 @@ t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("host enqueue %.3f ms/step, wall %.3f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
 PY
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_gm -o gm --output-format csv -- python3 /tmp/gm_drv.py > /tmp/prof_gm.log 2>&1
-tail -2 /tmp/prof_gm.log
+tail -2 /tmp/prof_gm.log | tee $ROOT/gpurun_out/${TAG}_gm_host.txt
 f=$(find /tmp/prof_gm -name '*kernel_stats.csv' | head -1)
 head -45 "$f" | cut -c1-200 > $ROOT/gpurun_out/${TAG}_gm_kernel_stats.txt
 python3 - "$f" <<'PY' | tee -a $ROOT/gpurun_out/${TAG}_gm_kernel_stats.txt

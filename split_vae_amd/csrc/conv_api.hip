@@ -867,6 +867,21 @@ extern "C" int sv_conv2d_nhwc_dgrad(const sv_conv_desc* d, const void* dy, const
       if (rc != SV_E_UNSUPPORTED) return rc;
     }
   }
+  if (!dx_f32_atomic && svg_dgrad_classes(d) == 4) {       // (stride 2; SPLIT-SPAIR's stride-3 backbone layer has nine classes and stays on the per-class loop)
+    // the parity classes of a stride-2 layer as ONE launch (they plan to the same tile grid; lgvae_plan.hip: run_dgrad_layers does the same): SPLIT-GMVAE's 128-channel
+    // encoder layers -- too wide for the merged form above -- went out as four launches of 32 / 128 workgroups each (4 x 21 + 4 x 36 us of its 64-image fp32 step)
+    TapGemmArgs a[4];
+    int64_t o2 = 0;
+    const int ncls = svg_dgrad_classes(d);
+    for (int c = 0; c < ncls; ++c) {
+      uint8_t srctap[SV_MAX_TAPS];
+      svg_dgrad_args(d, c, &a[c], srctap);
+      a[c].A = dy; a[c].Wt = (const char*)w_dgrad + o2 * esz; a[c].out = dx; a[c].mask = relu_mask;
+      o2 += svg_wprep_elems_class(d, 1, c);
+    }
+    rc = svk_conv_dispatch_multi(a, ncls, d->dtype, svg_im2col_cfg(a[0], svg_pick_cfg(d->Cin)), (hipStream_t)stream);
+    if (rc != SV_E_UNSUPPORTED) return rc;
+  }
   for (int c = 0; c < svg_dgrad_classes(d); ++c) {
     TapGemmArgs a;
     uint8_t srctap[SV_MAX_TAPS];

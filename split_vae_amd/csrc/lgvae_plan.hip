@@ -141,26 +141,46 @@ struct sv_lgvae_plan {
   // batch-independent time off the critical path of every shard size.  ev_early is waited for before the decoders' forward / the backward / the end of the call.
   hipEvent_t ev_early = nullptr;
   bool early_pending = false;
+  // captured steps: SV_GRAPH_SIDE=1 lets the capture fork to the side streams too (every fork / join on its OWN event and only the streams a call really used are
+  // joined: round 3's capture, which re-recorded one fork event and joined every stream, replayed wrongly on ROCm 7.2).  Off by default: see DESIGN.md section 7.
+  static bool graph_side() { static const bool on = getenv("SV_GRAPH_SIDE") && atoi(getenv("SV_GRAPH_SIDE")) != 0; return on; }
   bool side_allowed() const {
     static const bool off = getenv("SV_NO_SIDE") != nullptr;
-    return !(off || (prof_on && prof_filter.empty()) || graph_on || dyn);
+    return !(off || (prof_on && prof_filter.empty()) || ((graph_on || dyn) && !graph_side()));
+  }
+  // fork / join events: one per use while graph replay is on (a captured event node per dependency), the two fixed ones otherwise
+  enum { CAP_EV = 96 };
+  hipEvent_t ev_cap[CAP_EV] = {};
+  int n_cap = 0;
+  bool side_used[SIDE_MAX] = {false, false, false, false};
+  hipEvent_t fresh_event(hipEvent_t fixed) {
+    if (!(graph_on || dyn) || n_cap >= CAP_EV) return fixed;
+    if (!ev_cap[n_cap] && hipEventCreateWithFlags(&ev_cap[n_cap], hipEventDisableTiming) != hipSuccess) return fixed;
+    return ev_cap[n_cap++];
   }
   hipStream_t early_stream(hipStream_t st) {          // side stream 0, ordered behind everything `st` holds now; nullptr: no side streams (serial modes)
-    static const bool off = getenv("SV_NO_EARLY_SIDE") != nullptr;
-    if (off || !side_allowed() || !ensure_side()) return nullptr;
+    // OPT-IN (SV_EARLY_SIDE=1).  Measured (profiles/r06_ab.txt): the step is no shorter for it at any shard size -- fp32 512 images 9.152 against 9.138 ms without,
+    // 64 images 1.690 / 1.689, bf16 512 images 1.661 / 1.646: the encoders' first layers are HBM-bound themselves (e1 reads the whole batch), the weight images' 165 MB
+    // beside them slow them by what the overlap saves (fwd.e1 25 -> 52 us at 64 images).  Same finding as round 3's early optimizer tail: no idle resource to hide it in.
+    static const bool on = getenv("SV_EARLY_SIDE") && atoi(getenv("SV_EARLY_SIDE")) != 0;
+    if (!on || !side_allowed() || !ensure_side()) return nullptr;
     if (!ev_early && hipEventCreateWithFlags(&ev_early, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[0], ev_fork, 0) != hipSuccess) return nullptr;
+    hipEvent_t ef = fresh_event(ev_fork);
+    if (hipEventRecord(ef, st) != hipSuccess || hipStreamWaitEvent(side[0], ef, 0) != hipSuccess) return nullptr;
+    side_used[0] = true;
     return side[0];
   }
+  hipEvent_t ev_early_now = nullptr;
   int early_done(hipStream_t side0) {                 // the early work is enqueued: mark it
-    if (hipEventRecord(ev_early, side0) != hipSuccess) return (int)hipGetLastError();
+    ev_early_now = fresh_event(ev_early);
+    if (hipEventRecord(ev_early_now, side0) != hipSuccess) return (int)hipGetLastError();
     early_pending = true;
     return SV_OK;
   }
   int early_wait(hipStream_t st) {
     if (!early_pending) return SV_OK;
     early_pending = false;
-    return hipStreamWaitEvent(st, ev_early, 0) == hipSuccess ? SV_OK : (int)hipGetLastError();
+    return hipStreamWaitEvent(st, ev_early_now, 0) == hipSuccess ? SV_OK : (int)hipGetLastError();
   }
   bool ensure_side() {
     if (nside) return true;
@@ -188,7 +208,9 @@ struct sv_lgvae_plan {
     int slot = side_next % use;
     if (order && order[0]) { const int c = order[side_count % (int)strlen(order)] - '0'; if (c >= 0 && c < use) slot = c; }
     ++side_count;
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(side[slot], ev_fork, 0) != hipSuccess) return st;
+    hipEvent_t ef = fresh_event(ev_fork);
+    if (hipEventRecord(ef, st) != hipSuccess || hipStreamWaitEvent(side[slot], ef, 0) != hipSuccess) return st;
+    side_used[slot] = true;
     // test hook (sv_lgvae_plan_debug "side_delay_us", tests/test_gpu_dist.py): hold the side stream back at its first use of a step, so that a consumer
     // of the gradients that does not wait for the side stream's part (a missing bucket dependency) reads them before they exist
     if (dbg_side_delay_us > 0 && side_count == 1) sv_plan_spin(side[slot], dbg_side_delay_us);
@@ -198,12 +220,16 @@ struct sv_lgvae_plan {
     return side[slot];
   }
   int join_side(hipStream_t st) {
-    if (!side_pending) return SV_OK;
+    const bool cap = graph_on || dyn;
+    if (!side_pending && !(cap && side_used[0])) return SV_OK;        // (a captured call joins the early work's stream too: every forked stream must rejoin the capture)
     side_pending = false;
     side_next = 0;                     // every step hands the layers to the same streams
     side_count = 0;
-    for (int i = 0; i < nside; ++i)
-      if (hipEventRecord(ev_join[i], side[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return (int)hipGetLastError();
+    for (int i = 0; i < nside; ++i) {
+      if (cap && !side_used[i]) continue;                              // (an event of a stream outside the capture must not be waited for inside it)
+      hipEvent_t ej = fresh_event(ev_join[i]);
+      if (hipEventRecord(ej, side[i]) != hipSuccess || hipStreamWaitEvent(st, ej, 0) != hipSuccess) return (int)hipGetLastError();
+    }
     return SV_OK;
   }
   // per-plan test hooks (sv_lgvae_plan_debug): never read from the environment, so nothing a job inherits can switch them on
@@ -1400,6 +1426,8 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_early) (void)hipEventDestroy(p->ev_early);
+  for (auto e : p->ev_cap)
+    if (e) (void)hipEventDestroy(e);
   for (auto& row : p->ev_bucket)
     for (auto e : row)
       if (e) (void)hipEventDestroy(e);
@@ -1441,6 +1469,8 @@ extern "C" int sv_lgvae_buffer(const sv_lgvae_plan* p, const char* name, int64_t
 
 static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t st) {
   const int ph = s->phases;
+  p->n_cap = 0;                                  // this call's fork / join events and the side streams it uses
+  for (auto& u : p->side_used) u = false;
   {
     // Two weight-gradient side streams for a whole step at >= 768 images per launch, one otherwise.  Re-measured in round 3 (round 2: +-0):
     // B = 512 2.056 -> 2.005 ms (three launches in flight fill the CUs the rolling-window d4 kernel and the row-ring input gradients leave);

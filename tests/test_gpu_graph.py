@@ -165,3 +165,23 @@ def test_replay_restores_the_host_flags_the_phases_leave_behind(ops):
             assert float((gm - want_mean).abs().max()) <= 2e-2 * float(want_mean.abs().max()) + 1e-6, t
             assert float((gs - want_sd).abs().max()) <= 2e-2 * float(want_sd.abs().max()) + 1e-6, t
     assert plan.graph_count() >= 2
+
+
+def test_capture_that_forks_to_the_side_streams_replays_the_same_step(lib_built):
+    """SV_GRAPH_SIDE=1 (opt-in): the captured step forks to the weight-gradient side streams -- every fork / join on its own event, only the streams the call
+    used joined back.  Round 3's capture (one re-recorded fork event, every stream joined) replayed corrupt gradients on ROCm 7.2; this form must replay the
+    eager step BIT FOR BIT (the bf16 step is bit-reproducible): equal parameter hashes after 30 steps, in fresh processes.  (It is not the default: the replay of a
+    multi-stream graph is 2.5x slower than the eager launches on this runtime, profiles/r06_graph_side.txt.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("eager", "graph_side"):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r06_graph_side.py"), mode, "bf16", "16", "30"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith(mode)][-1].split()
+        out[mode] = (line[line.index("params") + 1], int(line[line.index("ms/step") + 1].split("=")[1]))
+    assert out["eager"][0] == out["graph_side"][0], out
+    assert out["eager"][1] == 0 and out["graph_side"][1] == 1, out           # eager: no graph; replay: one captured graph
