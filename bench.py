@@ -382,12 +382,13 @@ def gm_row(dev, B=64, steps=100, warmup=10, dtype="bf16"):
     m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype=dtype, device=dev, seed=3)
     m.beta, m.alpha = 40.0, 40.0
     opt = Adam(learning_rate=1e-4)
+    plan = m.plan(B)                       # plan=: the augmentation kernel also writes the step's padded inputs (as the SPLIT-VAE rows do)
     for _ in range(warmup):
-        train_step_lg_gm_vae(m, aug.augment(x), opt)
+        train_step_lg_gm_vae(m, aug.augment(x, plan=plan), opt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        train_step_lg_gm_vae(m, aug.augment(x), opt)
+        train_step_lg_gm_vae(m, aug.augment(x, plan=plan), opt)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / steps
     # 135.0 M forward MACs per image for the whole LGGMVae at SVHN-32 [derived]; train FLOP = 6 MACs_fwd - 4 MACs of the two first convs

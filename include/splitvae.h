@@ -451,6 +451,10 @@ int sv_lgvae_bucket_wait(sv_lgvae_plan* plan, int32_t bucket, void* stream);
  *   "bucket_skip_side" = 1 sv_lgvae_bucket_wait drops the side streams' events (the negative control of the dependency test).
  * SV_E_BADARG: unknown key / value out of range. */
 int sv_lgvae_plan_debug(sv_lgvae_plan* plan, const char* key, int64_t value);
+/* The library's side streams: hipStream_t `index` (0 .. 2) of the CURRENT device, created once per process and shared by every plan (weight-gradient
+ * streams), tape (lanes) and by the SPLIT-GMVAE step's second encoder stream -- a stream per object put a later object's stream on the hardware queue of the
+ * compute stream it should run beside (csrc/streams.hip).  A host binding that wants a library-compatible side stream of its own takes it from here. */
+int sv_side_stream(int32_t index, void** stream);
 /* number of captured (instantiated) step graphs, or a negative SV_E_* */
 int sv_lgvae_graph_count(const sv_lgvae_plan* plan);
 
@@ -514,6 +518,10 @@ typedef struct {
   int32_t B, H, W, C, Cout, k, stride, Ho, Wo, Hc, Wc, inverse, training;
   int32_t loss_idx, dyn_idx, mode, R, stream_id;
   int32_t group;                /* UNARY: consecutive nodes with the same non-zero group are independent of each other and run as ONE launch */
+  int32_t lane;                 /* 0: the caller's stream; 1..3: a HIP stream of the tape's own.  Independent branches of the model (LG-SPAIR's x-hat / background
+                                   networks beside the object pipeline, spair/spair.py:84-104) recorded on another lane run concurrently with lane 0; sv_tape_finalize
+                                   derives every cross-lane dependency from the nodes' tensors and sv_tape_run orders conflicting accesses in tape order with events,
+                                   so any lane assignment computes the single-stream step bit for bit (SV_TAPE_LANES=0: everything on the caller's stream) */
 } sv_tape_node;
 typedef struct {
   float* params;                /* flat fp32 variables (updated by the ADAM phase) */

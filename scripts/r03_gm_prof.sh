@@ -18,9 +18,9 @@ aug = Augmentator("scramble", size=4, seed=1)
 m = LGGMVae(128, 128, [-1, 32, 32, 3], 30, 0.4, dtype=__import__("os").environ.get("GM_DTYPE", "bf16"), device="cuda", seed=3)
 m.beta, m.alpha = 40.0, 40.0
 opt = Adam(learning_rate=1e-4)
-for _ in range(10): train_step_lg_gm_vae(m, aug.augment(x), opt)
+for _ in range(10): train_step_lg_gm_vae(m, aug.augment(x, plan=m.plan(64)), opt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): train_step_lg_gm_vae(m, aug.augment(x), opt)
+for _ in range(20): train_step_lg_gm_vae(m, aug.augment(x, plan=m.plan(64)), opt)
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("host enqueue %.3f ms/step, wall %.3f ms/step" % ((t1 - t0) / 20 * 1e3, (t2 - t0) / 20 * 1e3))
 PY

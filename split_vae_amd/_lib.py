@@ -52,7 +52,7 @@ class TapeNode(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("kind", "x", "y", "t2", "t3", "t4", "t5", "t6", "xo", "yo", "o2", "o3", "n", "rep", "op", "act")] +
                 [("p0", C.c_float), ("p1", C.c_float), ("w_off", C.c_int64), ("b_off", C.c_int64)] +
                 [(n, C.c_int32) for n in ("B", "H", "W", "C", "Cout", "k", "stride", "Ho", "Wo", "Hc", "Wc", "inverse", "training",
-                                          "loss_idx", "dyn_idx", "mode", "R", "stream_id", "group")])
+                                          "loss_idx", "dyn_idx", "mode", "R", "stream_id", "group", "lane")])
 
 
 class TapeRunArgs(C.Structure):
@@ -186,6 +186,7 @@ SYMBOLS = {
     "sv_lgvae_graph_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_bucket_wait": (C.c_int, [_vp, _i32, _vp]),
     "sv_lgvae_plan_debug": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "sv_side_stream": (C.c_int, [_i32, _vp]),
     "sv_lgvae_graph_count": (C.c_int, [_vp]),
     "sv_lgvae_profile_enable": (C.c_int, [_vp, _i32]),
     "sv_lgvae_profile_filter": (C.c_int, [_vp, C.c_char_p]),

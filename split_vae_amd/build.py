@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("SV_LIB_NAME", "libsplitvae_hip.so"))
 OBJ_TAG = os.environ.get("SV_OBJ_TAG", "")          # build variants side by side (kernel A/B experiments)
 EXTRA = os.environ.get("SV_EXTRA_FLAGS", "").split()
-SOURCES = ["pointwise.hip", "gm_pointwise.hip", "tap_gemm.hip", "tile_conv.hip", "row_conv.hip", "poly_fix.hip", "poly_wgrad.hip", "polyc_wgrad.hip", "polyd_dgrad.hip", "stn.hip", "spair_render.hip", "spair_loss.hip", "wgrad.hip", "wgrad_tile.hip", "wgrad_tile_f32.hip", "wgrad_roll.hip", "wgrad_p5.hip", "wgrad_e1.hip", "wgrad_e2.hip", "conv_api.hip", "lgvae_plan.hip", "gm_encoder.hip", "hostio.hip", "comm.hip", "dense_f32.hip", "tape.hip", "latent_gemm.hip"]
+SOURCES = ["pointwise.hip", "gm_pointwise.hip", "tap_gemm.hip", "tile_conv.hip", "row_conv.hip", "poly_fix.hip", "poly_wgrad.hip", "polyc_wgrad.hip", "polyd_dgrad.hip", "stn.hip", "spair_render.hip", "spair_loss.hip", "wgrad.hip", "wgrad_tile.hip", "wgrad_tile_f32.hip", "wgrad_roll.hip", "wgrad_p5.hip", "wgrad_e1.hip", "wgrad_e2.hip", "conv_api.hip", "lgvae_plan.hip", "gm_encoder.hip", "hostio.hip", "comm.hip", "dense_f32.hip", "tape.hip", "latent_gemm.hip", "streams.hip"]
 # per-file extra flags (measured and rejected for row_conv.hip: -fno-slp-vectorize with a scalar fp32 blend -- +7 % time, the
 # packed v_pk_fma_f32 blend issues half the instructions)
 FILE_FLAGS = {}

@@ -101,6 +101,9 @@ struct TileConvArgs {
   int8_t dx[SV_MAX_TAPS];
 };
 #define SV_MAX_MULTI 8
+// process-wide side streams (streams.hip): index 0 / 1 = the plan's weight-gradient streams; the tape's lanes 1.. and the SPLIT-GMVAE step's second stream share them
+#define SV_SHARED_STREAMS 3
+hipStream_t sv_shared_stream(int k);
 struct TileConvMulti { TileConvArgs a[SV_MAX_MULTI]; };   // kernel argument: blockIdx.z selects the problem
 bool svk_tile_conv_plan(const TapGemmArgs& t, int dtype, int B, TileConvArgs* a, int* cfg_out);
 int svk_tile_conv_multi(const TileConvArgs* a, int n, int dtype, int cfg, hipStream_t st);

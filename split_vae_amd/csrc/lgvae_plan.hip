@@ -191,8 +191,9 @@ struct sv_lgvae_plan {
       static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 2;      // created; `side_use` of them are used per call
       const int k = want < 1 ? 1 : want > SIDE_MAX - 1 ? SIDE_MAX - 1 : want;   // the last workspace slot belongs to the main stream
       if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
-      for (int i = 0; i < k; ++i) {
-        if (hipStreamCreateWithPriority(&side[i], hipStreamNonBlocking, normal ? 0 : lo) != hipSuccess) { side[i] = nullptr; break; }
+      for (int i = 0; i < k && i < SV_SHARED_STREAMS; ++i) {
+        side[i] = sv_shared_stream(i);               // the process's shared side streams (streams.hip): never a stream per plan
+        if (!side[i]) break;
         (void)hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
         ++nside;
       }
@@ -1420,8 +1421,7 @@ extern "C" void sv_lgvae_plan_destroy(sv_lgvae_plan* p) {
   for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
   for (auto e : p->event_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < p->nside; ++i) {
-    (void)hipStreamSynchronize(p->side[i]);
-    (void)hipStreamDestroy(p->side[i]);
+    (void)hipStreamSynchronize(p->side[i]);          // (shared with every other plan / tape of the process: not destroyed)
     (void)hipEventDestroy(p->ev_join[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);

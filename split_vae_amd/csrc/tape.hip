@@ -16,7 +16,15 @@
 // stream-ordered), so fan-out needs no bookkeeping; kernels that can only assign go through a scratch buffer when their target has
 // other writers.  The loss nodes add their (weight / B)-scaled gradients during the forward pass: total = sum_i w_i * mean_b(loss_i),
 // weights per run (the annealed beta of spair/trainer.py:165-167 moves with the step).
+//
+// LANES (round 6): a node may name a lane (sv_tape_node::lane, 0 = the caller's stream).  Independent branches of the model -- LG-SPAIR's x-hat / background
+// encoders and decoders beside the object pipeline (spair/spair.py:84-104) -- then run on their own HIP streams: the step is ~240 launches of 5-30 us, bound by
+// their latency, not by any unit of the chip.  sv_tape_finalize derives every cross-lane dependency from the nodes' tensors (read-after-write, write-after-read,
+// write-after-write, and the read-modify-write of every gradient accumulation, in tape order) and sv_tape_run turns them into events: conflicting accesses keep
+// the tape's order, so the lanes compute the single-stream step bit for bit (tests/test_gpu_spair_model.py).
 #include <string.h>
+#include <algorithm>
+#include <set>
 #include <vector>
 #include "common.hip.h"
 #include "kernels.h"
@@ -286,12 +294,35 @@ struct sv_tape {
   int n_report = 0;
   bool finalized = false;
   char* ws = nullptr;
+  // lanes: unit = one node or one UNARY group (units are launched in tape order; a lane's launches are stream-ordered among themselves)
+  enum { MAX_LANES = 4 };
+  struct Sched {
+    std::vector<std::vector<int>> waits;   // [first node of a unit] -> nodes whose event the unit's stream waits for first
+    std::vector<char> rec;                 // [last node of a unit] -> record the unit's event behind it
+  };
+  Sched fs, bs;                            // forward / backward pass
+  int nlanes = 1;
+  hipStream_t lane_st[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_node;
+  ~sv_tape() {
+    for (int l = 1; l < MAX_LANES; ++l) {
+      if (lane_st[l]) (void)hipStreamSynchronize(lane_st[l]);          // (shared: not destroyed)
+      if (ev_join[l]) (void)hipEventDestroy(ev_join[l]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto e : ev_node)
+      if (e) (void)hipEventDestroy(e);
+  }
 
   float* act(int t) const { return (float*)(ws + off_act) + tens[t].off; }
   float* grad(int t) const { return tens[t].goff < 0 ? nullptr : (float*)(ws + off_grad) + tens[t].goff; }
   float* scr(int64_t o) const { return (float*)(ws + off_scratch) + o; }
   // LDS-tile weight gradients (wgrad_tile*.hip) flush per-workgroup slabs here and sum them in a fixed order; SV_TAPE_NO_WGRAD_WS: atomics / im2col
-  void* wgrad_ws() const { static const bool off = getenv("SV_TAPE_NO_WGRAD_WS") != nullptr; return (off || off_wgrad < 0) ? nullptr : ws + off_wgrad; }
+  void* wgrad_ws(int lane = 0) const {                      // one slab region per lane (conv weight gradients of two lanes may be in flight together)
+    static const bool off = getenv("SV_TAPE_NO_WGRAD_WS") != nullptr;
+    return (off || off_wgrad < 0) ? nullptr : ws + off_wgrad + (int64_t)lane * SV_WGRAD_WS_BYTES;
+  }
   float* loss_sums() const { return (float*)(ws + off_loss); }                                   // [n_loss][B]
   float* loss_out() const { return loss_sums() + (int64_t)SV_TAPE_MAX_LOSS * B; }                 // total, reported[16], means[16]
   float* metric() const { return loss_out() + 2 * SV_TAPE_MAX_LOSS + 2; }                         // sums of total / reported, count
@@ -391,6 +422,7 @@ extern "C" int sv_tape_add(sv_tape* t, const sv_tape_node* nd) {
     default: return SV_E_BADARG;
   }
   if (n.kind == SV_TAPE_ZPRES || n.kind == SV_TAPE_LOSS) t->n_loss = n.loss_idx + 1 > t->n_loss ? n.loss_idx + 1 : t->n_loss;
+  if (n.lane < 0 || n.lane >= sv_tape::MAX_LANES) return SV_E_BADARG;
   t->nodes.push_back(n);
   t->ex.push_back(e);
   return SV_OK;
@@ -401,6 +433,104 @@ extern "C" int sv_tape_set_report(sv_tape* t, const float* matrix, int32_t n_rep
   memcpy(t->report, matrix, sizeof(float) * SV_TAPE_MAX_LOSS * n_report);
   t->n_report = n_report;
   return SV_OK;
+}
+
+// units of the forward pass in launch order: [first, last] node indices (a UNARY group of one lane is one launch)
+static std::vector<std::pair<int, int>> tape_units(const sv_tape* t) {
+  std::vector<std::pair<int, int>> u;
+  for (size_t i = 0; i < t->nodes.size();) {
+    const sv_tape_node& n = t->nodes[i];
+    size_t e = i + 1;
+    if (n.kind == SV_TAPE_UNARY && n.group)
+      while (e < t->nodes.size() && e - i < SV_TAPE_MAX_PARTS && t->nodes[e].kind == SV_TAPE_UNARY && t->nodes[e].group == n.group && t->nodes[e].lane == n.lane) ++e;
+    u.push_back({(int)i, (int)e - 1});
+    i = e;
+  }
+  return u;
+}
+
+// Resources: activation storage of a root tensor (id r), its gradient storage (NT + r), a layer's variable gradients (2 NT + k).  Conservative access sets per node
+// (more edges than strictly needed, never fewer): the forward pass READS a node's input activations and WRITES its outputs; loss nodes ADD into their operands'
+// gradients there; the backward pass reads activations only (never a conflict) and READ-MODIFY-WRITES the gradient of every tensor the node touches plus its own
+// variables' gradients.  An edge u -> v is kept when the two units are on different lanes; a lane's own launches are ordered by its stream, so per (unit, other lane)
+// only the latest producer is waited for, and not again if an earlier unit of the same lane already waited for it or a later one.
+static void build_schedules(sv_tape* t) {
+  const int NT = (int)t->tens.size(), N = (int)t->nodes.size();
+  std::vector<int64_t> wkeys;
+  auto wres = [&](int64_t w_off) {
+    for (size_t k = 0; k < wkeys.size(); ++k) if (wkeys[k] == w_off) return 2 * NT + (int)k;
+    wkeys.push_back(w_off);
+    return 2 * NT + (int)wkeys.size() - 1;
+  };
+  auto acc = [&](const sv_tape_node& n, bool backward, std::vector<int>& rd, std::vector<int>& wr) {
+    const int ins[6] = {n.x, n.t2, n.t3, n.t4, n.t5, n.t6};
+    auto A = [&](int id) { return t->tens[id].root; };
+    auto G = [&](int id) { return NT + t->tens[id].root; };
+    auto hasg = [&](int id) { return id >= 0 && t->tens[id].goff >= 0; };
+    if (!backward) {
+      const bool stn_box = n.kind == SV_TAPE_STN && n.t3 >= 0;
+      for (int k = 0; k < 6; ++k) if (ins[k] >= 0 && !(stn_box && k == 2)) rd.push_back(A(ins[k]));
+      if (n.y >= 0 && n.kind != SV_TAPE_ZPRES && n.kind != SV_TAPE_LOSS) wr.push_back(A(n.y));
+      if (stn_box) wr.push_back(A(n.t3));
+      if (n.kind == SV_TAPE_ZPRES || n.kind == SV_TAPE_LOSS)
+        for (int k = 0; k < 3; ++k) if (hasg(ins[k])) wr.push_back(G(ins[k]));
+    } else {
+      for (int k = 0; k < 6; ++k) if (ins[k] >= 0) rd.push_back(A(ins[k]));
+      if (n.y >= 0) rd.push_back(A(n.y));
+      for (int k = 0; k < 6; ++k) if (hasg(ins[k])) wr.push_back(G(ins[k]));
+      if (hasg(n.y)) wr.push_back(G(n.y));
+      if ((n.kind == SV_TAPE_DENSE || n.kind == SV_TAPE_CONV) && n.w_off >= 0) wr.push_back(wres(n.w_off));
+    }
+  };
+  const std::vector<std::pair<int, int>> units = tape_units(t);
+  for (int pass = 0; pass < 2; ++pass) {
+    sv_tape::Sched& S = pass ? t->bs : t->fs;
+    S.waits.assign(N, {});
+    S.rec.assign(N, 0);
+    const int NR = 2 * NT + N + 1;
+    std::vector<int> last_w(NR, -1);                 // unit that last wrote the resource
+    std::vector<std::vector<int>> readers(NR);       // units that read it since
+    const int U = (int)units.size();
+    std::vector<int> ulane(U), upos(U);              // (upos: position in this pass's launch order)
+    int seen[sv_tape::MAX_LANES][sv_tape::MAX_LANES];
+    for (auto& r : seen) for (auto& v : r) v = -1;
+    for (int k = 0; k < U; ++k) {
+      const int u = pass ? U - 1 - k : k;
+      upos[u] = k;
+      ulane[u] = t->nodes[units[u].first].lane;
+      std::vector<int> rd, wr;
+      for (int i = units[u].first; i <= units[u].second; ++i) acc(t->nodes[i], pass == 1, rd, wr);
+      std::set<int> deps;
+      for (int r : rd) if (last_w[r] >= 0) deps.insert(last_w[r]);
+      for (int w : wr) {
+        if (last_w[w] >= 0) deps.insert(last_w[w]);
+        for (int q : readers[w]) deps.insert(q);
+      }
+      int latest[sv_tape::MAX_LANES];
+      for (auto& v : latest) v = -1;
+      for (int d : deps)
+        if (d != u && ulane[d] != ulane[u] && (latest[ulane[d]] < 0 || upos[d] > upos[latest[ulane[d]]])) latest[ulane[d]] = d;
+      for (int l = 0; l < sv_tape::MAX_LANES; ++l) {
+        const int d = latest[l];
+        if (d < 0 || upos[d] <= seen[ulane[u]][l]) continue;
+        seen[ulane[u]][l] = upos[d];
+        // the producer unit's event sits behind its last launched node: forward = the unit's last node, backward = its first
+        const int evn = pass ? units[d].first : units[d].second;
+        S.waits[pass ? units[u].second : units[u].first].push_back(evn);
+        S.rec[evn] = 1;
+      }
+      for (int r : rd) readers[r].push_back(u);
+      for (int w : wr) { last_w[w] = u; readers[w].clear(); }
+    }
+    if (getenv("SV_TAPE_LANES_DEBUG")) {              // the schedule, one line per unit with a cross-lane wait
+      int nw = 0;
+      for (int k = 0; k < U; ++k) {
+        const int u = pass ? U - 1 - k : k, at = pass ? units[u].second : units[u].first;
+        for (int d : S.waits[at]) { fprintf(stderr, "tape %s: unit %d (nodes %d..%d kind %d lane %d) waits for node %d (lane %d)\n", pass ? "bwd" : "fwd", k, units[u].first, units[u].second, t->nodes[units[u].first].kind, ulane[u], d, t->nodes[d].lane); ++nw; }
+      }
+      fprintf(stderr, "tape %s: %d units, %d cross-lane waits\n", pass ? "bwd" : "fwd", U, nw);
+    }
+  }
 }
 
 extern "C" int sv_tape_finalize(sv_tape* t) {
@@ -477,7 +607,20 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
   t->off_loss = o; o += al(((int64_t)SV_TAPE_MAX_LOSS * t->B + 4 * SV_TAPE_MAX_LOSS + 8) * 4);
   bool any_conv = false;
   for (const sv_tape::Extra& e : t->ex) any_conv = any_conv || e.has_conv;
-  if (any_conv) { t->off_wgrad = o; o += al(SV_WGRAD_WS_BYTES); }
+  // ---- lanes: cross-stream dependencies of the two passes
+  // SV_TAPE_LANES = the number of extra streams the tape may use: 0 everything on the caller's stream (A/B, the equivalence test), k: lanes above k fold onto lane k
+  // Default 1.  Measured (profiles/r06_spair_lanes.txt; lg_spair Multi-Bird-Hard flags, 32 images, fp32): one stream 2.98 ms per step at every GPU_MAX_HW_QUEUES setting;
+  // ONE extra stream for both image branches 2.63 ms at every setting (-12 %); two extra streams 2.65 ms with two hardware queues and 2.85-2.96 with three or four (a third
+  // active queue costs what the overlap saves: the same finding as the SPLIT-VAE step's fourth queue).
+  static const int lanes_cap = getenv("SV_TAPE_LANES") ? atoi(getenv("SV_TAPE_LANES")) : 1;
+  int maxlane = 0;
+  for (sv_tape_node& n : t->nodes) {
+    if (n.lane > lanes_cap) n.lane = lanes_cap < 0 ? 0 : lanes_cap;
+    maxlane = n.lane > maxlane ? n.lane : maxlane;
+  }
+  t->nlanes = maxlane + 1;
+  if (any_conv) { t->off_wgrad = o; o += al(SV_WGRAD_WS_BYTES) * t->nlanes; }
+  if (t->nlanes > 1) { build_schedules(t); t->ev_node.assign(t->nodes.size(), nullptr); }
   t->ws_bytes = o;
   t->finalized = true;
   return SV_OK;
@@ -644,11 +787,11 @@ int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t s
         const int64_t n4 = y.rows * y.ld / 4;
         hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n4)), dim3(256), 0, st, gy, (bf16_t*)t->scr(e.scratch2), n4);
         SV_LAUNCH_CHECK();
-        SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(), SV_WGRAD_WS_BYTES, st));
+        SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(t->nlanes > 1 ? n.lane : 0), SV_WGRAD_WS_BYTES, st));
         if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, t->scr(e.scratch2), t->ws + t->off_arena + e.wd_off * es, nullptr, gx, 1, st));
         return SV_OK;
       }
-      SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(), SV_WGRAD_WS_BYTES, st));
+      SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(t->nlanes > 1 ? n.lane : 0), SV_WGRAD_WS_BYTES, st));
       if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, gy, t->ws + t->off_arena + e.wd_off * es, nullptr, gx, multi(n.x) ? 1 : 0, st));
       return SV_OK;
     }
@@ -726,14 +869,14 @@ size_t group_end(const sv_tape* t, size_t i) {
   const sv_tape_node& n = t->nodes[i];
   if (n.kind != SV_TAPE_UNARY || !n.group) return i + 1;
   size_t e = i + 1;
-  while (e < t->nodes.size() && e - i < SV_TAPE_MAX_PARTS && t->nodes[e].kind == SV_TAPE_UNARY && t->nodes[e].group == n.group) ++e;
+  while (e < t->nodes.size() && e - i < SV_TAPE_MAX_PARTS && t->nodes[e].kind == SV_TAPE_UNARY && t->nodes[e].group == n.group && t->nodes[e].lane == n.lane) ++e;
   return e;
 }
 size_t group_begin(const sv_tape* t, size_t i) {       // the run that ENDS at i, as the forward pass cut it (scan from the group's first node)
   const sv_tape_node& n = t->nodes[i];
   if (n.kind != SV_TAPE_UNARY || !n.group) return i;
   size_t f = i;
-  while (f > 0 && t->nodes[f - 1].kind == SV_TAPE_UNARY && t->nodes[f - 1].group == n.group) --f;
+  while (f > 0 && t->nodes[f - 1].kind == SV_TAPE_UNARY && t->nodes[f - 1].group == n.group && t->nodes[f - 1].lane == n.lane) --f;
   size_t b = f;
   while (b + SV_TAPE_MAX_PARTS <= i) b += SV_TAPE_MAX_PARTS;
   return b;
@@ -775,6 +918,43 @@ int group_backward(sv_tape* t, size_t b, size_t e, hipStream_t st) {
   return SV_OK;
 }
 
+// ---- lanes at run time: lane 0 is the caller's stream; the others are created on first use
+hipStream_t lane_stream(sv_tape* t, int lane, hipStream_t st) {
+  if (lane <= 0) return st;
+  if (!t->lane_st[lane]) {
+    t->lane_st[lane] = sv_shared_stream(lane - 1);       // the process's shared side streams (streams.hip): a stream per tape aliased the caller's hardware queue
+    if (!t->lane_st[lane]) return st;
+  }
+  return t->lane_st[lane];
+}
+int lanes_fork(sv_tape* t, hipStream_t st) {             // every lane behind what the caller's stream holds now
+  if (!t->ev_fork && hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  if (hipEventRecord(t->ev_fork, st) != hipSuccess) return (int)hipGetLastError();
+  for (int l = 1; l < t->nlanes; ++l) {
+    hipStream_t s = lane_stream(t, l, st);
+    if (s != st && hipStreamWaitEvent(s, t->ev_fork, 0) != hipSuccess) return (int)hipGetLastError();
+  }
+  return SV_OK;
+}
+int lanes_join(sv_tape* t, hipStream_t st) {             // the caller's stream behind every lane
+  for (int l = 1; l < t->nlanes; ++l) {
+    hipStream_t s = lane_stream(t, l, st);
+    if (s == st) continue;
+    if (!t->ev_join[l] && hipEventCreateWithFlags(&t->ev_join[l], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventRecord(t->ev_join[l], s) != hipSuccess || hipStreamWaitEvent(st, t->ev_join[l], 0) != hipSuccess) return (int)hipGetLastError();
+  }
+  return SV_OK;
+}
+int lane_waits(sv_tape* t, const std::vector<int>& w, hipStream_t s) {
+  for (int nd : w)
+    if (t->ev_node[nd] && hipStreamWaitEvent(s, t->ev_node[nd], 0) != hipSuccess) return (int)hipGetLastError();
+  return SV_OK;
+}
+int lane_record(sv_tape* t, int nd, hipStream_t s) {
+  if (!t->ev_node[nd] && hipEventCreateWithFlags(&t->ev_node[nd], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  return hipEventRecord(t->ev_node[nd], s) == hipSuccess ? SV_OK : (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int sv_tape_run(sv_tape* t, const sv_tape_run_args* a, void* stream) {
@@ -792,11 +972,17 @@ extern "C" int sv_tape_run(sv_tape* t, const sv_tape_run_args* a, void* stream) 
       if (t->grad_floats && hipMemsetAsync(t->ws + t->off_grad, 0, (size_t)t->grad_floats * 4, st) != hipSuccess) return (int)hipGetLastError();
       if (hipMemsetAsync(a->grads, 0, (size_t)a->n_params * 4, st) != hipSuccess) return (int)hipGetLastError();
     }
+    const bool lanes = t->nlanes > 1;
+    if (lanes) SV_TRY(lanes_fork(t, st));
     for (size_t i = 0; i < t->nodes.size(); ++i) {
       const size_t e = group_end(t, i);
-      if (e > i + 1) { SV_TRY(group_forward(t, i, e, st)); i = e - 1; }
-      else SV_TRY(node_forward(t, i, a, bwd, st));
+      hipStream_t s = lanes ? lane_stream(t, t->nodes[i].lane, st) : st;
+      if (lanes) SV_TRY(lane_waits(t, t->fs.waits[i], s));
+      if (e > i + 1) { SV_TRY(group_forward(t, i, e, s)); i = e - 1; }
+      else SV_TRY(node_forward(t, i, a, bwd, s));
+      if (lanes && t->fs.rec[i]) SV_TRY(lane_record(t, (int)i, s));          // (i = the unit's last node by now)
     }
+    if (lanes) SV_TRY(lanes_join(t, st));
     if (t->n_loss) {
       FinalArgs f;
       memset(&f, 0, sizeof(f));
@@ -807,12 +993,19 @@ extern "C" int sv_tape_run(sv_tape* t, const sv_tape_run_args* a, void* stream) 
       SV_LAUNCH_CHECK();
     }
   }
-  if (bwd)
+  if (bwd) {
+    const bool lanes = t->nlanes > 1;
+    if (lanes) SV_TRY(lanes_fork(t, st));
     for (size_t i = t->nodes.size(); i-- > 0;) {
       const size_t b = group_begin(t, i);
-      if (b < i) { SV_TRY(group_backward(t, b, i + 1, st)); i = b; }
-      else SV_TRY(node_backward(t, i, a, st));
+      hipStream_t s = lanes ? lane_stream(t, t->nodes[i].lane, st) : st;
+      if (lanes) SV_TRY(lane_waits(t, t->bs.waits[i], s));
+      if (b < i) { SV_TRY(group_backward(t, b, i + 1, s)); i = b; }
+      else SV_TRY(node_backward(t, i, a, s));
+      if (lanes && t->bs.rec[i]) SV_TRY(lane_record(t, (int)i, s));          // (i = the unit's first node by now)
     }
+    if (lanes) SV_TRY(lanes_join(t, st));
+  }
   if (adam) {
     if (a->clipnorm > 0.f) {
       if (!a->tensor_off || !a->norm_ws || a->n_tensors < 1) return SV_E_BADARG;

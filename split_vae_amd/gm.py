@@ -26,7 +26,12 @@ import torch
 
 from . import _lib, ops
 from ._lib import (PHASE_ADAM, PHASE_BWD_DECODERS, PHASE_BWD_ENC_CONVS, PHASE_BWD_ENC_HEADS, PHASE_FWD_DECODERS,
-                   PHASE_FWD_ENCODERS, PHASE_LOSS, PHASE_PREP)
+                   PHASE_FWD_ENCODERS, PHASE_INPUTS_STAGED, PHASE_LOSS, PHASE_PREP)
+
+# the global (GM) encoder and the local encoder on two HIP streams, forward (when the augmentation staged the step's inputs) and backward: SV_GM_STREAMS=0 keeps
+# everything on the caller's stream (A/B, the equivalence test).  Measured: profiles/r06_gm_streams.txt
+_GM_STREAMS = int(os.environ.get("SV_GM_STREAMS", "3"))        # bit 0: the forward, bit 1: the backward
+_SIDE_STREAMS = {}                                              # device index -> the process's one side stream (LGGMVae._side_stream)
 from .model import LGVae
 
 GM_RATE = 0.2      # Dropout(rate=0.2): y_block (vae/model.py:56) and do5 (:72)
@@ -261,15 +266,43 @@ class LGGMVae(LGVae):
         u, k1, k5 = (None, None, None) if noise is None else noise
         kw = dict(params=self.flat, images6=inputs.contiguous(), eps_x_hat=eh, seed=self.seed, step=self._calls)
         kw.update(plan_kw)
-        plan.step(PHASE_PREP | PHASE_FWD_ENCODERS, **kw)
-        enc.prep(self.gm_flat)
         Lc = self.global_latent_dims + self.local_latent_dims
-        enc.forward(self.gm_flat, plan.buffer("in8_x", self.dtype, (B, self.H, self.W, 8)),
-                    plan.buffer("zcat", self.dtype, (B, Lc)), bool(training) and self.dropout_in_training, eps=ex, u=u,
-                    keep1=k1, keep5=k5, seed=self.seed,
-                    step=self._calls, sample_offset=kw.get("sample_offset", 0))
+
+        def gm_forward():
+            enc.prep(self.gm_flat)
+            enc.forward(self.gm_flat, plan.buffer("in8_x", self.dtype, (B, self.H, self.W, 8)),
+                        plan.buffer("zcat", self.dtype, (B, Lc)), bool(training) and self.dropout_in_training, eps=ex, u=u,
+                        keep1=k1, keep5=k5, seed=self.seed,
+                        step=self._calls, sample_offset=kw.get("sample_offset", 0))
+        # Augmentator.augment(..., plan=plan) left this batch's padded inputs in in8_x / in8_xh (still current: generation, version counter): the global (GM)
+        # encoder then depends on nothing the local encoder's launches produce -- the two encoders of vae/model.py:236-240 run on two HIP streams
+        staged = getattr(inputs, "_sv_staged_plan", None) is plan and inputs._sv_staged_gen == plan.in8_gen and inputs._sv_staged_version == inputs._version
+        if getattr(inputs, "_sv_staged_plan", None) is plan:
+            inputs._sv_staged_plan = None                     # one step per staging
+        if staged and (_GM_STREAMS & 1):
+            cur, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), ops.hold_stream():
+                gm_forward()
+            plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | PHASE_INPUTS_STAGED, **kw)
+            cur.wait_stream(side)
+        else:
+            plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | (PHASE_INPUTS_STAGED if staged else 0), **kw)
+            gm_forward()
         plan.step(PHASE_FWD_DECODERS | (PHASE_LOSS if want_loss else 0), **kw)
         return plan, enc, kw
+
+    def _side_stream(self):
+        # ONE side stream per process and device, whatever the number of models: a stream per model left a second model's stream on the hardware queue of
+        # the first one's compute stream, and its cross-stream waits cost 3x the step (profiles/r06_gm_streams.txt: 1.19 -> 3.84 ms)
+        # ... and it is the LIBRARY's shared side stream 1 (sv_side_stream: the plan's second weight-gradient stream, idle at the shard sizes this model trains at)
+        dev = torch.cuda.current_device()
+        s = _SIDE_STREAMS.get(dev)
+        if s is None:
+            h = C.c_void_p()
+            ops.check(_lib.load().sv_side_stream(1, C.byref(h)), "sv_side_stream")
+            s = _SIDE_STREAMS[dev] = torch.cuda.ExternalStream(h.value, device=dev)
+        return s
 
     def __call__(self, inputs, training=False, eps=None, noise=None, copy=True):
         """vae/model.py:236-246 -> the 14-tuple (the LGVae 10-tuple, then y, y_logits, z_prior_mean, z_prior_sig)."""
@@ -344,10 +377,23 @@ def _train_step_lg_gm_vae(model, images, optimizer, eps, noise, sample_offset):
     model._calls += 1
     plan.step(PHASE_BWD_DECODERS, **kw)
     Lc = model.global_latent_dims + model.local_latent_dims
-    model.gm_grad_flat.zero_()
-    enc.backward(model.gm_flat, model.gm_grad_flat, plan.buffer("in8_x", model.dtype, (B, model.H, model.W, 8)),
-                 plan.buffer("gz_x", torch.float32, (B, Lc)), model.beta, model.alpha)
-    plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)
+
+    def gm_backward():
+        model.gm_grad_flat.zero_()
+        enc.backward(model.gm_flat, model.gm_grad_flat, plan.buffer("in8_x", model.dtype, (B, model.H, model.W, 8)),
+                     plan.buffer("gz_x", torch.float32, (B, Lc)), model.beta, model.alpha)
+    if _GM_STREAMS & 2:
+        # the two encoders' adjoints read disjoint column blocks of dz and write disjoint gradient buffers: the global (GM) encoder's on a second stream
+        # beside the local encoder's phases (vae/trainer.py:167's tape.gradient has no order between them either)
+        cur, side = torch.cuda.current_stream(), model._side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), ops.hold_stream():
+            gm_backward()
+        plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)
+        cur.wait_stream(side)
+    else:
+        gm_backward()
+        plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)
     metrics = _metrics(model, plan, enc, B)
     plan.step(PHASE_ADAM, **kw)
     ops.adam_step(model.gm_flat, model.gm_grad_flat, gm_m, gm_v, t, lr, optimizer.beta_1, optimizer.beta_2, optimizer.epsilon)

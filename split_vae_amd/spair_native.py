@@ -51,6 +51,7 @@ class NativeStep:
         self.device = model.store.flat.device
         self.n_nodes = 0
         self._group = 0
+        self._lane = 0                                # sv_tape_node.lane of the nodes being recorded (include/splitvae.h): 0 = the caller's stream
         self._views = {}
         self.noise = {}                               # name -> (T, kind, std)
         self.out = {}                                 # name -> (T, column offset, columns, shape)
@@ -102,10 +103,24 @@ class NativeStep:
         n.dyn_idx = n.loss_idx = -1
         n.rep = 1
         n.kind = kind
+        n.lane = self._lane
         for k, v in kw.items():
             setattr(n, k, v.id if isinstance(v, T) else v)
         check(self.lib.sv_tape_add(self.h, C.byref(n)), "sv_tape_add(kind %d)" % kind)
         self.n_nodes += 1
+
+    def lane(self, k):
+        """with self.lane(k): the nodes recorded inside run on the tape's HIP stream k (an independent branch of the model beside the object pipeline);
+        the tape orders every conflicting tensor access across lanes itself, so this is a scheduling hint only."""
+        step = self
+
+        class _Lane:
+            def __enter__(self_):
+                self_.prev, step._lane = step._lane, k
+
+            def __exit__(self_, *exc):
+                step._lane = self_.prev
+        return _Lane()
 
     def _offs(self, layer):
         o = self.store.offsets
@@ -238,8 +253,11 @@ class NativeStep:
             else:
                 xh8 = self.tensor(B * H * W, Cc, 8, grad=False)
                 self.unary(TAPE_COPY, self.images, xh8, Cc, xo=3, group=g0)
-            z_l, zl_mean, zl_sig = self._image_encoder(m.x_hat_encoder, xh3, xh8, "eps_l", m.Ll, 6)
-            z_bg, zb_mean, zb_sig = self._image_encoder(m.bg_encoder, x3, x8, "eps_bg", m.Lbg, 5)
+            # the x-hat and background networks are independent of the object pipeline until the renderer / the losses: their own lanes (HIP streams)
+            with self.lane(1):
+                z_l, zl_mean, zl_sig = self._image_encoder(m.x_hat_encoder, xh3, xh8, "eps_l", m.Ll, 6)
+            with self.lane(2):
+                z_bg, zb_mean, zb_sig = self._image_encoder(m.bg_encoder, x3, x8, "eps_bg", m.Lbg, 5)
         # ---- Encoder.call :403-496
         e = m.encoder
         a, h1, w1 = self.conv(e.conv1, x8, B, H, W)
@@ -289,16 +307,19 @@ class NativeStep:
         zin, Lw = zt, L
         bg = None
         if lg:
-            xh = self._image_decoder(m.x_hat_decoder, z_l)
-            if m.concat_z_bg:
-                z_bg = self.concat([(z_bg, 0, m.Lbg), (z_l, 0, m.Ll)], B)
-            bg = self._image_decoder(m.bg_decoder, z_bg)
+            with self.lane(1):
+                xh = self._image_decoder(m.x_hat_decoder, z_l)
+            with self.lane(2):
+                if m.concat_z_bg:
+                    z_bg = self.concat([(z_bg, 0, m.Lbg), (z_l, 0, m.Ll)], B)
+                bg = self._image_decoder(m.bg_decoder, z_bg)
             if m.concat_z_what:
                 zin = self.concat([(zt, 0, L), (z_l, 0, m.Ll, CELLS)], n)
                 Lw = L + m.Ll
         elif m.bg_model is not None:
-            z_bg, zb_mean, zb_sig = self._image_encoder(m.bg_model.enc, x3, x8, "eps_bg", m.bg_latent_size, 5)
-            bg = self._image_decoder(m.bg_model.dec, z_bg)
+            with self.lane(2):
+                z_bg, zb_mean, zb_sig = self._image_encoder(m.bg_model.enc, x3, x8, "eps_bg", m.bg_latent_size, 5)
+                bg = self._image_decoder(m.bg_model.dec, z_bg)
         if bg is None:
             bg = self.tensor(B * H * W, Cc, Cc, grad=False)                               # bg_recon = 0.0 (:39): never written, stays zero
         # Decoder.call :514-532

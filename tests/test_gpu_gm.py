@@ -186,3 +186,33 @@ def test_gm_training_descends_with_device_rng(ops):
             keep1 = model.encoder(B).buf["keep1"]
             frac = float(keep1.mean())
             assert 0.75 < frac < 0.85, frac                             # Dropout(rate=0.2) keeps ~80 %
+
+
+def test_two_stream_step_on_staged_inputs_equals_the_plain_step(ops):
+    """Inputs staged by the augmentation (Augmentator.augment(..., plan=)): the global (GM) encoder runs on a second HIP stream beside the local encoder, forward
+    and backward (gm.py: _forward / _train_step_lg_gm_vae; vae/model.py:236-240 has no order between the two encoders).  Three train steps on the same batch,
+    weights and Philox streams against the un-staged step (single-stream forward): the six metrics of every step and the updated variables agree to the noise of
+    the step's split-K atomics -- a missing stream dependency would feed the decoders a zcat that does not exist yet."""
+    from split_vae_amd import data
+    from split_vae_amd.augmentation import Augmentator
+    from split_vae_amd.gm import LGGMVae, train_step_lg_gm_vae
+    from split_vae_amd.optimizer import Adam
+    B = 32
+    x = data.synthetic_images(B, H, H, seed=0, device="cuda")
+    res = []
+    for staged in (False, False, True):
+        model = LGGMVae(128, 128, [-1, H, H, 3], K, TAU, dtype="f32", device="cuda", seed=4)
+        model.beta, model.alpha = BETA, ALPHA
+        opt = Adam(learning_rate=1e-3)
+        aug = Augmentator("scramble", size=PATCH, seed=1)
+        ms = []
+        for _ in range(3):
+            img = aug.augment(x, plan=model.plan(B) if staged else None)
+            assert (getattr(img, "_sv_staged_plan", None) is not None) == staged
+            ms.append(train_step_lg_gm_vae(model, img, opt).cpu().numpy().astype(np.float64))
+        torch.cuda.synchronize()
+        res.append((np.stack(ms), model.flat.cpu().numpy().astype(np.float64), model.gm_flat.cpu().numpy().astype(np.float64)))
+    (m0, p0, g0), (m1, p1, g1), (m2, p2, g2) = res
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-30))
+    assert rel(m0, m2) <= 10 * rel(m0, m1) + 1e-5, (rel(m0, m2), rel(m0, m1))
+    assert rel(p0, p2) <= 10 * rel(p0, p1) + 1e-5 and rel(g0, g2) <= 10 * rel(g0, g1) + 1e-5, (rel(p0, p2), rel(p0, p1), rel(g0, g2), rel(g0, g1))

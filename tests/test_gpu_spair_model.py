@@ -349,3 +349,30 @@ def test_spair_weights_round_trip(lib_built, tmp_path, ext):
     with torch.no_grad():
         ya, yb = a(images, training=True, noise=noise)[0], b(images, training=True, noise=noise)[0]
     assert torch.equal(ya, yb)
+
+
+def test_lanes_compute_the_single_stream_step(lib_built, tmp_path):
+    """The tape's lanes (include/splitvae.h: sv_tape_node.lane; the x-hat and background networks of LG-SPAIR on their own HIP streams beside the object pipeline,
+    spair/spair.py:84-104) against the same tape on ONE stream (SV_TAPE_LANES=0), in fresh processes: every loss of six consecutive train steps, the last
+    gradients and the updated variables agree to the run-to-run noise of the step itself (the split-K Dense layers add with fp32 atomics) -- a missing
+    cross-lane dependency would read a tensor before it exists and move them by orders of magnitude more."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("one", {"SV_TAPE_LANES": "0"}), ("one_b", {"SV_TAPE_LANES": "0"}), ("lanes", {}), ("lanes3", {"SV_TAPE_LANES": "3"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "spair_lanes_probe.py"), out, "6"], capture_output=True, text=True, timeout=600,
+                           env=dict({k: v for k, v in os.environ.items() if k != "SV_TAPE_LANES"}, **env), cwd=root)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        res[tag] = np.load(out)
+    one, twin = res["one"], res["one_b"]
+
+    def dist(a, b, k):
+        return float(np.linalg.norm(a[k] - b[k]) / max(np.linalg.norm(a[k]), 1e-30))
+    for tag in ("lanes", "lanes3"):                      # the default (one extra stream for both image branches) and a stream per branch
+        for k in ("losses", "grads", "params"):
+            floor = dist(one, twin, k)                   # two single-stream runs: the step's own noise
+            assert dist(one, res[tag], k) <= 10 * floor + (1e-5 if k != "grads" else 1e-3), (tag, k, dist(one, res[tag], k), floor)
+        assert np.all(np.isfinite(res[tag]["losses"]))
