@@ -304,7 +304,7 @@ struct sv_tape {
   int nlanes = 1;
   hipStream_t lane_st[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> ev_node;
+  std::vector<hipEvent_t> ev_node, ev_wg;      // per node: the unit's cross-lane event; "dY is ready" for a weight gradient sent to lane 1's stream
   ~sv_tape() {
     for (int l = 1; l < MAX_LANES; ++l) {
       if (lane_st[l]) (void)hipStreamSynchronize(lane_st[l]);          // (shared: not destroyed)
@@ -312,6 +312,8 @@ struct sv_tape {
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto e : ev_node)
+      if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_wg)
       if (e) (void)hipEventDestroy(e);
   }
 
@@ -620,7 +622,7 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
   }
   t->nlanes = maxlane + 1;
   if (any_conv) { t->off_wgrad = o; o += al(SV_WGRAD_WS_BYTES) * t->nlanes; }
-  if (t->nlanes > 1) { build_schedules(t); t->ev_node.assign(t->nodes.size(), nullptr); }
+  if (t->nlanes > 1) { build_schedules(t); t->ev_node.assign(t->nodes.size(), nullptr); t->ev_wg.assign(t->nodes.size(), nullptr); }
   t->ws_bytes = o;
   t->finalized = true;
   return SV_OK;
@@ -759,6 +761,8 @@ int node_forward(sv_tape* t, size_t i, const sv_tape_run_args* a, bool with_grad
   return SV_E_BADARG;
 }
 
+hipStream_t lane_stream(sv_tape* t, int lane, hipStream_t st);
+
 int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t st) {
   const sv_tape_node& n = t->nodes[i];
   const sv_tape::Extra& e = t->ex[i];
@@ -775,10 +779,31 @@ int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t s
         SV_LAUNCH_CHECK();
       }
       float* gx = t->grad(n.x);
+      // (where a lane-0 layer's weight gradient goes: see the Dense case)
+      static const bool wside = !(getenv("SV_TAPE_WGRAD_SIDE") && atoi(getenv("SV_TAPE_WGRAD_SIDE")) == 0);
+      auto wgrad_stream = [&](hipStream_t* ws, int* wlane) -> int {     // call when everything the weight gradient reads has been enqueued on st
+        *ws = st; *wlane = t->nlanes > 1 ? n.lane : 0;
+        if (!(wside && t->nlanes > 1 && n.lane == 0 && gx)) return SV_OK;
+        // conv layers: at bf16 only.  Measured (profiles/r06_spair_lanes.txt, 32 images): Dense layers' weight gradients on lane 1 2.65 -> 2.49 ms (fp32) / 2.60 -> 2.38
+        // (bf16); the conv layers' too: 2.52 (fp32: the 77-85 us fp32 weight gradients of the object decoder make lane 1 the longer one) / 2.35 (bf16)
+        if (n.kind == SV_TAPE_CONV && t->dtype != SV_BF16) return SV_OK;
+        hipStream_t s1 = lane_stream(t, 1, st);
+        if (s1 == st) return SV_OK;
+        if (!t->ev_wg[i] && hipEventCreateWithFlags(&t->ev_wg[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        if (hipEventRecord(t->ev_wg[i], st) != hipSuccess || hipStreamWaitEvent(s1, t->ev_wg[i], 0) != hipSuccess) return (int)hipGetLastError();
+        *ws = s1; *wlane = 1;                  // (lane 1's slab workspace: its own conv layers use it in the same stream's order)
+        return SV_OK;
+      };
       if (n.kind == SV_TAPE_DENSE) {
         const float* gate = n.act == SV_ACT_RELU ? t->act(n.y) : nullptr;
+        // The weight gradient feeds only Adam: with lanes on, a lane-0 layer's goes to lane 1's stream behind an event (dY is final here: every consumer of y ran
+        // its adjoint already, and nothing writes the gradient buffers again before the next step's zero fill, which follows the join) and the input-gradient chain --
+        // the critical path of the adjoint, ~11 us per launch -- continues at once.  The variables' gradients are written by this launch alone.
+        hipStream_t ws;
+        int wl;
+        SV_TRY(wgrad_stream(&ws, &wl));
         SV_TRY(svk_dense_f32_wgrad(t->act(n.x), x.ld, gy, y.ld, a->grads + n.w_off, n.b_off >= 0 ? a->grads + n.b_off : nullptr, (int)x.rows, x.cols,
-                                   y.cols, 1, gate, st));
+                                   y.cols, 1, gate, ws));
         if (gx) SV_TRY(svk_dense_f32_dgrad(gy, y.ld, a->params + n.w_off, gx, x.ld, (int)x.rows, x.cols, y.cols, multi(n.x) ? 1 : 2, gate, st));
         return SV_OK;
       }
@@ -787,11 +812,17 @@ int node_backward(sv_tape* t, size_t i, const sv_tape_run_args* a, hipStream_t s
         const int64_t n4 = y.rows * y.ld / 4;
         hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n4)), dim3(256), 0, st, gy, (bf16_t*)t->scr(e.scratch2), n4);
         SV_LAUNCH_CHECK();
-        SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(t->nlanes > 1 ? n.lane : 0), SV_WGRAD_WS_BYTES, st));
+        hipStream_t ws;
+        int wl;
+        SV_TRY(wgrad_stream(&ws, &wl));          // (behind the cast: the weight gradient reads the bf16 copy of dY)
+        SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->scr(e.scratch), t->scr(e.scratch2), a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(wl), SV_WGRAD_WS_BYTES, ws));
         if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, t->scr(e.scratch2), t->ws + t->off_arena + e.wd_off * es, nullptr, gx, 1, st));
         return SV_OK;
       }
-      SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(t->nlanes > 1 ? n.lane : 0), SV_WGRAD_WS_BYTES, st));
+      hipStream_t ws;
+      int wl;
+      SV_TRY(wgrad_stream(&ws, &wl));
+      SV_TRY(sv_conv2d_nhwc_wgrad_ws(&e.cd, t->act(n.x), gy, a->grads + n.w_off, a->grads + n.b_off, t->wgrad_ws(wl), SV_WGRAD_WS_BYTES, ws));
       if (gx) SV_TRY(sv_conv2d_nhwc_dgrad(&e.cd, gy, t->ws + t->off_arena + e.wd_off * es, nullptr, gx, multi(n.x) ? 1 : 0, st));
       return SV_OK;
     }
