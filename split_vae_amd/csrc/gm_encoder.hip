@@ -85,6 +85,13 @@ struct sv_gm_encoder {
   float rate = 0.f;                          // dropout rate of the last forward (its backward uses the same)
   int64_t F;
   int Kp;
+  hipEvent_t ev_dy[NLAYER] = {};             // "dY of layer l is ready": its weight gradient runs on the library's shared side stream 0 behind this
+  hipEvent_t ev_wjoin = nullptr;
+  ~sv_gm_encoder() {
+    for (auto ev : ev_dy)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ev_wjoin) (void)hipEventDestroy(ev_wjoin);
+  }
 
   size_t esz() const { return d.dtype == SV_BF16 ? 2 : 4; }
   void add(const std::string& n, int64_t bytes) {
@@ -301,9 +308,23 @@ extern "C" int sv_gm_encoder_backward(sv_gm_encoder* e, const sv_gm_args* a, voi
     char* z1 = e->bp("acc_end");
     if (hipMemsetAsync(z0, 0, (size_t)(z1 - z0), st) != hipSuccess) return (int)hipGetLastError();
   }
-  auto wg = [&](int l, const void* x, const void* dy) {
+  // The weight gradients feed only Adam: they go to the library's shared side stream 0 behind a "dY is ready" event, the input-gradient chain (the critical
+  // path: 12 layers, one after the other) continues at once; joined at the end of the call.  Every dY buffer is written once per call, the forward activations
+  // are read-only here, each layer's variable gradients have one writer.  SV_GM_WGRAD_SIDE=0: everything on `stream` (A/B).  profiles/r06_gm_streams.txt
+  static const bool wside = !(getenv("SV_GM_WGRAD_SIDE") && atoi(getenv("SV_GM_WGRAD_SIDE")) == 0);
+  hipStream_t ws2 = wside ? sv_shared_stream(0) : nullptr;
+  if (ws2 == st) ws2 = nullptr;
+  bool forked = false;
+  auto wg = [&](int l, const void* x, const void* dy) -> int {
+    void* wst = stream;
+    if (ws2) {
+      if (!e->ev_dy[l] && hipEventCreateWithFlags(&e->ev_dy[l], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+      if (hipEventRecord(e->ev_dy[l], st) != hipSuccess || hipStreamWaitEvent(ws2, e->ev_dy[l], 0) != hipSuccess) return (int)hipGetLastError();
+      wst = (void*)ws2;
+      forked = true;
+    }
     return sv_conv2d_nhwc_wgrad_ws(&e->conv[l], x, dy, a->grads + e->params[2 * l].off, a->grads + e->params[2 * l + 1].off, e->bp("wgrad_ws"),
-                                   e->bufs.at("wgrad_ws").bytes, stream);
+                                   e->bufs.at("wgrad_ws").bytes, wst);
   };
   auto dg_acc = [&](int l, const void* dy, const char* acc) {   // split-K input gradient added into an fp32 buffer
     return sv_conv2d_nhwc_dgrad(&e->conv[l], dy, e->wdgrad(l), nullptr, e->bp(acc), 1, stream);
@@ -341,6 +362,10 @@ extern "C" int sv_gm_encoder_backward(sv_gm_encoder* e, const sv_gm_args* a, voi
   SV_TRY(dg(C2, e->bp("g_c2"), "g_h1d"));
   SV_TRY(act_bwd("g_h1d", dt, 128, nullptr, "h1", 0.f, nullptr, "g_c1", (int64_t)B * (H / 2) * (H / 2), 128));
   SV_TRY(wg(C1, a->in8_x, e->bp("g_c1")));
+  if (forked) {
+    if (!e->ev_wjoin && hipEventCreateWithFlags(&e->ev_wjoin, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventRecord(e->ev_wjoin, ws2) != hipSuccess || hipStreamWaitEvent(st, e->ev_wjoin, 0) != hipSuccess) return (int)hipGetLastError();
+  }
   return SV_OK;
 }
 
