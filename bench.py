@@ -45,7 +45,7 @@ split_vae_amd.configure_hw_queues()                 # before any HIP call (a 4th
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 TRAIN_FLOP_PER_IMAGE = {64: 2.249196e9, 32: 0.562299e9}
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")            # profiles/<tag>_*traffic.json: the committed PMC passes `traffic` cites (newest round first)
 
 
 def _traffic_file(dtype="bf16"):
@@ -339,7 +339,8 @@ def spair_row(dev, which="hard", B=32, steps=60, warmup=5):
     from split_vae_amd import spair, spair_main, spair_trainer
     from split_vae_amd.augmentation import Augmentator
     out = {"unit": "images/s", "batch": B, "steps": steps, "workload": SPAIR_WORKLOAD[which],
-           "launch": "one native launch sequence per step (sv_tape_run: forward, losses, adjoint, Adam; eager launches); f32 = the reference's "
+           "launch": "one native launch sequence per step (sv_tape_run: forward, losses, adjoint, Adam; eager launches) on two HIP streams: the x-hat / background "
+                     "networks on a lane beside the object pipeline, the lane-0 layers' weight gradients on that lane too (csrc/tape.hip); f32 = the reference's "
                      "precision, bf16 = bf16 operands in the spatial convolutions only"}
     for dt_ in ("f32", "bf16"):
         cfg = spair_main.default_config(dtype=dt_, **SPAIR_FLAGS[which])
