@@ -475,8 +475,9 @@ def print_table(table, dtype, H, B):
     sys.stderr.write("per-launch table (%s %dx%d B=%d, serial launches, hipEvents):\n" % (dtype, H, H, B))
     for r in table:
         g = grade(r, dtype)
-        sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline (direct count)  %5.1f%% issued\n" %
-                         (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"], 100 * g["frac_issued"]))
+        tail = " (direct FLOP count; %5.1f%% at the FLOPs the launch really multiplies)" % (100 * g["frac_issued"]) if g["bound"] == "mfma" else ""
+        sys.stderr.write("%-18s n=%3d avg %8.3f ms  %5.1f%%  %8.1f TFLOP/s %8.1f GB/s  %5.1f%% of the %s roofline%s\n" %
+                         (r["name"], r["launches"], g["avg_ms"], 100 * r["total_ms"] / tot, g["tflops"], g["gbs"], 100 * g["frac"], g["bound"], tail))
 
 
 DTYPE_NOTE = {"f32": "f32 operands, f32 accumulate (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the reference's precision (vae/model.py:12)",
