@@ -1481,7 +1481,9 @@ static int run_phases(sv_lgvae_plan* p, const sv_lgvae_step_args* s, hipStream_t
     const bool whole = (ph & SV_PHASE_ALL) == SV_PHASE_ALL;
     // fp32 (round 5, polyphase decoder layers + 52-KB weight-gradient tiles): two side streams 9.60-9.62 -> 9.37-9.39 ms at B = 512 (profiles/r05_f32_streams.txt)
     // (fp32, 256 images per network: 5.14 -> 5.09 ms; 128: 2.84 -> 2.87: from 256)
-    p->side_use = forced > 0 ? forced : (whole && 2 * p->d.B >= (p->d.dtype == SV_F32 ? 512 : 768)) ? 2 : 1;
+    // (round 6, with the process's fixed side streams: bf16 256 images per network 1.068-1.080 -> 1.054-1.056 ms with two: the bf16 threshold moved from 768 to 512 too;
+    //  profiles/r06_sweep_bf16.txt)
+    p->side_use = forced > 0 ? forced : (whole && 2 * p->d.B >= 512) ? 2 : 1;
   }
   // early side work: the decoders' weight images and the gradient buffer's zero fill on side stream 0 beside the encoders' forward (see early_stream)
   const bool zero_here = (ph & SV_PHASE_LOSS) && s->grads;
