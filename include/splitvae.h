@@ -543,6 +543,10 @@ void sv_tape_destroy(sv_tape* t);
 int32_t sv_tape_tensor(sv_tape* t, int64_t rows, int32_t cols, int32_t ld, int32_t need_grad);       /* -> tensor id (>= 0) or SV_E_* */
 int32_t sv_tape_view(sv_tape* t, int32_t src, int64_t rows, int32_t cols, int32_t ld);               /* same storage, other 2-D shape */
 int sv_tape_add(sv_tape* t, const sv_tape_node* node);
+/* The cross-lane schedule of a finalized tape, node by node (pass 0 forward, 1 backward): returns how many nodes' events the launch of `node` waits for (their indices in
+ * waits[0 .. max_waits)), *records = 1 when an event is recorded behind it for another lane.  A UNARY group is one launch (waits on its first node forwards / its last
+ * backwards).  Host logic only -- no GPU needed: what tests/test_abi.py pins.  0 for a single-lane tape. */
+int sv_tape_schedule(const sv_tape* t, int32_t pass, int32_t node, int32_t* waits, int32_t max_waits, int32_t* records);
 /* reported[j] = sum_i matrix[j * 16 + i] * mean_b loss_i: the `losses` list of train_step (spair/trainer.py:158-160, :208-216) */
 int sv_tape_set_report(sv_tape* t, const float* matrix, int32_t n_report);
 int sv_tape_finalize(sv_tape* t);

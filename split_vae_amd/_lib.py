@@ -162,6 +162,7 @@ SYMBOLS = {
     "sv_tape_tensor": (_i32, [_vp, _i64, _i32, _i32, _i32]),
     "sv_tape_view": (_i32, [_vp, _i32, _i64, _i32, _i32]),
     "sv_tape_add": (C.c_int, [_vp, C.POINTER(TapeNode)]),
+    "sv_tape_schedule": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "sv_tape_set_report": (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
     "sv_tape_finalize": (C.c_int, [_vp]),
     "sv_tape_workspace_bytes": (_i64, [_vp]),

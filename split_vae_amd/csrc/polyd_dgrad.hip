@@ -21,7 +21,7 @@ struct PolydEdgeMulti { const void* dy[2]; const void* wedge[2]; const void* wco
 // NT = 2R+1 taps along the strip, NGRP = MFMA groups over the (padded) dY channels, NLI = strip pieces per thread and image (host-checked bound).
 // One image per barrier pair; the NEXT image's strip is fetched into registers before the current image's MFMAs and written to LDS after them (the loop is
 // latency otherwise: 174 us per launch at 2 x 512 images for 8 GFLOP).
-template <typename T, int NT, int NGRP, int NLI>
+template <typename T, int NT, int NGRP, int NLI, int DEPTH>
 __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg, int B, int h, int w, int Cin, int gdy, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPP = ElemTraits<T>::EPP, CPG = FixMma<T>::CPG, COP = NGRP * CPG, NPC = COP / EPP, R = (NT - 1) / 2;
@@ -62,21 +62,24 @@ __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg
       }
     }
   }
-  uint4 rs[NLI];
-  auto fetch = [&](int b) {
+  // DEPTH 2 (round 6, opt-in): two images' strips in flight per thread -- register set A holds image b, B image b + 1, a set is refilled with image b + 2 as soon as
+  // it has been written to LDS.  The loop is one global-load latency per image at DEPTH 1; the second register set costs a resident workgroup, which costs more (launcher).
+  uint4 rsA[NLI], rsB[NLI];
+  auto fetch = [&](int b, uint4 (&rs)[NLI]) {
     const T* dyb = dy + (int64_t)b * H2 * W2 * gdy;
 #pragma unroll
     for (int s = 0; s < NLI; ++s) rs[s] = s_src[s] >= 0 ? *(const uint4*)(dyb + s_src[s]) : make_uint4(0, 0, 0, 0);
   };
   const int per = (B + (int)gridDim.y - 1) / (int)gridDim.y, b_lo = (int)blockIdx.y * per, b_hi = min(B, b_lo + per);
-  if (b_lo < b_hi) fetch(b_lo);
-  for (int b = b_lo; b < b_hi; ++b) {
+  if (b_lo < b_hi) fetch(b_lo, rsA);
+  if (DEPTH == 2 && b_lo + 1 < b_hi) fetch(b_lo + 1, rsB);
+  auto image = [&](int b, uint4 (&rs)[NLI]) {
     __syncthreads();                                           // the previous image's strip and partial sums are consumed
 #pragma unroll
     for (int s = 0; s < NLI; ++s)
       if (s_dst[s] >= 0) *(uint4*)(sStrip + s_dst[s]) = rs[s];
     __syncthreads();
-    if (b + 1 < b_hi) fetch(b + 1);                            // in flight during this image's MFMAs
+    if (b + DEPTH < b_hi) fetch(b + DEPTH, rs);                // in flight during this image's (and, DEPTH 2, the next image's) MFMAs
     for (int pf = 0; pf < npf; ++pf) {                         // every wave its strip row
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (wave < nq) {
@@ -102,6 +105,14 @@ __global__ __launch_bounds__(256) void polyd_edge_kernel(const PolydEdgeMulti mg
       float* p = rows ? mg.erow[blockIdx.z] + (((int64_t)b * 2 + (e & 1)) * w + pos) * Cin + ci
                       : mg.ecol[blockIdx.z] + (((int64_t)b * h + pos) * 2 + (e & 1)) * Cin + ci;
       *(float4*)p = sm;
+    }
+  };
+  if (DEPTH == 1) {
+    for (int b = b_lo; b < b_hi; ++b) image(b, rsA);
+  } else {
+    for (int b = b_lo; b < b_hi; b += 2) {
+      image(b, rsA);
+      if (b + 1 < b_hi) image(b + 1, rsB);
     }
   }
 }
@@ -156,8 +167,16 @@ template <typename T, int NT, int NGRP, int NLI>
 static int launch_edge_n(const PolydEdgeMulti& m, int n, int B, int h, int w, int Cin, int gdy, int K, size_t lds, hipStream_t st) {
   int groups = (B + 7) / 8;                                 // ~8 images per workgroup
   if (groups < 1) groups = 1;
-  sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NLI>, lds);
-  hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NLI>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
+  // strips in flight per thread: SV_POLYD_DEPTH (1: one image ahead, the default; 2: two register sets).  Measured and NOT kept (profiles/r06_polyd_depth.txt): depth 2 costs
+  // 20 VGPRs (152 -> 172: two resident workgroups per CU instead of three) and the 512-image fp32 step goes 9.13 -> 9.29 ms, the 64-image one 1.690 -> 1.697
+  static const int depth = getenv("SV_POLYD_DEPTH") ? atoi(getenv("SV_POLYD_DEPTH")) : 1;
+  if (depth >= 2) {
+    sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NLI, 2>, lds);
+    hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NLI, 2>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
+  } else {
+    sv_ensure_dynamic_lds((const void*)polyd_edge_kernel<T, NT, NGRP, NLI, 1>, lds);
+    hipLaunchKernelGGL((polyd_edge_kernel<T, NT, NGRP, NLI, 1>), dim3(4 * (Cin >> 4), groups, n), dim3(256), lds, st, m, B, h, w, Cin, gdy, K);
+  }
   SV_LAUNCH_CHECK();
   hipLaunchKernelGGL((polyd_corner_kernel<T, NGRP>), dim3(4 * (Cin >> 4), (B + 63) / 64, n), dim3(256), 0, st, m, B, h, w, Cin, gdy, K);
   SV_LAUNCH_CHECK();

@@ -628,6 +628,21 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
   return SV_OK;
 }
 
+// The cross-lane schedule sv_tape_finalize derived, one node at a time (host logic: tests/test_abi.py checks it without a GPU).  pass 0: forward, 1: backward.
+// Returns the number of nodes whose event `node`'s launch waits for (written to waits[0 .. max_waits)); *records = 1 when an event is recorded behind the node's
+// launch for a later node of another lane.  A UNARY group is one launch: its waits sit on its first node in the forward pass and on its last in the backward
+// pass, its event behind its last / first node.  SV_E_BADARG: not finalized, bad pass / node.  A single-lane tape has no schedule: 0 waits, *records = 0.
+extern "C" int sv_tape_schedule(const sv_tape* t, int32_t pass, int32_t node, int32_t* waits, int32_t max_waits, int32_t* records) {
+  if (!t || !t->finalized || pass < 0 || pass > 1 || node < 0 || node >= (int)t->nodes.size()) return SV_E_BADARG;
+  if (records) *records = 0;
+  if (t->nlanes <= 1) return 0;
+  const sv_tape::Sched& S = pass ? t->bs : t->fs;
+  if (records) *records = S.rec[node];
+  const int n = (int)S.waits[node].size();
+  for (int i = 0; i < n && i < max_waits && waits; ++i) waits[i] = S.waits[node][i];
+  return n;
+}
+
 extern "C" int64_t sv_tape_workspace_bytes(const sv_tape* t) { return (t && t->finalized) ? t->ws_bytes : -1; }
 
 extern "C" int sv_tape_bind(sv_tape* t, void* workspace, int64_t bytes, void* stream) {

@@ -215,3 +215,59 @@ def test_tape_with_conv_layers_reserves_the_weight_gradient_slabs(lib_built):
     slabs = lib.sv_conv2d_wgrad_workspace_bytes(C.byref(d))
     assert slabs > 0
     assert build(True) >= slabs and build(False) < slabs
+
+
+def test_tape_lane_schedule_without_gpu(lib_built):
+    """The cross-lane dependencies sv_tape_finalize derives from the nodes' tensors (csrc/tape.hip: build_schedules), on a diamond: x -> A (lane 0) -> ya,
+    x -> B (lane 1) -> yb, C (lane 0) = concat(ya, yb) -> z, loss on z.  Forward: C waits for B (read-after-write across lanes), nothing else crosses.  Backward
+    (reverse order: loss, C, B, A): B (lane 1) waits for C's adjoint -- it wrote grad(yb) --, and A (lane 0) waits for B: both ADD into grad(x), and conflicting
+    accumulations keep the tape's order.  Pure host code: no GPU."""
+    import ctypes as C
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    if os.environ.get("SV_TAPE_LANES") == "0":
+        pytest.skip("lanes are switched off in this environment")
+    h = C.c_void_p()
+    assert lib.sv_tape_create(C.byref(h), 4, _lib.SV_F32) == 0
+    x = lib.sv_tape_tensor(h, 16, 32, 32, 1)
+    ya = lib.sv_tape_tensor(h, 16, 8, 8, 1)
+    yb = lib.sv_tape_tensor(h, 16, 8, 8, 1)
+    z = lib.sv_tape_tensor(h, 16, 16, 16, 1)
+
+    def node(kind, **kw):
+        n = _lib.TapeNode()
+        for f in ("x", "y", "t2", "t3", "t4", "t5", "t6"):
+            setattr(n, f, -1)
+        n.w_off = n.b_off = -1
+        n.dyn_idx = n.loss_idx = -1
+        n.rep, n.kind = 1, kind
+        for k, val in kw.items():
+            setattr(n, k, val)
+        assert lib.sv_tape_add(h, C.byref(n)) == 0
+
+    node(_lib.TAPE_DENSE, x=x, y=ya, w_off=0, b_off=256, lane=0)                      # node 0: A
+    node(_lib.TAPE_DENSE, x=x, y=yb, w_off=512, b_off=768, lane=1)                    # node 1: B
+    node(_lib.TAPE_UNARY, op=_lib.TAPE_COPY, x=ya, y=z, xo=0, yo=0, n=8, group=1)     # nodes 2, 3: C = one launch (a group)
+    node(_lib.TAPE_UNARY, op=_lib.TAPE_COPY, x=yb, y=z, xo=0, yo=8, n=8, group=1)
+    node(_lib.TAPE_LOSS, loss_idx=0, mode=1, x=z, xo=0, t2=z, o2=8, R=4, n=8)         # node 4
+    bad = _lib.TapeNode()
+    bad.kind, bad.x, bad.y, bad.lane = _lib.TAPE_UNARY, z, z, 9
+    assert lib.sv_tape_add(h, C.byref(bad)) == _lib.STATUS_BADARG                     # lanes 0 .. 3
+    assert lib.sv_tape_schedule(h, 0, 0, None, 0, None) == _lib.STATUS_BADARG         # not finalized
+    assert lib.sv_tape_finalize(h) == 0
+
+    def sched(p, nd):
+        w = (C.c_int32 * 8)()
+        rec = C.c_int32()
+        k = lib.sv_tape_schedule(h, p, nd, w, 8, C.byref(rec))
+        assert k >= 0
+        return sorted(w[i] for i in range(k)), rec.value
+
+    fwd = [sched(0, i) for i in range(5)]
+    bwd = [sched(1, i) for i in range(5)]
+    # forward: B waits for nothing (x is an input); the group C (waits on its first node, 2) waits for B's event; B records, nobody else
+    assert fwd[0] == ([], 0) and fwd[1] == ([], 1) and fwd[2] == ([1], 0) and fwd[3][0] == [] and fwd[4] == ([], 0), fwd
+    # backward: the group C's waits sit on its LAST node (3): none; its event behind its FIRST node (2), which B waits for; A waits for B
+    assert bwd[4] == ([], 0) and bwd[3][0] == [] and bwd[2] == ([], 1) and bwd[1] == ([2], 1) and bwd[0] == ([1], 0), bwd
+    assert lib.sv_tape_schedule(h, 2, 0, None, 0, None) == _lib.STATUS_BADARG and lib.sv_tape_schedule(h, 0, 5, None, 0, None) == _lib.STATUS_BADARG
+    lib.sv_tape_destroy(h)
