@@ -103,6 +103,8 @@ class NativeGradReducer:
         self.handle = C.c_void_p()
         _lib.check(self.lib.sv_comm_init(C.c_char_p(bytes(idbuf.cpu().numpy().tobytes())), self.rank, self.world,
                                          C.byref(self.handle)), "sv_comm_init")
+        # RCCL runs ON this stream: a stream of its own (on the library's low-priority shared stream 1 the one-rank step went 1.74 -> 2.96 ms: profiles/r06_dp_ab.txt);
+        # the torch-process-group reducer below only HANDS OVER on a stream (the collective runs on torch's), and takes the library's
         self.stream = torch.cuda.Stream()
         self._ranges = {}
         for k, spans in self.buckets.items():
@@ -157,6 +159,16 @@ class NativeGradReducer:
             pass
 
 
+def library_side_stream(index):
+    """The library's shared side stream `index` of the current device (include/splitvae.h: sv_side_stream) as a torch stream.  The data-parallel step uses one
+    weight-gradient side stream (index 0); index 1 is free for the communication hand-over."""
+    import ctypes as C
+    from . import _lib
+    h = C.c_void_p()
+    _lib.check(_lib.load().sv_side_stream(int(index), C.byref(h)), "sv_side_stream")
+    return torch.cuda.ExternalStream(h.value, device=torch.cuda.current_device())
+
+
 class GradReducer:
     """Bucketed asynchronous all-reduce(sum) of a flat gradient buffer."""
 
@@ -189,7 +201,7 @@ class GradReducer:
                 self._pending.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         if getattr(self, "_aux", None) is None:
-            self._aux = torch.cuda.Stream()
+            self._aux = library_side_stream(1)     # (not a stream of our own: HIP maps streams onto hardware queues in creation order, csrc/streams.hip)
         after[0].bucket_wait(after[1], self._aux)
         with torch.cuda.stream(self._aux):
             for b, e in self.buckets[bucket]:
