@@ -1,6 +1,6 @@
 """Eager launches vs hipGraph replay (single-stream capture) vs replay of a capture that FORKS to the weight-gradient side streams (SV_GRAPH_SIDE=1):
 ms/step and a hash of the parameters after the run (the bf16 step and the default fp32 step are bit-reproducible: equal hashes = the replay computed the same step).
-usage: python scripts/r06_graph_side.py <mode: eager|graph|graph_side> <dtype> <batch> [steps]      (one mode per process: a bad capture must not take the others down)"""
+usage: python scripts/r06_graph_side.py <mode: eager|graph|graph_side|early_side> <dtype> <batch> [steps]      (one mode per process: a bad capture must not take the others down)"""
 import hashlib
 import os
 import sys
@@ -8,7 +8,9 @@ import time
 
 mode, dtype, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 300
-os.environ["SV_GRAPH"] = "0" if mode == "eager" else "1"
+os.environ["SV_GRAPH"] = "1" if mode in ("graph", "graph_side") else "0"
+if mode == "early_side":            # the decoders' weight images + the gradient zero fill on side stream 0 beside the encoders' forward (opt-in)
+    os.environ["SV_EARLY_SIDE"] = "1"
 if mode == "graph_side":
     os.environ["SV_GRAPH_SIDE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -177,7 +177,7 @@ def test_capture_that_forks_to_the_side_streams_replays_the_same_step(lib_built)
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for mode in ("eager", "graph_side"):
+    for mode in ("eager", "graph_side", "early_side"):
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r06_graph_side.py"), mode, "bf16", "16", "30"], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
         assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
@@ -185,3 +185,5 @@ def test_capture_that_forks_to_the_side_streams_replays_the_same_step(lib_built)
         out[mode] = (line[line.index("params") + 1], int(line[line.index("ms/step") + 1].split("=")[1]))
     assert out["eager"][0] == out["graph_side"][0], out
     assert out["eager"][1] == 0 and out["graph_side"][1] == 1, out           # eager: no graph; replay: one captured graph
+    # SV_EARLY_SIDE=1 (opt-in too: no gain measured): the decoders' weight images and the gradient zero fill on side stream 0 beside the encoders' forward
+    assert out["eager"][0] == out["early_side"][0] and out["early_side"][1] == 0, out
