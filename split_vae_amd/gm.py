@@ -281,10 +281,12 @@ class LGGMVae(LGVae):
             inputs._sv_staged_plan = None                     # one step per staging
         if staged and (_GM_STREAMS & 1):
             cur, side = torch.cuda.current_stream(), self._side_stream()
-            side.wait_stream(cur)
+            side.wait_stream(cur)                            # (the side stream starts from the state BEFORE the local encoder's phase)
+            # the local encoder first: ONE library call enqueues its ~10 launches in ~60 us of host time, and they run while the host is still issuing the GM
+            # encoder's ~40 (the other order left the compute stream idle for 370 us of a 1.77 ms step: profiles/r06_f_gm_timeline.txt)
+            plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | PHASE_INPUTS_STAGED, **kw)
             with torch.cuda.stream(side), ops.hold_stream():
                 gm_forward()
-            plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | PHASE_INPUTS_STAGED, **kw)
             cur.wait_stream(side)
         else:
             plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | (PHASE_INPUTS_STAGED if staged else 0), **kw)
@@ -386,10 +388,10 @@ def _train_step_lg_gm_vae(model, images, optimizer, eps, noise, sample_offset):
         # the two encoders' adjoints read disjoint column blocks of dz and write disjoint gradient buffers: the global (GM) encoder's on a second stream
         # beside the local encoder's phases (vae/trainer.py:167's tape.gradient has no order between them either)
         cur, side = torch.cuda.current_stream(), model._side_stream()
-        side.wait_stream(cur)
+        side.wait_stream(cur)                                # (behind the decoders' backward, not behind the local encoder's)
+        plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)       # one call, issued first: it runs while the host issues the GM encoder's ~60 launches
         with torch.cuda.stream(side), ops.hold_stream():
             gm_backward()
-        plan.step(PHASE_BWD_ENC_HEADS | PHASE_BWD_ENC_CONVS, **kw)
         cur.wait_stream(side)
     else:
         gm_backward()

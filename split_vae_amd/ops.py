@@ -405,6 +405,7 @@ class LGVaePlan:
         # pass of any step that runs the encoders' forward); a staged batch is only valid while its generation is the current one
         self.in8_gen = 0
         self.graph_on = False
+        self._views = {}
 
     def __del__(self):
         try:
@@ -415,9 +416,15 @@ class LGVaePlan:
             pass
 
     def buffer(self, name, dtype, shape):
-        off, nb = C.c_int64(), C.c_int64()
-        check(self.lib.sv_lgvae_buffer(self.handle, name.encode(), C.byref(off), C.byref(nb)), "sv_lgvae_buffer " + name)
-        return self.workspace[off.value: off.value + nb.value].view(dtype).view(*shape)
+        """A named buffer of the plan's workspace as a tensor view (memoised: the same view object for the same request -- a step asks for half a dozen of
+        them, ~25 us of ctypes + view arithmetic each, and the launch-bound steps are host-bound by now)."""
+        key = (name, dtype, tuple(shape))
+        v = self._views.get(key)
+        if v is None:
+            off, nb = C.c_int64(), C.c_int64()
+            check(self.lib.sv_lgvae_buffer(self.handle, name.encode(), C.byref(off), C.byref(nb)), "sv_lgvae_buffer " + name)
+            v = self._views[key] = self.workspace[off.value: off.value + nb.value].view(dtype).view(*shape)
+        return v
 
     def step(self, phases, params=None, grads=None, adam_m=None, adam_v=None, images6=None, eps_x=None,
              eps_x_hat=None, seed=0, step=0, sample_offset=0, lr=1e-4, beta1=0.9, beta2=0.999, adam_eps=1e-7, t=1,
