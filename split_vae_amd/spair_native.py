@@ -10,6 +10,7 @@ Tensors are [rows, cols | row pitch]: per-cell quantities have rows = B*16, imag
 zero-copy (strided) views of the workspace, valid until the next step.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -253,17 +254,28 @@ class NativeStep:
             else:
                 xh8 = self.tensor(B * H * W, Cc, 8, grad=False)
                 self.unary(TAPE_COPY, self.images, xh8, Cc, xo=3, group=g0)
+
+        def image_encoders():
             # the x-hat and background networks are independent of the object pipeline until the renderer / the losses: their own lanes (HIP streams)
             with self.lane(1):
-                z_l, zl_mean, zl_sig = self._image_encoder(m.x_hat_encoder, xh3, xh8, "eps_l", m.Ll, 6)
+                zl = self._image_encoder(m.x_hat_encoder, xh3, xh8, "eps_l", m.Ll, 6)
             with self.lane(2):
-                z_bg, zb_mean, zb_sig = self._image_encoder(m.bg_encoder, x3, x8, "eps_bg", m.Lbg, 5)
+                zb = self._image_encoder(m.bg_encoder, x3, x8, "eps_bg", m.Lbg, 5)
+            return zl, zb
+        # Tape order = the order the host issues the launches in.  The backbone's three convolutions (the longest launches of lane 0) are recorded BEFORE the image
+        # encoders, so that the compute stream has work while the host issues the other lane's ~16 launches.  Measured: no difference in steady state (2.444 against
+        # 2.44-2.46 ms: the host runs a step ahead of the GPU; profiles/r06_spair_lanes.txt).  SV_SPAIR_BRANCH_FIRST=1: the reference's source order (spair/spair.py:84-90).
+        branch_first = os.environ.get("SV_SPAIR_BRANCH_FIRST", "0") == "1"
+        if lg and branch_first:
+            (z_l, zl_mean, zl_sig), (z_bg, zb_mean, zb_sig) = image_encoders()
         # ---- Encoder.call :403-496
         e = m.encoder
         a, h1, w1 = self.conv(e.conv1, x8, B, H, W)
         a, h2, w2 = self.conv(e.conv2, a, B, h1, w1)
         a, Hc, Wc = self.conv(e.conv3, a, B, h2, w2)
         assert Hc * Wc == CELLS, (Hc, Wc)
+        if lg and not branch_first:
+            (z_l, zl_mean, zl_sig), (z_bg, zb_mean, zb_sig) = image_encoders()
         fv = self.dense(e.z3, self.dense(e.z2, self.dense(e.z1, a)))                    # 1x1 convolutions = Dense over the cells
         Fv = fv.cols
         if lg and m.concat_backbone:
