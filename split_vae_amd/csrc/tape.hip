@@ -99,6 +99,17 @@ __global__ __launch_bounds__(256) void unary_bwd_kernel(int op, float* __restric
   if (inplace) gx[r * ldx + xo + j] = s;
   else gx[r * ldx + xo + j] += s;
 }
+// zero fill of up to SV_TAPE_MAX_ZERO ranges in ONE launch (the outputs of the split-K Dense layers, which add their K slices with atomics): the step's first
+// launch instead of one 5-us fill in front of every such layer, inside the dependent chain (15 per LG-SPAIR step)
+#define SV_TAPE_MAX_ZERO 32
+struct ZeroList { float* p[SV_TAPE_MAX_ZERO]; int64_t start[SV_TAPE_MAX_ZERO + 1]; int n; };       // start: prefix sums of the ranges' float4 counts
+__global__ __launch_bounds__(256) void multi_zero_kernel(const ZeroList z) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= z.start[z.n]) return;
+  int k = 0;
+  for (int q = 1; q < z.n; ++q) k += i >= z.start[q] ? 1 : 0;
+  ((float4*)z.p[k])[i - z.start[k]] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 // up to 8 independent UNARY nodes in one launch (a tf.concat's column blocks, the activations of a head's column blocks)
 #define SV_TAPE_MAX_PARTS 8
 struct UPart { const float* x; float* y; const float* gy; float* gx; int ldx, xo, ldy, yo, n, rep, op, inplace; float p0, p1; int64_t start; };
@@ -294,6 +305,8 @@ struct sv_tape {
   int n_report = 0;
   bool finalized = false;
   char* ws = nullptr;
+  std::vector<std::pair<int, int64_t>> zero_y;     // (tensor, floats) of the split-K Dense outputs: zeroed by ONE launch at the start of the forward pass
+  bool zero_at_start = false;
   // lanes: unit = one node or one UNARY group (units are launched in tape order; a lane's launches are stream-ordered among themselves)
   enum { MAX_LANES = 4 };
   struct Sched {
@@ -609,6 +622,14 @@ extern "C" int sv_tape_finalize(sv_tape* t) {
   t->off_loss = o; o += al(((int64_t)SV_TAPE_MAX_LOSS * t->B + 4 * SV_TAPE_MAX_LOSS + 8) * 4);
   bool any_conv = false;
   for (const sv_tape::Extra& e : t->ex) any_conv = any_conv || e.has_conv;
+  // split-K Dense outputs: one zero fill for all of them (storage is 256-B granular: whole float4s)
+  static const bool zero_once = !(getenv("SV_TAPE_ZERO_PER_LAYER") && atoi(getenv("SV_TAPE_ZERO_PER_LAYER")) != 0);
+  for (size_t i = 0; i < t->nodes.size(); ++i)
+    if (t->nodes[i].kind == SV_TAPE_DENSE && t->ex[i].split_fwd) {
+      const TT& y = t->tens[t->nodes[i].y];
+      t->zero_y.push_back({t->nodes[i].y, (y.rows * y.ld + 3) / 4 * 4});
+    }
+  t->zero_at_start = zero_once && !t->zero_y.empty() && t->zero_y.size() <= SV_TAPE_MAX_ZERO;
   // ---- lanes: cross-stream dependencies of the two passes
   // SV_TAPE_LANES = the number of extra streams the tape may use: 0 everything on the caller's stream (A/B, the equivalence test), k: lanes above k fold onto lane k
   // Default 1.  Measured (profiles/r06_spair_lanes.txt; lg_spair Multi-Bird-Hard flags, 32 images, fp32): one stream 2.98 ms per step at every GPU_MAX_HW_QUEUES setting;
@@ -685,7 +706,7 @@ int node_forward(sv_tape* t, size_t i, const sv_tape_run_args* a, bool with_grad
       const float* W = a->params + n.w_off;
       const float* b = n.b_off >= 0 ? a->params + n.b_off : nullptr;
       if (e.split_fwd) {
-        if (hipMemsetAsync(t->act(n.y), 0, (size_t)y.rows * y.ld * 4, st) != hipSuccess) return (int)hipGetLastError();
+        if (!t->zero_at_start && hipMemsetAsync(t->act(n.y), 0, (size_t)y.rows * y.ld * 4, st) != hipSuccess) return (int)hipGetLastError();
         const int rc = svk_dense_f32_fwd(t->act(n.x), x.ld, W, b, t->act(n.y), y.ld, (int)x.rows, x.cols, y.cols, SV_ACT_NONE, 1, st);
         if (rc < 0 || rc > 1) return rc;
         if (n.act == SV_ACT_RELU)
@@ -1017,6 +1038,20 @@ extern "C" int sv_tape_run(sv_tape* t, const sv_tape_run_args* a, void* stream) 
     if (bwd) {
       if (t->grad_floats && hipMemsetAsync(t->ws + t->off_grad, 0, (size_t)t->grad_floats * 4, st) != hipSuccess) return (int)hipGetLastError();
       if (hipMemsetAsync(a->grads, 0, (size_t)a->n_params * 4, st) != hipSuccess) return (int)hipGetLastError();
+    }
+    if (t->zero_at_start) {                  // (every lane forks behind this: the previous step's readers of these tensors were joined at its end)
+      ZeroList z;
+      memset(&z, 0, sizeof(z));
+      int64_t tot = 0;
+      for (size_t k = 0; k < t->zero_y.size(); ++k) {
+        z.p[k] = t->act(t->zero_y[k].first);
+        z.start[k] = tot;
+        tot += t->zero_y[k].second / 4;
+      }
+      z.n = (int)t->zero_y.size();
+      z.start[z.n] = tot;
+      hipLaunchKernelGGL(multi_zero_kernel, dim3(nblk(tot)), dim3(256), 0, st, z);
+      SV_LAUNCH_CHECK();
     }
     const bool lanes = t->nlanes > 1;
     if (lanes) SV_TRY(lanes_fork(t, st));
