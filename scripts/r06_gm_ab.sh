@@ -8,7 +8,7 @@ r = bench.gm_row(torch.device("cuda", 0), dtype=sys.argv[1], steps=200)
 print(sys.argv[1], r["ms_per_step"])
 PY
 : > $OUT
-for rep in 1 2; do for dt in f32 bf16; do for k in A=0 SV_GM_WGRAD_SIDE=0 SV_GM_STREAMS=0; do echo -n "[$k] " >> $OUT; env $k timeout 300 python /tmp/gmb.py $dt 2>/dev/null >> $OUT; done; done; done
-echo -n "[SV_GM_STREAMS=0 SV_GM_WGRAD_SIDE=0] " >> $OUT; SV_GM_STREAMS=0 SV_GM_WGRAD_SIDE=0 timeout 300 python /tmp/gmb.py f32 2>/dev/null >> $OUT
+for rep in 1 2; do for dt in f32; do for k in A=0 SV_CONV_SPLITK_TILES=0 SV_CONV_SPLITK_TILES=32 SV_CONV_SPLITK_TILES=8; do echo -n "[$k] " >> $OUT; env $k timeout 300 python /tmp/gmb.py $dt 2>/dev/null >> $OUT; done; done; done
+
 cat $OUT
-timeout 900 python -m pytest tests/test_gpu_gm.py tests/test_gpu_determinism.py -m gpu -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_gm.py tests/test_gpu_kernels.py -k "gm or k_split" -m gpu -x -q 2>&1 | tail -2

@@ -827,6 +827,22 @@ extern "C" int sv_conv2d_nhwc_fwd_ws(const sv_conv_desc* d, const void* x, const
         return svk_tap_gemm(a, d->dtype, cfg, (hipStream_t)stream);
       }
     }
+    // fp32 conv layers whose output is a handful of tiles but whose K is deep (SPLIT-GMVAE's 128 -> 128 stride-2 layers at 64 images: 8 x 8 -> 4 x 4 pixels, K = 2048:
+    // the tile kernel ran 32 workgroups for 77 us): K split over workgroups on the im2col GEMM, fp32 partial sums added into the zeroed output (the bias rides on slice 0).
+    // Only without an activation (atomics cannot apply one), never under SV_DETERMINISTIC (svg_choose_splitk returns 1).  SV_CONV_SPLITK_TILES: the largest 128 x 128-tile
+    // count that takes the form (0: off).  Measured: profiles/r06_gm_streams.txt
+    // (SPLIT-GMVAE fp32, 64 images: off 1.708 ms per step, 8 tiles -- the 4 x 4 layer -- 1.656, 32 tiles -- the 8 x 8 layer too -- 1.633)
+    static const int sk_tiles = getenv("SV_CONV_SPLITK_TILES") ? atoi(getenv("SV_CONV_SPLITK_TILES")) : 32;
+    if (sk_tiles > 0 && d->dtype == SV_F32 && d->act == SV_ACT_NONE && !d->ups_in && !polyc && !svg_s2d3(d) && !svg_packx(d) && d->KH > 1 && d->ldy == d->Cout &&
+        (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128) <= sk_tiles && a.P >= 256) {
+      int cfg = svg_pick_cfg(d->Cout);
+      const int sk = svg_choose_splitk(a.M, a.N, (a.P + 7) / 8, &cfg);
+      if (sk > 1) {
+        if (hipMemsetAsync(y, 0, (size_t)a.M * d->ldy * sizeof(float), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+        a.splitk = sk; a.out_f32 = 1;
+        return svk_tap_gemm(a, d->dtype, cfg, (hipStream_t)stream);
+      }
+    }
     return svk_conv_dispatch(a, d->dtype, svg_im2col_cfg(a, svg_pick_cfg(d->Cout)), (hipStream_t)stream);
   }
   const void* wfix = (const char*)w_fwd + (int64_t)32 * 25 * svg_cin_pad(d) * (d->dtype == SV_BF16 ? 2 : 4);

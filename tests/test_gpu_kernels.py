@@ -1021,3 +1021,31 @@ def test_fp32_three_by_three_weight_gradient_on_lds_tiles(ops, layer, B):
         torch.testing.assert_close(db.double().cpu(), br.grad, rtol=F32_RTOL, atol=F32_ATOL * float(br.grad.abs().max()))
     dw_u, db_u = conv.wgrad(xg, dy.cuda(), workspace=True)
     assert torch.equal(dw_t, dw_u) and torch.equal(db_t, db_u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [("gm_c3", 8, 128, 128, 4, 64), ("gm_c2", 16, 128, 128, 6, 16), ("gm_c3_b5", 8, 128, 128, 4, 5)], ids=lambda g: g[0])
+def test_fp32_conv_forward_with_k_split_over_workgroups(ops, geom, monkeypatch):
+    """SPLIT-GMVAE's 128 -> 128 stride-2 encoder layers (vae/model.py:49-52, no activation in the descriptor: ELU follows) at small grids: the forward's K is split
+    over workgroups on the im2col GEMM (conv_api.hip: SV_CONV_SPLITK_TILES), partial sums added into the zeroed fp32 output, the bias on slice 0.  Against the fp64
+    conv from the same fp32 operands, and against the tile kernel (SV_CONV_SPLITK_TILES=0 is read once per process: the comparison runs through SV_DETERMINISTIC,
+    which keeps one workgroup per output tile)."""
+    name, H, Cin, Cout, k, B = geom
+    rng = np.random.default_rng(7 + H + B)
+    x = torch.from_numpy(rng.standard_normal((B, H, H, Cin)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(-1, 1, (k, k, Cin, Cout)).astype(np.float32)) * math.sqrt(6.0 / (k * k * (Cin + Cout)))
+    b = torch.from_numpy(rng.standard_normal((Cout,)).astype(np.float32)) * 0.1
+    conv = ops.Conv2D(B, H, H, Cin, Cout, k, 2, act=None, dtype=torch.float32)
+    conv.prep(w.cuda())
+    y = conv.fwd(x.cuda(), b.cuda())
+    ref = torch_ref.conv2d_same(x.double(), w.double(), b.double(), 2, None)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(y[..., :Cout].double().cpu(), ref, rtol=F32_RTOL, atol=F32_ATOL * scale)
+    from split_vae_amd import _lib
+    lib = _lib.load()
+    assert lib.sv_set_deterministic(1) == 0
+    try:
+        y_det = conv.fwd(x.cuda(), b.cuda())                   # fixed-order mode: the tile kernel (no K split)
+    finally:
+        assert lib.sv_set_deterministic(-1) == 0
+    torch.testing.assert_close(y, y_det, rtol=1e-5, atol=1e-5 * scale)
