@@ -699,7 +699,12 @@ def main():
                            SV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
                 procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpus", "2", "--dtype", "f32", "--steps", "40", "--warmup", "5",
                                                "--no-rows", "--no-other-precision", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
-            outs = [p_.communicate(timeout=400)[0] for p_ in procs]
+            try:
+                outs = [p_.communicate(timeout=240)[0] for p_ in procs]
+            finally:
+                for p_ in procs:                         # (a rank that is still alive here is stuck: never leave it behind on the GPU)
+                    if p_.poll() is None:
+                        p_.kill()
             c = [json.loads(ln) for ln in outs[0].splitlines() if ln.startswith("{")][-1]
             base = 2 * rows["celeba64_b256_f32"]["ms_per_step"]
             rows["dp2_shared_gpu_b256_f32"] = {"value": c["value"], "unit": "images/s", "ms_per_step": c["ms_per_step"], "steps": c["steps"], "n_ranks": 2,
