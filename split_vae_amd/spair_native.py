@@ -38,6 +38,9 @@ class T:
         self.id, self.rows, self.cols, self.ld = id_, rows, cols, ld
 
 
+_NOISE_ON_LANE1 = os.environ.get("SV_SPAIR_NOISE_LANE", "1") != "0"      # (A/B: the NOISE nodes on their consumer's lane)
+
+
 class NativeStep:
     def __init__(self, model, config, B, training=True):
         self.lib = _lib.load()
@@ -178,7 +181,9 @@ class NativeStep:
 
     def draw(self, name, rows, cols, kind, std=1.0, stream_id=0):
         t = self.tensor(rows, cols, cols, grad=False)
-        self.add(TAPE_NOISE, y=t, op=0 if kind == "normal" else 1, p0=std, stream_id=stream_id)
+        # the Philox draws depend on nothing: always on lane 1, off the object pipeline's dependent chain (their consumers wait on an event)
+        with self.lane(1 if _NOISE_ON_LANE1 else self._lane):
+            self.add(TAPE_NOISE, y=t, op=0 if kind == "normal" else 1, p0=std, stream_id=stream_id)
         self.noise[name] = t
         return t
 
