@@ -185,10 +185,8 @@ struct sv_lgvae_plan {
   bool ensure_side() {
     if (nside) return true;
     {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      static const bool normal = getenv("SV_SIDE_PRIO_NORMAL") != nullptr;
-      static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 2;      // created; `side_use` of them are used per call
+      // (priority: streams.hip creates the shared streams at the lowest priority; SV_SIDE_PRIO_NORMAL is read there)
+      static const int want = getenv("SV_SIDE_STREAMS") ? atoi(getenv("SV_SIDE_STREAMS")) : 2;      // taken; `side_use` of them are used per call
       const int k = want < 1 ? 1 : want > SIDE_MAX - 1 ? SIDE_MAX - 1 : want;   // the last workspace slot belongs to the main stream
       if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return false;
       for (int i = 0; i < k && i < SV_SHARED_STREAMS; ++i) {
