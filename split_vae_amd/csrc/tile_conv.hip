@@ -560,8 +560,15 @@ static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConv
   const bool small = t.N % 128 == 0 && (wgs128 < small_wgs || narrow) && (dtype == SV_BF16 || small_f32) && !t.cls_n;
   static const int tiny_wgs = getenv("SV_TC_TINY_WGS") ? atoi(getenv("SV_TC_TINY_WGS")) : 100;   // ... and on 32-column tiles below this (64-image shards: -1.3 .. -1.9 %)
   const bool tiny = small && wgs128 < tiny_wgs;
+  // (round 6) the same for 64-column stride-1 layers: d3 of a 64-image SVHN-32 shard ran 64-128 workgroups of 128 x 64 on 256 CUs (89 us); 32-column tiles below
+  // SV_TC_SMALL64_WGS workgroups per problem (fp32; 0: off).  Measured (profiles/r06_small64.txt): SVHN-32 64 images 1.062-1.074 -> 1.029-1.033 ms, CelebA-64 64 images
+  // +-0; the stride-2 64-column layer (e2) LOSES on 32-column tiles (CelebA-64 64 images 1.69 -> 1.71): stride 1 only (SV_TC_SMALL64_S: 0 every stride, 2 stride 2)
+  static const int small64_wgs = getenv("SV_TC_SMALL64_WGS") ? atoi(getenv("SV_TC_SMALL64_WGS")) : 300;
+  const int64_t wgs64 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 64);
+  static const int small64_s = getenv("SV_TC_SMALL64_S") ? atoi(getenv("SV_TC_SMALL64_S")) : 1;
+  const bool tiny64 = dtype == SV_F32 && t.N % 64 == 0 && t.N % 128 != 0 && wgs64 < small64_wgs && !t.cls_n && !t.d2s && (!small64_s || t.S == small64_s);
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
-  else if (t.N % 64 == 0 && !tiny) { BN = 64; cfgN = 1; }
+  else if (t.N % 64 == 0 && !tiny && !tiny64) { BN = 64; cfgN = 1; }
   else if (t.N % 32 == 0) { BN = 32; cfgN = 2; }
   else if (t.N <= 16) { BN = 16; cfgN = 3; }
   else return false;
