@@ -634,6 +634,12 @@ static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConv
     }
     static const int nph_max = getenv("SV_TC_NPH") ? atoi(getenv("SV_TC_NPH")) : 4;     // tuning knob (1 = off)
     const int64_t wgs = (int64_t)(OX / TW) * (OY / TH) * ((B + NB - 1) / NB) * ((t.N + BN - 1) / BN);
+    // (round 6) fp32 32-column layers of small launches: 256-row tiles left 64-128 workgroups per problem on 256 CUs (SVHN-32, 64 images: e1 / the d4 class
+    // problems); 128-row tiles below SV_TC_SMALL32_WGS workgroups per problem.  SVHN-32 64 images 1.029-1.038 -> 0.980 ms, 256 images 1.79 -> 1.78; CelebA-64 64 images
+    // 1.689 -> 1.680, 128 images +-0 (forcing 128-row tiles on EVERY 32-column layer, SV_TC_MF2=b, costs CelebA-64 64 images 1 %).  Not the fused-loss head (one
+    // partial per 256-pixel tile).  profiles/r06_small64.txt
+    static const int small32_wgs = getenv("SV_TC_SMALL32_WGS") ? atoi(getenv("SV_TC_SMALL32_WGS")) : 300;
+    if (MF == 4 && BN == 32 && dtype == SV_F32 && !t.nll_part && wgs < small32_wgs) continue;
     int lnph = 0, PS = 0, plane_bytes = 0;
     int64_t in_bytes = 0;
     bool planar = false;
