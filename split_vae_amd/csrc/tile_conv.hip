@@ -566,7 +566,9 @@ static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConv
   static const int small64_wgs = getenv("SV_TC_SMALL64_WGS") ? atoi(getenv("SV_TC_SMALL64_WGS")) : 300;
   const int64_t wgs64 = (((int64_t)B * OY * OX + 127) / 128) * (t.N / 64);
   static const int small64_s = getenv("SV_TC_SMALL64_S") ? atoi(getenv("SV_TC_SMALL64_S")) : 1;
-  const bool tiny64 = dtype == SV_F32 && t.N % 64 == 0 && t.N % 128 != 0 && wgs64 < small64_wgs && !t.cls_n && !t.d2s && (!small64_s || t.S == small64_s);
+  // (forward layers only -- OS == 1: the parity-class problems of a stride-2 input gradient are stride-1 problems too, and e3's at 512 images, 256 workgroups
+  //  each, went 0.172 -> 0.201 ms on 32-column tiles)
+  const bool tiny64 = dtype == SV_F32 && t.N % 64 == 0 && t.N % 128 != 0 && wgs64 < small64_wgs && !t.cls_n && !t.d2s && t.OS == 1 && (!small64_s || t.S == small64_s);
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
   else if (t.N % 64 == 0 && !tiny && !tiny64) { BN = 64; cfgN = 1; }
   else if (t.N % 32 == 0) { BN = 32; cfgN = 2; }
