@@ -283,7 +283,7 @@ class LGGMVae(LGVae):
             cur, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(cur)                            # (the side stream starts from the state BEFORE the local encoder's phase)
             # the local encoder first: ONE library call enqueues its ~10 launches in ~60 us of host time, and they run while the host is still issuing the GM
-            # encoder's ~40 (the other order left the compute stream idle for 370 us of a 1.77 ms step: profiles/r06_h_gm_timeline.txt)
+            # encoder's ~40 (the other order left the compute stream idle for 370 us of a 1.77 ms step: profiles/r06_j_gm_timeline.txt)
             plan.step(PHASE_PREP | PHASE_FWD_ENCODERS | PHASE_INPUTS_STAGED, **kw)
             with torch.cuda.stream(side), ops.hold_stream():
                 gm_forward()
