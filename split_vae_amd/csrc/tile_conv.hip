@@ -568,6 +568,7 @@ static bool tile_conv_plan_impl(const TapGemmArgs& t, int dtype, int B, TileConv
   static const int small64_s = getenv("SV_TC_SMALL64_S") ? atoi(getenv("SV_TC_SMALL64_S")) : 1;
   // (forward layers only -- OS == 1: the parity-class problems of a stride-2 input gradient are stride-1 problems too, and e3's at 512 images, 256 workgroups
   //  each, went 0.172 -> 0.201 ms on 32-column tiles)
+  // (the stride-2 polyphase input gradient of d4 on 32-column tiles: measured, slower -- 64 images 1.679 -> 1.694 ms, 128: 2.732 -> 2.783)
   const bool tiny64 = dtype == SV_F32 && t.N % 64 == 0 && t.N % 128 != 0 && wgs64 < small64_wgs && !t.cls_n && !t.d2s && t.OS == 1 && (!small64_s || t.S == small64_s);
   if (t.N % 128 == 0 && !small) { BN = 128; cfgN = 0; }
   else if (t.N % 64 == 0 && !tiny && !tiny64) { BN = 64; cfgN = 1; }
