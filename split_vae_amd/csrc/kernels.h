@@ -208,7 +208,7 @@ struct WgradReduceMulti { const float* slab[SV_WGRAD_MAX_MULTI]; float* dW[SV_WG
 // fp32 (the reference's precision): LDS tiles + v_mfma_f32_16x16x4_f32 + the same slabs (wgrad_tile_f32.hip); SV_E_UNSUPPORTED -> im2col kernel
 int svk_wgrad_tile_f32_multi(const WgradArgs* w, int n, hipStream_t st);
 // the four parity classes of n <= 2 per-class polyphase layers in one launch (cls[c * n + i]); appends the 4 n slab-reduce descriptors
-int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, WgradReduceDesc* rd, int* nrd, hipStream_t st);
+int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, int mask, WgradReduceDesc* rd, int* nrd, hipStream_t st);
 int svk_wgrad_tile(const WgradArgs& w, hipStream_t st);   // SV_E_UNSUPPORTED -> use svk_wgrad
 int svk_wgrad_tile_multi(const WgradArgs* w, int n, hipStream_t st);   // n twin layers, one launch (own ws each)
 int svk_wgrad_dispatch_multi(const WgradArgs* w, int n, int dtype, int cfg, hipStream_t st);

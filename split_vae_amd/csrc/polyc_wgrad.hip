@@ -293,20 +293,29 @@ int svk_polyc_wgrad_multi(const sv_conv_desc* d, int n, const void* const* x_lo,
   // dbias); the main terms' reduce ADDS its bias partials, the projection sums the blocks in a fixed order
   for (int i = 0; i < n; ++i)
     if (hipMemsetAsync(pw[i] + ndwp, 0, 128 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+  // OPT-IN forms that stage the input tile once for several classes (wgrad_tile_f32.hip: wgrad_polyc_f32_kernel).  SV_WGRAD_POLYC_FUSED=1: all four classes in one launch
+  // (168 accumulator registers; profiles/r05_polyc_fused_ab.txt: 1.078 -> 0.949 ms alone on the chip, the 512-image step +2 %); =2: classes {0, 3} and {1, 2} as two launches
+  static const int fuse_mode = getenv("SV_WGRAD_POLYC_FUSED") ? atoi(getenv("SV_WGRAD_POLYC_FUSED")) : 0;
   bool fused = false;
-  if (!merged) {                       // all four classes in one launch: the input tile staged once (wgrad_tile_f32.hip: wgrad_polyc_f32_kernel)
+  if (!merged && (fuse_mode == 1 || fuse_mode == 2)) {
     WgradArgs cls[8];
+    const int masks[2] = {fuse_mode == 1 ? 0xF : 0x9, 0x6}, nl = fuse_mode == 1 ? 1 : 2;
     for (int c = 0; c < 4; ++c)
       for (int i = 0; i < n; ++i) {
         WgradArgs& q = cls[c * n + i];
         svg_polyc_wgrad_args(d, c, &q);
         q.A = x_lo[i]; q.dY = dy[i]; q.dW = pw[i] + pj.coff[c];
-        q.dbias = (c == 0 && dbias && dbias[i]) ? pw[i] + ndwp : nullptr;          // ONE bias partial for all classes (their dY tiles cover every pixel once): block 0 of dbias'
+        // ONE bias partial per launch (its classes' dY tiles cover their pixels once): block c of dbias' for the launch's lowest class c; the projection sums the blocks
+        const bool lead = c == 0 || (fuse_mode == 2 && c == 1);
+        q.dbias = (lead && dbias && dbias[i]) ? pw[i] + ndwp + c * 32 : nullptr;
         q.ws = (float*)((char*)slab_ws[i] + c * part); q.ws_bytes = part;
       }
-    const int rc = svk_wgrad_polyc_f32_multi(cls, n, pend, &npend, st);
-    if (rc == SV_OK) fused = true;
-    else if (rc != SV_E_UNSUPPORTED) return rc;
+    for (int l = 0; l < nl; ++l) {
+      const int rc = svk_wgrad_polyc_f32_multi(cls, n, masks[l], pend, &npend, st);
+      if (rc == SV_OK) fused = true;
+      else if (rc != SV_E_UNSUPPORTED || l) return rc == SV_E_UNSUPPORTED ? SV_E_STATE : rc;      // (the second pair cannot fail where the first passed: same geometry)
+      else break;
+    }
   }
   for (int c = 0; c < (merged ? 1 : 4) && !fused; ++c) {
     for (int i = 0; i < n; ++i) {

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPoly
   const int ci0 = (int)blockIdx.y * g.CW;
   const int TW = 1 << g.lTW, TH = 1 << g.lTH, NB = 1 << g.lNB, BM = TW * TH * NB;
   const int in_lane = kq * PS + lr * 4, dy_lane = kq * YS + lr * 4;
-  int off0[T0], off1[T1], off2[T2], off3[T3];
+  // a class with T == 0 is not part of this launch (the two-pair form: classes {0, 3} and {1, 2} as two launches of 88 / 80 accumulator registers)
+  int off0[T0 ? T0 : 1], off1[T1 ? T1 : 1], off2[T2 ? T2 : 1], off3[T3 ? T3 : 1];
   auto taps = [&](int c, int TPWc, int* out) {
     for (int t = 0; t < TPWc; ++t) {
       const int tap = min(wave * TPWc + t, pa.ntaps[c] - 1);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPoly
     }
   };
   taps(0, T0, off0); taps(1, T1, off1); taps(2, T2, off2); taps(3, T3, off3);
-  f32x4 a0[T0][COF], a1[T1][COF], a2[T2][COF], a3[T3][COF];
+  f32x4 a0[T0 ? T0 : 1][COF], a1[T1 ? T1 : 1][COF], a2[T2 ? T2 : 1][COF], a3[T3 ? T3 : 1][COF];
 #pragma unroll
   for (int j = 0; j < COF; ++j) {
 #pragma unroll
@@ -341,9 +342,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPoly
       const TileStageGeom sg = {g.B, g.IH, g.IW, g.lda, g.cl2, g.TIW, g.TIH, g.PS, NB, 0};
       stage_tile_plain<float, 256, true>(Ab, sg, b0, ty0 + g.y_lo, tx0 + g.x_lo, sIn, tid);
     }
+    bool first = true;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (c) __syncthreads();             // the previous class's dY tile is consumed
+      if ((c == 0 && !T0) || (c == 1 && !T1) || (c == 2 && !T2) || (c == 3 && !T3)) continue;
+      if (!first) __syncthreads();        // the previous class's dY tile is consumed
+      first = false;
       for (int q = tid; q < dy_total; q += 256) {
         const int r = q >> lycp, cc = q & ((1 << lycp) - 1);
         const int tx = r & (TW - 1), ty = (r >> g.lTW) & (TH - 1), bl = r >> (g.lTW + g.lTH);
@@ -353,10 +357,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPoly
         *(uint4*)(sDy + r * YS + cc * 16) = v;
       }
       __syncthreads();
-      if (c == 0) polyc_rows<T0, COF, G4, YS, 4 * PS>(a0, bacc, off0, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
-      else if (c == 1) polyc_rows<T1, COF, G4, YS, 4 * PS>(a1, bacc, off1, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
-      else if (c == 2) polyc_rows<T2, COF, G4, YS, 4 * PS>(a2, bacc, off2, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
-      else polyc_rows<T3, COF, G4, YS, 4 * PS>(a3, bacc, off3, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      if constexpr (T0 > 0) if (c == 0) polyc_rows<T0, COF, G4, YS, 4 * PS>(a0, bacc, off0, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      if constexpr (T1 > 0) if (c == 1) polyc_rows<T1, COF, G4, YS, 4 * PS>(a1, bacc, off1, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      if constexpr (T2 > 0) if (c == 2) polyc_rows<T2, COF, G4, YS, 4 * PS>(a2, bacc, off2, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
+      if constexpr (T3 > 0) if (c == 3) polyc_rows<T3, COF, G4, YS, 4 * PS>(a3, bacc, off3, sIn, sDy, dy_lane, nrow, TH, g.lTH, g.TIH, g.TIW, PS, do_bias, wave);
     }
   }
   auto flush = [&](int c, int TPWc, auto& acc) {
@@ -368,7 +372,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_polyc_f32_kernel(const WgradPoly
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) sl[((t2 * COF + j) * 4 + r4) * 64] = acc[t2][j][r4];
   };
-  flush(0, T0, a0); flush(1, T1, a1); flush(2, T2, a2); flush(3, T3, a3);
+  if constexpr (T0 > 0) flush(0, T0, a0);
+  if constexpr (T1 > 0) flush(1, T1, a1);
+  if constexpr (T2 > 0) flush(2, T2, a2);
+  if constexpr (T3 > 0) flush(3, T3, a3);
   if (do_bias && lane < 16) {
 #pragma unroll
     for (int j = 0; j < COF; ++j)
@@ -532,13 +539,15 @@ int svk_wgrad_tile_f32_multi(const WgradArgs* wv, int n, hipStream_t st) {
 
 // The four class problems of n <= 2 per-class polyphase layers as ONE launch (see wgrad_polyc_f32_kernel).  cls[c * n + i]: class c of network i (svg_polyc_wgrad_args
 // + pointers; ws = the class's slab region); descriptors of the 4 n slab reduces are appended to rd.  SV_E_UNSUPPORTED: no instantiation / small workspace (nothing launched).
-int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, WgradReduceDesc* rd, int* nrd, hipStream_t st) {
+int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, int mask, WgradReduceDesc* rd, int* nrd, hipStream_t st) {
   static const bool trace = getenv("SV_TRACE_DISPATCH") != nullptr;
   // OPT-IN (SV_WGRAD_POLYC_FUSED=1).  Measured (2 x 512 images, profiles/r05_polyc_fused_ab.txt): alone on the chip the d4 weight gradient goes 1.078 -> 0.949 ms (the input
   // tile moves once), but the 512-image STEP goes 9.355 -> 9.54 ms: at 239 VGPRs the kernel leaves no room beside it for the other streams' workgroups, and the step lives
   // on that co-residency (same finding as the 52-KB tiles).  The default keeps the four class launches.
-  static const bool off = !(getenv("SV_WGRAD_POLYC_FUSED") && atoi(getenv("SV_WGRAD_POLYC_FUSED")) != 0);
-  if (off || n < 1 || n > SV_WGRAD_MAX_MULTI) F32_REJ("off / problems");
+  // mask: the classes of THIS launch (bit c).  0xF: all four; 0x9 and 0x6: the two-pair form (SV_WGRAD_POLYC_FUSED=2) -- classes {0, 3} (25 + 16 taps, 88 accumulator
+  // registers) and {1, 2} (20 + 20, 80): the input tile moves twice instead of four times and the workgroup keeps the register budget of a co-resident one.  The bias partial
+  // rides with the lowest class of the mask (that class's dbias / slab region).
+  if (n < 1 || n > SV_WGRAD_MAX_MULTI || (mask != 0xF && mask != 0x9 && mask != 0x6)) F32_REJ("problems / classes");
   const WgradArgs& w = cls[0];
   if (w.lOY < 0 || w.lOX < 0 || w.S != 1 || !w.clampin || w.dy_os != 2 || w.ldy != 32 || w.ycols != 32 || w.N != 32) F32_REJ("form");
   const int ntc[4] = {cls[0].ntaps, cls[n].ntaps, cls[2 * n].ntaps, cls[3 * n].ntaps};
@@ -579,31 +588,37 @@ int svk_wgrad_polyc_f32_multi(const WgradArgs* cls, int n, WgradReduceDesc* rd, 
   if (msplit > a.ntiles) msplit = a.ntiles;
   if (msplit < 1) msplit = 1;
   static const int tpw[4] = {7, 5, 5, 4};
+  const int c_lead = mask & 1 ? 0 : 1, nrd0 = *nrd;
   WgradPolycMulti m;
   for (int i = 0; i < n; ++i) {
     WgradPolycArgs& p = m.a[i];
     p.g = a;
-    p.g.A = cls[i].A; p.dY = (const float*)cls[i].dY; p.g.dbias = cls[i].dbias;
+    p.g.A = cls[i].A; p.dY = (const float*)cls[i].dY;
     for (int c = 0; c < 4; ++c) {
+      p.slab[c] = nullptr; p.ntaps[c] = 0;
+      if (!(mask >> c & 1)) continue;
       const WgradArgs& wc = cls[c * n + i];
+      const bool lead = c == c_lead;
       const int64_t PER = 4LL * tpw[c] * 2 * 256;
-      const int64_t need = (int64_t)msplit * groups * PER * 4 + (c == 0 ? (int64_t)msplit * 128 * 4 : 0);
-      if (!wc.ws || wc.ws_bytes < need) F32_REJ("workspace");
+      const int64_t need = (int64_t)msplit * groups * PER * 4 + (lead ? (int64_t)msplit * 128 * 4 : 0);
+      if (!wc.ws || wc.ws_bytes < need) { *nrd = nrd0; F32_REJ("workspace"); }
       p.slab[c] = wc.ws;
       p.ntaps[c] = wc.ntaps;
       for (int t = 0; t < wc.ntaps; ++t) { p.cdy[c][t] = wc.dy[t]; p.cdx[c][t] = wc.dx[t]; }
-      if (c == 0) p.g.bslab = cls[i].dbias ? wc.ws + (int64_t)msplit * groups * PER : nullptr;
-      rd[(*nrd)++] = WgradReduceDesc{p.slab[c], wc.dW, c == 0 ? p.g.bslab : nullptr, c == 0 ? cls[i].dbias : nullptr, msplit, groups, a.ncg, CW, a.Cin_real, 32,
+      if (lead) { p.g.dbias = wc.dbias; p.g.bslab = wc.dbias ? wc.ws + (int64_t)msplit * groups * PER : nullptr; }
+      rd[(*nrd)++] = WgradReduceDesc{p.slab[c], wc.dW, lead ? p.g.bslab : nullptr, lead ? wc.dbias : nullptr, msplit, groups, a.ncg, CW, a.Cin_real, 32,
                                      wc.ntaps, 0, 0, 0, 1, tpw[c], 1, 2, 0};
     }
     if (!p.g.bslab) p.g.dbias = nullptr;
   }
   const size_t lds = ((size_t)a.in_bytes + a.dy_bytes) * (a.db ? 2 : 1);
   const dim3 grid(msplit, groups, n);
-#define POLYC_CASE(G) if (G4 == G) { sv_ensure_dynamic_lds((const void*)wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>, lds); \
-    hipLaunchKernelGGL((wgrad_polyc_f32_kernel<7, 5, 5, 4, 2, 32, 16, G>), grid, dim3(256), lds, st, m); }
-  POLYC_CASE(4) else POLYC_CASE(2) else POLYC_CASE(1) else { *nrd -= 4 * n; F32_REJ("tile row"); }
+#define POLYC_LAUNCH(T0, T1, T2, T3, G) { sv_ensure_dynamic_lds((const void*)wgrad_polyc_f32_kernel<T0, T1, T2, T3, 2, 32, 16, G>, lds); \
+    hipLaunchKernelGGL((wgrad_polyc_f32_kernel<T0, T1, T2, T3, 2, 32, 16, G>), grid, dim3(256), lds, st, m); }
+#define POLYC_CASE(G) if (G4 == G) { if (mask == 0xF) POLYC_LAUNCH(7, 5, 5, 4, G) else if (mask == 0x9) POLYC_LAUNCH(7, 0, 0, 4, G) else POLYC_LAUNCH(0, 5, 5, 0, G) }
+  POLYC_CASE(4) else POLYC_CASE(2) else POLYC_CASE(1) else { *nrd = nrd0; F32_REJ("tile row"); }
 #undef POLYC_CASE
+#undef POLYC_LAUNCH
   SV_LAUNCH_CHECK();
   return SV_OK;
 }

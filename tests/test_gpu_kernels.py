@@ -943,6 +943,41 @@ def test_fp32_polyphase_weight_gradient_against_fp64(ops, layer, B):
 
 
 @pytest.mark.gpu
+def test_fp32_class_pairs_and_four_classes_per_launch_equal_the_class_launches(lib_built, tmp_path):
+    """d4's polyphase weight gradient (vae/model.py:165, Conv2DBackpropFilter behind the resize) with the input tile staged once per class PAIR
+    (SV_WGRAD_POLYC_FUSED=2: classes {0, 3} and {1, 2}) and once for all FOUR classes (=1) against the default of one launch per class, in separate
+    processes (the knob is latched at first use): same slabs, same reduce, same projection -- only which launch leaves a class's slab differs, so the
+    weight gradients agree to fp32 addition order of the bias partials; the opt-in forms are also bitwise run to run.  32 / 64-pixel outputs, a ragged batch."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, numpy as np; sys.path.insert(0, %r)\n"
+        "from split_vae_amd import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "outs = []\n"
+        "for (H, Cin, Cout, k, B) in ((32, 64, 32, 6, 5), (64, 64, 32, 6, 19), (16, 64, 32, 6, 40)):\n"
+        "    x = torch.randn(B, H // 2, H // 2, Cin, generator=g).cuda()\n"
+        "    dy = torch.randn(B, H, H, Cout, generator=g).cuda()\n"
+        "    c = ops.Conv2D(B, H, H, Cin, Cout, k, 1, act=None, dtype=torch.float32, ups_in=True)\n"
+        "    dw, db = c.wgrad(x, dy, workspace=True)\n"
+        "    dw2, db2 = c.wgrad(x, dy, workspace=True)\n"
+        "    assert torch.equal(dw, dw2) and torch.equal(db, db2)\n"
+        "    outs += [dw.cpu().numpy(), db.cpu().numpy()]\n"
+        "np.savez(sys.argv[1], *outs)\n" % root)
+    res = []
+    for tag, env in (("classes", {"SV_WGRAD_POLYC_FUSED": "0"}), ("pairs", {"SV_WGRAD_POLYC_FUSED": "2"}), ("four", {"SV_WGRAD_POLYC_FUSED": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    for other in res[1:]:
+        for key in res[0].files:
+            a, b = other[key].astype(np.float64), res[0][key].astype(np.float64)
+            assert np.abs(b).max() > 0
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), key
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 5, 19])
 @pytest.mark.parametrize("layer", [("d4_64", 32, 64, 32, 6, False), ("d4_128", 64, 64, 32, 6, False), ("d5", 32, 32, 6, 6, True), ("d5_64", 64, 32, 6, 6, True)],
                          ids=lambda l: l[0])
