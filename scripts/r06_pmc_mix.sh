@@ -11,7 +11,7 @@ for f in glob.glob("$O/_pmc/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("# per launch, alone on the chip (bench.py --dtype $DT --table-only 2).  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8) / 1024: the busy cycles are summed over the chip's")
 print("# 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md: effective clock = GRBM_GUI_ACTIVE / 8 / wall time) -- round 5's file divided by the")
-print("# un-normalised GUI count and read 8x too low.  = the fraction of the launch's cycles a SIMD's matrix pipe was busy: the figure `roofline.*_issued` is an estimate of")
+print("# un-normalised GUI count and read 8x too low.  = the fraction of the launch's cycles a SIMD's matrix pipe was busy: the figure roofline.*_issued is an estimate of")
 rows = []
 for k, c in acc.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
