@@ -6,6 +6,6 @@ T=${1:-r06_a}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; OUT=$O/${T}_bf16_ablate.txt
 export SV_LIB_NAME=libsplitvae_dbg.so
 for d in 0 1 2 4 3 6 7 8 16; do
   echo "SV_TC_DBG=$d" >> $OUT
-  SV_TC_DBG=$d timeout 200 python bench.py --dtype bf16 --table-only 3 2>&1 | grep -E "^(fwd.d5|dgrad.d2|dgrad.e3|dgrad.head|fwd.d1) " | cut -c1-100 >> $OUT
+  SV_TC_DBG=$d timeout 200 python bench.py --dtype bf16 --table-only 10 2>&1 | grep -E "^(fwd.d5|dgrad.d2|dgrad.e3|dgrad.head|fwd.d1) " | cut -c1-100 >> $OUT
 done
 cat $OUT
