@@ -336,6 +336,26 @@ SPAIR_WORKLOAD = {
 }
 
 
+def timed_blocks(step, steps, blocks=3):
+    """`steps` steps of a host-launch-bound row timed as `blocks` equal blocks (synchronize on both sides of each): returns (median block's seconds per step,
+    every block's ms per step, seconds per step over all blocks).  The extra rows report the MEDIAN block: a one-off host stall (allocator trim after the
+    previous row's model was freed, a page fault storm) inside a 60-step window once read 3.51 ms for a 2.29-ms step (profiles/r06_m_bench.json); the
+    all-blocks mean stays in the row as `ms_per_step_mean`.  The headline metric is NOT timed this way (exactly K steps, one window: main())."""
+    import torch
+    per = max(steps // blocks, 1)
+    ts = []
+    k = 0
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(per):
+            step(k)
+            k += 1
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / per)
+    return sorted(ts)[len(ts) // 2], [round(1e3 * t, 4) for t in ts], sum(ts) / len(ts)
+
+
 def spair_row(dev, which="hard", B=32, steps=60, warmup=5):
     """SPLIT-SPAIR (config 5; `which` picks README.md:107 Multi-Bird-Hard -- what BASELINE names -- or README.md:93 Multi-Bird-Easy) train step:
     forward + losses + backward + clipnorm Adam as one native launch sequence (sv_tape_run); fp32 like the reference and with bf16 convolutions."""
@@ -355,13 +375,9 @@ def spair_row(dev, which="hard", B=32, steps=60, warmup=5):
         step_fn = lambda im, i: spair_trainer.train_step(model, im, opt, i, cfg)          # noqa: E731 (native: spair_native.NativeStep)
         for i in range(warmup):
             step_fn(images, i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step_fn(images, warmup + i)
-        torch.cuda.synchronize()
-        t = (time.perf_counter() - t0) / steps
-        out[dt_] = {"value": round(B / t, 1), "ms_per_step": round(1e3 * t, 4)}
+        t, blocks_ms, t_mean = timed_blocks(lambda i: step_fn(images, warmup + i), steps)
+        out[dt_] = {"value": round(B / t, 1), "ms_per_step": round(1e3 * t, 4), "blocks_ms": blocks_ms, "ms_per_step_mean": round(1e3 * t_mean, 4),
+                    "timing": "ms_per_step = the median of the equal blocks in blocks_ms (bench.py: timed_blocks); ms_per_step_mean = all of them"}
         if dt_ == "f32":
             ns = model.native(B, cfg)
             # algorithmic HBM bytes of the step: the variables once per pass (forward, input gradients, weight gradients written) + Adam's
@@ -390,16 +406,13 @@ def gm_row(dev, B=64, steps=100, warmup=10, dtype="bf16"):
     plan = m.plan(B)                       # plan=: the augmentation kernel also writes the step's padded inputs (as the SPLIT-VAE rows do)
     for _ in range(warmup):
         train_step_lg_gm_vae(m, aug.augment(x, plan=plan), opt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        train_step_lg_gm_vae(m, aug.augment(x, plan=plan), opt)
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / steps
+    t, blocks_ms, t_mean = timed_blocks(lambda i: train_step_lg_gm_vae(m, aug.augment(x, plan=plan), opt), steps, blocks=4)
     # 135.0 M forward MACs per image for the whole LGGMVae at SVHN-32 [derived]; train FLOP = 6 MACs_fwd - 4 MACs of the two first convs
     # (gmvae encoder 16 x 16 x 128 x 108 = 3.54 M, local encoder 0.88 M: no input gradient).  A 64-image step is launch-bound: the fraction says so.
     fl = 6 * 135.0e6 - 4 * (3.54e6 + 0.88e6)
-    return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "steps": steps, "batch": B, "dtype": dtype,
+    return {"value": round(B / t, 1), "unit": "images/s", "ms_per_step": round(1e3 * t, 4), "blocks_ms": blocks_ms, "ms_per_step_mean": round(1e3 * t_mean, 4),
+            "timing": "ms_per_step = the median of the equal blocks in blocks_ms (bench.py: timed_blocks); ms_per_step_mean = all of them",
+            "steps": steps, "batch": B, "dtype": dtype,
             "workload": "BASELINE configs[2]: SPLIT-GMVAE SVHN-32 y_size=30 beta=40 alpha=40 patch_size=4 tau=0.4" + (" at the reference's precision" if dtype == "f32" else ""),
             "roofline": {"bound": "mfma", "flops_per_image": fl, "achieved": round(B / t * fl / 1e12, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": round(B / t * fl / 1e12 / PEAK_TFLOPS[dtype], 4),
