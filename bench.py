@@ -191,6 +191,10 @@ class Workload:
         import torch.distributed as tdist
         for _ in range(max(warmup, 1)):
             self.step()
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()                                 # (as timeit does: no cyclic-GC pass of the interpreter inside a 20-step window; nothing of the step is skipped)
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
@@ -201,6 +205,8 @@ class Workload:
         if world > 1:
             tdist.barrier()
         dt = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         self.last_rank_dt = dt                       # this rank's own time (the reported one is the MAX over ranks)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
